@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SP two-stream training step (BASELINE.json configs[1]/[2]).
+
+One "step" = one pass of the hot path over one synthetic minibatch of 32 frames per GPU, exactly the body of
+SP.trainSP's loop (reference SP.py:132-138): model_SP forward (train-mode BN) -> floss -> backward -> Adam ->
+zero_grad, every kernel hand-written HIP behind the C-ABI.  Inputs are resident in HBM before the timed region.
+N>1: one process per GPU (torch.distributed.run), gradient all-reduce over RCCL overlapped with backward.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` (dominant kernel: the f32-MFMA
+implicit-GEMM 3x3 conv, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle, i.e.
+the reference's PyTorch-CPU algorithm, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md:41
+HBM_PEAK_GBS = 8000.0               # :35
+FLOP_PER_FRAME_FWD_BWD = 341.2e9    # BASELINE.md section 3 (all parameters trainable)
+BYTES_PER_FRAME = 1.046e9
+
+
+def cpu_baseline(batch=8, size=224):
+    """The reference's CPU algorithm (oracle/, pinned to the reference by golden vectors) on the host cores:
+    one warm-up + one timed SP train step (fwd + floss + bwd + Adam) at a bounded batch."""
+    from oracle import egaze_oracle as O
+    from oracle import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.synth_state_dict(O.sp_shapes(), seed=1, head_gain=0.25)
+    x_s, x_t, gt, _ = synth.synth_sp_batch(batch, size, seed=0)
+    opt = {}
+    O.sp_train_step(sd, opt, 1, x_s, x_t, gt, 1e-7)
+    t0 = time.perf_counter()
+    O.sp_train_step(sd, opt, 2, x_s, x_t, gt, 1e-7)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle SP train step (fwd+floss+bwd+Adam), batch {batch}, {size}x{size}, "
+                      f"1 warm-up + 1 timed step, {dt:.2f} s, torch-CPU fp32 on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU (BASELINE: 32)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import egaze_amd  # noqa: F401
+    import egaze_amd.hipops as H
+    from egaze_amd.models.model_SP import model_SP
+    from egaze_amd.utils import make_layers, cfg
+    from egaze_amd.floss import floss
+    from egaze_amd.optim import FusedAdam
+    from egaze_amd import dp, synthetic
+
+    torch.manual_seed(1234)
+    model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20)).to(dev)   # random init (no weights offline)
+    model.train()
+    criterion = floss().to(dev)
+    optimizer = FusedAdam(model.parameters(), lr=1e-7)          # gaze_full.py --lr default
+    if world > 1:
+        dp.attach(optimizer)
+    batch = synthetic.sp_batch(args.batch, args.size, dev, seed=100 + rank)
+    input_s, input_t, target = batch["image"], batch["flow"], batch["gt"]
+
+    def step():
+        output = model(input_s, input_t)
+        loss = criterion(output, target.view(output.size()))
+        loss.backward()
+        optimizer.step()
+        optimizer.zero_grad()
+        return loss
+
+    optimizer.zero_grad()
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = args.batch * world * args.steps / elapsed
+    last_loss = loss.item()
+
+    roofline = None
+    breakdown = None
+    if rank == 0 and not args.no_roofline:
+        H.PROF.start()
+        step()
+        prof = H.PROF.stop()
+        ig = prof.get("egz_conv3x3_fwd", {"calls": 0, "ms": 0.0, "flops": 0.0})
+        if ig["ms"] > 0:
+            achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (egz_conv3x3_fwd: fwd + dgrad launches)",
+                        "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
+                        "algorithmic_flop_per_step": ig["flops"]}
+        tot = sum(v["ms"] for v in prof.values())
+        breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        breakdown["_sum_kernel_ms"] = round(tot, 3)
+    if dist is not None:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        step_flops = FLOP_PER_FRAME_FWD_BWD * args.batch * (args.size / 224.0) ** 2
+        out = {
+            "metric": "SP+AT train frames/sec/node (224x224, bs32/GPU)",
+            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SP two-stream (RGB + 10-pair flow stack) forward + floss + backward + Adam, "
+                                   f"batch {args.batch}/GPU, {args.size}x{args.size}, train-mode BN, all "
+                                   f"46.5M params trainable (--sp_resume 0)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "precision": "exact f32 MFMA (v_mfma_f32_32x32x2_f32)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+            "step_hbm_frac": BYTES_PER_FRAME * args.batch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "loss": last_loss, "kernel_ms_breakdown": breakdown,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI shared library ``csrc/libegaze_hip.so`` (see include/egaze_hip.h).
+
+There is NO fallback: if the library is missing or does not export a declared symbol the import of
+any compute module raises, and every op raises on non-HIP tensors.  Build it with
+``python __graft_entry__.py`` (or ``csrc/build.sh``); hipcc cross-compiles gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libegaze_hip.so")
+
+P = c_void_p          # device pointer
+S = c_void_p          # hipStream_t
+
+# name -> (restype, argtypes).  Must list every symbol include/egaze_hip.h declares
+# (tests/test_cabi_symbols.py cross-checks the header against this table and the .so).
+SIGNATURES = {
+    "egz_version": (c_char_p, []),
+    "egz_last_error": (c_char_p, []),
+    # --- 3x3 conv, implicit GEMM on f32 MFMA
+    "egz_pack_w3x3_fwd": (c_int, [P, P, c_int, c_int, S]),
+    "egz_pack_w3x3_dgrad": (c_int, [P, P, c_int, c_int, S]),
+    "egz_conv3x3_stat_rows": (c_int, [c_int, c_int, c_int]),
+    "egz_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, S]),
+    "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
+    # --- first encoder conv (NCHW input, Cin 3 / 20)
+    "egz_conv_first_stat_rows": (c_int, [c_int, c_int, c_int]),
+    "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
+    "egz_conv_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "egz_conv_first_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
+    # --- BatchNorm / ReLU / pool / fusion max / misc streaming passes
+    "egz_bn_ws_bytes": (c_size_t, [c_int]),
+    "egz_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P,
+                                c_size_t, S]),
+    "egz_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P, S]),
+    "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
+    "egz_bn_relu_pool_bwd_ws_bytes": (c_size_t, [c_int]),
+    "egz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
+                                     c_size_t, S]),
+    "egz_pairmax_fwd": (c_int, [P, P, c_long, S]),
+    "egz_pairmax_bwd": (c_int, [P, P, P, c_long, S]),
+    "egz_channel_stats_rows": (c_int, []),
+    "egz_channel_stats": (c_int, [P, c_long, c_int, P, S]),
+    "egz_relu_bwd": (c_int, [P, P, P, c_long, S]),
+    "egz_upsample2x_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_colsum": (c_int, [P, c_long, c_int, P, P, c_size_t, S]),
+    "egz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    # --- head + losses
+    "egz_conv1x1_sigmoid_fwd": (c_int, [P, P, P, P, P, c_long, c_int, S]),
+    "egz_conv1x1_sigmoid_bwd_ws_bytes": (c_size_t, [c_int]),
+    "egz_conv1x1_sigmoid_bwd": (c_int, [P, P, P, P, P, P, P, c_long, c_int, P, c_size_t, S]),
+    "egz_loss_ws_bytes": (c_size_t, [c_int]),
+    "egz_floss_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, S]),
+    "egz_floss_bwd": (c_int, [P, P, P, P, P, c_long, S]),
+    "egz_mse_fwd": (c_int, [P, P, P, c_long, P, c_size_t, S]),
+    "egz_mse_bwd": (c_int, [P, P, P, P, c_long, S]),
+    # --- optimizer
+    "egz_adam_step": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, S]),
+}
+
+
+class EgazeHipError(RuntimeError):
+    """Raised when a C-ABI entry point returns a non-zero code (mirrors the reference's convention of
+    plain Python exceptions: utils.generalException / RuntimeError)."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is mandatory (no CPU fallback). "
+            "Build it with `python __graft_entry__.py` or `csrc/build.sh`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+LIB = _load()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = LIB.egz_last_error().decode(errors="replace")
+        raise EgazeHipError(f"{what or 'egaze-hip'} failed (code {rc}): {msg}")
+
+
+def version() -> str:
+    return LIB.egz_version().decode()

@@ -1,0 +1,60 @@
+// Fused Adam step over one flat fp32 parameter buffer (torch.optim.Adam defaults as the reference configures it:
+// SP.py:110-113, AT.py:84, LF.py:77 -- betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
+// HBM-bound: reads p, g, m, v and writes p, m, v once (7 fp32 streams), float4 per lane, grid-stride.
+// Mirrors torch's single-tensor update order:  m.lerp_(g, 1-b1);  v = v*b2 + (1-b2)*g*g;
+//   denom = sqrt(v)/sqrt(1-b2^t) + eps;  p -= (lr/(1-b1^t)) * m/denom.
+#include "egz_common.h"
+
+namespace {
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float beta1, float beta2, float eps,
+                                                   float step_size, float bc2_sqrt, float grad_scale) {
+    const long n4 = n >> 2;
+    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * grad_scale;
+            mv[e] = mv[e] + omb1 * (ge - mv[e]);
+            vv[e] = vv[e] * beta2 + omb2 * ge * ge;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pv[e] = pv[e] - step_size * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    const long t = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float ge = g[t] * grad_scale;
+        const float mm = m[t] + omb1 * (ge - m[t]);
+        const float vq = v[t] * beta2 + omb2 * ge * ge;
+        m[t] = mm;
+        v[t] = vq;
+        p[t] = p[t] - step_size * (mm / (sqrtf(vq) / bc2_sqrt + eps));
+    }
+}
+}  // namespace
+
+// step: 1-based step count.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+EGZ_API int egz_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                          float eps, int step, float grad_scale, hipStream_t st) {
+    EGZ_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "egz_adam_step: bad arguments");
+    EGZ_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                  "egz_adam_step: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    long g4 = (n / 4 + 255) / 256;
+    if (g4 < 1) g4 = 1;
+    const int grid = (int)(g4 > 8192 ? 8192 : g4);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+    EGZ_CHECK_LAUNCH("egz_adam_step");
+    return 0;
+}

@@ -1,0 +1,595 @@
+// HBM-bound streaming passes of the SP/LF path (NHWC fp32, float4 over channels, grid-stride):
+//   * train-mode BatchNorm2d statistics finalisation + running-stat update   (utils.py:72, model_SP.py:12,45)
+//   * BN-apply + ReLU (+ 2x2/2 max-pool) forward and its backward            (utils.py:68,72)
+//   * element-wise max of the two fusion streams (Conv3d k=(1,3,3) + MaxPool3d((2,1,1)), model_SP.py:38-44)
+//   * ReLU mask, nearest-x2 upsample backward (2x2 sum), bias gradient (column sums)
+// Channel reductions: every block keeps fp64 per-channel partials, writes them to a small workspace and a
+// second tiny kernel sums them in a fixed order (deterministic, no atomics).
+#include "egz_common.h"
+
+namespace {
+
+constexpr int RED_ROWS = 64;   // row-splits of the generic column reduction (stage A)
+
+// ------------------------------------------------------------------ generic column sums of a [rows][cols] matrix
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ in, double* __restrict__ part,
+                                                             long rows, int cols) {
+    __shared__ double red[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    double s = 0.0;
+    if (col < cols)
+        for (long r = r0 + ry; r < r1; r += 8) s += (double)in[r * cols + col];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < cols) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cx];
+        part[(long)blockIdx.y * cols + col] = t;
+    }
+}
+
+template <typename T>
+int colsum_partial(const T* in, double* part, long rows, int cols, hipStream_t st) {
+    dim3 grid(egz_cdiv(cols, 32), RED_ROWS);
+    hipLaunchKernelGGL(colsum_partial_kernel<T>, grid, dim3(256), 0, st, in, part, rows, cols);
+    EGZ_CHECK_LAUNCH("colsum_partial");
+    return 0;
+}
+
+// ------------------------------------------------------------------ BN forward finalise
+// part2: [RED_ROWS][2][K] fp64 (sum, sumsq).  Batch mean / biased var -> invstd; running stats use the
+// unbiased variance (torch BatchNorm2d semantics).  scale = gamma*invstd, shift = beta - mean*scale.
+__global__ void bn_finalize_kernel(const double* __restrict__ part2, int nparts, int K, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += part2[((long)p * 2 + 0) * K + k];
+        s2 += part2[((long)p * 2 + 1) * K + k];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[k] : 1.f, bt = beta ? beta[k] : 0.f;
+    const float sc = g * invstd;
+    mean_out[k] = (float)mean;
+    invstd_out[k] = invstd;
+    scale[k] = sc;
+    shift[k] = bt - (float)mean * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mean;
+        running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(int K, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float invstd = 1.f / sqrtf(rv[k] + eps);
+    const float sc = (gamma ? gamma[k] : 1.f) * invstd;
+    scale[k] = sc;
+    shift[k] = (beta ? beta[k] : 0.f) - rm[k] * sc;
+}
+
+// ------------------------------------------------------------------ BN-apply + ReLU (+pool) forward
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               float* __restrict__ out, int B, int H, int W, int K) {
+    const int K4 = K >> 2;
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const long n = (long)B * Ho * Wo * K4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % K4);
+        const long pix = i / K4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        f32x4 r;
+        if (!POOL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * K + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(v[e] * sc[e] + sh[e], 0.f);
+        } else {
+            const int xo = (int)(pix % Wo);
+            const long t = pix / Wo;
+            const int yo = (int)(t % Ho);
+            const long b = t / Ho;
+            const float* p = y + (((b * H + 2 * yo) * (long)W + 2 * xo) * K + c4 * 4);
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 v01 = *reinterpret_cast<const f32x4*>(p + K);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(p + (long)W * K);
+            const f32x4 v11 = *reinterpret_cast<const f32x4*>(p + (long)W * K + K);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = fmaxf(v00[e] * sc[e] + sh[e], v01[e] * sc[e] + sh[e]);
+                const float c = fmaxf(v10[e] * sc[e] + sh[e], v11[e] * sc[e] + sh[e]);
+                r[e] = fmaxf(fmaxf(a, c), 0.f);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + pix * K + c4 * 4) = r;
+    }
+}
+
+// dz at the four (or one) input positions of an output pixel: ReLU mask and first-max-wins pool routing
+// (torch's max_pool2d scan order (0,0),(0,1),(1,0),(1,1); strictly-greater replaces).
+__device__ __forceinline__ void pool_route(const float z[4], float dout, float dz[4]) {
+    int best = 0;
+    float bv = z[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (z[q] > bv) {
+            bv = z[q];
+            best = q;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dz[q] = (q == best && bv > 0.f) ? dout : 0.f;
+}
+
+// ------------------------------------------------------------------ BN backward, pass 1: per-channel sum(dz), sum(dz*xhat)
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            double* __restrict__ part, int B, int H, int W, int K) {
+    extern __shared__ double sred[];   // [rows_per_block][2][K]
+    const int K4 = K >> 2;
+    const int rpb = blockDim.x / K4;               // output-pixel rows handled concurrently by a block
+    const int c4 = threadIdx.x % K4, rr = threadIdx.x / K4;
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const long npix = (long)B * Ho * Wo;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (rr < rpb) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        for (long pix = (long)blockIdx.x * rpb + rr; pix < npix; pix += (long)gridDim.x * rpb) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dout + pix * K + c4 * 4);
+            if (!POOL) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * K + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = v[e] * sc[e] + sh[e];
+                    const float dz = z > 0.f ? g[e] : 0.f;
+                    s1[e] += (double)dz;
+                    s2[e] += (double)(dz * ((v[e] - mu[e]) * is[e]));
+                }
+            } else {
+                const int xo = (int)(pix % Wo);
+                const long t = pix / Wo;
+                const int yo = (int)(t % Ho);
+                const long b = t / Ho;
+                const float* p = y + (((b * H + 2 * yo) * (long)W + 2 * xo) * K + c4 * 4);
+                f32x4 v[4];
+                v[0] = *reinterpret_cast<const f32x4*>(p);
+                v[1] = *reinterpret_cast<const f32x4*>(p + K);
+                v[2] = *reinterpret_cast<const f32x4*>(p + (long)W * K);
+                v[3] = *reinterpret_cast<const f32x4*>(p + (long)W * K + K);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float z[4], dz[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) z[q] = v[q][e] * sc[e] + sh[e];
+                    pool_route(z, g[e], dz);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        s1[e] += (double)dz[q];
+                        s2[e] += (double)(dz[q] * ((v[q][e] - mu[e]) * is[e]));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sred[((long)rr * 2 + 0) * K + c4 * 4 + e] = s1[e];
+            sred[((long)rr * 2 + 1) * K + c4 * 4 + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * K; i += blockDim.x) {
+        double t = 0.0;
+        for (int r = 0; r < rpb; ++r) t += sred[(long)r * 2 * K + i];
+        part[(long)blockIdx.x * 2 * K + i] = t;
+    }
+}
+
+// part: [nparts][2][K] -> dgamma, dbeta and the two per-channel means the apply pass needs
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nparts, int K, double count,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ mdz, float* __restrict__ mdzx) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int p = 0; p < nparts; ++p) {
+        s1 += part[((long)p * 2 + 0) * K + k];
+        s2 += part[((long)p * 2 + 1) * K + k];
+    }
+    if (dbeta) dbeta[k] = (float)s1;
+    if (dgamma) dgamma[k] = (float)s2;
+    mdz[k] = (float)(s1 / count);
+    mdzx[k] = (float)(s2 / count);
+}
+
+// ------------------------------------------------------------------ BN backward, pass 2: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ mdz, const float* __restrict__ mdzx,
+                                                           float* __restrict__ dy, int B, int H, int W, int K) {
+    const int K4 = K >> 2;
+    const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
+    const long n = (long)B * Ho * Wo * K4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % K4);
+        const long pix = i / K4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(mdz + c4 * 4);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(mdzx + c4 * 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dout + pix * K + c4 * 4);
+        if (!POOL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + pix * K + c4 * 4);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = v[e] * sc[e] + sh[e];
+                const float dz = z > 0.f ? g[e] : 0.f;
+                const float xh = (v[e] - mu[e]) * is[e];
+                r[e] = sc[e] * (dz - m1[e] - xh * m2[e]);
+            }
+            *reinterpret_cast<f32x4*>(dy + pix * K + c4 * 4) = r;
+        } else {
+            const int xo = (int)(pix % Wo);
+            const long t = pix / Wo;
+            const int yo = (int)(t % Ho);
+            const long b = t / Ho;
+            const long base = ((b * H + 2 * yo) * (long)W + 2 * xo) * K + c4 * 4;
+            const long off[4] = {0, (long)K, (long)W * K, (long)W * K + K};
+            f32x4 v[4], r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(y + base + off[q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float z[4], dz[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) z[q] = v[q][e] * sc[e] + sh[e];
+                pool_route(z, g[e], dz);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xh = (v[q][e] - mu[e]) * is[e];
+                    r[q][e] = sc[e] * (dz[q] - m1[e] - xh * m2[e]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dy + base + off[q]) = r[q];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fusion: z = max(ys, yt) (ys wins ties)
+__global__ __launch_bounds__(256) void pairmax_fwd_kernel(const float* __restrict__ y2, float* __restrict__ z, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(y2)[i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(y2)[n4 + i];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = a[e] >= b[e] ? a[e] : b[e];
+        reinterpret_cast<f32x4*>(z)[i] = r;
+    }
+}
+__global__ __launch_bounds__(256) void pairmax_bwd_kernel(const float* __restrict__ y2, const float* __restrict__ dz,
+                                                          float* __restrict__ dy2, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(y2)[i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(y2)[n4 + i];
+        const f32x4 g = reinterpret_cast<const f32x4*>(dz)[i];
+        f32x4 ra, rb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool first = a[e] >= b[e];
+            ra[e] = first ? g[e] : 0.f;
+            rb[e] = first ? 0.f : g[e];
+        }
+        reinterpret_cast<f32x4*>(dy2)[i] = ra;
+        reinterpret_cast<f32x4*>(dy2)[n4 + i] = rb;
+    }
+}
+
+// dy = dout * (out > 0)   (nn.ReLU backward; in place allowed)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                       float* __restrict__ dy, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+        const f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = o[e] > 0.f ? g[e] : 0.f;
+        reinterpret_cast<f32x4*>(dy)[i] = r;
+    }
+}
+
+// nn.Upsample(scale_factor=2, nearest) backward: dx[b][y][x][c] = sum of the 2x2 block of dxu
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dxu, float* __restrict__ dx,
+                                                             int B, int H, int W, int C) {
+    const int C4 = C >> 2;
+    const long n = (long)B * H * W * C4;
+    const int W2 = 2 * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long pix = i / C4;
+        const int xo = (int)(pix % W);
+        const long t = pix / W;
+        const int yo = (int)(t % H);
+        const long b = t / H;
+        const float* p = dxu + (((b * 2 * H + 2 * yo) * (long)W2 + 2 * xo) * C + c4 * 4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(p + C);
+        const f32x4 c = *reinterpret_cast<const f32x4*>(p + (long)W2 * C);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p + (long)W2 * C + C);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (a[e] + bb[e]) + (c[e] + d[e]);
+        *reinterpret_cast<f32x4*>(dx + pix * C + c4 * 4) = r;
+    }
+}
+
+__global__ void colsum_final_kernel(const double* __restrict__ part, int nparts, int cols, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= cols) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * cols + k];
+    out[k] = (float)s;
+}
+
+// layout transposes between the reference's NCHW tensors and the library's NHWC activations
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int B, int C, long HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const long p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? in[((long)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const long p = p0 + j;
+        const int c = c0 + tx;
+        if (c < C && p < HW) out[((long)b * HW + p) * C + c] = tile[tx][j];
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int B, int C, long HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const long p = p0 + j;
+        const int c = c0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? in[((long)b * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const long p = p0 + tx;
+        if (c < C && p < HW) out[((long)b * C + c) * HW + p] = tile[tx][j];
+    }
+}
+
+inline int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+constexpr int BWD_BLOCKS = 1024;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+EGZ_API size_t egz_bn_ws_bytes(int K) {
+    // stage-A partials of the forward stats ([RED_ROWS][2][K]) or the backward reduction ([BWD_BLOCKS][2][K])
+    const size_t a = (size_t)RED_ROWS * 2 * K * sizeof(double);
+    const size_t b = (size_t)BWD_BLOCKS * 2 * K * sizeof(double);
+    return a > b ? a : b;
+}
+
+// stat_partial: [rows][2][K] fp64 as written by the conv epilogues.  Produces batch mean / invstd and the fused
+// affine (scale, shift); updates running_mean / running_var in place when they are non-null.
+EGZ_API int egz_bn_finalize(const double* stat_partial, int rows, int K, double count, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                            float* mean_out, float* invstd_out, float* scale, float* shift, void* workspace,
+                            size_t ws_bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(stat_partial && mean_out && invstd_out && scale && shift && workspace, "egz_bn_finalize: null pointer");
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)RED_ROWS * 2 * K * sizeof(double), "egz_bn_finalize: workspace too small");
+    EGZ_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "egz_bn_finalize: running stats must come in pairs");
+    double* part2 = static_cast<double*>(workspace);
+    const double* src = stat_partial;
+    int nparts = rows;
+    if (rows > RED_ROWS) {
+        int rc = colsum_partial<double>(stat_partial, part2, rows, 2 * K, st);
+        if (rc) return rc;
+        src = part2;
+        nparts = RED_ROWS;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, src, nparts, K, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift);
+    EGZ_CHECK_LAUNCH("egz_bn_finalize");
+    return 0;
+}
+
+EGZ_API int egz_bn_eval_coeffs(int K, const float* gamma, const float* beta, const float* running_mean,
+                               const float* running_var, float eps, float* scale, float* shift, hipStream_t st) {
+    EGZ_CHECK_ARG(running_mean && running_var && scale && shift, "egz_bn_eval_coeffs: null pointer");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, K, gamma, beta, running_mean,
+                       running_var, eps, scale, shift);
+    EGZ_CHECK_LAUNCH("egz_bn_eval_coeffs");
+    return 0;
+}
+
+// out = relu(y*scale + shift), optionally followed by MaxPool2d(2,2) (out is then [B][H/2][W/2][K]).
+EGZ_API int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, float* out, int B, int H,
+                                 int W, int K, int pool, hipStream_t st) {
+    EGZ_CHECK_ARG(y && scale && shift && out, "egz_bn_relu_pool_fwd: null pointer");
+    EGZ_CHECK_ARG(K % 4 == 0, "egz_bn_relu_pool_fwd: K=%d must be a multiple of 4", K);
+    EGZ_CHECK_ARG(!pool || (H % 2 == 0 && W % 2 == 0), "egz_bn_relu_pool_fwd: pooled map must be even");
+    const long n = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (K / 4);
+    if (pool) hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K);
+    else      hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K);
+    EGZ_CHECK_LAUNCH("egz_bn_relu_pool_fwd");
+    return 0;
+}
+
+// Backward of [BN(train) -> ReLU -> (pool)] given the saved pre-BN tensor y and the batch statistics.
+// dgamma/dbeta may be null (frozen BN).  dy gets the gradient w.r.t. y ([B][H][W][K]).
+EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
+                                 int B, int H, int W, int K, int pool, void* workspace, size_t ws_bytes,
+                                 hipStream_t st) {
+    EGZ_CHECK_ARG(y && dout && scale && shift && mean && invstd && dy && workspace, "egz_bn_relu_pool_bwd: null pointer");
+    EGZ_CHECK_ARG(K % 4 == 0 && K <= 1024, "egz_bn_relu_pool_bwd: K=%d must be a multiple of 4, <= 1024", K);
+    EGZ_CHECK_ARG(!pool || (H % 2 == 0 && W % 2 == 0), "egz_bn_relu_pool_bwd: pooled map must be even");
+    const int K4 = K / 4;
+    const int threads = 256 > K4 ? 256 : K4;
+    const int rpb = threads / K4;
+    const long npix = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    int blocks = (int)((npix + rpb - 1) / rpb);
+    if (blocks > BWD_BLOCKS) blocks = BWD_BLOCKS;
+    const size_t need = (size_t)blocks * 2 * K * sizeof(double) + 2 * (size_t)K * sizeof(float);
+    EGZ_CHECK_ARG(ws_bytes >= need, "egz_bn_relu_pool_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
+    double* part = static_cast<double*>(workspace);
+    float* mdz = reinterpret_cast<float*>(part + (size_t)blocks * 2 * K);
+    float* mdzx = mdz + K;
+    const size_t shm = (size_t)rpb * 2 * K * sizeof(double);
+    if (pool) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
+    else      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
+    EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(reduce)");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, part, blocks, K,
+                       (double)B * H * W, dgamma, dbeta, mdz, mdzx);
+    EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(finalize)");
+    const long n = npix * K4;
+    if (pool) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K);
+    else      hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K);
+    EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(apply)");
+    return 0;
+}
+EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {
+    return (size_t)BWD_BLOCKS * 2 * K * sizeof(double) + 2 * (size_t)K * sizeof(float);
+}
+
+// y2: [2][n] (stream s then stream t), z: [n];  n must be a multiple of 4.
+EGZ_API int egz_pairmax_fwd(const float* y2, float* z, long n, hipStream_t st) {
+    EGZ_CHECK_ARG(y2 && z && n % 4 == 0, "egz_pairmax_fwd: bad arguments");
+    hipLaunchKernelGGL(pairmax_fwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, y2, z, n / 4);
+    EGZ_CHECK_LAUNCH("egz_pairmax_fwd");
+    return 0;
+}
+EGZ_API int egz_pairmax_bwd(const float* y2, const float* dz, float* dy2, long n, hipStream_t st) {
+    EGZ_CHECK_ARG(y2 && dz && dy2 && n % 4 == 0, "egz_pairmax_bwd: bad arguments");
+    hipLaunchKernelGGL(pairmax_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, y2, dz, dy2, n / 4);
+    EGZ_CHECK_LAUNCH("egz_pairmax_bwd");
+    return 0;
+}
+
+// per-channel sum / sum-of-squares partials of an NHWC tensor [rows][K] in the conv-epilogue format, so that
+// egz_bn_finalize can consume them: stat_partial must hold RED_ROWS*2*K doubles.
+EGZ_API int egz_channel_stats(const float* x, long rows, int K, double* stat_partial, hipStream_t st);
+EGZ_API int egz_channel_stats_rows(void) { return RED_ROWS; }
+
+namespace {
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                            long rows, int K) {
+    __shared__ double red[2][8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + cx;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    double s1 = 0.0, s2 = 0.0;
+    if (col < K)
+        for (long r = r0 + ry; r < r1; r += 8) {
+            const double v = (double)x[r * K + col];
+            s1 += v;
+            s2 += v * v;
+        }
+    red[0][ry][cx] = s1;
+    red[1][ry][cx] = s2;
+    __syncthreads();
+    if (ry < 2 && col < K) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[ry][i][cx];
+        part[((long)blockIdx.y * 2 + ry) * K + col] = t;
+    }
+}
+}  // namespace
+
+EGZ_API int egz_channel_stats(const float* x, long rows, int K, double* stat_partial, hipStream_t st) {
+    EGZ_CHECK_ARG(x && stat_partial && rows > 0 && K > 0, "egz_channel_stats: bad arguments");
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(egz_cdiv(K, 32), RED_ROWS), dim3(256), 0, st, x, stat_partial, rows, K);
+    EGZ_CHECK_LAUNCH("egz_channel_stats");
+    return 0;
+}
+
+EGZ_API int egz_relu_bwd(const float* out, const float* dout, float* dy, long n, hipStream_t st) {
+    EGZ_CHECK_ARG(out && dout && dy && n % 4 == 0, "egz_relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, out, dout, dy, n / 4);
+    EGZ_CHECK_LAUNCH("egz_relu_bwd");
+    return 0;
+}
+
+// dxu: [B][2H][2W][C] -> dx: [B][H][W][C]
+EGZ_API int egz_upsample2x_bwd(const float* dxu, float* dx, int B, int H, int W, int C, hipStream_t st) {
+    EGZ_CHECK_ARG(dxu && dx && C % 4 == 0, "egz_upsample2x_bwd: bad arguments");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((long)B * H * W * (C / 4))), dim3(256), 0, st, dxu, dx, B, H, W, C);
+    EGZ_CHECK_LAUNCH("egz_upsample2x_bwd");
+    return 0;
+}
+
+// out[k] = sum_r x[r][k]  (conv bias gradient).  workspace: RED_ROWS*K doubles.
+EGZ_API int egz_colsum(const float* x, long rows, int K, float* out, void* workspace, size_t ws_bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(x && out && workspace, "egz_colsum: null pointer");
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)RED_ROWS * K * sizeof(double), "egz_colsum: workspace too small");
+    double* part = static_cast<double*>(workspace);
+    int rc = colsum_partial<float>(x, part, rows, K, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, part, RED_ROWS, K, out);
+    EGZ_CHECK_LAUNCH("egz_colsum");
+    return 0;
+}
+
+EGZ_API int egz_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t st) {
+    EGZ_CHECK_ARG(in && out, "egz_nchw_to_nhwc: null pointer");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(egz_cdiv(HW, 32), egz_cdiv(C, 32), B), dim3(256), 0, st, in, out, B, C, HW);
+    EGZ_CHECK_LAUNCH("egz_nchw_to_nhwc");
+    return 0;
+}
+EGZ_API int egz_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t st) {
+    EGZ_CHECK_ARG(in && out, "egz_nhwc_to_nchw: null pointer");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(egz_cdiv(HW, 32), egz_cdiv(C, 32), B), dim3(256), 0, st, in, out, B, C, HW);
+    EGZ_CHECK_LAUNCH("egz_nhwc_to_nchw");
+    return 0;
+}

@@ -1,0 +1,268 @@
+// 3x3 / pad 1 / stride 1 convolution as an implicit GEMM on the exact-f32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32).  Replaces every nn.Conv2d(Cin>=32, Cout>=64, 3, padding=1) the SP path
+// executes: the 12 wide encoder convs per stream (reference utils.py:70), the shared `fusion` conv
+// (models/model_SP.py:10,41) and the 12 decoder convs (models/model_SP.py:13-29).  The same kernel
+// computes the data gradient when it is handed dgrad-packed (tap-flipped, transposed) weights.
+//
+// GEMM view:  Y[m][n] = sum_{tap,c} X[pix(m) + tap][c] * Wp[tap][c][n],   m = (b,y,x) flat, NHWC.
+//   block tile 128(m) x BN(n) (BN = 128 or 64), K-slice = one tap x 32 channels,
+//   4 waves as 2(m) x 2(n), each wave 64 x BN/2 = 2 x (BN/64) MFMA 32x32 tiles,
+//   LDS double-buffered, register-staged global loads (issue next slice -> MFMAs -> write LDS).
+// Optional fusions: nearest x2 upsample folded into the input gather (decoder.4/.11/.18/.23),
+// bias, ReLU, and per-channel sum / sum-of-squares partials (fp64) for train-mode BatchNorm.
+#include "egz_common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDA = BK + 4;   // 36 floats: 16-B aligned rows, conflict-free ds_read_b128
+
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
+
+template <int BN, bool UPS, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K) {
+    constexpr int NR = BN / 64;   // 32-wide n-tiles per wave
+    constexpr int WN = BN / 2;    // n-extent per wave
+    constexpr int BLD = (BN == 128) ? 4 : 2;   // float4 B loads per thread per slice
+
+    __shared__ __attribute__((aligned(16))) float As[2 * BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hl = lane >> 5, l31 = lane & 31;
+    const int ntn = K / BN;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long HW = (long)H * W;
+    const long M = (long)B * HW;
+    const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
+
+    // ---- per-thread A rows (fixed for the whole K loop)
+    const int a_c4 = tid & 7;
+    int a_y[4], a_x[4];
+    long a_img[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long m = m0 + (tid >> 3) + 32 * j;
+        if (m < M) {
+            const long b = m / HW;
+            const int rem = (int)(m - b * HW);
+            a_y[j] = rem / W;
+            a_x[j] = rem - a_y[j] * W;
+            a_img[j] = b * (long)Hs * Ws;
+        } else {
+            a_y[j] = -(1 << 20);
+            a_x[j] = 0;
+            a_img[j] = 0;
+        }
+    }
+    const int b_n4 = (BN == 128) ? (tid & 31) : (tid & 15);
+    const int b_k0 = (BN == 128) ? (tid >> 5) : (tid >> 4);
+    constexpr int b_kstep = (BN == 128) ? 8 : 16;
+
+    f32x4 ra[4], rb[BLD];
+    auto gload = [&](int s) {
+        const int cblk = s / 9, tap = s - cblk * 9;
+        const int c0 = cblk * BK;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_y[j] + dy, ix = a_x[j] + dx;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+            const float* p = x + ((a_img[j] + (long)sy * Ws + sx) * C + c0 + a_c4 * 4);
+            ra[j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < BLD; ++j) {
+            const int kr = b_k0 + b_kstep * j;
+            const float* p = wp + ((long)(tap * C + c0 + kr) * K + n0 + b_n4 * 4);
+            rb[j] = *reinterpret_cast<const f32x4*>(p);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * BM * LDA;
+        float* b = Bs + buf * BK * BN;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(a + ((tid >> 3) + 32 * j) * LDA + a_c4 * 4) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BLD; ++j)
+            *reinterpret_cast<f32x4*>(b + (b_k0 + b_kstep * j) * BN + b_n4 * 4) = rb[j];
+    };
+
+    f32x16 acc[2][NR];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int S = (C / BK) * 9;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < S) gload(s + 1);
+        const float* Ab = As + buf * BM * LDA + (wm * 64 + l31) * LDA + 4 * hl;
+        const float* Bb = Bs + buf * BK * BN + (4 * hl) * BN + wn * WN + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + 8 * q);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + 32 * LDA + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float bv[NR];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) bv[nr] = Bb[(8 * q + j) * BN + nr * 32];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    acc[0][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv[nr], acc[0][nr], 0, 0, 0);
+                    acc[1][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv[nr], acc[1][nr], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < S) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias (+ReLU) (+BN statistic partials), NHWC store
+    double* red = reinterpret_cast<double*>(As);   // [2 (wm)][2 (sum, sumsq)][BN]
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int col = wn * WN + nr * 32 + l31;
+        const float bz = bias ? bias[n0 + col] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm * 64 + mr * 32 + egz_acc_row(r, lane);
+                if (m < M) {
+                    float v = acc[mr][nr][r] + bz;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    y[m * K + n0 + col] = v;
+                    if (EPI == EPI_BIAS_STATS) {
+                        s1 += (double)v;
+                        s2 += (double)v * (double)v;
+                    }
+                }
+            }
+        }
+        if (EPI == EPI_BIAS_STATS) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hl == 0) {
+                red[(wm * 2 + 0) * BN + col] = s1;
+                red[(wm * 2 + 1) * BN + col] = s2;
+            }
+        }
+    }
+    if (EPI == EPI_BIAS_STATS) {
+        __syncthreads();
+        if (tid < BN) {
+            stat[((long)tile_m * 2 + 0) * K + n0 + tid] = red[(0 * 2 + 0) * BN + tid] + red[(1 * 2 + 0) * BN + tid];
+            stat[((long)tile_m * 2 + 1) * K + n0 + tid] = red[(0 * 2 + 1) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+        }
+    }
+}
+
+// wp[(tap*C + c)*K + k] = w[(k*C + c)*9 + tap]
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K) {
+    const long n = (long)9 * C * K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const long t = i / K;
+        const int c = (int)(t % C), tap = (int)(t / C);
+        wp[i] = w[((long)k * C + c) * 9 + tap];
+    }
+}
+// dgrad view: dX = conv3x3(dY, Wd) with Wd[(8-tap)][k][c] = w[k][c][tap]  (tap flip + in/out transpose)
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K) {
+    const long n = (long)9 * C * K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long t = i / C;
+        const int k = (int)(t % K), tapf = (int)(t / K);
+        wp[i] = w[((long)k * C + c) * 9 + (8 - tapf)];
+    }
+}
+
+template <int BN, bool UPS, int EPI>
+int launch_igemm(const float* x, const float* wp, const float* bias, float* y, double* stat, int B, int H,
+                 int W, int C, int K, hipStream_t st) {
+    const long M = (long)B * H * W;
+    const int grid = egz_cdiv(M, BM) * (K / BN);
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BN, UPS, EPI>), dim3(grid), dim3(256), 0, st, x, wp, bias, y,
+                       stat, B, H, W, C, K);
+    EGZ_CHECK_LAUNCH("egz_conv3x3_fwd");
+    return 0;
+}
+
+template <int BN, bool UPS>
+int dispatch_epi(int epi, const float* x, const float* wp, const float* bias, float* y, double* stat, int B,
+                 int H, int W, int C, int K, hipStream_t st) {
+    switch (epi) {
+        case EPI_BIAS: return launch_igemm<BN, UPS, EPI_BIAS>(x, wp, bias, y, stat, B, H, W, C, K, st);
+        case EPI_BIAS_RELU: return launch_igemm<BN, UPS, EPI_BIAS_RELU>(x, wp, bias, y, stat, B, H, W, C, K, st);
+        default: return launch_igemm<BN, UPS, EPI_BIAS_STATS>(x, wp, bias, y, stat, B, H, W, C, K, st);
+    }
+}
+
+int pick_bn(long M, int K, int flags) {
+    if (flags & 0x100) return 64;
+    if (flags & 0x200) return 128;
+    if (K % 128 != 0) return 64;
+    // under ~1.5 waves of 128x128 tiles the 64-wide tile fills the 256 CUs better
+    const long blocks128 = ((M + BM - 1) / BM) * (K / 128);
+    return blocks128 < 384 ? 64 : 128;
+}
+
+}  // namespace
+
+EGZ_API int egz_conv3x3_stat_rows(int B, int H, int W) { return egz_cdiv((long)B * H * W, BM); }
+
+EGZ_API int egz_pack_w3x3_fwd(const float* w, float* wp, int C, int K, hipStream_t st) {
+    EGZ_CHECK_ARG(w && wp && C > 0 && K > 0, "egz_pack_w3x3_fwd: bad arguments");
+    const long n = (long)9 * C * K;
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256)), dim3(256), 0, st, w,
+                       wp, C, K);
+    EGZ_CHECK_LAUNCH("egz_pack_w3x3_fwd");
+    return 0;
+}
+
+EGZ_API int egz_pack_w3x3_dgrad(const float* w, float* wp, int C, int K, hipStream_t st) {
+    EGZ_CHECK_ARG(w && wp && C > 0 && K > 0, "egz_pack_w3x3_dgrad: bad arguments");
+    const long n = (long)9 * C * K;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256)), dim3(256), 0, st,
+                       w, wp, C, K);
+    EGZ_CHECK_LAUNCH("egz_pack_w3x3_dgrad");
+    return 0;
+}
+
+// flags: bit0 = input is nearest-x2 upsampled on the fly (x is [B][H/2][W/2][C]);
+//        bits 4-5 = epilogue (0 bias, 1 bias+relu, 2 bias + BN stat partials);
+//        0x100 / 0x200 force the 64 / 128 wide n-tile (benchmarking).
+EGZ_API int egz_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* y, double* stat_partial,
+                            int B, int H, int W, int C, int K, int flags, hipStream_t st) {
+    EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd: null pointer");
+    EGZ_CHECK_ARG(B > 0 && H > 0 && W > 0, "egz_conv3x3_fwd: bad shape %dx%dx%d", B, H, W);
+    EGZ_CHECK_ARG(C % 32 == 0 && C > 0, "egz_conv3x3_fwd: Cin=%d must be a positive multiple of 32", C);
+    EGZ_CHECK_ARG(K % 64 == 0 && K > 0, "egz_conv3x3_fwd: Cout=%d must be a positive multiple of 64", K);
+    const bool ups = flags & 1;
+    EGZ_CHECK_ARG(!ups || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_fwd: upsampled output must be even");
+    const int epi = (flags >> 4) & 3;
+    EGZ_CHECK_ARG(epi <= 2, "egz_conv3x3_fwd: bad epilogue %d", epi);
+    EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd: stats epilogue needs stat_partial");
+    const int bn = pick_bn((long)B * H * W, K, flags);
+    if (bn == 128)
+        return ups ? dispatch_epi<128, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
+                   : dispatch_epi<128, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st);
+    return ups ? dispatch_epi<64, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
+               : dispatch_epi<64, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st);
+}

@@ -1,0 +1,187 @@
+// Weight gradient of the 3x3 / pad 1 convolution on exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//   dW[k][c][tap] = sum_{m=(b,y,x)} dY[m][k] * X[pix(m)+tap][c]          (autograd of nn.Conv2d;
+//   reference call sites: loss.backward() in SP.py:136, LF.py:99)
+// GEMM view per tap: OUT[c][k] (C x K) with the reduction over the B*H*W pixels.  The pixel range is
+// split S ways (split-K) so the grid fills the chip; each block writes its fp32 partial tile to the
+// workspace and a second kernel sums the S partials in a fixed order (deterministic, no atomics) and
+// writes dW in the reference (Cout, Cin, 3, 3) layout.
+//   block tile BT(c) x BT(k), BT = 128 or 64, 4 waves as 2 x 2; reduction chunk = 32 pixels;
+//   both operands are pixel-major in LDS ([pixel][channel]) which is exactly the MFMA A/B fragment
+//   order (lane -> consecutive channel) so every ds_read_b32 is conflict-free without padding.
+#include "egz_common.h"
+
+namespace {
+
+constexpr int PK = 32;   // pixels per LDS stage
+
+template <int BT, bool UPS>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, long pix_per_split) {
+    constexpr int TR = BT / 64;             // 32-wide MFMA tiles per wave per dim
+    constexpr int LD4 = BT / 4;             // float4 per LDS row
+    constexpr int NLD = (PK * LD4) / 256;   // float4 loads per thread per operand per stage (4 or 2)
+    constexpr int PSTEP = 256 / LD4;        // pixel stride between a thread's loads (8 or 16)
+
+    __shared__ __attribute__((aligned(16))) float Xs[2 * PK * BT];
+    __shared__ __attribute__((aligned(16))) float Ds[2 * PK * BT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wk = wave & 1, hl = lane >> 5, l31 = lane & 31;
+    const int tk = K / BT;
+    const int tap = blockIdx.x % 9;
+    const int tile = blockIdx.x / 9;
+    const int c0 = (tile / tk) * BT, k0 = (tile % tk) * BT;
+    const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
+    const long HW = (long)H * W, M = (long)B * HW;
+    const long mbeg = (long)blockIdx.y * pix_per_split;
+    const long mend = (mbeg + pix_per_split < M) ? (mbeg + pix_per_split) : M;
+    const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
+
+    const int ch4 = tid % LD4, p0 = tid / LD4;
+
+    f32x4 rx[NLD], rd[NLD];
+    auto gload = [&](long mb) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const long m = mb + p0 + PSTEP * j;
+            f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vd = {0.f, 0.f, 0.f, 0.f};
+            if (m < mend) {
+                vd = *reinterpret_cast<const f32x4*>(dy + m * K + k0 + ch4 * 4);
+                const long b = m / HW;
+                const int rem = (int)(m - b * HW);
+                const int yy = rem / W, xx = rem - yy * W;
+                const int iy = yy + dyy, ix = xx + dxx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+                    vx = *reinterpret_cast<const f32x4*>(x + ((b * Hs + sy) * (long)Ws + sx) * C + c0 + ch4 * 4);
+                }
+            }
+            rx[j] = vx;
+            rd[j] = vd;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            *reinterpret_cast<f32x4*>(Xs + buf * PK * BT + (p0 + PSTEP * j) * BT + ch4 * 4) = rx[j];
+            *reinterpret_cast<f32x4*>(Ds + buf * PK * BT + (p0 + PSTEP * j) * BT + ch4 * 4) = rd[j];
+        }
+    };
+
+    f32x16 acc[TR][TR];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nst = (int)((mend - mbeg + PK - 1) / PK);
+    if (nst > 0) {
+        gload(mbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) gload(mbeg + (long)(s + 1) * PK);
+        const float* Ab = Xs + buf * PK * BT + hl * BT + wc * (BT / 2) + l31;
+        const float* Bb = Ds + buf * PK * BT + hl * BT + wk * (BT / 2) + l31;
+#pragma unroll
+        for (int t = 0; t < PK / 2; ++t) {
+            float av[TR], bv[TR];
+#pragma unroll
+            for (int i = 0; i < TR; ++i) av[i] = Ab[(2 * t) * BT + i * 32];
+#pragma unroll
+            for (int j = 0; j < TR; ++j) bv[j] = Bb[(2 * t) * BT + j * 32];
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nst) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial tile -> workspace [split][tap][C][K]
+    float* out = part + ((long)blockIdx.y * 9 + tap) * C * K;
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = c0 + wc * (BT / 2) + i * 32 + egz_acc_row(r, lane);
+                const int k = k0 + wk * (BT / 2) + j * 32 + l31;
+                out[(long)c * K + k] = acc[i][j][r];
+            }
+}
+
+// dw[(k*C + c)*9 + tap] = sum_s part[s][tap][c][k]   (fixed order -> deterministic)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int K, int S) {
+    const long n = (long)9 * C * K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        // i enumerates (tap, c, k) with k fastest -> coalesced reads of the partials
+        const int k = (int)(i % K);
+        const long t = i / K;
+        const int c = (int)(t % C), tap = (int)(t / C);
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += part[(long)sp * n + i];
+        dw[((long)k * C + c) * 9 + tap] = s;
+    }
+}
+
+int pick_splits(long M, int C, int K, int BT) {
+    const long tiles = (long)(C / BT) * (K / BT) * 9;
+    long s = (768 + tiles - 1) / tiles;           // aim at ~3 blocks per CU
+    const long smax = (M + 1023) / 1024;          // at least ~1k pixels per split
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+int pick_bt(int C, int K, int flags) {
+    if (flags & 0x100) return 64;
+    return (C % 128 == 0 && K % 128 == 0) ? 128 : 64;
+}
+
+}  // namespace
+
+EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags) {
+    const int bt = pick_bt(C, K, flags);
+    const int S = pick_splits((long)B * H * W, C, K, bt);
+    return (size_t)S * 9 * C * K * sizeof(float);
+}
+
+// flags: bit0 = the conv input was the nearest-x2 upsampling of x ([B][H/2][W/2][C]); 0x100 forces 64 tiles.
+// x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
+EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
+                              int flags, void* workspace, size_t ws_bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(x && dy && dw && workspace, "egz_conv3x3_wgrad: null pointer");
+    EGZ_CHECK_ARG(C % 64 == 0 && K % 64 == 0 && C > 0 && K > 0, "egz_conv3x3_wgrad: C=%d K=%d must be multiples of 64", C, K);
+    const bool ups = flags & 1;
+    EGZ_CHECK_ARG(!ups || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_wgrad: upsampled output must be even");
+    const long M = (long)B * H * W;
+    const int bt = pick_bt(C, K, flags);
+    const int S = pick_splits(M, C, K, bt);
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)S * 9 * C * K * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+    long pps = (M + S - 1) / S;
+    pps = (pps + PK - 1) / PK * PK;
+    float* part = static_cast<float*>(workspace);
+    dim3 grid((C / bt) * (K / bt) * 9, S);
+    if (bt == 128) {
+        if (ups) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+        else     hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+    } else {
+        if (ups) hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+        else     hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+    }
+    EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad");
+    const long n = (long)9 * C * K;
+    const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, part, dw, C, K, S);
+    EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce)");
+    return 0;
+}

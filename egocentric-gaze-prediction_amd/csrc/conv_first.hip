@@ -1,0 +1,268 @@
+// First encoder convolution of each stream: nn.Conv2d(3 -> 64) on the RGB frame and nn.Conv2d(20 -> 64)
+// on the 10-pair optical-flow stack (reference utils.py:70 instantiated at SP.py:53; inputs follow
+// data/STdatas.py:50-73 and arrive NCHW exactly as the reference's DataLoader yields them).
+// K = 9*Cin is tiny (27 / 180), so the im2col A tile is built in LDS straight from the NCHW planes --
+// consecutive lanes read consecutive x of one channel plane (coalesced 256-B rows of the 20-channel
+// flow stack) -- and multiplied on v_mfma_f32_32x32x2_f32.  Output is NHWC (the library's internal
+// activation layout) with the same bias / BN-statistics epilogue as the wide kernel.
+// The weight gradient (no data gradient: the network input needs none) reduces over all pixels with
+// split-K partials + a deterministic second pass.
+#include "egz_common.h"
+
+namespace {
+
+constexpr int FM = 128;        // pixels per block
+constexpr int CCH = 4;         // channels per K chunk
+constexpr int KCH = CCH * 9;   // 36 k per chunk
+constexpr int FLDA = KCH + 1;  // 37: odd stride -> conflict-free column reads
+
+// y[m][k] (NHWC, 64 channels) = bias[k] + sum_{c,tap} x[b][c][y+dy][x+dx] * w[k][c][tap]
+template <bool STATS>
+__global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C) {
+    constexpr int K = 64;
+    __shared__ float As[FM * FLDA];
+    __shared__ float Bs[KCH * K];
+    __shared__ double red[4 * 2 * K];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
+    const long HW = (long)H * W, M = (long)B * HW;
+    const long m0 = (long)blockIdx.x * FM;
+
+    // the pixel this thread gathers for (p = tid & 127)
+    const int p = tid & 127;
+    const long mp = m0 + p;
+    int py = -(1 << 20), px = 0;
+    long pimg = 0;
+    if (mp < M) {
+        const long b = mp / HW;
+        const int rem = (int)(mp - b * HW);
+        py = rem / W;
+        px = rem - py * W;
+        pimg = b * C * HW;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+
+    for (int cc0 = 0; cc0 < C; cc0 += CCH) {
+        // ---- im2col gather: As[p][kk], kk = (c - cc0)*9 + tap
+#pragma unroll
+        for (int j = 0; j < KCH / 2; ++j) {
+            const int kk = (tid >> 7) + 2 * j;
+            const int c = cc0 + kk / 9, tap = kk % 9;
+            const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+            float v = 0.f;
+            if (c < C && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = x[pimg + (long)c * HW + (long)iy * W + ix];
+            As[p * FLDA + kk] = v;
+        }
+        // ---- weights: Bs[kk][k] = w[k][cc0 + kk/9][kk%9]
+        for (int i = tid; i < KCH * K; i += 256) {
+            const int k = i / KCH, kk = i - k * KCH;     // consecutive threads walk (c,tap) of one filter
+            const int c = cc0 + kk / 9;
+            Bs[kk * K + k] = (c < C) ? w[((long)k * C + c) * 9 + (kk % 9)] : 0.f;
+        }
+        __syncthreads();
+        const float* Ab = As + (wave * 32 + l31) * FLDA + hl;
+        const float* Bb = Bs + hl * K + l31;
+#pragma unroll
+        for (int t = 0; t < KCH / 2; ++t) {
+            const float a = Ab[2 * t];
+            const float b0 = Bb[(2 * t) * K], b1 = Bb[(2 * t) * K + 32];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) {
+        const int col = nr * 32 + l31;
+        const float bz = bias ? bias[col] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wave * 32 + egz_acc_row(r, lane);
+            if (m < M) {
+                const float v = acc[nr][r] + bz;
+                y[m * K + col] = v;
+                if (STATS) {
+                    s1 += (double)v;
+                    s2 += (double)v * (double)v;
+                }
+            }
+        }
+        if (STATS) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hl == 0) {
+                red[(wave * 2 + 0) * K + col] = s1;
+                red[(wave * 2 + 1) * K + col] = s2;
+            }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        if (tid < 2 * K) {
+            const int which = tid / K, col = tid % K;
+            double s = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) s += red[(wv * 2 + which) * K + col];
+            stat[((long)blockIdx.x * 2 + which) * K + col] = s;
+        }
+    }
+}
+
+// partial[split][k][kkp] with kkp = c*9 + tap padded to KP (multiple of 32):
+//   sum over the split's pixels of dy[m][k] * x[b][c][y+dy][x+dx]
+template <int NT>   // NT = KP/32 : 1 (Cin=3) or 6 (Cin=20)
+__global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, long pix_per_split) {
+    constexpr int K = 64, KP = NT * 32, PKS = 32;
+    constexpr int TW = (NT == 1) ? 1 : NT / 2;      // n-tiles per wave
+    __shared__ float Ds[PKS * K];                   // [pixel][k]
+    __shared__ float Xs[PKS * KP];                  // [pixel][kkp]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
+    const int wk = wave >> 1, wn = wave & 1;        // k-half (32 filters), kkp-half
+    const long HW = (long)H * W, M = (long)B * HW;
+    const long mbeg = (long)blockIdx.x * pix_per_split;
+    const long mend = (mbeg + pix_per_split < M) ? (mbeg + pix_per_split) : M;
+    const int KK = C * 9;
+
+    f32x16 acc[TW];
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const bool active = (NT != 1) || (wn == 0);     // Cin=3: only one 32-wide kkp tile exists
+    for (long mb = mbeg; mb < mend; mb += PKS) {
+        // dy tile: 32 pixels x 64 filters = 512 float4
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + 256 * j;
+            const int pp = i >> 4, k4 = i & 15;
+            const long m = mb + pp;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < mend) v = *reinterpret_cast<const f32x4*>(dy + m * K + k4 * 4);
+            *reinterpret_cast<f32x4*>(Ds + pp * K + k4 * 4) = v;
+        }
+        // im2col tile: lanes walk the 32 pixels (consecutive x -> coalesced plane reads)
+        {
+            const int pp = tid & 31;
+            const long m = mb + pp;
+            int yy = -(1 << 20), xx = 0;
+            long img = 0;
+            if (m < mend) {
+                const long b = m / HW;
+                const int rem = (int)(m - b * HW);
+                yy = rem / W;
+                xx = rem - yy * W;
+                img = b * C * HW;
+            }
+            for (int kk = tid >> 5; kk < KP; kk += 8) {
+                float v = 0.f;
+                if (kk < KK) {
+                    const int c = kk / 9, tap = kk - c * 9;
+                    const int iy = yy + tap / 3 - 1, ix = xx + tap % 3 - 1;
+                    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                        v = x[img + (long)c * HW + (long)iy * W + ix];
+                }
+                Xs[pp * KP + kk] = v;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const float* Ab = Ds + hl * K + wk * 32 + l31;
+            const float* Bb = Xs + hl * KP + wn * (TW * 32) + l31;
+#pragma unroll
+            for (int t = 0; t < PKS / 2; ++t) {
+                const float a = Ab[(2 * t) * K];
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bb[(2 * t) * KP + j * 32], acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float* out = part + (long)blockIdx.x * K * KP;
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = wk * 32 + egz_acc_row(r, lane);
+                const int kk = wn * (TW * 32) + j * 32 + l31;
+                out[k * KP + kk] = acc[j][r];
+            }
+    }
+}
+
+// dw[k][c][tap] (= [k][kk], kk < 9C) = sum_s part[s][k][kk]
+__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int KK, int KP, int S) {
+    const int n = 64 * KK;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int k = i / KK, kk = i - k * KK;
+        float s = 0.f;
+        for (int sp = 0; sp < S; ++sp) s += part[((long)sp * 64 + k) * KP + kk];
+        dw[i] = s;
+    }
+}
+
+int first_splits(long M) {
+    long s = (M + 2047) / 2048;
+    if (s > 1024) s = 1024;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+int first_kp(int C) { return (9 * C + 31) / 32 * 32; }
+
+}  // namespace
+
+EGZ_API int egz_conv_first_stat_rows(int B, int H, int W) { return egz_cdiv((long)B * H * W, FM); }
+
+// x: [B][C][H][W] (NCHW, as the reference DataLoader yields it), w: (64, C, 3, 3), y: [B][H][W][64].
+EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, double* stat_partial,
+                               int B, int H, int W, int C, int K, hipStream_t st) {
+    EGZ_CHECK_ARG(x && w && y, "egz_conv_first_fwd: null pointer");
+    EGZ_CHECK_ARG(K == 64, "egz_conv_first_fwd: Cout must be 64 (got %d)", K);
+    EGZ_CHECK_ARG(C > 0 && C <= 64 && B > 0 && H > 0 && W > 0, "egz_conv_first_fwd: bad shape");
+    const int grid = egz_cdiv((long)B * H * W, FM);
+    if (stat_partial)
+        hipLaunchKernelGGL(conv_first_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
+    else
+        hipLaunchKernelGGL(conv_first_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
+    EGZ_CHECK_LAUNCH("egz_conv_first_fwd");
+    return 0;
+}
+
+EGZ_API size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C) {
+    return (size_t)first_splits((long)B * H * W) * 64 * first_kp(C) * sizeof(float);
+}
+
+EGZ_API int egz_conv_first_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
+                                 void* workspace, size_t ws_bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(x && dy && dw && workspace, "egz_conv_first_wgrad: null pointer");
+    EGZ_CHECK_ARG(K == 64, "egz_conv_first_wgrad: Cout must be 64 (got %d)", K);
+    const int KP = first_kp(C);
+    EGZ_CHECK_ARG(KP == 32 || KP == 192, "egz_conv_first_wgrad: Cin=%d unsupported (3 or 20..21)", C);
+    const long M = (long)B * H * W;
+    const int S = first_splits(M);
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)S * 64 * KP * sizeof(float), "egz_conv_first_wgrad: workspace too small");
+    long pps = (M + S - 1) / S;
+    pps = (pps + 31) / 32 * 32;
+    float* part = static_cast<float*>(workspace);
+    if (KP == 32)
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
+    else
+        hipLaunchKernelGGL(conv_first_wgrad_kernel<6>, dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
+    EGZ_CHECK_LAUNCH("egz_conv_first_wgrad");
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(egz_cdiv(64 * 9 * C, 256)), dim3(256), 0, st, part, dw, 9 * C, KP, S);
+    EGZ_CHECK_LAUNCH("egz_conv_first_wgrad(reduce)");
+    return 0;
+}

@@ -1,0 +1,198 @@
+"""``torch.autograd.Function`` nodes of the SP / LF path -- one per *fused block*, each a short
+sequence of C-ABI kernel launches (hipops).  Tensors crossing these nodes have the reference's
+logical shape (B, C, H, W) but live in NHWC memory (``channels_last`` strides), so the module
+surface (models/model_SP.py etc.) is unchanged while the kernels see their native layout.
+
+Block boundaries follow the reference graph:
+  ConvBNReLUPool  = Conv2d 3x3 -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)]        utils.py:64-76
+  FusionBlock     = Conv3d (1,3,3) on the 2-deep stack -> MaxPool3d((2,1,1)) -> BN -> ReLU
+                                                                                models/model_SP.py:38-47
+  ConvReLU        = [Upsample x2 nearest ->] Conv2d 3x3 -> ReLU                  models/model_SP.py:13-29
+  HeadSigmoid     = Conv2d 1x1 (C -> 1) -> Sigmoid                               models/model_SP.py:30,49
+  FlossLoss       = floss / BCELoss                                              floss.py:9-41
+"""
+from __future__ import annotations
+
+import torch
+
+from . import hipops as H
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Logical (B,C,H,W) tensor -> contiguous (B,H,W,C) buffer (zero-copy when already channels_last)."""
+    x = x.detach()
+    xp = x.permute(0, 2, 3, 1)
+    if xp.is_contiguous():
+        return xp
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return H.nchw_to_nhwc(x)
+
+
+def from_nhwc(y: torch.Tensor) -> torch.Tensor:
+    return y.permute(0, 3, 1, 2)
+
+
+class ConvBNReLUPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, pool,
+                first):
+        K, C = weight.shape[0], weight.shape[1]
+        if first:
+            xin = H._req(x.detach(), "network input (NCHW)")
+            y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training)
+        else:
+            xin = to_nhwc(x)
+            y, stat = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd"), bias.detach() if bias is not None else None,
+                                    K, ups=False, epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS)
+        B, Hh, Ww, _ = y.shape
+        if training:
+            coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
+                                 running_var, momentum, eps)
+        else:
+            coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+        out = H.bn_relu_pool_fwd(y, coef, pool)
+        ctx.save_for_backward(xin, y, coef, weight)
+        ctx.cfg = (training, pool, first, C, K)
+        return from_nhwc(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, y, coef, weight = ctx.saved_tensors
+        training, pool, first, C, K = ctx.cfg
+        if not training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path "
+                                      "(SP.py:119 trains in model.train(); eval runs under torch.no_grad())")
+        dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, to_nhwc(dout), coef, pool)
+        ng = ctx.needs_input_grad
+        dx = dw = db = None
+        if ng[2]:
+            db = H.colsum(dy)
+        if ng[1]:
+            dw = H.conv_first_wgrad(xin, dy) if first else H.conv3x3_wgrad(xin, dy)
+        if ng[0]:
+            if first:
+                raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
+            dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C))
+        return (dx, dw, db, dgamma if ng[3] else None, dbeta if ng[4] else None, None, None, None, None, None,
+                None, None)
+
+
+class ConvReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, ups):
+        K, C = weight.shape[0], weight.shape[1]
+        xin = to_nhwc(x)
+        y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd"), bias.detach() if bias is not None else None, K,
+                             ups=ups, epi=H.EPI_BIAS_RELU)
+        ctx.save_for_backward(xin, y, weight)
+        ctx.cfg = (ups, C, K)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, y, weight = ctx.saved_tensors
+        ups, C, K = ctx.cfg
+        dy = H.relu_bwd(y, to_nhwc(dout))
+        ng = ctx.needs_input_grad
+        dx = dw = db = None
+        if ng[2]:
+            db = H.colsum(dy)
+        if ng[1]:
+            dw = H.conv3x3_wgrad(xin, dy, ups=ups)
+        if ng[0]:
+            dxu = H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C)
+            dx = from_nhwc(H.upsample2x_bwd(dxu) if ups else dxu)
+        return dx, dw, db, None
+
+
+class FusionBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fs, ft, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps):
+        K, C = weight.shape[0], weight.shape[1]
+        x2 = torch.cat((to_nhwc(fs), to_nhwc(ft)), 0)            # depth-2 stack folded into the batch dim
+        y2, _ = H.conv3x3_fwd(x2, H.packed_weight(weight, "fwd"), bias.detach() if bias is not None else None, K,
+                              ups=False, epi=H.EPI_BIAS)
+        z = H.pairmax_fwd(y2)
+        B, Hh, Ww, _ = z.shape
+        if training:
+            coef = H.bn_finalize(H.channel_stats(z), float(B * Hh * Ww), gamma.detach(), beta.detach(),
+                                 running_mean, running_var, momentum, eps)
+        else:
+            coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+        out = H.bn_relu_pool_fwd(z, coef, False)
+        ctx.save_for_backward(x2, y2, z, coef, weight)
+        ctx.cfg = (training, C, K)
+        return from_nhwc(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, y2, z, coef, weight = ctx.saved_tensors
+        training, C, K = ctx.cfg
+        if not training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path")
+        dz, dgamma, dbeta = H.bn_relu_pool_bwd(z, to_nhwc(dout), coef, False)
+        dy2 = H.pairmax_bwd(y2, dz)
+        ng = ctx.needs_input_grad
+        dfs = dft = dw = db = None
+        if ng[3]:
+            db = H.colsum(dy2)
+        if ng[2]:
+            dw = H.conv3x3_wgrad(x2, dy2).view(weight.shape)
+        if ng[0] or ng[1]:
+            dx2 = H.conv3x3_dgrad(dy2, H.packed_weight(weight, "dgrad"), C)
+            B = dx2.shape[0] // 2
+            dfs, dft = from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
+        return (dfs, dft, dw, db, dgamma if ng[4] else None, dbeta if ng[5] else None, None, None, None, None,
+                None)
+
+
+class HeadSigmoid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xin = to_nhwc(x)
+        out, _ = H.conv1x1_sigmoid_fwd(xin, H._req(weight.detach(), "weight"), bias.detach() if bias is not None else None)
+        ctx.save_for_backward(xin, out, weight)
+        B, Hh, Ww = out.shape
+        return out.view(B, 1, Hh, Ww)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, out, weight = ctx.saved_tensors
+        dx, dw, db = H.conv1x1_sigmoid_bwd(xin, weight.detach(), out, dout.contiguous(), need_dx=ctx.needs_input_grad[0])
+        return (from_nhwc(dx) if dx is not None else None, dw if ctx.needs_input_grad[1] else None,
+                db if ctx.needs_input_grad[2] else None)
+
+
+class FlossLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, target, weighted):
+        x = H._req(inp.detach().contiguous(), "input")
+        t = H._req(target.detach().contiguous(), "target")
+        if x.shape != t.shape:
+            raise ValueError(f"Using a target size ({tuple(t.shape)}) that is different to the input size "
+                             f"({tuple(x.shape)}) is deprecated. Please ensure they have the same size.")
+        loss, weights = H.floss_fwd(x, t, weighted)
+        ctx.save_for_backward(x, t, weights if weights is not None else torch.empty(0, device=x.device))
+        ctx.weighted = weighted
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, t, weights = ctx.saved_tensors
+        g = gout.detach().contiguous().to(torch.float32)
+        return H.floss_bwd(x, t, weights if ctx.weighted else None, g), None, None
+
+
+class MSELoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a_ = H._req(a.detach().contiguous(), "input")
+        b_ = H._req(b.detach().contiguous(), "target")
+        ctx.save_for_backward(a_, b_)
+        return H.mse_fwd(a_, b_)
+
+    @staticmethod
+    def backward(ctx, gout):
+        a_, b_ = ctx.saved_tensors
+        return H.mse_bwd(a_, b_, gout.detach().contiguous()), None

@@ -1,0 +1,373 @@
+"""Tensor-level wrappers over the C-ABI (``include/egaze_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every wrapper passes raw
+``data_ptr()``s, explicit shapes and ``torch.cuda.current_stream()`` to ``libegaze_hip.so``.
+Activations are NHWC fp32 (``(B, H, W, C)`` contiguous tensors); weights keep the reference layout
+``(Cout, Cin, 3, 3)`` and are re-packed on the device when they change.
+All wrappers raise on CPU tensors -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import LIB as _RAW_LIB, check
+
+EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_STATS = 0, 1, 2
+
+
+class _Profiler:
+    """Optional per-entry-point timing with HIP events recorded on the launch stream (the stream every
+    C-ABI call is issued on is torch's current stream, so torch.cuda.Event brackets exactly those kernels).
+    Used by bench.py's roofline leg; off by default (zero overhead beyond one attribute test)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+        self.flops = {}
+
+    def start(self):
+        self.events, self.flops, self.enabled = {}, {}, True
+
+    def stop(self):
+        """-> {entry point: {'calls', 'ms', 'flops'}}"""
+        self.enabled = False
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.events.items():
+            out[name] = {"calls": len(evs), "ms": sum(a.elapsed_time(b) for a, b in evs),
+                         "flops": self.flops.get(name, 0.0)}
+        return out
+
+    def note_flops(self, name, v):
+        if self.enabled:
+            self.flops[name] = self.flops.get(name, 0.0) + v
+
+
+PROF = _Profiler()
+
+
+class _LibProxy:
+    def __init__(self, raw):
+        self._raw = raw
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+
+        def call(*a):
+            if not PROF.enabled:
+                return fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            PROF.events.setdefault(name, []).append((e0, e1))
+            return rc
+        setattr(self, name, call)
+        return call
+
+
+LIB = _LibProxy(_RAW_LIB)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a HIP ('cuda') tensor -- this package has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous buffer, got strides {t.stride()} for {tuple(t.shape)}")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+# ----------------------------------------------------------------------------- workspace
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Stream-ordered scratch (one buffer per device, grown on demand; the C-ABI never allocates)."""
+    key = torch.device(device).index or 0
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- packed weights
+_WEIGHT_EPOCH = [0]
+_PACKED = {}
+
+
+def bump_weight_epoch():
+    """Called by the fused optimizer after it rewrote parameters behind torch's back."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
+    """(Cout, Cin, [1,] 3, 3) -> [9][Cin][Cout] ('fwd') or tap-flipped [9][Cout][Cin] ('dgrad')."""
+    w = _req(w.detach(), "weight")
+    K, C = w.shape[0], w.shape[1]
+    key = (w.data_ptr(), kind, K, C)
+    tag = (_WEIGHT_EPOCH[0], w._version)
+    hit = _PACKED.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    buf = hit[1] if hit is not None else torch.empty(9 * C * K, dtype=torch.float32, device=w.device)
+    fn = LIB.egz_pack_w3x3_fwd if kind == "fwd" else LIB.egz_pack_w3x3_dgrad
+    check(fn(w.data_ptr(), buf.data_ptr(), C, K, _stream()), "pack_w3x3")
+    _PACKED[key] = (tag, buf)
+    return buf
+
+
+# ----------------------------------------------------------------------------- convolutions
+def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups: bool = False,
+                epi: int = EPI_BIAS, tile_flag: int = 0):
+    """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups."""
+    _req(x, "x")
+    B, Hin, Win, C = x.shape
+    H, W = (2 * Hin, 2 * Win) if ups else (Hin, Win)
+    y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
+    stat = None
+    if epi == EPI_BIAS_STATS:
+        rows = LIB.egz_conv3x3_stat_rows(B, H, W)
+        stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
+    flags = (1 if ups else 0) | (epi << 4) | tile_flag
+    PROF.note_flops("egz_conv3x3_fwd", 2.0 * B * H * W * K * 9 * C)
+    check(LIB.egz_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K, flags,
+                              _stream()), "egz_conv3x3_fwd")
+    return y, stat
+
+
+def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int) -> torch.Tensor:
+    """dy: (B,H,W,K) -> dx (B,H,W,C) (for an upsampled conv this is the gradient of the upsampled input)."""
+    y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS)
+    return y
+
+
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False) -> torch.Tensor:
+    _req(x, "x"); _req(dy, "dy")
+    B, H, W, K = dy.shape
+    C = x.shape[3]
+    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
+    flags = 1 if ups else 0
+    nb = LIB.egz_conv3x3_wgrad_ws_bytes(B, H, W, C, K, flags)
+    ws = workspace(nb, x.device)
+    PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * C)
+    check(LIB.egz_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, C, K, flags, ws.data_ptr(),
+                                ws.numel(), _stream()), "egz_conv3x3_wgrad")
+    return dw
+
+
+def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stats: bool):
+    _req(x_nchw, "x"); _req(w, "weight")
+    B, C, H, W = x_nchw.shape
+    K = w.shape[0]
+    y = torch.empty((B, H, W, K), dtype=torch.float32, device=x_nchw.device)
+    stat = None
+    if stats:
+        stat = torch.empty((LIB.egz_conv_first_stat_rows(B, H, W), 2, K), dtype=torch.float64, device=y.device)
+    PROF.note_flops("egz_conv_first_fwd", 2.0 * B * H * W * K * 9 * C)
+    check(LIB.egz_conv_first_fwd(x_nchw.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
+                                 _stream()), "egz_conv_first_fwd")
+    return y, stat
+
+
+def conv_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _req(x_nchw, "x"); _req(dy, "dy")
+    B, C, H, W = x_nchw.shape
+    K = dy.shape[3]
+    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=dy.device)
+    ws = workspace(LIB.egz_conv_first_wgrad_ws_bytes(B, H, W, C), dy.device)
+    PROF.note_flops("egz_conv_first_wgrad", 2.0 * B * H * W * K * 9 * C)
+    check(LIB.egz_conv_first_wgrad(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, C, K, ws.data_ptr(),
+                                   ws.numel(), _stream()), "egz_conv_first_wgrad")
+    return dw
+
+
+# ----------------------------------------------------------------------------- BN / ReLU / pool
+def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, running_var, momentum: float,
+                eps: float):
+    rows, _, K = stat.shape
+    dev = stat.device
+    coef = torch.empty((4, K), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
+    ws = workspace(LIB.egz_bn_ws_bytes(K), dev)
+    check(LIB.egz_bn_finalize(stat.data_ptr(), rows, K, float(count), _p(gamma), _p(beta), _p(running_mean),
+                              _p(running_var), momentum, eps, coef[0].data_ptr(), coef[1].data_ptr(),
+                              coef[2].data_ptr(), coef[3].data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "egz_bn_finalize")
+    return coef
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps: float):
+    K = running_mean.numel()
+    coef = torch.zeros((4, K), dtype=torch.float32, device=running_mean.device)
+    check(LIB.egz_bn_eval_coeffs(K, _p(gamma), _p(beta), running_mean.data_ptr(), running_var.data_ptr(), eps,
+                                 coef[2].data_ptr(), coef[3].data_ptr(), _stream()), "egz_bn_eval_coeffs")
+    return coef
+
+
+def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool) -> torch.Tensor:
+    _req(y, "y")
+    B, H, W, K = y.shape
+    out = torch.empty((B, H // 2, W // 2, K) if pool else (B, H, W, K), dtype=torch.float32, device=y.device)
+    check(LIB.egz_bn_relu_pool_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), out.data_ptr(), B, H, W, K,
+                                   int(pool), _stream()), "egz_bn_relu_pool_fwd")
+    return out
+
+
+def bn_relu_pool_bwd(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, pool: bool):
+    """Returns (dy, dgamma, dbeta)."""
+    _req(y, "y"); _req(dout, "dout")
+    B, H, W, K = y.shape
+    dy = torch.empty_like(y)
+    dgb = torch.empty((2, K), dtype=torch.float32, device=y.device)
+    ws = workspace(LIB.egz_bn_relu_pool_bwd_ws_bytes(K), y.device)
+    check(LIB.egz_bn_relu_pool_bwd(y.data_ptr(), dout.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
+                                   coef[0].data_ptr(), coef[1].data_ptr(), dy.data_ptr(), dgb[0].data_ptr(),
+                                   dgb[1].data_ptr(), B, H, W, K, int(pool), ws.data_ptr(), ws.numel(), _stream()),
+          "egz_bn_relu_pool_bwd")
+    return dy, dgb[0], dgb[1]
+
+
+def pairmax_fwd(y2: torch.Tensor) -> torch.Tensor:
+    """y2: (2B, H, W, K) = stream s rows then stream t rows -> (B, H, W, K) element-wise max (s wins ties)."""
+    _req(y2, "y2")
+    B2 = y2.shape[0]
+    z = torch.empty((B2 // 2,) + tuple(y2.shape[1:]), dtype=torch.float32, device=y2.device)
+    check(LIB.egz_pairmax_fwd(y2.data_ptr(), z.data_ptr(), z.numel(), _stream()), "egz_pairmax_fwd")
+    return z
+
+
+def pairmax_bwd(y2: torch.Tensor, dz: torch.Tensor) -> torch.Tensor:
+    _req(y2, "y2"); _req(dz, "dz")
+    dy2 = torch.empty_like(y2)
+    check(LIB.egz_pairmax_bwd(y2.data_ptr(), dz.data_ptr(), dy2.data_ptr(), dz.numel(), _stream()), "egz_pairmax_bwd")
+    return dy2
+
+
+def channel_stats(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "x")
+    K = x.shape[-1]
+    rows = x.numel() // K
+    stat = torch.empty((LIB.egz_channel_stats_rows(), 2, K), dtype=torch.float64, device=x.device)
+    check(LIB.egz_channel_stats(x.data_ptr(), rows, K, stat.data_ptr(), _stream()), "egz_channel_stats")
+    return stat
+
+
+def relu_bwd(out: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
+    _req(out, "out"); _req(dout, "dout")
+    dy = torch.empty_like(dout)
+    check(LIB.egz_relu_bwd(out.data_ptr(), dout.data_ptr(), dy.data_ptr(), out.numel(), _stream()), "egz_relu_bwd")
+    return dy
+
+
+def upsample2x_bwd(dxu: torch.Tensor) -> torch.Tensor:
+    _req(dxu, "dxu")
+    B, H2, W2, C = dxu.shape
+    dx = torch.empty((B, H2 // 2, W2 // 2, C), dtype=torch.float32, device=dxu.device)
+    check(LIB.egz_upsample2x_bwd(dxu.data_ptr(), dx.data_ptr(), B, H2 // 2, W2 // 2, C, _stream()),
+          "egz_upsample2x_bwd")
+    return dx
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """Sum over all leading dims of an NHWC tensor -> (K,) (conv bias gradient)."""
+    _req(x, "x")
+    K = x.shape[-1]
+    rows = x.numel() // K
+    out = torch.empty((K,), dtype=torch.float32, device=x.device)
+    ws = workspace(64 * K * 8, x.device)
+    check(LIB.egz_colsum(x.data_ptr(), rows, K, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "egz_colsum")
+    return out
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    check(LIB.egz_nchw_to_nhwc(x.data_ptr(), out.data_ptr(), B, C, H, W, _stream()), "egz_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
+    _req(x, "x")
+    B, H, W, C = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    check(LIB.egz_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), B, C, H, W, _stream()), "egz_nhwc_to_nchw")
+    return out
+
+
+# ----------------------------------------------------------------------------- head + losses
+def conv1x1_sigmoid_fwd(x: torch.Tensor, w: torch.Tensor, bias, want_logits: bool = False):
+    _req(x, "x"); _req(w, "weight")
+    C = x.shape[-1]
+    M = x.numel() // C
+    out = torch.empty(tuple(x.shape[:-1]), dtype=torch.float32, device=x.device)
+    logits = torch.empty_like(out) if want_logits else None
+    check(LIB.egz_conv1x1_sigmoid_fwd(x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr(), _p(logits), M, C,
+                                      _stream()), "egz_conv1x1_sigmoid_fwd")
+    return out, logits
+
+
+def conv1x1_sigmoid_bwd(x, w, out, dout, need_dx: bool = True):
+    _req(x, "x"); _req(out, "out"); _req(dout, "dout")
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty((1, C, 1, 1), dtype=torch.float32, device=x.device)
+    db = torch.empty((1,), dtype=torch.float32, device=x.device)
+    ws = workspace(LIB.egz_conv1x1_sigmoid_bwd_ws_bytes(C), x.device)
+    check(LIB.egz_conv1x1_sigmoid_bwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), dout.data_ptr(), _p(dx),
+                                      dw.data_ptr(), db.data_ptr(), M, C, ws.data_ptr(), ws.numel(), _stream()),
+          "egz_conv1x1_sigmoid_bwd")
+    return dx, dw, db
+
+
+def floss_fwd(inp: torch.Tensor, target: torch.Tensor, weighted: bool = True):
+    """Returns (loss 0-dim tensor, weights or None).  inp/target: (B,1,H,W) or (B,H,W)."""
+    _req(inp, "input"); _req(target, "target")
+    B, H, W = inp.shape[0], inp.shape[-2], inp.shape[-1]
+    loss = torch.empty((), dtype=torch.float32, device=inp.device)
+    weights = torch.empty(inp.numel(), dtype=torch.float32, device=inp.device) if weighted else None
+    ws = workspace(LIB.egz_loss_ws_bytes(B), inp.device)
+    check(LIB.egz_floss_fwd(inp.data_ptr(), target.data_ptr(), _p(weights), loss.data_ptr(), B, H, W, int(weighted),
+                            ws.data_ptr(), ws.numel(), _stream()), "egz_floss_fwd")
+    return loss, weights
+
+
+def floss_bwd(inp, target, weights, grad_out: Optional[torch.Tensor]) -> torch.Tensor:
+    dinp = torch.empty_like(inp)
+    check(LIB.egz_floss_bwd(inp.data_ptr(), target.data_ptr(), _p(weights), _p(grad_out), dinp.data_ptr(),
+                            inp.numel(), _stream()), "egz_floss_bwd")
+    return dinp
+
+
+def mse_fwd(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _req(a, "a"); _req(b, "b")
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    ws = workspace(1024 * 8, a.device)
+    check(LIB.egz_mse_fwd(a.data_ptr(), b.data_ptr(), loss.data_ptr(), a.numel(), ws.data_ptr(), ws.numel(),
+                          _stream()), "egz_mse_fwd")
+    return loss
+
+
+def mse_bwd(a, b, grad_out) -> torch.Tensor:
+    da = torch.empty_like(a)
+    check(LIB.egz_mse_bwd(a.data_ptr(), b.data_ptr(), _p(grad_out), da.data_ptr(), a.numel(), _stream()),
+          "egz_mse_bwd")
+    return da
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
+    check(LIB.egz_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                            int(step), grad_scale, _stream()), "egz_adam_step")

@@ -1,0 +1,107 @@
+"""Fused Adam over flat fp32 buffers -- the optimizer the drivers use where the reference calls
+``torch.optim.Adam(params, lr=...)`` (SP.py:110-113, AT.py:84, LF.py:77; torch defaults: betas
+(0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
+
+On construction every trainable parameter is re-homed into ONE flat buffer (``p.data`` becomes a view)
+and gets a persistent ``.grad`` view into a flat gradient buffer, so that
+  * one ``egz_adam_step`` launch updates the whole model (7 fp32 streams, HBM-bound),
+  * ``zero_grad`` is one memset,
+  * data-parallel training all-reduces contiguous buckets of the flat gradient in place (dp.py).
+``state_dict()`` / ``load_state_dict()`` use torch.optim.Adam's format so SP checkpoints
+({'optimizer': ...}, SP.py:205-208, resume mode '2' SP.py:40-50,114-115) stay interchangeable.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+
+from . import hipops as H
+
+
+class FusedAdam:
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        params = list(params)
+        if params and isinstance(params[0], dict):           # torch-style param groups (SP.py:110)
+            if len(params) != 1:
+                raise NotImplementedError("the reference uses a single parameter group")
+            group = params[0]
+            lr = group.get("lr", lr)
+            params = list(group["params"])
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedAdam needs parameters on the HIP device (move the model first)")
+        self.defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False)
+        self.lr, self.betas, self.eps = lr, tuple(betas), eps
+        self.step_count = 0
+        self.grad_scale = 1.0
+        # 16-byte aligned slots so every parameter starts on a float4 boundary
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        self.numel = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                n = p.numel()
+                self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + n].view(p.shape)
+                p.grad = self.flat_g[o:o + n].view(p.shape)
+        H.bump_weight_epoch()
+        self.pre_step_hooks = []          # dp.GradReducer registers its wait() here
+
+    # -- torch.optim.Optimizer surface used by the drivers
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.offsets):         # re-attach if something dropped the views
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    @torch.no_grad()
+    def step(self):
+        for hook in self.pre_step_hooks:
+            hook()
+        self.step_count += 1
+        H.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
+                    self.eps, self.step_count, self.grad_scale)
+        H.bump_weight_epoch()
+
+    @property
+    def param_groups(self):
+        return [dict(self.defaults, lr=self.lr, params=list(range(len(self.params))))]
+
+    def state_dict(self):
+        state = {}
+        if self.step_count > 0:
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                n = p.numel()
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.flat_m[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.flat_v[o:o + n].view(p.shape).clone()}
+        return {"state": state, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        groups = sd.get("param_groups", [])
+        if groups:
+            self.lr = groups[0].get("lr", self.lr)
+            self.betas = tuple(groups[0].get("betas", self.betas))
+            self.eps = groups[0].get("eps", self.eps)
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                st = sd["state"].get(i)
+                if st is None:
+                    continue
+                n = p.numel()
+                self.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_count = int(float(st["step"]))
+
+
+Adam = FusedAdam

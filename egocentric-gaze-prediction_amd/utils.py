@@ -1,0 +1,211 @@
+"""Host-side mirror of the reference's ``utils.py`` (same names, arguments and behaviour).
+
+``make_layers`` / ``cfg`` build the VGG16-BN encoder with the reference's child indices and
+state-dict keys (utils.py:57-76), but the returned ``nn.Sequential`` subclass executes fused
+[conv3x3 -> BatchNorm -> ReLU (-> max-pool)] blocks on the HIP kernels instead of calling its
+children one by one.  Host glue (AverageMeter, repackage_hidden, change_key_names, computeAAEAUC,
+plot_loss, save_checkpoint, generalException) keeps the reference semantics.
+"""
+from __future__ import annotations
+
+import collections
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .functions import ConvBNReLUPool, ConvReLU
+
+# utils.py:57-62 -- last max pooling removed
+cfg = {
+    'A': [64, 'M', 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512],
+    'B': [64, 64, 'M', 128, 128, 'M', 256, 256, 'M', 512, 512, 'M', 512, 512],
+    'D': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512],
+    'E': [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512],
+}
+
+
+class generalException(Exception):
+    pass
+
+
+def _bn_args(bn: nn.BatchNorm2d):
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm (momentum=None) is not used by the reference")
+    return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps)
+
+
+def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first: bool):
+    """One fused encoder block on the HIP path; keeps BatchNorm's num_batches_tracked bookkeeping."""
+    if conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.stride != (1, 1):
+        raise NotImplementedError("only 3x3 / pad 1 / stride 1 convolutions are on the reference path")
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    g, b, rm, rv, training, mom, eps = _bn_args(bn)
+    return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first)
+
+
+class EncoderSequential(nn.Sequential):
+    """nn.Sequential with the reference's children (so indices / state-dict keys / hooks / .parameters()
+    are identical) whose forward runs fused HIP blocks.  The first conv reads the NCHW network input
+    directly; later tensors are channels_last."""
+
+    def forward(self, x):
+        mods = list(self.children())
+        i, n = 0, len(mods)
+        first = True
+        while i < n:
+            m = mods[i]
+            if isinstance(m, nn.Conv2d) and i + 2 < n and isinstance(mods[i + 1], nn.BatchNorm2d) \
+                    and isinstance(mods[i + 2], nn.ReLU):
+                pool = i + 3 < n and isinstance(mods[i + 3], nn.MaxPool2d)
+                is_first = first and m.in_channels < 32
+                x = conv_bn_relu_pool(x, m, mods[i + 1], pool, is_first)
+                i += 4 if pool else 3
+            elif isinstance(m, nn.Conv2d) and i + 1 < n and isinstance(mods[i + 1], nn.ReLU):
+                x = ConvReLU.apply(x, m.weight, m.bias, False)      # batch_norm=False variant (utils.py:73-74)
+                i += 2
+            else:
+                raise NotImplementedError(f"layer pattern at index {i} ({type(m).__name__}) is not on the HIP path")
+            first = False
+        return x
+
+
+def make_layers(cfg, in_channels, batch_norm=True):
+    """utils.make_layers (utils.py:64-76): same children, same indices, fused execution."""
+    layers = []
+    for v in cfg:
+        if v == 'M':
+            layers += [nn.MaxPool2d(kernel_size=2, stride=2)]
+        else:
+            conv2d = nn.Conv2d(in_channels, v, kernel_size=3, padding=1)
+            if batch_norm:
+                layers += [conv2d, nn.BatchNorm2d(v), nn.ReLU(inplace=False)]
+            else:
+                layers += [conv2d, nn.ReLU(inplace=True)]
+            in_channels = v
+    return EncoderSequential(*layers)
+
+
+def init_like_reference(root: nn.Module):
+    """The init both model_SP and late_fusion apply to every sub-module (models/model_SP.py:52-65,
+    models/late_fusion.py:25-38): Conv2d ~ N(0, sqrt(2/(kh*kw*Cout))) (fan-out), zero bias; BatchNorm
+    gamma 1 / beta 0; Linear ~ N(0, 0.01).  Conv3d is not matched and keeps torch's default init."""
+    for m in root.modules():
+        if isinstance(m, nn.Conv2d):
+            fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            m.weight.data.normal_(0, math.sqrt(2. / fan_out))
+            if m.bias is not None:
+                m.bias.data.zero_()
+        elif isinstance(m, nn.BatchNorm2d):
+            m.weight.data.fill_(1)
+            m.bias.data.zero_()
+        elif isinstance(m, nn.Linear):
+            m.weight.data.normal_(0, 0.01)
+            m.bias.data.zero_()
+
+
+def save_checkpoint(state, filename, save_path):
+    torch.save(state, os.path.join(save_path, filename))
+
+
+def var_to_image(var):
+    ten = var.data.cpu()
+    if ten.dim() == 4:
+        ten = ten[0, :, :, :].squeeze()
+    if ten.dim() == 3:
+        ten = ten.mul(torch.FloatTensor([0.229, 0.224, 0.225]).view(3, 1, 1))
+        ten = ten.add(torch.FloatTensor([0.485, 0.456, 0.406]).view(3, 1, 1))
+        return ten.numpy().transpose((1, 2, 0))
+    elif ten.dim() == 2:
+        return ten.numpy()
+    print('warning: input variable is invalid to transfer to image')
+    return np.zeros((224, 224))
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def repackage_hidden(h):
+    """Detach the LSTM state from its history (utils.py:49-55)."""
+    if isinstance(h, tuple):
+        return tuple(repackage_hidden(v) for v in h)
+    if h is None:
+        return None
+    return h.detach()
+
+
+def change_key_names(old_params, in_channels):
+    """utils.change_key_names (utils.py:78-94): first 25 entries of a vgg16_bn state dict; entry 0
+    (RGB conv1 weight) -> mean over RGB repeated ``in_channels`` times for the flow stream."""
+    new_params = collections.OrderedDict()
+    for n, (key, val) in enumerate(old_params.items()):
+        if n >= 25:
+            break
+        if n == 0:
+            new_params[key] = torch.mean(val, dim=1, keepdim=True).repeat(1, in_channels, 1, 1)
+        else:
+            new_params[key] = val
+    return new_params
+
+
+def _aae_auc_one(out_sq, tar_sq, npix):
+    from scipy import ndimage
+    predicted = ndimage.center_of_mass(out_sq)
+    (i, j) = np.unravel_index(tar_sq.argmax(), tar_sq.shape)
+    d = 112 / math.tan(math.pi / 6)
+    r1 = np.array([predicted[0] - 112, predicted[1] - 112, d])
+    r2 = np.array([i - 112, j - 112, d])
+    angle = math.degrees(math.atan2(np.linalg.norm(np.cross(r1, r2)), np.dot(r1, r2)))
+    z = np.zeros((224, 224))
+    z[int(predicted[0])][int(predicted[1])] = 1
+    z = ndimage.gaussian_filter(z, 14)
+    z = z - np.min(z)
+    z = z / np.max(z)
+    fp = (z > z[i][j]).sum()
+    return angle, 1 - float(fp) / npix, [i, j]
+
+
+def computeAAEAUC(output, target):
+    """utils.computeAAEAUC (utils.py:96-140): AAE (deg, 60-degree field of view over 224 px) and the
+    single-threshold AUC proxy, on the host like the reference (validation metric, not on the fwd/bwd path)."""
+    if output.ndim == 3:
+        aae, auc, gp = [], [], []
+        for b in range(output.shape[0]):
+            a, u, p = _aae_auc_one(output[b].squeeze(), target[b].squeeze(), output.shape[2] * output.shape[1])
+            aae.append(a); auc.append(u); gp.append(p)
+        return np.mean(aae), np.mean(auc), gp
+    a, u, p = _aae_auc_one(output, target, output.shape[0] * output.shape[1])
+    return a, u, [p]
+
+
+def plot_loss(train_loss, test_loss, save_path):
+    try:
+        import matplotlib
+        matplotlib.use('agg')
+        import matplotlib.pyplot as plt
+    except Exception:       # plotting is cosmetic; never fail a training run on it
+        return
+    plt.plot(train_loss)
+    plt.plot(test_loss)
+    plt.ylabel('loss')
+    plt.xlabel('epoch')
+    plt.legend(['train', 'test'], loc='upper right')
+    plt.savefig(save_path)
+    plt.close()

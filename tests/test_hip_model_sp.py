@@ -1,0 +1,161 @@
+"""GPU parity tests of the assembled SP path (model_SP + floss + FusedAdam through the C-ABI) against
+(a) golden vectors produced by the real reference (tests/golden/model_sp_*.npz, floss.npz) and
+(b) the CPU oracle on the same seeded inputs.  Bar (BASELINE.json north_star): gaze map within 1e-3
+relative of the reference's PyTorch CPU path; observed ~1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import egaze_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TOL_MAP = 1e-3          # the north_star parity bar on the gaze map
+TOL_TIGHT = 1e-4        # what exact-f32 MFMA actually delivers (summation order only)
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def build_model():
+    from egaze_amd.models.model_SP import model_SP
+    from egaze_amd.utils import make_layers, cfg
+    model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20))
+    sd = synth.synth_state_dict(O.sp_shapes(), seed=1, head_gain=0.25)
+    model.load_state_dict(sd)
+    return model.to(DEV), sd
+
+
+@pytest.mark.parametrize("tag,size", [("s32", 32), ("s224", 224)])
+def test_model_sp_eval_forward_and_hook(tag, size):
+    gold = np.load(os.path.join(GOLDEN, f"model_sp_{tag}.npz"))
+    model, _ = build_model()
+    x_s, x_t, gt, _ = synth.synth_sp_batch(2, size, seed=0)
+    feats = []
+    hook = model._modules.get('features_s').register_forward_hook(lambda m, i, o: feats.append(o))   # AT.py:105
+    model.eval()
+    with torch.no_grad():
+        out = model(x_s.to(DEV), x_t.to(DEV))
+    hook.remove()
+    assert tuple(out.shape) == (2, 1, size, size)
+    r = rel(out.cpu().numpy(), gold["eval_out"])
+    assert r < TOL_MAP and r < TOL_TIGHT, r
+    f = feats[0]
+    assert tuple(f.shape) == (2, 512, size // 16, size // 16)
+    assert rel(f.double().sum(dim=(2, 3)).cpu().numpy(), gold["eval_features_s_sum"]) < TOL_TIGHT
+    assert rel(f[0, 0].cpu().numpy(), gold["eval_features_s_b0c0"]) < TOL_TIGHT
+
+
+@pytest.mark.parametrize("tag,size", [("s32", 32), ("s224", 224)])
+def test_model_sp_train_step(tag, size):
+    """One literal SP.trainSP iteration (SP.py:126-138): train-mode forward, floss, backward, Adam."""
+    from egaze_amd.floss import floss
+    from egaze_amd.optim import FusedAdam
+    gold = np.load(os.path.join(GOLDEN, f"model_sp_{tag}.npz"))
+    model, sd0 = build_model()
+    x_s, x_t, gt, _ = synth.synth_sp_batch(2, size, seed=0)
+    lr = float(gold["lr"])
+    model.train()
+    criterion = floss().to(DEV)
+    optimizer = FusedAdam(model.parameters(), lr=lr)
+    optimizer.zero_grad()
+    output = model(x_s.to(DEV), x_t.to(DEV))
+    target = gt.to(DEV).view(output.size())
+    loss = criterion(output, target)
+    loss.backward()
+    grads = {k: p.grad.detach().clone().cpu() for k, p in model.named_parameters()}
+    before = {k: p.detach().clone().cpu() for k, p in model.named_parameters()}
+    optimizer.step()
+    optimizer.zero_grad()
+
+    r = rel(output.detach().cpu().numpy(), gold["train_out"])
+    assert r < TOL_MAP and r < TOL_TIGHT, r
+    assert abs(loss.item() - float(gold["train_loss"])) < 1e-4 * abs(float(gold["train_loss"]))
+    keys = [k[5:] for k in gold.files if k.startswith("gsum/")]
+    assert set(keys) == set(grads.keys())
+    floor = 1e-5 * max(gold["gsum/" + k][0] for k in keys)
+    for k in keys:
+        want = gold["gsum/" + k][0]
+        got = grads[k].double().norm().item()
+        assert abs(got - want) <= 2e-3 * want + floor, (k, got, want)
+    for k in [f[5:] for f in gold.files if f.startswith("grad/")]:
+        if gold["gsum/" + k][0] > 100 * floor:
+            assert rel(grads[k].numpy(), gold["grad/" + k]) < 2e-3, k
+    sd = model.state_dict()
+    for f in gold.files:
+        if f.startswith("after/"):
+            assert rel(sd[f[6:]].cpu().numpy(), gold[f]) < 1e-4, f
+        elif f.startswith("after_sum/"):
+            v = sd[f[10:]].double().cpu()
+            assert np.allclose([v.sum().item(), v.norm().item()], gold[f], rtol=1e-4), f
+        elif f.startswith("delta/") and gold["gsum/" + f[6:]][0] > 100 * floor:
+            d = (sd[f[6:]].cpu() - before[f[6:]]).double()
+            assert abs(d.abs().max().item() - gold[f][1]) < 2e-2 * lr + 1e-9, f
+    assert int(sd["bn.num_batches_tracked"]) == 1
+    assert int(sd["features_s.1.num_batches_tracked"]) == 1
+
+
+def test_model_sp_vs_oracle_full_grads_small():
+    """Every gradient tensor element-wise against the CPU oracle at 32x32 (seconds on CPU)."""
+    from egaze_amd.floss import floss
+    model, sd0 = build_model()
+    x_s, x_t, gt, _ = synth.synth_sp_batch(3, 32, seed=5)
+    model.train()
+    out = model(x_s.to(DEV), x_t.to(DEV))
+    loss = floss()(out, gt.to(DEV).view(out.size()))
+    loss.backward()
+    work = {k: v.clone() for k, v in sd0.items()}
+    oloss, oout, ograds = O.sp_train_step(work, {}, 1, x_s, x_t, gt, 0.0)
+    assert rel(out.detach().cpu().numpy(), oout.numpy()) < TOL_TIGHT
+    assert abs(loss.item() - oloss.item()) < 1e-4 * abs(oloss.item())
+    gmax = max(g.abs().max().item() for g in ograds.values())
+    for k, p in model.named_parameters():
+        ref = ograds[k]
+        if ref.abs().max().item() < 1e-5 * gmax:      # analytically-zero bias grads in front of BN
+            assert p.grad.abs().max().item() < 1e-4 * gmax, k
+            continue
+        assert rel(p.grad.cpu().numpy(), ref.numpy()) < 2e-3, k
+
+
+def test_floss_golden_bit_exact_weights():
+    import egaze_amd.hipops as h
+    gold = np.load(os.path.join(GOLDEN, "floss.npz"))
+    rs = np.random.RandomState(5)
+    size = 224
+    gt = synth.synth_gt(3, size, rs)
+    single = np.zeros((1, 1, size, size), np.float32); single[0, 0, 37, 181] = 1.0
+    flat = np.full((1, 1, size, size), 0.25, np.float32)
+    two = np.zeros((1, 1, size, size), np.float32); two[0, 0, 10, 20] = 0.5; two[0, 0, 200, 101] = 0.5
+    target = np.concatenate([gt, single, flat, two], 0)
+    x = rs.uniform(0.02, 0.98, target.shape).astype(np.float32)
+    x[0, 0, 0, :4] = [0.0, 1.0, 1e-30, 1 - 1e-7]
+    xd, td = torch.from_numpy(x).to(DEV), torch.from_numpy(target).to(DEV)
+    loss, w = h.floss_fwd(xd, td, True)
+    w = w.view(target.shape).cpu().numpy()
+    assert np.array_equal(w[:, 0, ::37, :], gold["weights_rows"])                 # plateau ties, flat map, two peaks
+    assert np.array_equal(w, O.floss_weights(target))
+    assert abs(loss.item() - float(gold["loss"])) < 2e-6 * abs(float(gold["loss"]))
+    g = h.floss_bwd(xd, td, w_dev := torch.from_numpy(w).to(DEV).view(-1), None).cpu().numpy()
+    assert rel(g[0, 0], gold["grad_b0"]) < 1e-5          # includes the clamp / EPS=1e-12 corner cases
+    assert rel(g[3, 0], gold["grad_b3"]) < 1e-5
+    assert rel(g.astype(np.float64).sum(axis=(1, 2, 3)), gold["grad_sum"]) < 1e-5
+    # plain BCE (--loss_function != 'f')
+    loss2, _ = h.floss_fwd(xd, td, False)
+    ref2 = O.bce_weighted(torch.from_numpy(x), torch.from_numpy(target), None)
+    assert abs(loss2.item() - ref2.item()) < 2e-6 * abs(ref2.item())
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-device."""
+    from egaze_amd.models.model_SP import model_SP
+    from egaze_amd.utils import make_layers, cfg
+    model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20))
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 32, 32), torch.zeros(1, 20, 32, 32))

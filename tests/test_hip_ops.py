@@ -1,0 +1,228 @@
+"""GPU parity tests, per C-ABI op: HIP kernel vs the same op in plain torch-CPU fp32 (the oracle's
+building blocks) on seeded inputs.  Tolerance: max|d|/max|ref| <= 2e-5 for fp32 contractions (only the
+summation order differs from the reference), bit-exact where the arithmetic is order-free."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def H():
+    import egaze_amd.hipops as h
+    return h
+
+
+def rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def nhwc(t):   # (B,C,H,W) cpu -> (B,H,W,C) cuda contiguous
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):   # (B,H,W,C) cuda -> (B,C,H,W) cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C,K,tile", [
+    (2, 12, 12, 64, 64, 0),          # ragged M (288 = 2*128 + 32), BN=64
+    (1, 14, 14, 128, 128, 0x200),    # BN=128 forced
+    (3, 9, 7, 32, 192, 0),           # odd sizes, K=192 -> BN=64
+    (2, 16, 16, 256, 256, 0x200),
+])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_conv3x3_fwd(B, Hh, Ww, C, K, tile, epi):
+    h = H()
+    x = rnd(B, C, Hh, Ww, seed=1)
+    w = rnd(K, C, 3, 3, seed=2, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=3, scale=0.1)
+    ref = F.conv2d(x, w, b, padding=1)
+    if epi == 1:
+        ref = F.relu(ref)
+    wd = w.to(DEV)
+    y, stat = h.conv3x3_fwd(nhwc(x), h.packed_weight(wd, "fwd"), b.to(DEV), K, ups=False, epi=epi, tile_flag=tile)
+    assert rel(nchw(y), ref) < 2e-5
+    if epi == 2:
+        s = stat.sum(0).cpu()                       # (2, K) fp64
+        assert rel(s[0], ref.double().sum(dim=(0, 2, 3))) < 1e-5
+        assert rel(s[1], (ref.double() ** 2).sum(dim=(0, 2, 3))) < 1e-5
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 6, 6, 64, 64), (1, 7, 5, 128, 128)])
+def test_conv3x3_upsample_fused(B, Hh, Ww, C, K):
+    h = H()
+    x = rnd(B, C, Hh, Ww, seed=4)
+    w = rnd(K, C, 3, 3, seed=5, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=6, scale=0.1)
+    ref = F.relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1))
+    y, _ = h.conv3x3_fwd(nhwc(x), h.packed_weight(w.to(DEV), "fwd"), b.to(DEV), K, ups=True, epi=1)
+    assert tuple(y.shape) == (B, 2 * Hh, 2 * Ww, K)
+    assert rel(nchw(y), ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [
+    (2, 12, 12, 64, 64, False), (1, 14, 14, 128, 256, False), (2, 10, 6, 192, 64, False),
+    (2, 12, 12, 64, 128, True), (1, 8, 8, 128, 128, True),
+])
+def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
+    """dgrad (same kernel, tap-flipped transposed weights), wgrad (split-K MFMA), bias grad, upsample bwd."""
+    h = H()
+    hin, win = (Hh // 2, Ww // 2) if ups else (Hh, Ww)
+    x = rnd(B, C, hin, win, seed=7).requires_grad_(True)
+    w = rnd(K, C, 3, 3, seed=8, scale=(2.0 / (9 * C)) ** 0.5).requires_grad_(True)
+    b = rnd(K, seed=9, scale=0.1).requires_grad_(True)
+    dy = rnd(B, K, Hh, Ww, seed=10)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    F.conv2d(xin, w, b, padding=1).backward(dy)
+    dyd = nhwc(dy)
+    dxu = h.conv3x3_dgrad(dyd, h.packed_weight(w.detach().to(DEV), "dgrad"), C)
+    dx = h.upsample2x_bwd(dxu) if ups else dxu
+    assert rel(nchw(dx), x.grad) < 2e-5
+    dw = h.conv3x3_wgrad(nhwc(x.detach()), dyd, ups=ups)
+    assert rel(dw.cpu(), w.grad) < 2e-5
+    assert rel(h.colsum(dyd).cpu(), b.grad) < 1e-5
+
+
+@pytest.mark.parametrize("C", [3, 20])
+@pytest.mark.parametrize("B,Hh,Ww", [(2, 16, 16), (1, 13, 21)])
+def test_conv_first(C, B, Hh, Ww):
+    h = H()
+    x = rnd(B, C, Hh, Ww, seed=11)
+    w = rnd(64, C, 3, 3, seed=12, scale=(2.0 / (9 * C)) ** 0.5).requires_grad_(True)
+    b = rnd(64, seed=13, scale=0.1)
+    ref = F.conv2d(x, w, b, padding=1)
+    y, stat = h.conv_first_fwd(x.to(DEV), w.detach().to(DEV), b.to(DEV), True)
+    assert rel(nchw(y), ref) < 2e-5
+    s = stat.sum(0).cpu()
+    assert rel(s[0], ref.detach().double().sum(dim=(0, 2, 3))) < 1e-5
+    assert rel(s[1], (ref.detach().double() ** 2).sum(dim=(0, 2, 3))) < 1e-5
+    dy = rnd(B, 64, Hh, Ww, seed=14)
+    ref.backward(dy)
+    dw = h.conv_first_wgrad(x.to(DEV), nhwc(dy))
+    assert rel(dw.cpu(), w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("B,Hh,Ww,K", [(2, 8, 8, 64), (3, 6, 10, 512), (2, 4, 4, 8)])
+def test_bn_relu_pool(pool, B, Hh, Ww, K):
+    h = H()
+    y = (rnd(B, K, Hh, Ww, seed=15) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(K, generator=torch.Generator().manual_seed(16)) + 0.5).requires_grad_(True)
+    beta = rnd(K, seed=17, scale=0.2).requires_grad_(True)
+    rm0, rv0 = rnd(K, seed=18, scale=0.1), torch.rand(K, generator=torch.Generator().manual_seed(19)) + 0.5
+    rm, rv = rm0.clone(), rv0.clone()
+    out = F.relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    if pool:
+        out = F.max_pool2d(out, 2, 2)
+    dout = rnd(*out.shape, seed=20)
+    out.backward(dout)
+    yd = nhwc(y.detach())
+    rmd, rvd = rm0.to(DEV), rv0.to(DEV)
+    coef = h.bn_finalize(h.channel_stats(yd), float(B * Hh * Ww), gamma.detach().to(DEV), beta.detach().to(DEV),
+                         rmd, rvd, 0.1, 1e-5)
+    o = h.bn_relu_pool_fwd(yd, coef, pool)
+    assert rel(nchw(o), out) < 1e-5
+    assert rel(rmd.cpu(), rm) < 1e-5 and rel(rvd.cpu(), rv) < 1e-5
+    dy, dg, db = h.bn_relu_pool_bwd(yd, nhwc(dout), coef, pool)
+    assert rel(nchw(dy), y.grad) < 5e-5
+    assert rel(dg.cpu(), gamma.grad) < 5e-5 and rel(db.cpu(), beta.grad) < 5e-5
+    # eval-mode coefficients
+    ce = h.bn_eval_coeffs(gamma.detach().to(DEV), beta.detach().to(DEV), rmd, rvd, 1e-5)
+    oe = h.bn_relu_pool_fwd(yd, ce, False)
+    refe = F.relu(F.batch_norm(y.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5))
+    assert rel(nchw(oe), refe) < 1e-5
+
+
+def test_pool_ties_first_wins():
+    """Equal positive maxima inside a 2x2 window: gradient goes to the first in scan order (torch)."""
+    h = H()
+    y = torch.zeros(1, 4, 2, 2)
+    y[0, :, 0, 1] = 2.0
+    y[0, :, 1, 0] = 2.0
+    y = y.requires_grad_(True)
+    K = 4
+    gamma, beta = torch.ones(K), torch.zeros(K)
+    out = F.max_pool2d(F.relu(y * 1.0), 2, 2)
+    out.backward(torch.ones_like(out))
+    coef = torch.zeros(4, K, device=DEV)
+    coef[1] = 1.0
+    coef[2] = 1.0                               # mean 0, invstd 1, scale 1, shift 0
+    yd = nhwc(y.detach())
+    o = h.bn_relu_pool_fwd(yd, coef, True)
+    assert torch.equal(nchw(o), out.detach())
+    dy, _, _ = h.bn_relu_pool_bwd(yd, torch.ones(1, 1, 1, K, device=DEV), coef, True)
+    dz = y.grad                                   # torch's routing: all of it at scan position (0,1)
+    assert dz[0, 0, 0, 1] == 1 and dz[0, 0, 1, 0] == 0
+    m1 = dz.mean(dim=(0, 2, 3), keepdim=True)
+    m2 = (dz * y.detach()).mean(dim=(0, 2, 3), keepdim=True)
+    assert rel(nchw(dy), dz - m1 - y.detach() * m2) < 1e-6
+
+
+def test_pairmax_relu_misc():
+    h = H()
+    a, b = rnd(2, 5, 5, 64, seed=21), rnd(2, 5, 5, 64, seed=22)
+    b[0, 0, 0, :8] = a[0, 0, 0, :8]                       # ties -> first stream wins
+    y2 = torch.cat((a, b), 0).to(DEV)
+    z = h.pairmax_fwd(y2)
+    assert torch.equal(z.cpu(), torch.maximum(a, b))
+    dz = rnd(2, 5, 5, 64, seed=23)
+    dy2 = h.pairmax_bwd(y2, dz.to(DEV)).cpu()
+    first = a >= b
+    assert torch.equal(dy2[:2], torch.where(first, dz, torch.zeros_like(dz)))
+    assert torch.equal(dy2[2:], torch.where(first, torch.zeros_like(dz), dz))
+    out, g = F.relu(rnd(3, 4, 4, 32, seed=24)), rnd(3, 4, 4, 32, seed=25)
+    assert torch.equal(h.relu_bwd(out.to(DEV), g.to(DEV)).cpu(), g * (out > 0))
+    x = rnd(2, 24, 5, 7, seed=26)
+    assert torch.equal(h.nhwc_to_nchw(h.nchw_to_nhwc(x.to(DEV))).cpu(), x)
+    assert torch.equal(h.nchw_to_nhwc(x.to(DEV)).cpu(), x.permute(0, 2, 3, 1).contiguous())
+
+
+@pytest.mark.parametrize("C", [64, 8])
+def test_head_sigmoid(C):
+    h = H()
+    x = rnd(2, C, 9, 11, seed=27).requires_grad_(True)
+    w = rnd(1, C, 1, 1, seed=28, scale=0.2).requires_grad_(True)
+    b = torch.tensor([0.1], requires_grad=True)
+    ref = torch.sigmoid(F.conv2d(x, w, b))
+    dout = rnd(2, 1, 9, 11, seed=29)
+    ref.backward(dout)
+    xd = nhwc(x.detach())
+    out, logits = h.conv1x1_sigmoid_fwd(xd, w.detach().to(DEV), b.detach().to(DEV), want_logits=True)
+    assert rel(out.cpu(), ref[:, 0]) < 1e-6
+    dx, dw, db = h.conv1x1_sigmoid_bwd(xd, w.detach().to(DEV), out, dout[:, 0].contiguous().to(DEV))
+    assert rel(nchw(dx), x.grad) < 1e-5
+    assert rel(dw.cpu(), w.grad) < 1e-5 and rel(db.cpu(), b.grad) < 1e-5
+
+
+def test_adam_matches_oracle():
+    from oracle import egaze_oracle as O
+    h = H()
+    n = 4099                                      # exercises the non-multiple-of-4 tail
+    p, g = rnd(n, seed=30), rnd(n, seed=31, scale=0.01)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, gd, md, vd = (t.clone().to(DEV) for t in (p, g, m, v))
+    for step in (1, 2, 3):
+        p, m, v = O.adam_step(p, g, m, v, step, 1e-3)
+        h.adam_step(pd, gd, md, vd, 1e-3, 0.9, 0.999, 1e-8, step)
+    assert rel(pd.cpu(), p) < 1e-6 and rel(md.cpu(), m) < 1e-6 and rel(vd.cpu(), v) < 1e-6
+
+
+def test_mse():
+    h = H()
+    a, b = rnd(1, 1, 512, seed=32).requires_grad_(True), rnd(1, 1, 512, seed=33)
+    ref = ((a - b) ** 2).mean()
+    ref.backward()
+    ad, bd = a.detach().to(DEV), b.to(DEV)
+    assert abs(h.mse_fwd(ad, bd).item() - ref.item()) < 1e-6 * abs(ref.item())
+    assert rel(h.mse_bwd(ad, bd, None).cpu(), a.grad) < 1e-6
