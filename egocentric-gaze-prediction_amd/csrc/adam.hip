@@ -1,16 +1,16 @@
 // Fused Adam step over one flat fp32 parameter buffer (torch.optim.Adam defaults as the reference configures it:
 // SP.py:110-113, AT.py:84, LF.py:77 -- betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
 // HBM-bound: reads p, g, m, v and writes p, m, v once (7 fp32 streams), float4 per lane, grid-stride.
+// 1-beta1 / 1-beta2 are formed in fp64 on the host like torch's Python scalars (1-0.999f in fp32 is off by 5e-5).
 // Mirrors torch's single-tensor update order:  m.lerp_(g, 1-b1);  v = v*b2 + (1-b2)*g*g;
 //   denom = sqrt(v)/sqrt(1-b2^t) + eps;  p -= (lr/(1-b1^t)) * m/denom.
 #include "egz_common.h"
 
 namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, float beta1, float beta2, float eps,
+                                                   float* __restrict__ v, long n, float omb1, float beta2, float omb2, float eps,
                                                    float step_size, float bc2_sqrt, float grad_scale) {
     const long n4 = n >> 2;
-    const float omb1 = 1.f - beta1, omb2 = 1.f - beta2;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
@@ -54,7 +54,8 @@ EGZ_API int egz_adam_step(float* p, const float* g, float* m, float* v, long n, 
     long g4 = (n / 4 + 255) / 256;
     if (g4 < 1) g4 = 1;
     const int grid = (int)(g4 > 8192 ? 8192 : g4);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, beta1, beta2, eps, step_size, bc2_sqrt, grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n,
+                       (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps, step_size, bc2_sqrt, grad_scale);
     EGZ_CHECK_LAUNCH("egz_adam_step");
     return 0;
 }

@@ -8,6 +8,7 @@ All wrappers raise on CPU tensors -- there is no CPU fallback.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -113,12 +114,33 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+_UID = [0]
+
+
+def _uid(w: torch.Tensor) -> int:
+    """Identity of a weight tensor that cannot be recycled the way a data_ptr can: a counter stored on the
+    tensor object (torch preserves the Python object of a live tensor); the cache entry dies with the tensor."""
+    uid = getattr(w, "_egz_uid", None)
+    if uid is None:
+        _UID[0] += 1
+        uid = _UID[0]
+        w._egz_uid = uid
+        weakref.finalize(w, _drop_packed, uid)
+    return uid
+
+
+def _drop_packed(uid: int):
+    _PACKED.pop((uid, "fwd"), None)
+    _PACKED.pop((uid, "dgrad"), None)
+
+
 def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
-    """(Cout, Cin, [1,] 3, 3) -> [9][Cin][Cout] ('fwd') or tap-flipped [9][Cout][Cin] ('dgrad')."""
-    w = _req(w.detach(), "weight")
+    """(Cout, Cin, [1,] 3, 3) -> [9][Cin][Cout] ('fwd') or tap-flipped [9][Cout][Cin] ('dgrad').
+    Pass the parameter object itself (not a detached alias) so the cache can follow its identity."""
+    _req(w, "weight")
     K, C = w.shape[0], w.shape[1]
-    key = (w.data_ptr(), kind, K, C)
-    tag = (_WEIGHT_EPOCH[0], w._version)
+    key = (_uid(w), kind)
+    tag = (_WEIGHT_EPOCH[0], w._version, w.data_ptr())
     hit = _PACKED.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
