@@ -28,13 +28,14 @@ FLOP_PER_FRAME_FWD_BWD = 341.2e9    # BASELINE.md section 3 (all parameters trai
 BYTES_PER_FRAME = 1.046e9
 
 
-def cpu_baseline(batch=8, size=224):
+def cpu_baseline(batch=4, size=224):
     """The reference's CPU algorithm (oracle/, pinned to the reference by golden vectors) on the host cores:
     one warm-up + one timed SP train step (fwd + floss + bwd + Adam) at a bounded batch."""
     from oracle import egaze_oracle as O
     from oracle import synth
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: {cores} host threads, batch {batch}", file=sys.stderr, flush=True)
     sd = synth.synth_state_dict(O.sp_shapes(), seed=1, head_gain=0.25)
     x_s, x_t, gt, _ = synth.synth_sp_batch(batch, size, seed=0)
     opt = {}

