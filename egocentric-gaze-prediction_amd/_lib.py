@@ -47,6 +47,8 @@ SIGNATURES = {
     "egz_channel_stats_rows": (c_int, []),
     "egz_channel_stats": (c_int, [P, c_long, c_int, P, S]),
     "egz_relu_bwd": (c_int, [P, P, P, c_long, S]),
+    "egz_relu_bwd_bias_ws_bytes": (c_size_t, [c_int]),
+    "egz_relu_bwd_bias": (c_int, [P, P, P, P, c_long, c_int, P, c_size_t, S]),
     "egz_upsample2x_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "egz_colsum": (c_int, [P, c_long, c_int, P, P, c_size_t, S]),
     "egz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
@@ -60,6 +62,13 @@ SIGNATURES = {
     "egz_floss_bwd": (c_int, [P, P, P, P, P, c_long, S]),
     "egz_mse_fwd": (c_int, [P, P, P, c_long, P, c_size_t, S]),
     "egz_mse_bwd": (c_int, [P, P, P, P, c_long, S]),
+    # --- AT: generic f32-MFMA GEMM + LSTM cell
+    "egz_gemm": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, S]),
+    "egz_lstm_cell_fwd": (c_int, [P, P, P, P, P, c_int, c_int, S]),
+    "egz_lstm_cell_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, S]),
+    "egz_tanh_fwd": (c_int, [P, P, c_long, S]),
+    "egz_tanh_bwd": (c_int, [P, P, P, c_long, S]),
+    "egz_add": (c_int, [P, P, P, c_long, S]),
     # --- optimizer
     "egz_adam_step": (c_int, [P, P, P, P, c_long, c_double, c_double, c_double, c_double, c_int, c_double, S]),
 }

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int c4 = threadIdx.x % K4, rr = threadIdx.x / K4;
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const long npix = (long)B * Ho * Wo;
-    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    // per-thread partials in fp32 (a thread sees <= a few hundred pixels), fp64 across threads / blocks
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (rr < rpb) {
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 for (int e = 0; e < 4; ++e) {
                     const float z = v[e] * sc[e] + sh[e];
                     const float dz = z > 0.f ? g[e] : 0.f;
-                    s1[e] += (double)dz;
-                    s2[e] += (double)(dz * ((v[e] - mu[e]) * is[e]));
+                    s1[e] += dz;
+                    s2[e] += dz * ((v[e] - mu[e]) * is[e]);
                 }
             } else {
                 const int xo = (int)(pix % Wo);
@@ -188,16 +189,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                     pool_route(z, g[e], dz);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        s1[e] += (double)dz[q];
-                        s2[e] += (double)(dz[q] * ((v[q][e] - mu[e]) * is[e]));
+                        s1[e] += dz[q];
+                        s2[e] += dz[q] * ((v[q][e] - mu[e]) * is[e]);
                     }
                 }
             }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            sred[((long)rr * 2 + 0) * K + c4 * 4 + e] = s1[e];
-            sred[((long)rr * 2 + 1) * K + c4 * 4 + e] = s2[e];
+            sred[((long)rr * 2 + 0) * K + c4 * 4 + e] = (double)s1[e];
+            sred[((long)rr * 2 + 1) * K + c4 * 4 + e] = (double)s2[e];
         }
     }
     __syncthreads();
@@ -323,6 +324,38 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = o[e] > 0.f ? g[e] : 0.f;
         reinterpret_cast<f32x4*>(dy)[i] = r;
+    }
+}
+
+// dy = dout * (out > 0) plus per-channel partial sums of dy (the conv bias gradient), one pass
+__global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                            float* __restrict__ dy, double* __restrict__ part,
+                                                            long rows, int K) {
+    extern __shared__ double sred[];   // [rpb][K]
+    const int K4 = K >> 2;
+    const int rpb = blockDim.x / K4;
+    const int c4 = threadIdx.x % K4, rr = threadIdx.x / K4;
+    float s[4] = {0, 0, 0, 0};
+    if (rr < rpb) {
+        for (long r = (long)blockIdx.x * rpb + rr; r < rows; r += (long)gridDim.x * rpb) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * K + c4 * 4);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * K + c4 * 4);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = o[e] > 0.f ? g[e] : 0.f;
+                s[e] += v[e];
+            }
+            *reinterpret_cast<f32x4*>(dy + r * K + c4 * 4) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sred[(long)rr * K + c4 * 4 + e] = (double)s[e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        double t = 0.0;
+        for (int r = 0; r < rpb; ++r) t += sred[(long)r * K + i];
+        part[(long)blockIdx.x * K + i] = t;
     }
 }
 
@@ -462,6 +495,10 @@ EGZ_API int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float
     return 0;
 }
 
+EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {
+    return ((size_t)BWD_BLOCKS + RED_ROWS) * 2 * K * sizeof(double) + 2 * (size_t)K * sizeof(float);
+}
+
 // Backward of [BN(train) -> ReLU -> (pool)] given the saved pre-BN tensor y and the batch statistics.
 // dgamma/dbeta may be null (frozen BN).  dy gets the gradient w.r.t. y ([B][H][W][K]).
 EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift,
@@ -477,16 +514,25 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
     const long npix = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
     int blocks = (int)((npix + rpb - 1) / rpb);
     if (blocks > BWD_BLOCKS) blocks = BWD_BLOCKS;
-    const size_t need = (size_t)blocks * 2 * K * sizeof(double) + 2 * (size_t)K * sizeof(float);
+    const size_t need = egz_bn_relu_pool_bwd_ws_bytes(K);
     EGZ_CHECK_ARG(ws_bytes >= need, "egz_bn_relu_pool_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     double* part = static_cast<double*>(workspace);
-    float* mdz = reinterpret_cast<float*>(part + (size_t)blocks * 2 * K);
+    double* part2 = part + (size_t)BWD_BLOCKS * 2 * K;
+    float* mdz = reinterpret_cast<float*>(part2 + (size_t)RED_ROWS * 2 * K);
     float* mdzx = mdz + K;
     const size_t shm = (size_t)rpb * 2 * K * sizeof(double);
     if (pool) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
     else      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(reduce)");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, part, blocks, K,
+    const double* fin = part;
+    int nfin = blocks;
+    if (blocks > RED_ROWS) {            // two-stage: keep the serial per-channel tail at <= RED_ROWS terms
+        int rc = colsum_partial<double>(part, part2, blocks, 2 * K, st);
+        if (rc) return rc;
+        fin = part2;
+        nfin = RED_ROWS;
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K,
                        (double)B * H * W, dgamma, dbeta, mdz, mdzx);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(finalize)");
     const long n = npix * K4;
@@ -495,9 +541,7 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(apply)");
     return 0;
 }
-EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {
-    return (size_t)BWD_BLOCKS * 2 * K * sizeof(double) + 2 * (size_t)K * sizeof(float);
-}
+
 
 // y2: [2][n] (stream s then stream t), z: [n];  n must be a multiple of 4.
 EGZ_API int egz_pairmax_fwd(const float* y2, float* z, long n, hipStream_t st) {
@@ -556,6 +600,37 @@ EGZ_API int egz_relu_bwd(const float* out, const float* dout, float* dy, long n,
     EGZ_CHECK_ARG(out && dout && dy && n % 4 == 0, "egz_relu_bwd: bad arguments");
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, out, dout, dy, n / 4);
     EGZ_CHECK_LAUNCH("egz_relu_bwd");
+    return 0;
+}
+
+EGZ_API size_t egz_relu_bwd_bias_ws_bytes(int K) { return ((size_t)BWD_BLOCKS + RED_ROWS) * K * sizeof(double); }
+
+// ReLU backward fused with the bias gradient of the conv that produced `out`: dy = dout*(out>0), db[k] = sum_rows dy.
+EGZ_API int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, float* db, long rows, int K,
+                              void* workspace, size_t ws_bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(out && dout && dy && db && workspace, "egz_relu_bwd_bias: null pointer");
+    EGZ_CHECK_ARG(K % 4 == 0 && K <= 1024, "egz_relu_bwd_bias: K=%d must be a multiple of 4, <= 1024", K);
+    EGZ_CHECK_ARG(ws_bytes >= egz_relu_bwd_bias_ws_bytes(K), "egz_relu_bwd_bias: workspace too small");
+    const int K4 = K / 4;
+    const int threads = 256 > K4 ? 256 : K4;
+    const int rpb = threads / K4;
+    int blocks = (int)((rows + rpb - 1) / rpb);
+    if (blocks > BWD_BLOCKS) blocks = BWD_BLOCKS;
+    double* part = static_cast<double*>(workspace);
+    double* part2 = part + (size_t)BWD_BLOCKS * K;
+    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(blocks), dim3(threads), (size_t)rpb * K * sizeof(double), st, out,
+                       dout, dy, part, rows, K);
+    EGZ_CHECK_LAUNCH("egz_relu_bwd_bias");
+    const double* fin = part;
+    int nfin = blocks;
+    if (blocks > RED_ROWS) {
+        int rc = colsum_partial<double>(part, part2, blocks, K, st);
+        if (rc) return rc;
+        fin = part2;
+        nfin = RED_ROWS;
+    }
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K, db);
+    EGZ_CHECK_LAUNCH("egz_relu_bwd_bias(final)");
     return 0;
 }
 

@@ -1,0 +1,198 @@
+// AT module (models/LSTMnet.py:15-37): tanh -> nn.LSTM(512, 512, num_layers=2) -> Linear(512,512) -> ReLU.
+// Building blocks, all fp32:
+//   * egz_gemm: generic strided GEMM on exact-f32 MFMA (v_mfma_f32_32x32x2_f32), C = alpha*op(A)*op(B) [+ C] [+ bias]
+//     [ReLU]; used for the input projections over all T at once, the per-step recurrent product h*W_hh^T,
+//     the Linear layer and every backward product (dX = dY*W, dW = dY^T*X).
+//   * LSTM cell point-wise forward / backward (gate order i,f,g,o, torch semantics), tanh forward/backward.
+// The recurrence is latency-bound (M = batch rows per step): one GEMM + one point-wise launch per step.
+#include "egz_common.h"
+
+namespace {
+
+constexpr int GM = 64, GN = 64, GK = 32, GLD = 65;   // odd row stride: conflict-free transposing writes
+
+// C[m][n] (ldc) = sum_k A(m,k) * B(k,n); A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
+// flags: bit0 accumulate into C, bit1 ReLU after bias.  bias: per-n or null.
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                   float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                   int K, long sam, long sak, long sbk, long sbn, long ldc, int flags) {
+    __shared__ float As[2][GK * GLD];   // [k][m]
+    __shared__ float Bs[2][GK * GLD];   // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
+
+    float ra[8], rb[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 256 * j;
+            int m, k;
+            if (a_kfast) { m = e >> 5; k = e & 31; } else { k = e >> 6; m = e & 63; }
+            ra[j] = (m0 + m < M && k0 + k < K) ? A[(long)(m0 + m) * sam + (long)(k0 + k) * sak] : 0.f;
+            int n, kb;
+            if (b_nfast) { kb = e >> 6; n = e & 63; } else { n = e >> 5; kb = e & 31; }
+            rb[j] = (n0 + n < N && k0 + kb < K) ? Bm[(long)(k0 + kb) * sbk + (long)(n0 + n) * sbn] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 256 * j;
+            int m, k;
+            if (a_kfast) { m = e >> 5; k = e & 31; } else { k = e >> 6; m = e & 63; }
+            As[buf][k * GLD + m] = ra[j];
+            int n, kb;
+            if (b_nfast) { kb = e >> 6; n = e & 63; } else { n = e >> 5; kb = e & 31; }
+            Bs[buf][kb * GLD + n] = rb[j];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk = (K + GK - 1) / GK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) gload((s + 1) * GK);
+        const float* Ab = As[buf] + hl * GLD + wm * 32 + l31;
+        const float* Bb = Bs[buf] + hl * GLD + wn * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < GK / 2; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[(2 * t) * GLD], Bb[(2 * t) * GLD], acc, 0, 0, 0);
+        if (s + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + l31;
+    if (n < N) {
+        const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + egz_acc_row(r, lane);
+            if (m < M) {
+                float v = acc[r] + bz;
+                if (flags & 1) v += C[(long)m * ldc + n];
+                if (flags & 2) v = fmaxf(v, 0.f);
+                C[(long)m * ldc + n] = v;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+// gates: [B][4H] pre-activations (i,f,g,o); c_prev/h_out/c_out: [B][H]; act (saved for backward): [B][4H] activated gates
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                            float* __restrict__ h_out, float* __restrict__ c_out,
+                                                            float* __restrict__ act, int B, int Hd) {
+    const int n = B * Hd;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int b = i / Hd, j = i - b * Hd;
+        const float* g = gates + (long)b * 4 * Hd;
+        const float gi = sigm(g[j]), gf = sigm(g[Hd + j]), gg = tanhf(g[2 * Hd + j]), go = sigm(g[3 * Hd + j]);
+        const float c = gf * c_prev[i] + gi * gg;
+        c_out[i] = c;
+        h_out[i] = go * tanhf(c);
+        if (act) {
+            float* a = act + (long)b * 4 * Hd;
+            a[j] = gi; a[Hd + j] = gf; a[2 * Hd + j] = gg; a[3 * Hd + j] = go;
+        }
+    }
+}
+
+// dh, dc_in: gradients w.r.t. h_t and c_t; writes dgates [B][4H] (pre-activation) and dc_prev.
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ act, const float* __restrict__ c,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ dh,
+                                                            const float* __restrict__ dc_in, float* __restrict__ dgates,
+                                                            float* __restrict__ dc_prev, int B, int Hd) {
+    const int n = B * Hd;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int b = i / Hd, j = i - b * Hd;
+        const float* a = act + (long)b * 4 * Hd;
+        const float gi = a[j], gf = a[Hd + j], gg = a[2 * Hd + j], go = a[3 * Hd + j];
+        const float tc = tanhf(c[i]);
+        const float dhv = dh[i];
+        const float dct = (dc_in ? dc_in[i] : 0.f) + dhv * go * (1.f - tc * tc);
+        float* d = dgates + (long)b * 4 * Hd;
+        d[j] = dct * gg * gi * (1.f - gi);
+        d[Hd + j] = dct * c_prev[i] * gf * (1.f - gf);
+        d[2 * Hd + j] = dct * gi * (1.f - gg * gg);
+        d[3 * Hd + j] = dhv * tc * go * (1.f - go);
+        dc_prev[i] = dct * gf;
+    }
+}
+
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = tanhf(x[i]);
+}
+// dx = dy * (1 - y^2) with y = tanh(x)
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float t = y[i];
+        dx[i] = dy[i] * (1.f - t * t);
+    }
+}
+// out = a + b (element-wise; used to merge the two LSTM bias vectors and to sum gradient paths)
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+
+inline int grid1d(long n) {
+    long g = (n + 255) / 256;
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+// C[M][N] (row stride ldc) = op(A)[M][K] * op(B)[K][N]  (+ C if flags&1) (+ bias[n]) (ReLU if flags&2).
+// Element (m,k) of op(A) is A[m*sam + k*sak]; element (k,n) of op(B) is B[k*sbk + n*sbn].
+EGZ_API int egz_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak,
+                     long sbk, long sbn, long ldc, int flags, hipStream_t st) {
+    EGZ_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "egz_gemm: bad arguments");
+    dim3 grid(egz_cdiv(N, GN), egz_cdiv(M, GM));
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, flags);
+    EGZ_CHECK_LAUNCH("egz_gemm");
+    return 0;
+}
+
+EGZ_API int egz_lstm_cell_fwd(const float* gates, const float* c_prev, float* h_out, float* c_out, float* act, int B,
+                              int Hd, hipStream_t st) {
+    EGZ_CHECK_ARG(gates && c_prev && h_out && c_out && B > 0 && Hd > 0, "egz_lstm_cell_fwd: bad arguments");
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid1d((long)B * Hd)), dim3(256), 0, st, gates, c_prev, h_out, c_out, act, B, Hd);
+    EGZ_CHECK_LAUNCH("egz_lstm_cell_fwd");
+    return 0;
+}
+
+EGZ_API int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, const float* dh, const float* dc_in,
+                              float* dgates, float* dc_prev, int B, int Hd, hipStream_t st) {
+    EGZ_CHECK_ARG(act && c && c_prev && dh && dgates && dc_prev && B > 0 && Hd > 0, "egz_lstm_cell_bwd: bad arguments");
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long)B * Hd)), dim3(256), 0, st, act, c, c_prev, dh, dc_in, dgates,
+                       dc_prev, B, Hd);
+    EGZ_CHECK_LAUNCH("egz_lstm_cell_bwd");
+    return 0;
+}
+
+EGZ_API int egz_tanh_fwd(const float* x, float* y, long n, hipStream_t st) {
+    EGZ_CHECK_ARG(x && y && n > 0, "egz_tanh_fwd: bad arguments");
+    hipLaunchKernelGGL(tanh_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, st, x, y, n);
+    EGZ_CHECK_LAUNCH("egz_tanh_fwd");
+    return 0;
+}
+EGZ_API int egz_tanh_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t st) {
+    EGZ_CHECK_ARG(y && dy && dx && n > 0, "egz_tanh_bwd: bad arguments");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, st, y, dy, dx, n);
+    EGZ_CHECK_LAUNCH("egz_tanh_bwd");
+    return 0;
+}
+EGZ_API int egz_add(const float* a, const float* b, float* out, long n, hipStream_t st) {
+    EGZ_CHECK_ARG(a && b && out && n > 0, "egz_add: bad arguments");
+    hipLaunchKernelGGL(add_kernel, dim3(grid1d(n)), dim3(256), 0, st, a, b, out, n);
+    EGZ_CHECK_LAUNCH("egz_add");
+    return 0;
+}

@@ -33,6 +33,14 @@ def from_nhwc(y: torch.Tensor) -> torch.Tensor:
     return y.permute(0, 3, 1, 2)
 
 
+def _zero_bias_grad(dy: torch.Tensor, K: int) -> torch.Tensor:
+    """Gradient of a conv bias that feeds a train-mode BatchNorm.  BN subtracts the batch mean, so the loss
+    does not depend on that bias: sum(dy) = scale * (sum dz - N*mean(dz) - mean(dz*xhat) * sum(xhat)) = 0
+    identically.  The reference's autograd evaluates that sum in fp32 and gets round-off noise (~1e-9,
+    tests/test_oracle_golden.py); we return the exact value instead of spending an HBM pass on noise."""
+    return torch.zeros((K,), dtype=torch.float32, device=dy.device)
+
+
 class ConvBNReLUPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, pool,
@@ -67,7 +75,7 @@ class ConvBNReLUPool(torch.autograd.Function):
         ng = ctx.needs_input_grad
         dx = dw = db = None
         if ng[2]:
-            db = H.colsum(dy)
+            db = _zero_bias_grad(dy, K)
         if ng[1]:
             dw = H.conv_first_wgrad(xin, dy) if first else H.conv3x3_wgrad(xin, dy)
         if ng[0]:
@@ -93,11 +101,12 @@ class ConvReLU(torch.autograd.Function):
     def backward(ctx, dout):
         xin, y, weight = ctx.saved_tensors
         ups, C, K = ctx.cfg
-        dy = H.relu_bwd(y, to_nhwc(dout))
         ng = ctx.needs_input_grad
         dx = dw = db = None
         if ng[2]:
-            db = H.colsum(dy)
+            dy, db = H.relu_bwd_bias(y, to_nhwc(dout))
+        else:
+            dy = H.relu_bwd(y, to_nhwc(dout))
         if ng[1]:
             dw = H.conv3x3_wgrad(xin, dy, ups=ups)
         if ng[0]:
@@ -136,7 +145,7 @@ class FusionBlock(torch.autograd.Function):
         ng = ctx.needs_input_grad
         dfs = dft = dw = db = None
         if ng[3]:
-            db = H.colsum(dy2)
+            db = _zero_bias_grad(dy2, K)
         if ng[2]:
             dw = H.conv3x3_wgrad(x2, dy2).view(weight.shape)
         if ng[0] or ng[1]:

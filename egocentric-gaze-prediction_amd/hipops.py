@@ -293,6 +293,19 @@ def relu_bwd(out: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
     return dy
 
 
+def relu_bwd_bias(out: torch.Tensor, dout: torch.Tensor):
+    """ReLU backward fused with the producing conv's bias gradient: (dy, db)."""
+    _req(out, "out"); _req(dout, "dout")
+    K = out.shape[-1]
+    rows = out.numel() // K
+    dy = torch.empty_like(dout)
+    db = torch.empty((K,), dtype=torch.float32, device=out.device)
+    ws = workspace(LIB.egz_relu_bwd_bias_ws_bytes(K), out.device)
+    check(LIB.egz_relu_bwd_bias(out.data_ptr(), dout.data_ptr(), dy.data_ptr(), db.data_ptr(), rows, K,
+                                ws.data_ptr(), ws.numel(), _stream()), "egz_relu_bwd_bias")
+    return dy, db
+
+
 def upsample2x_bwd(dxu: torch.Tensor) -> torch.Tensor:
     _req(dxu, "dxu")
     B, H2, W2, C = dxu.shape
@@ -393,3 +406,71 @@ def mse_bwd(a, b, grad_out) -> torch.Tensor:
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     check(LIB.egz_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                             int(step), grad_scale, _stream()), "egz_adam_step")
+
+
+# ----------------------------------------------------------------------------- AT: GEMM + LSTM cell
+def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, a_strides, b_strides, out: torch.Tensor = None,
+         bias: torch.Tensor = None, accumulate: bool = False, relu: bool = False) -> torch.Tensor:
+    """out[M][N] = op(A)[M][K] @ op(B)[K][N] (+out) (+bias) (relu).  a_strides = (stride_m, stride_k) of op(A) in
+    elements, b_strides = (stride_k, stride_n) of op(B) -- transposes are expressed through strides."""
+    _req(a, "A"); _req(b, "B")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    flags = (1 if accumulate else 0) | (2 if relu else 0)
+    PROF.note_flops("egz_gemm", 2.0 * M * N * K)
+    check(LIB.egz_gemm(a.data_ptr(), b.data_ptr(), out.data_ptr(), _p(bias), M, N, K, a_strides[0], a_strides[1],
+                       b_strides[0], b_strides[1], N if out.dim() < 2 else out.stride(-2), flags, _stream()), "egz_gemm")
+    return out
+
+
+def linear_fwd(x2d: torch.Tensor, w: torch.Tensor, bias=None, relu=False, out=None, accumulate=False):
+    """x2d [M][K] @ w[N][K]^T (+bias): the nn.Linear / LSTM gate projection."""
+    M, K = x2d.shape
+    N = w.shape[0]
+    return gemm(x2d, w, M, N, K, (K, 1), (1, K), out=out, bias=bias, accumulate=accumulate, relu=relu)
+
+
+def matmul_nn(a2d: torch.Tensor, w: torch.Tensor):
+    """a2d [M][N] @ w[N][K] -> [M][K]  (data gradient of a Linear)."""
+    M, N = a2d.shape
+    K = w.shape[1]
+    return gemm(a2d, w, M, K, N, (N, 1), (K, 1))
+
+
+def matmul_tn(a2d: torch.Tensor, b2d: torch.Tensor):
+    """a2d[R][M]^T @ b2d[R][N] -> [M][N]  (weight gradient: dY^T X)."""
+    R, M = a2d.shape
+    N = b2d.shape[1]
+    return gemm(a2d, b2d, M, N, R, (1, M), (N, 1))
+
+
+def lstm_cell_fwd(gates, c_prev, h_out, c_out, act):
+    B, Hd = c_prev.shape
+    check(LIB.egz_lstm_cell_fwd(gates.data_ptr(), c_prev.data_ptr(), h_out.data_ptr(), c_out.data_ptr(), _p(act), B, Hd,
+                                _stream()), "egz_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(act, c, c_prev, dh, dc_in, dgates, dc_prev):
+    B, Hd = c.shape
+    check(LIB.egz_lstm_cell_bwd(act.data_ptr(), c.data_ptr(), c_prev.data_ptr(), dh.data_ptr(), _p(dc_in),
+                                dgates.data_ptr(), dc_prev.data_ptr(), B, Hd, _stream()), "egz_lstm_cell_bwd")
+
+
+def tanh_fwd(x):
+    _req(x, "x")
+    y = torch.empty_like(x)
+    check(LIB.egz_tanh_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "egz_tanh_fwd")
+    return y
+
+
+def tanh_bwd(y, dy):
+    dx = torch.empty_like(y)
+    check(LIB.egz_tanh_bwd(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), _stream()), "egz_tanh_bwd")
+    return dx
+
+
+def add(a, b):
+    _req(a, "a"); _req(b, "b")
+    out = torch.empty_like(a)
+    check(LIB.egz_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "egz_add")
+    return out

@@ -1,0 +1,130 @@
+"""GPU parity of the AT path (lstmnet + MSE + Adam through the C-ABI) against the reference's golden
+vectors (tests/golden/lstmnet.npz) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import egaze_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def build():
+    from egaze_amd.models.LSTMnet import lstmnet
+    net = lstmnet()
+    net.load_state_dict(synth.synth_state_dict(O.lstm_shapes(), seed=2))
+    return net.to(DEV)
+
+
+def test_gemm_variants():
+    import egaze_amd.hipops as h
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(70, 130, generator=g), torch.randn(50, 130, generator=g)
+    b = torch.randn(50, generator=g)
+    xd, wd = x.to(DEV), w.to(DEV)
+    assert rel(h.linear_fwd(xd, wd, bias=b.to(DEV)).cpu(), x @ w.t() + b) < 1e-5
+    assert rel(h.linear_fwd(xd, wd, relu=True).cpu(), torch.relu(x @ w.t())) < 1e-5
+    dy = torch.randn(70, 50, generator=g)
+    assert rel(h.matmul_nn(dy.to(DEV), wd).cpu(), dy @ w) < 1e-5
+    assert rel(h.matmul_tn(dy.to(DEV), xd).cpu(), dy.t() @ x) < 1e-5
+    acc = torch.randn(70, 50, generator=g)
+    out = acc.clone().to(DEV)
+    h.linear_fwd(xd, wd, out=out, accumulate=True)
+    assert rel(out.cpu(), acc + x @ w.t()) < 1e-5
+
+
+def test_lstmnet_golden_t3b2():
+    gold = np.load(os.path.join(GOLDEN, "lstmnet.npz"))
+    from egaze_amd.functions import MSELoss
+    net = build()
+    inp, tgt = synth.synth_at_batch(3, 2, seed=3)
+    h0 = torch.zeros(2, 2, 512, device=DEV)
+    c0 = torch.zeros(2, 2, 512, device=DEV)
+    out, (hn, cn) = net(inp.to(DEV), (h0, c0))
+    loss = MSELoss.apply(out, torch.tanh(tgt).to(DEV))
+    loss.backward()
+    assert rel(out.detach().cpu().numpy(), gold["t3b2_out"]) < 1e-5
+    assert rel(hn.detach().cpu().numpy(), gold["t3b2_hn"]) < 1e-5
+    assert rel(cn.detach().cpu().numpy(), gold["t3b2_cn"]) < 1e-5
+    assert abs(loss.item() - float(gold["t3b2_loss"])) < 1e-5 * abs(float(gold["t3b2_loss"]))
+    for k, p in net.named_parameters():
+        g = p.grad.double().cpu()
+        got = np.array([g.norm().item(), g.sum().item(), g.abs().max().item()])
+        assert rel(got, gold["t3b2_gsum/" + k]) < 1e-3, (k, got, gold["t3b2_gsum/" + k])
+    assert rel(net.lin.bias.grad.cpu().numpy(), gold["t3b2_grad/lin.bias"]) < 1e-4
+    assert rel(net.lstm.bias_ih_l1.grad.cpu().numpy(), gold["t3b2_grad/lstm.bias_ih_l1"]) < 1e-4
+
+
+def test_lstmnet_hidden_none():
+    gold = np.load(os.path.join(GOLDEN, "lstmnet.npz"))
+    net = build()
+    inp1, _ = synth.synth_at_batch(1, 1, seed=4)
+    with torch.no_grad():
+        out1, (h1, c1) = net(inp1.to(DEV), None)
+    assert rel(out1.cpu().numpy(), gold["t1b1_out"]) < 1e-5
+    assert rel(h1.cpu().numpy(), gold["t1b1_hn"]) < 1e-5
+    inp, _ = synth.synth_at_batch(3, 2, seed=3)
+    with pytest.raises(RuntimeError):                  # batch 2 with hidden=None: the reference raises too
+        net(inp.to(DEV), None)
+
+
+def test_at_train_replay_golden():
+    """AT.trainLSTM (AT.py:118-147) replay: batch 1 / seq 1, detach hidden, off-by-one loss, Adam per sample."""
+    from egaze_amd.functions import MSELoss
+    from egaze_amd.optim import FusedAdam
+    from egaze_amd.utils import repackage_hidden
+    gold = np.load(os.path.join(GOLDEN, "lstmnet.npz"))
+    net = build()
+    opt = FusedAdam(net.parameters(), lr=1e-4)
+    ins, tgts = synth.synth_at_batch(5, 1, seed=6)
+    same = [1, 1, 1, 0, 1]
+    hidden, pred, losses = None, None, []
+    for i in range(5):
+        if int(same[i]) == 0:
+            hidden = None
+        a = ins[i].unsqueeze(0).to(DEV)
+        t = tgts[i].unsqueeze(0).to(DEV)
+        if pred is not None:
+            l = MSELoss.apply(pred, torch.tanh(t))
+            opt.zero_grad()
+            l.backward()
+            opt.step()
+            losses.append(l.item())
+        hidden = repackage_hidden(hidden)
+        pred, hidden = net(a, hidden)
+    assert np.allclose(losses, gold["replay_losses"], rtol=1e-4, atol=0)
+    assert rel(pred.detach().cpu().numpy(), gold["replay_final_pred"]) < 1e-4
+    assert rel(net.lin.bias.detach().cpu().numpy(), gold["replay_lin_bias"]) < 1e-4
+    ws = np.array([p.detach().double().sum().item() for p in net.parameters()])
+    assert np.allclose(ws, gold["replay_w_sum"], rtol=1e-4, atol=1e-5)
+
+
+def test_lstmnet_t16_b32_vs_oracle():
+    """BASELINE config 4 shape: T=16, B=32 with explicit (h, c); forward + full gradients vs the oracle."""
+    from egaze_amd.functions import MSELoss
+    net = build()
+    sd = synth.synth_state_dict(O.lstm_shapes(), seed=2)
+    inp, tgt = synth.synth_at_batch(16, 32, seed=9)
+    g = torch.Generator().manual_seed(3)
+    h0, c0 = torch.randn(2, 32, 512, generator=g) * 0.1, torch.randn(2, 32, 512, generator=g) * 0.1
+    out, (hn, cn) = net(inp.to(DEV), (h0.to(DEV), c0.to(DEV)))
+    MSELoss.apply(out, torch.tanh(tgt).to(DEV)).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout, (ohn, ocn) = O.lstmnet_forward(leaves, inp, (h0, c0))
+    O.mse(oout, torch.tanh(tgt)).backward()
+    assert rel(out.detach().cpu().numpy(), oout.detach().numpy()) < 2e-5
+    assert rel(hn.detach().cpu().numpy(), ohn.detach().numpy()) < 2e-5
+    assert rel(cn.detach().cpu().numpy(), ocn.detach().numpy()) < 2e-5
+    for k, p in net.named_parameters():
+        assert rel(p.grad.cpu().numpy(), leaves[k].grad.numpy()) < 2e-4, k

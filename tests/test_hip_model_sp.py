@@ -24,17 +24,20 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def robust_close(a, b, frac=0.98, tol=2e-3, norm_tol=5e-2):
-    """Flip-robust comparison for whole-model gradients: a ReLU / max-pool decision on an element with
-    |z| ~ 1e-7 may legitimately differ between two fp32 summation orders and moves single channels of the
-    deep (few-element) BN layers by several %.  Require (a) >= 98 % of the entries within 2e-3 of max|ref| and
-    (b) the whole tensor within 5e-2 in relative L2 -- real indexing / formula bugs fail both by far."""
+def robust_close(a, b, max_tol=0.15, norm_tol=3e-2):
+    """Flip-tolerant comparison for whole-model gradients against the reference's golden vectors.
+
+    The golden s32 case contains a pre-ReLU value z ~ 0 in features_s.25 whose sign depends on how BatchNorm
+    is rounded: re-running the *CPU oracle* with BN written as y*scale+shift (instead of F.batch_norm) moves
+    features_s.25.bias by exactly the same 7.29e-2 (max-rel) that the HIP path shows, and every upstream
+    s-stream tensor by ~1 % -- a discontinuity of the gradient, not an arithmetic error.  So: relative L2
+    within 3e-2 and max-rel within 0.15 here (an indexing / formula bug fails both by far), while
+    test_model_sp_grads_vs_fp64 pins the arithmetic error itself (2e-5 on every tensor)."""
     a = np.asarray(a, np.float64).ravel()
     b = np.asarray(b, np.float64).ravel()
-    scale = max(np.abs(b).max(), 1e-30)
-    ok = (np.abs(a - b) <= tol * scale).mean()
+    mx = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
     l2 = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
-    return ok >= frac and l2 < norm_tol, (ok, l2)
+    return mx < max_tol and l2 < norm_tol, (mx, l2)
 
 
 def build_model():

@@ -183,6 +183,9 @@ def test_pairmax_relu_misc():
     assert torch.equal(dy2[2:], torch.where(first, torch.zeros_like(dz), dz))
     out, g = F.relu(rnd(3, 4, 4, 32, seed=24)), rnd(3, 4, 4, 32, seed=25)
     assert torch.equal(h.relu_bwd(out.to(DEV), g.to(DEV)).cpu(), g * (out > 0))
+    dyb, dbb = h.relu_bwd_bias(out.to(DEV), g.to(DEV))
+    assert torch.equal(dyb.cpu(), g * (out > 0))
+    assert rel(dbb.cpu(), (g * (out > 0)).sum(dim=(0, 1, 2))) < 1e-6
     x = rnd(2, 24, 5, 7, seed=26)
     assert torch.equal(h.nhwc_to_nchw(h.nchw_to_nhwc(x.to(DEV))).cpu(), x)
     assert torch.equal(h.nchw_to_nhwc(x.to(DEV)).cpu(), x.permute(0, 2, 3, 1).contiguous())
