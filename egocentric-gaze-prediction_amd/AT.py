@@ -1,0 +1,175 @@
+"""Mirror of the reference's ``AT.py``: driver of the attention-transition module (AT.py:68-253) -- LSTM training /
+validation loops (batch 1, sequence 1, truncated BPTT via repackage_hidden, one Adam step per fixation sample) and
+the extraction of the late-fusion training data with the SP model + a forward hook on ``features_s``.
+Quirks reproduced, not fixed: the prediction made from sample i-1 is scored against
+tanh(target_i) (off-by-one), the loss also crosses video boundaries, and ``prevt`` is never updated so the train
+checkpoint is rewritten whenever the epoch loss is below 999."""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.utils.data import DataLoader
+
+from .data._io import imwrite, resize
+from .functions import MSELoss
+from .models.LSTMnet import lstmnet
+from .models.model_SP import model_SP
+from .optim import FusedAdam
+from .SP import _progress
+from .utils import (AverageMeter, cfg, computeAAEAUC, generalException, make_layers, plot_loss, repackage_hidden)
+
+hook_name = 'features_s'
+features_blobs = []
+
+
+def hook_feature(module, input, output):
+    features_blobs.append(output)
+
+
+def crop_feature(feature, maxind, size):
+    """size x size window of the (B,512,14,14) map around gaze_point // 16, clipped to the map (AT.py:25-39)."""
+    H = feature.size(2)
+    lo, hi = size // 2, int(math.ceil(size / 2.0))
+    out = []
+    for b in range(feature.size(0)):
+        f = np.clip(np.array(maxind[b]) // 16, lo, H - hi)
+        out.append(feature[b:b + 1, :, f[0] - lo:f[0] + hi, f[1] - lo:f[1] + hi])
+    return torch.cat(out, 0)
+
+
+def crop_align_feature(feature, maxind, size):
+    """Same crop on the bilinearly x16-upsampled map (AT.py:41-56; ``--align``)."""
+    size *= 16
+    feature = nn.functional.interpolate(feature.contiguous(), scale_factor=16, mode='bilinear', align_corners=True)
+    out = []
+    for b in range(feature.size(0)):
+        f = np.clip(np.array(maxind[b]), size // 2, 224 - size // 2)
+        out.append(feature[b:b + 1, :, f[0] - size // 2:f[0] + size // 2, f[1] - size // 2:f[1] + size // 2])
+    return torch.cat(out, 0)
+
+
+def get_weighted(chn_weight, feature):
+    """Channel-weighted sum of the (1,512,14,14) map, min-max normalised (AT.py:58-66)."""
+    feature = torch.sum(feature * chn_weight.view(1, 512, 1, 1), 1)
+    feature = feature - torch.min(feature)
+    return feature / torch.max(feature)
+
+
+class AT():
+    def __init__(self, pretrained_model=None, pretrained_lstm=None, extract_lstm=False, crop_size=3,
+                 num_epoch_lstm=30, lstm_save_img='loss_lstm.png', save_path='save', save_name='best_lstm.pth.tar',
+                 device='0', lstm_data_path='../512w', traindata=None, valdata=None, task=None, align=False):
+        if pretrained_model is None:
+            raise generalException('AT module have to use pretrained SP module.')
+        self.device = torch.device('cuda:' + device)
+        self.lstm = lstmnet().to(self.device)
+        if pretrained_lstm is not None:
+            self.reload_LSTM(pretrained_lstm)
+        self.criterion_lstm = MSELoss.apply
+        self.optimizer_lstm = FusedAdam(self.lstm.parameters(), lr=1e-4)
+        if extract_lstm:
+            from .extractLSTMw import extract_LSTM_training_data
+            extract_LSTM_training_data(save_path=lstm_data_path, trained_model=pretrained_model, device=device,
+                                       crop_size=crop_size, traindata=traindata, valdata=valdata, align=align)
+        self.crop_size, self.num_epoch_lstm, self.epochnow = crop_size, num_epoch_lstm, 0
+        self.lstm_save_img, self.save_path, self.save_name = lstm_save_img, save_path, save_name
+        self.lstm_data_path, self.batch_size, self.align = lstm_data_path, 1, align
+        self.model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20))
+        merged = self.model.state_dict()
+        merged.update(torch.load(pretrained_model, map_location='cpu')['state_dict'])
+        self.model.load_state_dict(merged, strict=False)
+        self.model.to(self.device)
+        self.model._modules.get(hook_name).register_forward_hook(hook_feature)
+        from .data.LSTMdatas import lstmDataset
+        self.lstmTrainLoader = DataLoader(dataset=lstmDataset(os.path.join(lstm_data_path, 'train'), task),
+                                          batch_size=1, shuffle=False, num_workers=0)
+        self.lstmValLoader = DataLoader(dataset=lstmDataset(os.path.join(lstm_data_path, 'test'), task),
+                                        batch_size=1, shuffle=False, num_workers=0)
+
+    def reload_LSTM(self, pretrained_lstm):
+        merged = self.lstm.state_dict()
+        merged.update(torch.load(pretrained_lstm, map_location='cpu'))
+        self.lstm.load_state_dict(merged)
+        print('loaded pretrained lstm from ' + pretrained_lstm)
+
+    def _epoch(self, loader, train):
+        losses = AverageMeter()
+        hidden, pred_chn_weight = None, None
+        for i, sample in enumerate(loader):
+            if int(sample['same']) == 0:             # reset the state only when a video is over
+                hidden = None
+            inp = sample['input'].unsqueeze(0).to(self.device)       # (1, 1, 512)
+            target = sample['gt'].unsqueeze(0).to(self.device)       # (1, 1, 512)
+            if pred_chn_weight is not None:
+                loss = self.criterion_lstm(pred_chn_weight, torch.tanh(target))
+                if train:
+                    self.optimizer_lstm.zero_grad()
+                    loss.backward()
+                    self.optimizer_lstm.step()
+                losses.update(loss.item())
+            hidden = repackage_hidden(hidden)
+            pred_chn_weight, hidden = self.lstm(inp, hidden)
+        return losses.avg
+
+    def trainLSTM(self):
+        self.lstm.train()
+        return self._epoch(self.lstmTrainLoader, True)
+
+    def testLSTM(self):
+        self.lstm.eval()
+        with torch.no_grad():
+            return self._epoch(self.lstmValLoader, False)
+
+    def train(self):
+        print('begin training LSTM...')
+        prev, prevt, loss_train, loss_val = 999, 999, [], []
+        for epoch in _progress(range(self.num_epoch_lstm)):
+            self.epochnow = epoch
+            l = self.trainLSTM()
+            loss_train.append(l)
+            if l < prevt:
+                torch.save(self.lstm.state_dict(), os.path.join(self.save_path, self.save_name))
+            l = self.testLSTM()
+            loss_val.append(l)
+            if l < prev:
+                prev = l
+                torch.save(self.lstm.state_dict(), os.path.join(self.save_path, 'val' + self.save_name))
+            plot_loss(loss_train, loss_val, os.path.join(self.save_path, self.lstm_save_img))
+        print('lstm training finished!')
+
+    def extract_late(self, st_loader, pred_folder='../new_pred/', feat_folder='../new_feat/'):
+        """pred = SP gaze map, feat = AT-weighted conv5_3 map, both written as uint8 PNGs (AT.py:199-253)."""
+        print('begin to extract files for training LF module ...')
+        os.makedirs(pred_folder, exist_ok=True)
+        os.makedirs(feat_folder, exist_ok=True)
+        global features_blobs
+        self.model.eval()
+        self.lstm.eval()
+        hidden = None
+        with torch.no_grad():
+            for i, sample in _progress(enumerate(st_loader)):
+                currname = sample['imname'][0]
+                fixsac = sample['fixsac']
+                input_s = sample['image'].float().to(self.device)
+                input_t = sample['flow'].float().to(self.device)
+                target = sample['gt'].float().to(self.device)
+                del features_blobs[:]
+                output = self.model(input_s, input_t)                 # (1,1,224,224)
+                feature_s = features_blobs[0]                          # (1,512,14,14)
+                outim = np.uint8(255 * output.cpu().numpy().squeeze())
+                imwrite(os.path.join(pred_folder, currname), outim)
+                # computeAAEAUC's third value is the GROUND-TRUTH arg-max, used as the "predicted" gaze point
+                _, _, pred_gp = computeAAEAUC(outim, target.cpu().numpy().squeeze())
+                crop = crop_align_feature if self.align else crop_feature
+                cfeature = crop(feature_s, pred_gp, self.crop_size).contiguous()
+                chn_weight = cfeature.view(cfeature.size(0), cfeature.size(1), -1).mean(2)      # (1,512)
+                if int(fixsac) != 1:
+                    hidden = repackage_hidden(hidden)
+                    chn_weight, hidden = self.lstm(chn_weight.unsqueeze(0), hidden)
+                    chn_weight = chn_weight.squeeze(0)
+                feat = get_weighted(chn_weight, feature_s)
+                feat = np.uint8(255 * feat.cpu().numpy().squeeze())
+                imwrite(os.path.join(feat_folder, currname), resize(feat, (224, 224)))
+        print('Finished extracting files for LF module!')

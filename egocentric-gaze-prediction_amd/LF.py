@@ -1,0 +1,117 @@
+"""Mirror of the reference's ``LF.py``: driver of the late-fusion module (LF.py:16-161) -- file listing with
+leave-one-subject-out split, Adam, train / validation loops with per-batch AAE / AUC, best-train and best-val
+checkpoints.  Model, loss and optimizer are the HIP-backed mirrors."""
+import os
+
+import torch
+from torch.utils.data import DataLoader
+
+from . import dp
+from .data.lateDataset import lateDataset
+from .floss import BCELoss, floss
+from .models.late_fusion import late_fusion
+from .optim import FusedAdam
+from .utils import AverageMeter, computeAAEAUC, plot_loss
+from .SP import _progress
+
+
+def _split(folder, val_name, task):
+    names = os.listdir(folder)
+    train = sorted(k for k in names if val_name not in k)
+    val = sorted(k for k in names if val_name in k)
+    if task is not None:
+        train = [k for k in train if task in k]
+        val = [k for k in val if task in k]
+    return train, val
+
+
+class LF():
+    def __init__(self, pretrained_model=None, save_path='save', late_save_img='loss_late.png',
+                 save_name='best_late.pth.tar', device='0', late_pred_path='../new_pred', num_epoch=10,
+                 late_feat_path='../new_feat', gt_path='../gtea_gts', val_name='Alireza', batch_size=32,
+                 loss_function='f', lr=1e-7, task=None):
+        self.model = late_fusion()
+        self.device = torch.device('cuda:' + device)
+        self.save_name, self.save_path = save_name, save_path
+        if pretrained_model is not None:
+            merged = self.model.state_dict()
+            merged.update(torch.load(pretrained_model, map_location='cpu')['state_dict'])
+            self.model.load_state_dict(merged)
+            print('loaded pretrained late fusion model from ' + pretrained_model)
+        self.model.to(self.device)
+        self.batch_size, self.num_epoch, self.epochnow, self.late_save_img = batch_size, num_epoch, 0, late_save_img
+        listGtFiles, listValGtFiles = _split(gt_path, val_name, task)
+        print('num of training LF samples: %d' % len(listGtFiles))
+        print('Loading SP predictions from /%s' % late_pred_path)
+        listTrainFiles, listValFiles = _split(late_pred_path, val_name, task)
+        print('num of LF val samples: ', len(listValFiles))
+        listTrainFeats, listValFeats = _split(late_feat_path, val_name, task)
+        assert(len(listTrainFeats) == len(listTrainFiles) and len(listGtFiles) > 0)
+        assert(len(listValGtFiles) == len(listValFiles))
+        self.train_loader = DataLoader(dataset=lateDataset(late_pred_path, gt_path, late_feat_path, listTrainFiles,
+                                                           listGtFiles, listTrainFeats),
+                                       batch_size=batch_size, shuffle=True, num_workers=0, pin_memory=True)
+        self.val_loader = DataLoader(dataset=lateDataset(late_pred_path, gt_path, late_feat_path, listValFiles,
+                                                         listValGtFiles, listValFeats),
+                                     batch_size=batch_size, shuffle=False, num_workers=0, pin_memory=True)
+        self.criterion = (floss() if loss_function == 'f' else BCELoss()).to(self.device)
+        self.optimizer = FusedAdam(self.model.parameters(), lr=lr)
+        self.reducer = dp.attach(self.optimizer) if torch.distributed.is_initialized() else None
+
+    def _run(self, loader, train, every):
+        losses, auc, aae = AverageMeter(), AverageMeter(), AverageMeter()
+        for i, sample in _progress(enumerate(loader)):
+            im = sample['im'].float().to(self.device)
+            gt = sample['gt'].float().to(self.device)
+            feat = sample['feat'].float().to(self.device)
+            out = self.model(feat, im)                       # channel 0 = AT map, channel 1 = SP map (LF.py:90)
+            loss = self.criterion(out, gt)
+            aae1, auc1, _ = computeAAEAUC(out.detach().cpu().numpy().squeeze(), gt.cpu().numpy().squeeze())
+            auc.update(auc1)
+            aae.update(aae1)
+            losses.update(loss.item())
+            if train:
+                self.optimizer.zero_grad()
+                loss.backward()
+                self.optimizer.step()
+            if (i + 1) % every == 0:
+                print('Epoch: [{0}][{1}/{2}]\t''AUCAAE_late {auc.avg:.3f} ({aae.avg:.3f})\t'
+                      'Loss {loss.val:.4f} ({loss.avg:.4f})\t'.format(self.epochnow, i + 1, len(loader) + 1, auc=auc,
+                                                                      loss=losses, aae=aae))
+        return losses.avg, auc.avg, aae.avg
+
+    def trainLate(self):
+        # like the reference, the model is never switched to eval(): BN uses batch statistics in both loops
+        return self._run(self.train_loader, True, 3000)
+
+    def testLate(self):
+        with torch.no_grad():
+            return self._run(self.val_loader, False, 1000)
+
+    def train(self):
+        print('begin training LF module...')
+        trainprev, valprev, loss_train, loss_val = 999, 999, [], []
+        for epoch in range(self.num_epoch):
+            self.epochnow = epoch
+            loss, auc, aae = self.trainLate()
+            loss_train.append(loss)
+            print('training, auc is %5f, aae is %5f' % (auc, aae))
+            if loss < trainprev:
+                torch.save({'state_dict': self.model.state_dict(), 'loss': loss, 'auc': auc, 'aae': aae},
+                           os.path.join(self.save_path, self.save_name))
+                trainprev = loss
+            loss, auc, aae = self.testLate()
+            loss_val.append(loss)
+            plot_loss(loss_train, loss_val, os.path.join(self.save_path, self.late_save_img))
+            if loss < valprev:
+                torch.save({'state_dict': self.model.state_dict(), 'loss': loss, 'auc': auc, 'aae': aae},
+                           os.path.join(self.save_path, 'val' + self.save_name))
+                valprev = loss
+            print('testing, auc is %5f, aae is %5f' % (auc, aae))
+        print('LF module training finished!')
+
+    def val(self):
+        print('begin testing LF module...')
+        loss, auc, aae = self.testLate()
+        print('AUC is : %04f, AAE is: %04f' % (auc, aae))
+        print('LF module testing finished!')

@@ -5,8 +5,9 @@
 // computes the data gradient when it is handed dgrad-packed (tap-flipped, transposed) weights.
 //
 // GEMM view:  Y[m][n] = sum_{tap,c} X[pix(m) + tap][c] * Wp[tap][c][n],   m = (b,y,x) flat, NHWC.
-//   block tile 128(m) x BN(n) (BN = 128 or 64), K-slice = one tap x 32 channels,
-//   4 waves as 2(m) x 2(n), each wave 64 x BN/2 = 2 x (BN/64) MFMA 32x32 tiles,
+//   block tile 128(m) x BN(n) (BN = 128 / 64, or 32 for the late-fusion widths), K-slice = one tap x 32 channels,
+//   4 waves as 2(m) x 2(n), each wave 64 x BN/2 = 2 x (BN/64) MFMA 32x32 tiles (BN = 32: 4(m) x 1(n)),
+//   channel counts that are not multiples of 32 are zero-padded in the packed weights and masked in x / y,
 //   LDS double-buffered, register-staged global loads (issue next slice -> MFMAs -> write LDS).
 // Optional fusions: nearest x2 upsample folded into the input gather (decoder.4/.11/.18/.23),
 // bias, ReLU, and per-channel sum / sum-of-squares partials (fp64) for train-mode BatchNorm.
@@ -23,17 +24,22 @@ enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
 template <int BN, bool UPS, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K) {
-    constexpr int NR = BN / 64;   // 32-wide n-tiles per wave
-    constexpr int WN = BN / 2;    // n-extent per wave
-    constexpr int BLD = (BN == 128) ? 4 : 2;   // float4 B loads per thread per slice
+    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp) {
+    // C / K: real channel counts (strides of x / y); Cp / Kp: the padded extents of the packed weights.
+    constexpr int WAVES_N = (BN >= 64) ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    constexpr int MR = BM / (32 * WAVES_M);    // 32-row m-tiles per wave (2, or 1 for BN = 32)
+    constexpr int NR = BN / (32 * WAVES_N);    // 32-wide n-tiles per wave
+    constexpr int WM = BM / WAVES_M;           // m-extent per wave
+    constexpr int WN = BN / WAVES_N;           // n-extent per wave
+    constexpr int BLD = BN / 32;               // float4 B loads per thread per slice (4, 2, 1)
 
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2 * BK * BN];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, hl = lane >> 5, l31 = lane & 31;
-    const int ntn = K / BN;
+    const int wm = (WAVES_N == 2) ? (wave >> 1) : wave, wn = (WAVES_N == 2) ? (wave & 1) : 0;
+    const int hl = lane >> 5, l31 = lane & 31;
+    const int ntn = Kp / BN;
     const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const long HW = (long)H * W;
@@ -59,9 +65,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
             a_img[j] = 0;
         }
     }
-    const int b_n4 = (BN == 128) ? (tid & 31) : (tid & 15);
-    const int b_k0 = (BN == 128) ? (tid >> 5) : (tid >> 4);
-    constexpr int b_kstep = (BN == 128) ? 8 : 16;
+    constexpr int BN4 = BN / 4;                // float4 per B row (32, 16, 8)
+    const int b_n4 = tid % BN4;
+    const int b_k0 = tid / BN4;
+    constexpr int b_kstep = 256 / BN4;         // 8, 16, 32
 
     f32x4 ra[4], rb[BLD];
     auto gload = [&](int s) {
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int iy = a_y[j] + dy, ix = a_x[j] + dx;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && (c0 + a_c4 * 4 < C);
             const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
             const float* p = x + ((a_img[j] + (long)sy * Ws + sx) * C + c0 + a_c4 * 4);
             ra[j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
 #pragma unroll
         for (int j = 0; j < BLD; ++j) {
             const int kr = b_k0 + b_kstep * j;
-            const float* p = wp + ((long)(tap * C + c0 + kr) * K + n0 + b_n4 * 4);
+            const float* p = wp + ((long)(tap * Cp + c0 + kr) * Kp + n0 + b_n4 * 4);
             rb[j] = *reinterpret_cast<const f32x4*>(p);
         }
     };
@@ -94,37 +101,38 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
             *reinterpret_cast<f32x4*>(b + (b_k0 + b_kstep * j) * BN + b_n4 * 4) = rb[j];
     };
 
-    f32x16 acc[2][NR];
+    f32x16 acc[MR][NR];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int S = (C / BK) * 9;
+    const int S = (Cp / BK) * 9;
     gload(0);
     lstore(0);
     __syncthreads();
     for (int s = 0; s < S; ++s) {
         const int buf = s & 1;
         if (s + 1 < S) gload(s + 1);
-        const float* Ab = As + buf * BM * LDA + (wm * 64 + l31) * LDA + 4 * hl;
+        const float* Ab = As + buf * BM * LDA + (wm * WM + l31) * LDA + 4 * hl;
         const float* Bb = Bs + buf * BK * BN + (4 * hl) * BN + wn * WN + l31;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(Ab + 8 * q);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(Ab + 32 * LDA + 8 * q);
+            f32x4 av[MR];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) av[mr] = *reinterpret_cast<const f32x4*>(Ab + mr * 32 * LDA + 8 * q);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float bv[NR];
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) bv[nr] = Bb[(8 * q + j) * BN + nr * 32];
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) {
-                    acc[0][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], bv[nr], acc[0][nr], 0, 0, 0);
-                    acc[1][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], bv[nr], acc[1][nr], 0, 0, 0);
-                }
+                for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][j], bv[nr], acc[mr][nr], 0, 0, 0);
             }
         }
         if (s + 1 < S) lstore(buf ^ 1);
@@ -132,18 +140,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
     }
 
     // ---- epilogue: bias (+ReLU) (+BN statistic partials), NHWC store
-    double* red = reinterpret_cast<double*>(As);   // [2 (wm)][2 (sum, sumsq)][BN]
+    double* red = reinterpret_cast<double*>(As);   // [WAVES_M][2 (sum, sumsq)][BN]
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int col = wn * WN + nr * 32 + l31;
-        const float bz = bias ? bias[n0 + col] : 0.f;
+        const bool nok = n0 + col < K;
+        const float bz = (bias && nok) ? bias[n0 + col] : 0.f;
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
+        for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long m = m0 + wm * 64 + mr * 32 + egz_acc_row(r, lane);
-                if (m < M) {
+                const long m = m0 + wm * WM + mr * 32 + egz_acc_row(r, lane);
+                if (m < M && nok) {
                     float v = acc[mr][nr][r] + bz;
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                     y[m * K + n0 + col] = v;
@@ -165,31 +174,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
     }
     if (EPI == EPI_BIAS_STATS) {
         __syncthreads();
-        if (tid < BN) {
-            stat[((long)tile_m * 2 + 0) * K + n0 + tid] = red[(0 * 2 + 0) * BN + tid] + red[(1 * 2 + 0) * BN + tid];
-            stat[((long)tile_m * 2 + 1) * K + n0 + tid] = red[(0 * 2 + 1) * BN + tid] + red[(1 * 2 + 1) * BN + tid];
+        if (tid < BN && n0 + tid < K) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < WAVES_M; ++w) {
+                t1 += red[(w * 2 + 0) * BN + tid];
+                t2 += red[(w * 2 + 1) * BN + tid];
+            }
+            stat[((long)tile_m * 2 + 0) * K + n0 + tid] = t1;
+            stat[((long)tile_m * 2 + 1) * K + n0 + tid] = t2;
         }
     }
 }
 
-// wp[(tap*C + c)*K + k] = w[(k*C + c)*9 + tap]
-__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K) {
-    const long n = (long)9 * C * K;
+// wp[(tap*Cp + c)*Kp + k] = w[(k*C + c)*9 + tap], zero in the padding (Cp, Kp = C, K rounded up to 32)
+__global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K, int Cp, int Kp) {
+    const long n = (long)9 * Cp * Kp;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % K);
-        const long t = i / K;
-        const int c = (int)(t % C), tap = (int)(t / C);
-        wp[i] = w[((long)k * C + c) * 9 + tap];
+        const int k = (int)(i % Kp);
+        const long t = i / Kp;
+        const int c = (int)(t % Cp), tap = (int)(t / Cp);
+        wp[i] = (c < C && k < K) ? w[((long)k * C + c) * 9 + tap] : 0.f;
     }
 }
-// dgrad view: dX = conv3x3(dY, Wd) with Wd[(8-tap)][k][c] = w[k][c][tap]  (tap flip + in/out transpose)
-__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K) {
-    const long n = (long)9 * C * K;
+// dgrad view: dX = conv3x3(dY, Wd) with Wd[(8-tap)][k][c] = w[k][c][tap]  (tap flip + in/out transpose), padded
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K, int Cp, int Kp) {
+    const long n = (long)9 * Cp * Kp;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long t = i / C;
-        const int k = (int)(t % K), tapf = (int)(t / K);
-        wp[i] = w[((long)k * C + c) * 9 + (8 - tapf)];
+        const int c = (int)(i % Cp);
+        const long t = i / Cp;
+        const int k = (int)(t % Kp), tapf = (int)(t / Kp);
+        wp[i] = (c < C && k < K) ? w[((long)k * C + c) * 9 + (8 - tapf)] : 0.f;
     }
 }
 
@@ -197,9 +212,10 @@ template <int BN, bool UPS, int EPI>
 int launch_igemm(const float* x, const float* wp, const float* bias, float* y, double* stat, int B, int H,
                  int W, int C, int K, hipStream_t st) {
     const long M = (long)B * H * W;
-    const int grid = egz_cdiv(M, BM) * (K / BN);
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const int grid = egz_cdiv(M, BM) * (Kp / BN);
     hipLaunchKernelGGL((conv3x3_igemm_kernel<BN, UPS, EPI>), dim3(grid), dim3(256), 0, st, x, wp, bias, y,
-                       stat, B, H, W, C, K);
+                       stat, B, H, W, C, K, Cp, Kp);
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd");
     return 0;
 }
@@ -215,6 +231,7 @@ int dispatch_epi(int epi, const float* x, const float* wp, const float* bias, fl
 }
 
 int pick_bn(long M, int K, int flags) {
+    if (K % 64 != 0) return 32;       // late-fusion widths (32, 8): one 32-wide n-tile, 4 waves along m
     if (flags & 0x100) return 64;
     if (flags & 0x200) return 128;
     if (K % 128 != 0) return 64;
@@ -227,20 +244,26 @@ int pick_bn(long M, int K, int flags) {
 
 EGZ_API int egz_conv3x3_stat_rows(int B, int H, int W) { return egz_cdiv((long)B * H * W, BM); }
 
+EGZ_API size_t egz_pack_w3x3_elems(int C, int K) {
+    return (size_t)9 * ((C + 31) / 32 * 32) * ((K + 31) / 32 * 32);
+}
+
 EGZ_API int egz_pack_w3x3_fwd(const float* w, float* wp, int C, int K, hipStream_t st) {
     EGZ_CHECK_ARG(w && wp && C > 0 && K > 0, "egz_pack_w3x3_fwd: bad arguments");
-    const long n = (long)9 * C * K;
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const long n = (long)9 * Cp * Kp;
     hipLaunchKernelGGL(pack_fwd_kernel, dim3(egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256)), dim3(256), 0, st, w,
-                       wp, C, K);
+                       wp, C, K, Cp, Kp);
     EGZ_CHECK_LAUNCH("egz_pack_w3x3_fwd");
     return 0;
 }
 
 EGZ_API int egz_pack_w3x3_dgrad(const float* w, float* wp, int C, int K, hipStream_t st) {
     EGZ_CHECK_ARG(w && wp && C > 0 && K > 0, "egz_pack_w3x3_dgrad: bad arguments");
-    const long n = (long)9 * C * K;
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const long n = (long)9 * Cp * Kp;
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256)), dim3(256), 0, st,
-                       w, wp, C, K);
+                       w, wp, C, K, Cp, Kp);
     EGZ_CHECK_LAUNCH("egz_pack_w3x3_dgrad");
     return 0;
 }
@@ -252,14 +275,18 @@ EGZ_API int egz_conv3x3_fwd(const float* x, const float* wp, const float* bias, 
                             int B, int H, int W, int C, int K, int flags, hipStream_t st) {
     EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd: null pointer");
     EGZ_CHECK_ARG(B > 0 && H > 0 && W > 0, "egz_conv3x3_fwd: bad shape %dx%dx%d", B, H, W);
-    EGZ_CHECK_ARG(C % 32 == 0 && C > 0, "egz_conv3x3_fwd: Cin=%d must be a positive multiple of 32", C);
-    EGZ_CHECK_ARG(K % 64 == 0 && K > 0, "egz_conv3x3_fwd: Cout=%d must be a positive multiple of 64", K);
+    EGZ_CHECK_ARG(C % 4 == 0 && C > 0, "egz_conv3x3_fwd: Cin=%d must be a positive multiple of 4", C);
+    EGZ_CHECK_ARG(K > 0 && (K % 64 == 0 || K <= 32), "egz_conv3x3_fwd: Cout=%d must be a multiple of 64 or <= 32", K);
+    EGZ_CHECK_ARG(((uintptr_t)x % 16 == 0), "egz_conv3x3_fwd: x must be 16-byte aligned");
     const bool ups = flags & 1;
     EGZ_CHECK_ARG(!ups || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_fwd: upsampled output must be even");
     const int epi = (flags >> 4) & 3;
     EGZ_CHECK_ARG(epi <= 2, "egz_conv3x3_fwd: bad epilogue %d", epi);
     EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd: stats epilogue needs stat_partial");
     const int bn = pick_bn((long)B * H * W, K, flags);
+    if (bn == 32)
+        return ups ? dispatch_epi<32, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
+                   : dispatch_epi<32, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st);
     if (bn == 128)
         return ups ? dispatch_epi<128, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
                    : dispatch_epi<128, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st);

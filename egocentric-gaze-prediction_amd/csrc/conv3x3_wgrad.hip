@@ -119,6 +119,84 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
             }
 }
 
+// Narrow layers (late_fusion: C = 32, K = 32 / 8): one 32(c) x 32(k) MFMA tile per block; the four waves split
+// each 32-pixel stage four ways (intra-block split-K) and are summed through LDS at the end.  Channel counts
+// that are not multiples of 32 are masked on load / store.
+template <bool UPS>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad32_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, long pix_per_split) {
+    __shared__ __attribute__((aligned(16))) float Xs[2 * PK * 32];
+    __shared__ __attribute__((aligned(16))) float Ds[2 * PK * 32];
+    __shared__ float red[4 * 32 * 33];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
+    const int tk = (K + 31) / 32;
+    const int tap = blockIdx.x % 9;
+    const int tile = blockIdx.x / 9;
+    const int c0 = (tile / tk) * 32, k0 = (tile % tk) * 32;
+    const int dyy = tap / 3 - 1, dxx = tap % 3 - 1;
+    const long HW = (long)H * W, M = (long)B * HW;
+    const long mbeg = (long)blockIdx.y * pix_per_split;
+    const long mend = (mbeg + pix_per_split < M) ? (mbeg + pix_per_split) : M;
+    const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
+    const int ch4 = tid & 7, p0 = tid >> 3;
+    const bool cok = c0 + ch4 * 4 < C, kok = k0 + ch4 * 4 < K;
+
+    f32x4 rx, rd;
+    auto gload = [&](long mb) {
+        const long m = mb + p0;
+        rx = f32x4{0.f, 0.f, 0.f, 0.f};
+        rd = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < mend) {
+            if (kok) rd = *reinterpret_cast<const f32x4*>(dy + m * K + k0 + ch4 * 4);
+            const long b = m / HW;
+            const int rem = (int)(m - b * HW);
+            const int yy = rem / W, xx = rem - yy * W;
+            const int iy = yy + dyy, ix = xx + dxx;
+            if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+                rx = *reinterpret_cast<const f32x4*>(x + ((b * Hs + sy) * (long)Ws + sx) * C + c0 + ch4 * 4);
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        *reinterpret_cast<f32x4*>(Xs + buf * PK * 32 + p0 * 32 + ch4 * 4) = rx;
+        *reinterpret_cast<f32x4*>(Ds + buf * PK * 32 + p0 * 32 + ch4 * 4) = rd;
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nst = (int)((mend - mbeg + PK - 1) / PK);
+    if (nst > 0) {
+        gload(mbeg);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nst) gload(mbeg + (long)(s + 1) * PK);
+        const float* Ab = Xs + buf * PK * 32 + (8 * wave + hl) * 32 + l31;
+        const float* Bb = Ds + buf * PK * 32 + (8 * wave + hl) * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[(2 * t) * 32], Bb[(2 * t) * 32], acc, 0, 0, 0);
+        if (s + 1 < nst) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 32 + egz_acc_row(r, lane)) * 33 + l31] = acc[r];
+    __syncthreads();
+    float* out = part + ((long)blockIdx.y * 9 + tap) * C * K;
+    for (int i = tid; i < 32 * 32; i += 256) {
+        const int c = i >> 5, k = i & 31;
+        if (c0 + c < C && k0 + k < K)
+            out[(long)(c0 + c) * K + k0 + k] = (red[(0 * 32 + c) * 33 + k] + red[(1 * 32 + c) * 33 + k]) +
+                                               (red[(2 * 32 + c) * 33 + k] + red[(3 * 32 + c) * 33 + k]);
+    }
+}
+
 // dw[(k*C + c)*9 + tap] = sum_s part[s][tap][c][k]   (fixed order -> deterministic)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int K, int S) {
     const long n = (long)9 * C * K;
@@ -134,7 +212,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 }
 
 int pick_splits(long M, int C, int K, int BT) {
-    const long tiles = (long)(C / BT) * (K / BT) * 9;
+    const long tiles = (long)((C + BT - 1) / BT) * ((K + BT - 1) / BT) * 9;
     long s = (768 + tiles - 1) / tiles;           // aim at ~3 blocks per CU
     const long smax = (M + 1023) / 1024;          // at least ~1k pixels per split
     if (s > smax) s = smax;
@@ -143,6 +221,7 @@ int pick_splits(long M, int C, int K, int BT) {
 }
 
 int pick_bt(int C, int K, int flags) {
+    if (C % 64 != 0 || K % 64 != 0) return 32;
     if (flags & 0x100) return 64;
     return (C % 128 == 0 && K % 128 == 0) ? 128 : 64;
 }
@@ -160,7 +239,7 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
                               int flags, void* workspace, size_t ws_bytes, hipStream_t st) {
     EGZ_CHECK_ARG(x && dy && dw && workspace, "egz_conv3x3_wgrad: null pointer");
-    EGZ_CHECK_ARG(C % 64 == 0 && K % 64 == 0 && C > 0 && K > 0, "egz_conv3x3_wgrad: C=%d K=%d must be multiples of 64", C, K);
+    EGZ_CHECK_ARG(C % 4 == 0 && K % 4 == 0 && C > 0 && K > 0, "egz_conv3x3_wgrad: C=%d K=%d must be multiples of 4", C, K);
     const bool ups = flags & 1;
     EGZ_CHECK_ARG(!ups || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_wgrad: upsampled output must be even");
     const long M = (long)B * H * W;
@@ -170,8 +249,11 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     long pps = (M + S - 1) / S;
     pps = (pps + PK - 1) / PK * PK;
     float* part = static_cast<float*>(workspace);
-    dim3 grid((C / bt) * (K / bt) * 9, S);
-    if (bt == 128) {
+    dim3 grid(((C + bt - 1) / bt) * ((K + bt - 1) / bt) * 9, S);
+    if (bt == 32) {
+        if (ups) hipLaunchKernelGGL(conv3x3_wgrad32_kernel<true>, grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+        else     hipLaunchKernelGGL(conv3x3_wgrad32_kernel<false>, grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+    } else if (bt == 128) {
         if (ups) hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
         else     hipLaunchKernelGGL((conv3x3_wgrad_kernel<128, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
     } else {

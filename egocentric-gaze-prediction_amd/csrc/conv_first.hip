@@ -17,11 +17,11 @@ constexpr int KCH = CCH * 9;   // 36 k per chunk
 constexpr int FLDA = KCH + 1;  // 37: odd stride -> conflict-free column reads
 
 // y[m][k] (NHWC, 64 channels) = bias[k] + sum_{c,tap} x[b][c][y+dy][x+dx] * w[k][c][tap]
-template <bool STATS>
+template <bool STATS, int KT>   // KT = Cout / 32 (2: SP encoders, 1: late-fusion first conv)
 __global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C) {
-    constexpr int K = 64;
+    constexpr int K = 32 * KT;
     __shared__ float As[FM * FLDA];
     __shared__ float Bs[KCH * K];
     __shared__ double red[4 * 2 * K];
@@ -43,9 +43,11 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
         pimg = b * C * HW;
     }
 
-    f32x16 acc[2];
+    f32x16 acc[KT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     for (int cc0 = 0; cc0 < C; cc0 += CCH) {
         // ---- im2col gather: As[p][kk], kk = (c - cc0)*9 + tap
@@ -71,15 +73,15 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < KCH / 2; ++t) {
             const float a = Ab[2 * t];
-            const float b0 = Bb[(2 * t) * K], b1 = Bb[(2 * t) * K + 32];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bb[(2 * t) * K + 32 * j], acc[j], 0, 0, 0);
         }
         __syncthreads();
     }
 
 #pragma unroll
-    for (int nr = 0; nr < 2; ++nr) {
+    for (int nr = 0; nr < KT; ++nr) {
         const int col = nr * 32 + l31;
         const float bz = bias ? bias[col] : 0.f;
         double s1 = 0.0, s2 = 0.0;
@@ -118,14 +120,15 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
 
 // partial[split][k][kkp] with kkp = c*9 + tap padded to KP (multiple of 32):
 //   sum over the split's pixels of dy[m][k] * x[b][c][y+dy][x+dx]
-template <int NT>   // NT = KP/32 : 1 (Cin=3) or 6 (Cin=20)
+template <int NT, int KT>   // NT = KP/32 : 1 (Cin <= 3) or 6 (Cin = 20);  KT = Cout/32
 __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
     int C, long pix_per_split) {
-    constexpr int K = 64, KP = NT * 32, PKS = 32;
+    constexpr int K = 32 * KT, KP = NT * 32, PKS = 32;
+    constexpr int XLD = KP + 1;                     // odd row stride: conflict-free transposing writes
     constexpr int TW = (NT == 1) ? 1 : NT / 2;      // n-tiles per wave
-    __shared__ float Ds[PKS * K];                   // [pixel][k]
-    __shared__ float Xs[PKS * KP];                  // [pixel][kkp]
+    __shared__ __attribute__((aligned(16))) float Ds[PKS * K];   // [pixel][k]
+    __shared__ float Xs[PKS * XLD];                 // [pixel][kkp]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
     const int wk = wave >> 1, wn = wave & 1;        // k-half (32 filters), kkp-half
@@ -140,13 +143,13 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    const bool active = (NT != 1) || (wn == 0);     // Cin=3: only one 32-wide kkp tile exists
+    const bool active = (wk < KT) && ((NT != 1) || (wn == 0));   // idle waves when a dimension has one tile
     for (long mb = mbeg; mb < mend; mb += PKS) {
-        // dy tile: 32 pixels x 64 filters = 512 float4
+        // dy tile: 32 pixels x K filters = 8*K float4
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < KT; ++j) {
             const int i = tid + 256 * j;
-            const int pp = i >> 4, k4 = i & 15;
+            const int pp = i / (K / 4), k4 = i % (K / 4);
             const long m = mb + pp;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (m < mend) v = *reinterpret_cast<const f32x4*>(dy + m * K + k4 * 4);
@@ -173,19 +176,19 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
                     if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
                         v = x[img + (long)c * HW + (long)iy * W + ix];
                 }
-                Xs[pp * KP + kk] = v;
+                Xs[pp * XLD + kk] = v;
             }
         }
         __syncthreads();
         if (active) {
             const float* Ab = Ds + hl * K + wk * 32 + l31;
-            const float* Bb = Xs + hl * KP + wn * (TW * 32) + l31;
+            const float* Bb = Xs + hl * XLD + wn * (TW * 32) + l31;
 #pragma unroll
             for (int t = 0; t < PKS / 2; ++t) {
                 const float a = Ab[(2 * t) * K];
 #pragma unroll
                 for (int j = 0; j < TW; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bb[(2 * t) * KP + j * 32], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bb[(2 * t) * XLD + j * 32], acc[j], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -204,12 +207,12 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
 }
 
 // dw[k][c][tap] (= [k][kk], kk < 9C) = sum_s part[s][k][kk]
-__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int KK, int KP, int S) {
-    const int n = 64 * KK;
+__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int K, int KK, int KP, int S) {
+    const int n = K * KK;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int k = i / KK, kk = i - k * KK;
         float s = 0.f;
-        for (int sp = 0; sp < S; ++sp) s += part[((long)sp * 64 + k) * KP + kk];
+        for (int sp = 0; sp < S; ++sp) s += part[((long)sp * K + k) * KP + kk];
         dw[i] = s;
     }
 }
@@ -230,39 +233,45 @@ EGZ_API int egz_conv_first_stat_rows(int B, int H, int W) { return egz_cdiv((lon
 EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, double* stat_partial,
                                int B, int H, int W, int C, int K, hipStream_t st) {
     EGZ_CHECK_ARG(x && w && y, "egz_conv_first_fwd: null pointer");
-    EGZ_CHECK_ARG(K == 64, "egz_conv_first_fwd: Cout must be 64 (got %d)", K);
+    EGZ_CHECK_ARG(K == 64 || K == 32, "egz_conv_first_fwd: Cout must be 64 or 32 (got %d)", K);
     EGZ_CHECK_ARG(C > 0 && C <= 64 && B > 0 && H > 0 && W > 0, "egz_conv_first_fwd: bad shape");
     const int grid = egz_cdiv((long)B * H * W, FM);
-    if (stat_partial)
-        hipLaunchKernelGGL(conv_first_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
-    else
-        hipLaunchKernelGGL(conv_first_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
+    if (K == 64) {
+        if (stat_partial) hipLaunchKernelGGL((conv_first_fwd_kernel<true, 2>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
+        else              hipLaunchKernelGGL((conv_first_fwd_kernel<false, 2>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
+    } else {
+        if (stat_partial) hipLaunchKernelGGL((conv_first_fwd_kernel<true, 1>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
+        else              hipLaunchKernelGGL((conv_first_fwd_kernel<false, 1>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);
+    }
     EGZ_CHECK_LAUNCH("egz_conv_first_fwd");
     return 0;
 }
 
 EGZ_API size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C) {
-    return (size_t)first_splits((long)B * H * W) * 64 * first_kp(C) * sizeof(float);
+    return (size_t)first_splits((long)B * H * W) * 64 * first_kp(C) * sizeof(float);   // sized for Cout = 64
 }
 
 EGZ_API int egz_conv_first_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
                                  void* workspace, size_t ws_bytes, hipStream_t st) {
     EGZ_CHECK_ARG(x && dy && dw && workspace, "egz_conv_first_wgrad: null pointer");
-    EGZ_CHECK_ARG(K == 64, "egz_conv_first_wgrad: Cout must be 64 (got %d)", K);
+    EGZ_CHECK_ARG(K == 64 || K == 32, "egz_conv_first_wgrad: Cout must be 64 or 32 (got %d)", K);
     const int KP = first_kp(C);
-    EGZ_CHECK_ARG(KP == 32 || KP == 192, "egz_conv_first_wgrad: Cin=%d unsupported (3 or 20..21)", C);
+    EGZ_CHECK_ARG(KP == 32 || KP == 192, "egz_conv_first_wgrad: Cin=%d unsupported (1..3 or 18..21)", C);
     const long M = (long)B * H * W;
     const int S = first_splits(M);
-    EGZ_CHECK_ARG(ws_bytes >= (size_t)S * 64 * KP * sizeof(float), "egz_conv_first_wgrad: workspace too small");
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)S * K * KP * sizeof(float), "egz_conv_first_wgrad: workspace too small");
     long pps = (M + S - 1) / S;
     pps = (pps + 31) / 32 * 32;
     float* part = static_cast<float*>(workspace);
-    if (KP == 32)
-        hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
-    else
-        hipLaunchKernelGGL(conv_first_wgrad_kernel<6>, dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
+    if (K == 64) {
+        if (KP == 32) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, 2>), dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
+        else          hipLaunchKernelGGL((conv_first_wgrad_kernel<6, 2>), dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
+    } else {
+        if (KP == 32) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, 1>), dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
+        else          hipLaunchKernelGGL((conv_first_wgrad_kernel<6, 1>), dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
+    }
     EGZ_CHECK_LAUNCH("egz_conv_first_wgrad");
-    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(egz_cdiv(64 * 9 * C, 256)), dim3(256), 0, st, part, dw, 9 * C, KP, S);
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(egz_cdiv(K * 9 * C, 256)), dim3(256), 0, st, part, dw, K, 9 * C, KP, S);
     EGZ_CHECK_LAUNCH("egz_conv_first_wgrad(reduce)");
     return 0;
 }

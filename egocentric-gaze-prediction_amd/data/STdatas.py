@@ -1,0 +1,55 @@
+"""Mirror of the reference's ``data/STdatas.py``: RGB frame + 10-pair optical-flow stack + ground-truth gaze map
++ fixation flag per sample (data/STdatas.py:9-73).  Host-side disk I/O, out of the kernel scope; what the hot path
+relies on is the tensor contract: 'image' (3,H,W) = (u8/255 - mean)/std on BGR-ordered channels, 'flow' (20,H,W) =
+(u8/255 - 0.5)/0.5 ordered x_t, y_t, x_{t-1}, y_{t-1}, ..., 'gt' (1,H,W) = u8/255, 'fixsac' (1,), 'imname'."""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from ._io import imread
+
+_MEAN = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+_STD = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+
+
+def build_temporal_list(imgPath, gtPath, listFolders, listGtFiles):
+    """Flow window looks backwards: frames n, n-1, ..., n-9 (data/STdatas.py:18-20); file-name parsing is
+    positional like the reference (gt[:-17] = folder, gt[-9:-4] = frame number)."""
+    imgx, imgy = [], []
+    for gt in listGtFiles:
+        folder, number = gt[:-17], int(gt[-9:-4])
+        assert folder in listFolders
+        imgx.append([os.path.join(imgPath, folder, 'flow_x_%05d.jpg' % (number - m)) for m in range(10)])
+        imgy.append([os.path.join(imgPath, folder, 'flow_y_%05d.jpg' % (number - m)) for m in range(10)])
+    return imgx, imgy
+
+
+class STDataset(Dataset):
+    def __init__(self, imgPath, imgPath_s, gtPath, listFolders, listTrainFiles, listGtFiles, listfixsacTrain,
+                 fixsacPath):
+        self.listFolders, self.listGtFiles = listFolders, listGtFiles
+        self.imgPath, self.imgPath_s, self.gtPath = imgPath, imgPath_s, gtPath
+        self.listTrainFiles = listTrainFiles
+        self.imgx, self.imgy = build_temporal_list(imgPath, gtPath, listFolders, listGtFiles)
+        chunks = []
+        for f in listfixsacTrain:          # dilate the fixation labels by one frame each side (:37-41)
+            a = np.loadtxt(os.path.join(fixsacPath, f))
+            chunks.append((np.convolve(a, np.array([1, 1, 1]))[1:-1] > 0).astype(float))
+        self.fixsac = np.concatenate(chunks) if chunks else np.zeros(0)
+
+    def __len__(self):
+        return len(self.listGtFiles)
+
+    def __getitem__(self, index):
+        im = torch.from_numpy(imread(os.path.join(self.imgPath_s, self.listTrainFiles[index])).transpose((2, 0, 1)).copy())
+        im = (im.float().div(255) - _MEAN) / _STD
+        planes = []
+        for fx, fy in zip(self.imgx[index], self.imgy[index]):
+            planes.append(torch.from_numpy(imread(fx, gray=True)))
+            planes.append(torch.from_numpy(imread(fy, gray=True)))
+        flow = (torch.stack(planes).float().div_(255) - 0.5) / 0.5
+        gt = torch.from_numpy(imread(os.path.join(self.gtPath, self.listGtFiles[index]), gray=True)).float().div(255)
+        return {'image': im, 'flow': flow, 'gt': gt.unsqueeze(0),
+                'fixsac': torch.FloatTensor([self.fixsac[index]]), 'imname': self.listTrainFiles[index]}

@@ -57,7 +57,7 @@ class _LibProxy:
         fn = getattr(self._raw, name)
 
         def call(*a):
-            if not PROF.enabled or name.endswith(("_bytes", "_rows")):      # size queries launch nothing
+            if not PROF.enabled or name.endswith(("_bytes", "_rows", "_elems")):      # size queries launch nothing
                 return fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -144,7 +144,8 @@ def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
     hit = _PACKED.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    buf = hit[1] if hit is not None else torch.empty(9 * C * K, dtype=torch.float32, device=w.device)
+    buf = hit[1] if hit is not None else torch.empty(LIB.egz_pack_w3x3_elems(C, K), dtype=torch.float32,
+                                                     device=w.device)
     fn = LIB.egz_pack_w3x3_fwd if kind == "fwd" else LIB.egz_pack_w3x3_dgrad
     check(fn(w.data_ptr(), buf.data_ptr(), C, K, _stream()), "pack_w3x3")
     _PACKED[key] = (tag, buf)

@@ -7,42 +7,12 @@ post-ReLU (B,512,14,14) activation.
 """
 import torch.nn as nn
 
-from ..functions import ConvReLU, FusionBlock, HeadSigmoid
-from ..utils import init_like_reference
+from ..functions import FusionBlock
+from ..utils import FusedSequential, init_like_reference
 
 # models/model_SP.py:13-31 as (Cin, Cout) 3x3+ReLU blocks and 'U' = nearest x2 upsample; a 1x1 head follows
 _DECODER_PLAN = [(512, 512), (512, 512), 'U', (512, 512), (512, 512), (512, 512), 'U', (512, 256), (256, 256),
                  (256, 256), 'U', (256, 128), (128, 128), 'U', (128, 64), (64, 64)]
-
-
-class DecoderSequential(nn.Sequential):
-    """The reference decoder's children (models/model_SP.py:13-31) with fused execution:
-    [Upsample x2 ->] Conv3x3 -> ReLU blocks (the upsample is folded into the conv's gather) and the
-    final Conv1x1 fused with the Sigmoid that follows it in model_SP.forward."""
-
-    def forward(self, x, fuse_sigmoid=False):
-        mods = list(self.children())
-        i, n = 0, len(mods)
-        ups = False
-        while i < n:
-            m = mods[i]
-            if isinstance(m, nn.Upsample):
-                if m.scale_factor not in (2, 2.0) or m.mode != 'nearest':
-                    raise NotImplementedError("only nearest x2 upsampling is on the reference path")
-                ups = True
-                i += 1
-            elif isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and i + 1 < n and isinstance(mods[i + 1], nn.ReLU):
-                x = ConvReLU.apply(x, m.weight, m.bias, ups)
-                ups = False
-                i += 2
-            elif isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.out_channels == 1 and i == n - 1:
-                if not fuse_sigmoid:
-                    raise NotImplementedError("the 1x1 head runs fused with the Sigmoid (model_SP.forward)")
-                x = HeadSigmoid.apply(x, m.weight, m.bias)
-                i += 1
-            else:
-                raise NotImplementedError(f"decoder layer {i} ({type(m).__name__}) is not on the HIP path")
-        return x
 
 
 class model_SP(nn.Module):
@@ -61,7 +31,7 @@ class model_SP(nn.Module):
             else:
                 layers += [nn.Conv2d(item[0], item[1], kernel_size=3, padding=1), nn.ReLU(inplace=True)]
         layers.append(nn.Conv2d(64, 1, kernel_size=1, padding=0))
-        self.decoder = DecoderSequential(*layers)            # 29 children, indices as the reference's
+        self.decoder = FusedSequential(*layers)            # 29 children, indices as the reference's
         self.final = nn.Sigmoid()
         self._initialize_weights()
 

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .functions import ConvBNReLUPool, ConvReLU
+from .functions import ConvBNReLUPool, ConvReLU, HeadSigmoid
 
 # utils.py:57-62 -- last max pooling removed
 cfg = {
@@ -47,30 +47,54 @@ def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first:
     return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first)
 
 
-class EncoderSequential(nn.Sequential):
-    """nn.Sequential with the reference's children (so indices / state-dict keys / hooks / .parameters()
-    are identical) whose forward runs fused HIP blocks.  The first conv reads the NCHW network input
-    directly; later tensors are channels_last."""
+class FusedSequential(nn.Sequential):
+    """nn.Sequential holding exactly the reference's children (so child indices, state-dict keys, hooks and
+    ``.parameters()`` are identical) whose ``forward`` executes fused HIP blocks instead of the children:
 
-    def forward(self, x):
+      Conv2d 3x3 -> BatchNorm2d -> ReLU [-> MaxPool2d(2,2)]   -> functions.ConvBNReLUPool
+      [Upsample x2 nearest ->] Conv2d 3x3 -> ReLU             -> functions.ConvReLU (upsample folded in)
+      Conv2d 1x1 (C -> 1) as last child, followed by Sigmoid  -> functions.HeadSigmoid (``fuse_sigmoid=True``)
+
+    Used for the VGG16-BN encoders (utils.py:64-76), the SP decoder (models/model_SP.py:13-31) and the
+    late-fusion stack (models/late_fusion.py:10-13).  A first conv with < 32 input channels reads the NCHW
+    network input directly; every later tensor is channels_last."""
+
+    def forward(self, x, fuse_sigmoid=False):
         mods = list(self.children())
         i, n = 0, len(mods)
-        first = True
+        first, ups = True, False
         while i < n:
             m = mods[i]
-            if isinstance(m, nn.Conv2d) and i + 2 < n and isinstance(mods[i + 1], nn.BatchNorm2d) \
-                    and isinstance(mods[i + 2], nn.ReLU):
+            nxt = mods[i + 1] if i + 1 < n else None
+            if isinstance(m, nn.Upsample):
+                if m.scale_factor not in (2, 2.0) or m.mode != 'nearest':
+                    raise NotImplementedError("only nearest x2 upsampling is on the reference path")
+                ups = True
+                i += 1
+                continue
+            if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and isinstance(nxt, nn.BatchNorm2d) \
+                    and i + 2 < n and isinstance(mods[i + 2], nn.ReLU):
+                if ups:
+                    raise NotImplementedError("upsample in front of a BatchNorm block is not on the reference path")
                 pool = i + 3 < n and isinstance(mods[i + 3], nn.MaxPool2d)
-                is_first = first and m.in_channels < 32
-                x = conv_bn_relu_pool(x, m, mods[i + 1], pool, is_first)
+                x = conv_bn_relu_pool(x, m, nxt, pool, first and m.in_channels < 32)
                 i += 4 if pool else 3
-            elif isinstance(m, nn.Conv2d) and i + 1 < n and isinstance(mods[i + 1], nn.ReLU):
-                x = ConvReLU.apply(x, m.weight, m.bias, False)      # batch_norm=False variant (utils.py:73-74)
+            elif isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and isinstance(nxt, nn.ReLU):
+                x = ConvReLU.apply(x, m.weight, m.bias, ups)
+                ups = False
                 i += 2
+            elif isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.out_channels == 1 and i == n - 1:
+                if not fuse_sigmoid:
+                    raise NotImplementedError("the 1x1 head runs fused with the Sigmoid that follows it")
+                x = HeadSigmoid.apply(x, m.weight, m.bias)
+                i += 1
             else:
                 raise NotImplementedError(f"layer pattern at index {i} ({type(m).__name__}) is not on the HIP path")
             first = False
         return x
+
+
+EncoderSequential = FusedSequential
 
 
 def make_layers(cfg, in_channels, batch_norm=True):
@@ -86,7 +110,7 @@ def make_layers(cfg, in_channels, batch_norm=True):
             else:
                 layers += [conv2d, nn.ReLU(inplace=True)]
             in_channels = v
-    return EncoderSequential(*layers)
+    return FusedSequential(*layers)
 
 
 def init_like_reference(root: nn.Module):

@@ -1,0 +1,139 @@
+/* egaze_hip.h -- C ABI of libegaze_hip.so (gfx950 / MI355X only).
+ *
+ * The drop-in boundary of the SP / AT / LF hot path of hyf015/egocentric-gaze-prediction.  The reference has no
+ * FFI layer of its own: its hot path is the set of torch.nn ops that models/model_SP.py, models/LSTMnet.py,
+ * models/late_fusion.py and floss.py execute.  Each entry point below replaces one of those
+ * op instances (forward and backward); the reference-side binding is the ctypes table in
+ * egocentric-gaze-prediction_amd/_lib.py (INTEGRATION.md shows how a maintainer wires it into the reference).
+ *
+ * Conventions
+ *   - device pointers only (fp32 unless stated); no allocation and no synchronisation inside: the caller passes
+ *     workspaces (sizes from the *_ws_bytes / *_rows / *_elems queries) and a hipStream_t; work is stream-ordered.
+ *   - activations are NHWC ([B][H][W][C]); network inputs (first conv) are NCHW as the reference's DataLoader
+ *     yields them; 1-channel maps are identical in both layouts; weights keep the reference layout (Cout,Cin,3,3).
+ *   - every function returns 0 on success or a non-zero hipError_t-style code; egz_last_error() returns the message
+ *     of the calling thread's last failure (the Python shim raises EgazeHipError / RuntimeError, matching the
+ *     reference's exception-based error behaviour, e.g. utils.py:151-152, extractLSTMw.py:111).
+ *   - reentrant per stream; one process per GPU (no cross-device state).
+ */
+#ifndef EGAZE_HIP_H
+#define EGAZE_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+const char* egz_version(void);
+const char* egz_last_error(void);
+
+/* ---- nn.Conv2d(Cin, Cout, 3, padding=1): utils.py:70 (encoders), models/model_SP.py:10,13-29 (fusion Conv3d
+ *      k=(1,3,3) == the same 3x3 conv on each stream; decoder), models/late_fusion.py:10-12.
+ *      Implicit GEMM on v_mfma_f32_32x32x2_f32.  Weights are re-packed on the device first:
+ *      fwd  : wp[tap][Cin_pad][Cout_pad]         dgrad: wp[8-tap][Cout_pad][Cin_pad]   (pad = round up to 32, zeros) */
+size_t egz_pack_w3x3_elems(int C, int K);
+int egz_pack_w3x3_fwd(const float* w, float* wp, int C, int K, hipStream_t stream);
+int egz_pack_w3x3_dgrad(const float* w, float* wp, int C, int K, hipStream_t stream);
+/* rows of the BatchNorm statistic partials written by the stats epilogue: stat_partial is [rows][2][K] fp64 */
+int egz_conv3x3_stat_rows(int B, int H, int W);
+/* y[B][H][W][K] = conv3x3(x) + bias.  H, W are OUTPUT dims.  flags: bit0 = x is [B][H/2][W/2][C] and is nearest-x2
+ * upsampled on the fly (nn.Upsample(scale_factor=2), models/model_SP.py:16,20,24,27); bits 4-5 epilogue: 0 bias,
+ * 1 bias+ReLU, 2 bias + per-channel (sum, sumsq) partials for train-mode BatchNorm; 0x100 / 0x200 force the
+ * 64 / 128 wide tile.  Called with dgrad-packed weights (and K = Cin) it computes the data gradient. */
+int egz_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* y, double* stat_partial, int B, int H,
+                    int W, int C, int K, int flags, hipStream_t stream);
+/* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
+size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
+int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,
+                      void* workspace, size_t ws_bytes, hipStream_t stream);
+
+/* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
+ *      per data/STdatas.py:50-73) and Conv2d(2,32) (models/late_fusion.py:10).  K in {64, 32}. */
+int egz_conv_first_stat_rows(int B, int H, int W);
+int egz_conv_first_fwd(const float* x_nchw, const float* w, const float* bias, float* y_nhwc, double* stat_partial,
+                       int B, int H, int W, int C, int K, hipStream_t stream);
+size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C);
+int egz_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw, int B, int H, int W, int C, int K,
+                         void* workspace, size_t ws_bytes, hipStream_t stream);
+
+/* ---- nn.BatchNorm2d (train: batch statistics + running-stat update with unbiased variance; eval: affine) fused with
+ *      the nn.ReLU and optional nn.MaxPool2d(2,2) that follow it (utils.py:68,72; models/model_SP.py:12,45-47;
+ *      models/late_fusion.py:10-12).  mean/invstd/scale/shift are [K] outputs kept for the backward pass. */
+size_t egz_bn_ws_bytes(int K);
+int egz_bn_finalize(const double* stat_partial, int rows, int K, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
+                    float* invstd_out, float* scale, float* shift, void* workspace, size_t ws_bytes,
+                    hipStream_t stream);
+int egz_bn_eval_coeffs(int K, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
+int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W,
+                         int K, int pool, hipStream_t stream);
+size_t egz_bn_relu_pool_bwd_ws_bytes(int K);
+int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int K,
+                         int pool, void* workspace, size_t ws_bytes, hipStream_t stream);
+
+/* ---- nn.MaxPool3d((2,1,1)) over the depth-2 stack == element-wise max of the two streams (model_SP.py:11,43);
+ *      y2 = [2][n] (stream s, then t), the first stream wins ties like torch's pooling scan. */
+int egz_pairmax_fwd(const float* y2, float* z, long n, hipStream_t stream);
+int egz_pairmax_bwd(const float* y2, const float* dz, float* dy2, long n, hipStream_t stream);
+/* per-channel (sum, sumsq) partials of an NHWC tensor, in the conv-epilogue format ([rows][2][K] fp64) */
+int egz_channel_stats_rows(void);
+int egz_channel_stats(const float* x, long rows, int K, double* stat_partial, hipStream_t stream);
+
+/* ---- nn.ReLU backward (decoder, models/model_SP.py:13-29), optionally fused with the conv bias gradient;
+ *      nn.Upsample(scale_factor=2) backward (2x2 sum); column sums; NCHW <-> NHWC transposes. */
+int egz_relu_bwd(const float* out, const float* dout, float* dy, long n, hipStream_t stream);
+size_t egz_relu_bwd_bias_ws_bytes(int K);
+int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, float* db, long rows, int K, void* workspace,
+                      size_t ws_bytes, hipStream_t stream);
+int egz_upsample2x_bwd(const float* dxu, float* dx, int B, int H, int W, int C, hipStream_t stream);
+int egz_colsum(const float* x, long rows, int K, float* out, void* workspace, size_t ws_bytes, hipStream_t stream);
+int egz_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
+int egz_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
+
+/* ---- nn.Conv2d(C, 1, 1) + nn.Sigmoid head (models/model_SP.py:30,32,49; models/late_fusion.py:13,15,22) */
+int egz_conv1x1_sigmoid_fwd(const float* x, const float* w, const float* bias, float* out, float* logits, long M,
+                            int C, hipStream_t stream);
+size_t egz_conv1x1_sigmoid_bwd_ws_bytes(int C);
+int egz_conv1x1_sigmoid_bwd(const float* x, const float* w, const float* out, const float* dout, float* dx, float* dw,
+                            float* db, long M, int C, void* workspace, size_t ws_bytes, hipStream_t stream);
+
+/* ---- floss.forward / build_weight_from_target (floss.py:9-41): W = width / (||p - centroid(argmax set)|| + 1),
+ *      F.binary_cross_entropy(input, target, W) with torch's -100 log clamp, mean reduction.  weighted = 0 gives
+ *      torch.nn.BCELoss() (SP.py:103-106).  Backward follows aten: w*(x-t)/max((1-x)x, 1e-12)/N.
+ *      nn.MSELoss (AT.py:83,138) likewise.  loss_out / grad_out are device scalars. */
+size_t egz_loss_ws_bytes(int B);
+int egz_floss_fwd(const float* inp, const float* target, float* weights_out, float* loss_out, int B, int H, int W,
+                  int weighted, void* workspace, size_t ws_bytes, hipStream_t stream);
+int egz_floss_bwd(const float* inp, const float* target, const float* weights, const float* grad_out, float* dinp,
+                  long n, hipStream_t stream);
+int egz_mse_fwd(const float* a, const float* b, float* loss_out, long n, void* workspace, size_t ws_bytes,
+                hipStream_t stream);
+int egz_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, long n, hipStream_t stream);
+
+/* ---- AT: nn.LSTM(512,512,2) + nn.Linear + tanh (models/LSTMnet.py:18-37) from a strided f32-MFMA GEMM and fused
+ *      cell kernels.  egz_gemm: C[M][N] (row stride ldc) = op(A) op(B) (+C if flags&1) (+bias[n]) (ReLU if flags&2),
+ *      op(A)(m,k) = A[m*sam + k*sak], op(B)(k,n) = B[k*sbk + n*sbn].  Gate order i,f,g,o. */
+int egz_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak,
+             long sbk, long sbn, long ldc, int flags, hipStream_t stream);
+int egz_lstm_cell_fwd(const float* gates, const float* c_prev, float* h_out, float* c_out, float* act, int B, int Hd,
+                      hipStream_t stream);
+int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, const float* dh, const float* dc_in,
+                      float* dgates, float* dc_prev, int B, int Hd, hipStream_t stream);
+int egz_tanh_fwd(const float* x, float* y, long n, hipStream_t stream);
+int egz_tanh_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream);
+int egz_add(const float* a, const float* b, float* out, long n, hipStream_t stream);
+
+/* ---- torch.optim.Adam step (defaults as configured at SP.py:110-113, AT.py:84, LF.py:77) over one flat buffer;
+ *      grad_scale multiplies the gradient first (1/world_size after the RCCL sum all-reduce). */
+int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                  double eps, int step, double grad_scale, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGAZE_HIP_H */

@@ -1,0 +1,115 @@
+"""GPU parity of the LF path (late_fusion + floss through the C-ABI) against the reference's golden vectors
+(tests/golden/late_fusion.npz) and the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import egaze_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def build():
+    from egaze_amd.models.late_fusion import late_fusion
+    net = late_fusion()
+    net.load_state_dict(synth.synth_state_dict(O.lf_shapes(), seed=3, head_gain=0.5))
+    return net.to(DEV)
+
+
+@pytest.mark.parametrize("C,K", [(32, 32), (32, 8), (8, 32)])
+def test_narrow_conv_ops(C, K):
+    """The 32-wide igemm tile, padded channel counts and the 32x32 wgrad tile used by late_fusion."""
+    import egaze_amd.hipops as h
+    g = torch.Generator().manual_seed(C * 100 + K)
+    x = torch.randn(2, C, 13, 10, generator=g).requires_grad_(True)
+    w = (torch.randn(K, C, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(K, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, padding=1)
+    dy = torch.randn(2, K, 13, 10, generator=g)
+    ref.backward(dy)
+    wd = w.detach().to(DEV)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y, stat = h.conv3x3_fwd(xd, h.packed_weight(wd, "fwd"), b.to(DEV), K, epi=h.EPI_BIAS_STATS)
+    assert rel(y.permute(0, 3, 1, 2).cpu().numpy(), ref.detach().numpy()) < 2e-5
+    assert rel(stat.sum(0)[0].cpu().numpy(), ref.detach().double().sum(dim=(0, 2, 3)).numpy()) < 1e-5
+    dx = h.conv3x3_dgrad(dyd, h.packed_weight(wd, "dgrad"), C)
+    assert rel(dx.permute(0, 3, 1, 2).cpu().numpy(), x.grad.numpy()) < 2e-5
+    dw = h.conv3x3_wgrad(xd, dyd)
+    assert rel(dw.cpu().numpy(), w.grad.numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("tag,size", [("s32", 32), ("s224", 224)])
+def test_late_fusion_golden(tag, size):
+    from egaze_amd.floss import floss
+    gold = np.load(os.path.join(GOLDEN, "late_fusion.npz"))
+    net = build()
+    im, feat, gt = synth.synth_lf_batch(2, size, seed=7)
+    imd, featd, gtd = im.to(DEV), feat.to(DEV), gt.to(DEV)
+    net.eval()
+    with torch.no_grad():
+        ev = net(featd, imd)
+        sw = net(imd, featd)
+    assert rel(ev.cpu().numpy(), gold[f"{tag}_eval_out"]) < 2e-5
+    assert abs(sw.double().sum().item() - float(gold[f"{tag}_eval_out_swapped_sum"])) < 1e-4 * abs(float(gold[f"{tag}_eval_out_swapped_sum"]))
+    net.train()
+    out = net(featd, imd)                                  # LF.py:90 argument order
+    loss = floss()(out, gtd)
+    loss.backward()
+    assert rel(out.detach().cpu().numpy(), gold[f"{tag}_train_out"]) < 5e-5
+    assert abs(loss.item() - float(gold[f"{tag}_loss"])) < 1e-4 * abs(float(gold[f"{tag}_loss"]))
+    gmax = max(np.abs(gold[f"{tag}_grad/{k}"]).max() for k, _ in net.named_parameters())
+    for k, p in net.named_parameters():
+        want = gold[f"{tag}_grad/{k}"]
+        if np.abs(want).max() < 1e-5 * gmax:               # conv biases in front of train-mode BN: exactly 0 here
+            assert p.grad.abs().max().item() < 1e-4 * gmax, k
+            continue
+        a, b = p.grad.cpu().numpy().ravel().astype(np.float64), want.ravel().astype(np.float64)
+        l2 = np.linalg.norm(a - b) / np.linalg.norm(b)
+        assert l2 < 2e-2 and rel(a, b) < 0.1, (k, l2, rel(a, b))
+    for k, v in net.state_dict().items():
+        if "running_" in k:
+            assert rel(v.cpu().numpy(), gold[f"{tag}_after/{k}"]) < 1e-4, k
+
+
+def test_late_fusion_grads_vs_fp64():
+    from egaze_amd.floss import floss
+    net = build()
+    sd = synth.synth_state_dict(O.lf_shapes(), seed=3, head_gain=0.5)
+    im, feat, gt = synth.synth_lf_batch(3, 48, seed=11)
+    net.train()
+    out = net(feat.to(DEV), im.to(DEV))
+    floss()(out, gt.to(DEV)).backward()
+
+    def run(dtype):
+        work = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        keys = O.trainable_keys(work)
+        for k in keys:
+            work[k].requires_grad_(True)
+        o = O.late_fusion_forward(work, feat.to(dtype), im.to(dtype), training=True)
+        O.floss_forward(o, gt.to(dtype)).backward()
+        return o.detach(), {k: work[k].grad for k in keys}
+    o32, g32 = run(torch.float32)
+    o64, g64 = run(torch.float64)
+    assert rel(out.detach().cpu().numpy(), o64.numpy()) < max(5 * rel(o32.numpy(), o64.numpy()), 2e-6)
+    eh, ec = [], []
+    for k, p in net.named_parameters():
+        if g64[k].abs().max().item() < 1e-9:
+            continue
+        eh.append(rel(p.grad.cpu().numpy(), g64[k].numpy()))
+        ec.append(rel(g32[k].numpy(), g64[k].numpy()))
+    print("LF HIP vs fp64: median %.2e max %.2e | CPU fp32: median %.2e max %.2e" %
+          (np.median(eh), max(eh), np.median(ec), max(ec)))
+    assert np.median(eh) < max(10 * np.median(ec), 1e-4) and max(eh) < 5e-2

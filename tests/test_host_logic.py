@@ -1,0 +1,90 @@
+"""CPU-only tests of the host side: C-ABI symbol table vs header vs the built .so, module construction /
+state-dict layout, CLI flags, host glue (change_key_names, computeAAEAUC, AverageMeter, repackage_hidden)."""
+import collections
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_cabi_header_table_and_library_agree():
+    import egaze_amd
+    from egaze_amd import _lib
+    header = open(os.path.join(ROOT, "include", "egaze_hip.h")).read()
+    declared = set(re.findall(r"\b(egz_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (egz_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert "gfx950" in egaze_amd.version()
+
+
+def test_state_dict_layouts_match_reference():
+    from oracle import egaze_oracle as O
+    from egaze_amd.models.model_SP import model_SP
+    from egaze_amd.models.LSTMnet import lstmnet
+    from egaze_amd.models.late_fusion import late_fusion
+    from egaze_amd.utils import make_layers, cfg
+    m = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20))
+    sd = m.state_dict()
+    assert list(sd) == list(O.sp_shapes()) and len(sd) == 215
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in O.sp_shapes().items())
+    assert sum(p.numel() for p in m.parameters()) == 46529409
+    assert len(list(m.decoder.children())) == 29 and len(list(m.features_s.children())) == 43
+    assert list(lstmnet().state_dict()) == list(O.lstm_shapes())
+    lf = late_fusion()
+    assert list(lf.state_dict()) == list(O.lf_shapes()) and sum(p.numel() for p in lf.parameters()) == 12321
+    # init semantics (models/model_SP.py:52-65): Conv2d fan-out normal + zero bias, BN 1/0, Conv3d untouched
+    assert float(m.decoder[0].bias.abs().max()) == 0 and float(m.bn.weight.min()) == 1
+    assert float(m.fusion.bias.abs().max()) > 0
+    std = float(m.decoder[0].weight.std())
+    assert abs(std - (2.0 / (9 * 512)) ** 0.5) < 0.05 * (2.0 / (9 * 512)) ** 0.5
+
+
+def test_cpu_tensors_are_rejected():
+    from egaze_amd.models.late_fusion import late_fusion
+    from egaze_amd.floss import floss
+    with pytest.raises(RuntimeError):
+        late_fusion()(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))
+    with pytest.raises(RuntimeError):
+        floss()(torch.rand(1, 1, 8, 8), torch.rand(1, 1, 8, 8))
+
+
+def test_cli_flags_match_reference():
+    from egaze_amd.gaze_full import build_parser
+    a = build_parser().parse_args([])
+    assert len(vars(a)) == 37
+    assert (a.lr, a.lr_late, a.batch_size, a.batch_size_sp, a.crop_size, a.val_name, a.loss_function, a.sp_resume,
+            a.num_epoch, a.num_epoch_lstm, a.device) == (1e-7, 1e-4, 64, 8, 3, 'Alireza', 'f', '0', 10, 120, '0')
+
+
+def test_host_glue_against_golden():
+    from egaze_amd.utils import change_key_names, computeAAEAUC, AverageMeter, repackage_hidden
+    from oracle import synth
+    gold = np.load(os.path.join(GOLDEN, "metrics_glue.npz"))
+    rs = np.random.RandomState(11)
+    gt = synth.synth_gt(3, 224, rs)[:, 0]
+    pred = synth.synth_gt(3, 224, rs)[:, 0] * 0.8 + rs.uniform(0, 0.05, (3, 224, 224)).astype(np.float32)
+    aae, auc, gp = computeAAEAUC(pred, gt)
+    assert np.allclose([aae, auc], gold["batch_aae_auc"], rtol=1e-12) and np.array_equal(np.array(gp), gold["batch_gp"])
+    a1, u1, g1 = computeAAEAUC(pred[1], gt[1])
+    assert np.allclose([a1, u1], gold["single_aae_auc"], rtol=1e-12) and np.array_equal(np.array(g1), gold["single_gp"])
+    od = collections.OrderedDict()
+    krs = np.random.RandomState(12)
+    od["features.0.weight"] = torch.from_numpy(krs.standard_normal((64, 3, 3, 3)).astype(np.float32))
+    for n in range(1, 30):
+        od[f"features.k{n}"] = torch.from_numpy(krs.standard_normal((4,)).astype(np.float32))
+    new = change_key_names(od, 20)
+    assert list(new) == list(gold["ckn_keys"]) and np.array_equal(new["features.0.weight"].numpy(), gold["ckn_w0"])
+    m = AverageMeter()
+    m.update(2.0, 3); m.update(4.0)
+    assert m.avg == 2.5 and m.count == 4
+    h = (torch.ones(2, requires_grad=True) * 2, torch.ones(2, requires_grad=True) * 3)
+    d = repackage_hidden(h)
+    assert not d[0].requires_grad and repackage_hidden(None) is None
