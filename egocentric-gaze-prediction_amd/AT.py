@@ -78,7 +78,7 @@ class AT():
         self.lstm_data_path, self.batch_size, self.align = lstm_data_path, 1, align
         self.model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20))
         merged = self.model.state_dict()
-        merged.update(torch.load(pretrained_model, map_location='cpu')['state_dict'])
+        merged.update(torch.load(pretrained_model, map_location='cpu', weights_only=False)['state_dict'])
         self.model.load_state_dict(merged, strict=False)
         self.model.to(self.device)
         self.model._modules.get(hook_name).register_forward_hook(hook_feature)
@@ -90,7 +90,7 @@ class AT():
 
     def reload_LSTM(self, pretrained_lstm):
         merged = self.lstm.state_dict()
-        merged.update(torch.load(pretrained_lstm, map_location='cpu'))
+        merged.update(torch.load(pretrained_lstm, map_location='cpu', weights_only=False))
         self.lstm.load_state_dict(merged)
         print('loaded pretrained lstm from ' + pretrained_lstm)
 

@@ -35,7 +35,7 @@ class LF():
         self.save_name, self.save_path = save_name, save_path
         if pretrained_model is not None:
             merged = self.model.state_dict()
-            merged.update(torch.load(pretrained_model, map_location='cpu')['state_dict'])
+            merged.update(torch.load(pretrained_model, map_location='cpu', weights_only=False)['state_dict'])
             self.model.load_state_dict(merged)
             print('loaded pretrained late fusion model from ' + pretrained_model)
         self.model.to(self.device)

@@ -31,7 +31,7 @@ def _load_vgg16_bn():
     """ImageNet VGG16-BN weights (SP.py:54).  Offline: point EGAZE_VGG16_BN at a local copy of the file."""
     local = os.environ.get('EGAZE_VGG16_BN')
     if local:
-        return torch.load(local, map_location='cpu')
+        return torch.load(local, map_location='cpu', weights_only=False)
     import torch.utils.model_zoo as model_zoo
     return model_zoo.load_url(VGG16_BN_URL)
 
@@ -61,7 +61,7 @@ class SP():
         pretrained_optimizer = None
         # NB the reference compares against the strings '2' / '0' while its default is the int 1 (SP.py:20,40,51)
         if resume == '2':            # resume from an SP checkpoint, optimizer state included (SP.py:40-50)
-            ckpt = torch.load(os.path.join(save_path, save_name), map_location='cpu')
+            ckpt = torch.load(os.path.join(save_path, save_name), map_location='cpu', weights_only=False)
             self.epochnow = ckpt['epoch']
             pretrained_optimizer = ckpt['optimizer']
             merged = self.model.state_dict()
@@ -77,8 +77,8 @@ class SP():
             self.model.features_s.load_state_dict(sd_s)
             self.model.features_t.load_state_dict(sd_t)
         else:                        # separately pre-trained streams, encoders frozen (SP.py:74-102)
-            ps = torch.load(self.pretrained_spatial, map_location='cpu')['state_dict']
-            pt = torch.load(self.pretrained_temporal, map_location='cpu')['state_dict']
+            ps = torch.load(self.pretrained_spatial, map_location='cpu', weights_only=False)['state_dict']
+            pt = torch.load(self.pretrained_temporal, map_location='cpu', weights_only=False)['state_dict']
             ps = {k: v for k, v in ps.items() if 'features' in k}
             pt = {k: v for k, v in pt.items() if 'features' in k}
             sd_s, sd_t = self.model.features_s.state_dict(), self.model.features_t.state_dict()

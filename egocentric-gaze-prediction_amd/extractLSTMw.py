@@ -43,7 +43,7 @@ def extractw(loader, model, savepath, crop_size=3, device='0', align=False):
 def extract_LSTM_training_data(save_path='../512w', trained_model='save/best_fusion.pth.tar', device='0', crop_size=3,
                                traindata=None, valdata=None, align=False):
     model = make_layers(cfg['D'], 3)
-    sd = torch.load(trained_model, map_location='cpu')['state_dict']
+    sd = torch.load(trained_model, map_location='cpu', weights_only=False)['state_dict']
     own = model.state_dict()
     own.update({k[len('features_s.'):]: v for k, v in sd.items() if k.startswith('features_s.')})
     model.load_state_dict(own)

@@ -57,7 +57,7 @@ def test_sp_driver_resume0_train_val_checkpoint(tmp_path, monkeypatch):
     before = sp.model.decoder[0].weight.detach().clone()
     sp.train()
     assert not torch.equal(before, sp.model.decoder[0].weight.detach())
-    ck = torch.load(os.path.join(save, 'best_SP.pth.tar'), map_location='cpu')
+    ck = torch.load(os.path.join(save, 'best_SP.pth.tar'), map_location='cpu', weights_only=False)
     assert set(ck) == {'epoch', 'arch', 'state_dict', 'optimizer', 'auc', 'aae'} and ck['arch'] == 'SP'
     assert len(ck['state_dict']) == 215
     # resume '2' restores weights and optimizer moments
@@ -129,7 +129,7 @@ def test_at_and_lf_drivers(tmp_path):
     w0 = lf.model.fusion[0].weight.detach().clone()
     lf.train()
     assert not torch.equal(w0, lf.model.fusion[0].weight.detach())
-    ck = torch.load(str(save / "best_late.pth.tar"), map_location='cpu')
+    ck = torch.load(str(save / "best_late.pth.tar"), map_location='cpu', weights_only=False)
     assert set(ck) == {'state_dict', 'loss', 'auc', 'aae'}
     lf.val()
     # glue parity with the golden vectors (AT.py:25-66)

@@ -94,7 +94,7 @@ def test_late_fusion_grads_vs_fp64():
     floss()(out, gt.to(DEV)).backward()
 
     def run(dtype):
-        work = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        work = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         keys = O.trainable_keys(work)
         for k in keys:
             work[k].requires_grad_(True)
