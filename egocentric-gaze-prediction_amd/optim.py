@@ -89,6 +89,11 @@ class FusedAdam:
 
     def load_state_dict(self, sd):
         groups = sd.get("param_groups", [])
+        if groups and "params" in groups[0] and len(groups[0]["params"]) != len(self.params):
+            # same failure torch.optim.Optimizer.load_state_dict reports (e.g. an all-parameter checkpoint of
+            # `--sp_resume 0` loaded into the fusion+bn+decoder optimizer of resume mode '2', SP.py:109-115)
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of "
+                             "optimizer's group")
         if groups:
             self.lr = groups[0].get("lr", self.lr)
             self.betas = tuple(groups[0].get("betas", self.betas))

@@ -60,20 +60,28 @@ def test_sp_driver_resume0_train_val_checkpoint(tmp_path, monkeypatch):
     ck = torch.load(os.path.join(save, 'best_SP.pth.tar'), map_location='cpu', weights_only=False)
     assert set(ck) == {'epoch', 'arch', 'state_dict', 'optimizer', 'auc', 'aae'} and ck['arch'] == 'SP'
     assert len(ck['state_dict']) == 215
-    # resume '2' restores weights and optimizer moments
-    sp2 = SP(lr=1e-4, save_path=save, save_name='best_SP.pth.tar', num_epoch=2, batch_size=2, device='0',
-             resume='2', traindata=_SPData(2, 32, 0), valdata=_SPData(2, 32, 1))
-    assert torch.equal(sp2.model.decoder[0].weight.detach().cpu(), ck['state_dict']['decoder.0.weight'])
-    assert sp2.optimizer.step_count == 2 and sp2.epochnow == 0
+    # resume '2' builds the fusion+bn+decoder optimizer (SP.py:109-111): an all-parameter optimizer state does
+    # not fit it -- torch raises ValueError there, so do we
+    with pytest.raises(ValueError):
+        SP(lr=1e-4, save_path=save, save_name='best_SP.pth.tar', num_epoch=2, batch_size=2, device='0',
+           resume='2', traindata=_SPData(2, 32, 0), valdata=_SPData(2, 32, 1))
     # resume '1'-style: encoders frozen, only fusion + bn + decoder in the optimizer
     torch.save({'state_dict': {}}, str(tmp_path / "s.pth"))
-    sp3 = SP(lr=1e-4, save_path=save, num_epoch=1, batch_size=2, device='0', resume=1,
+    sp3 = SP(lr=1e-4, save_path=save, save_name='frozen_SP.pth.tar', num_epoch=1, batch_size=2, device='0', resume=1,
              pretrained_spatial=str(tmp_path / "s.pth"), pretrained_temporal=str(tmp_path / "s.pth"),
              traindata=_SPData(2, 32, 0), valdata=_SPData(2, 32, 1))
     assert sum(p.numel() for p in sp3.optimizer.params) == 2359808 + 1024 + 14712513
     enc_before = sp3.model.features_s[0].weight.detach().clone()
-    loss = sp3.trainSP()
-    assert np.isfinite(loss) and torch.equal(enc_before, sp3.model.features_s[0].weight.detach())
+    sp3.train()
+    assert torch.equal(enc_before, sp3.model.features_s[0].weight.detach())
+    ck3 = torch.load(os.path.join(save, 'frozen_SP.pth.tar'), map_location='cpu', weights_only=False)
+    # resume '2' from that checkpoint restores weights, epoch and optimizer moments
+    sp2 = SP(lr=1e-4, save_path=save, save_name='frozen_SP.pth.tar', num_epoch=2, batch_size=2, device='0',
+             resume='2', traindata=_SPData(2, 32, 0), valdata=_SPData(2, 32, 1))
+    assert torch.equal(sp2.model.decoder[0].weight.detach().cpu(), ck3['state_dict']['decoder.0.weight'])
+    assert sp2.optimizer.step_count == 1 and sp2.epochnow == 0
+    m0 = ck3['optimizer']['state'][0]['exp_avg']
+    assert torch.equal(sp2.optimizer.flat_m[:m0.numel()].cpu().view(m0.shape), m0)
 
 
 def test_at_and_lf_drivers(tmp_path):
