@@ -33,8 +33,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
     constexpr int WN = BN / WAVES_N;           // n-extent per wave
     constexpr int BLD = BN / 32;               // float4 B loads per thread per slice (4, 2, 1)
 
+    // A: [pixel row][k], B: [output channel row][k]; both k-contiguous with the same padded row stride so both
+    // MFMA operands are fetched with conflict-free ds_read_b128 (4 consecutive k of the lane's half per read)
     __shared__ __attribute__((aligned(16))) float As[2 * BM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * BN];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BN * LDA];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (WAVES_N == 2) ? (wave >> 1) : wave, wn = (WAVES_N == 2) ? (wave & 1) : 0;
@@ -46,13 +48,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
     const long M = (long)B * HW;
     const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
 
-    // ---- per-thread A rows (fixed for the whole K loop)
-    const int a_c4 = tid & 7;
+    // ---- per-thread rows (fixed for the whole K loop): 4 A rows (pixels) and BLD B rows (output channels)
+    const int a_c4 = tid & 7, r0 = tid >> 3;
     int a_y[4], a_x[4];
     long a_img[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const long m = m0 + (tid >> 3) + 32 * j;
+        const long m = m0 + r0 + 32 * j;
         if (m < M) {
             const long b = m / HW;
             const int rem = (int)(m - b * HW);
@@ -65,10 +67,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
             a_img[j] = 0;
         }
     }
-    constexpr int BN4 = BN / 4;                // float4 per B row (32, 16, 8)
-    const int b_n4 = tid % BN4;
-    const int b_k0 = tid / BN4;
-    constexpr int b_kstep = 256 / BN4;         // 8, 16, 32
 
     f32x4 ra[4], rb[BLD];
     auto gload = [&](int s) {
@@ -85,20 +83,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
         }
 #pragma unroll
         for (int j = 0; j < BLD; ++j) {
-            const int kr = b_k0 + b_kstep * j;
-            const float* p = wp + ((long)(tap * Cp + c0 + kr) * Kp + n0 + b_n4 * 4);
+            const float* p = wp + ((long)(tap * Kp + n0 + r0 + 32 * j) * Cp + c0 + a_c4 * 4);
             rb[j] = *reinterpret_cast<const f32x4*>(p);
         }
     };
     auto lstore = [&](int buf) {
         float* a = As + buf * BM * LDA;
-        float* b = Bs + buf * BK * BN;
+        float* b = Bs + buf * BN * LDA;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<f32x4*>(a + ((tid >> 3) + 32 * j) * LDA + a_c4 * 4) = ra[j];
+            *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDA + a_c4 * 4) = ra[j];
 #pragma unroll
         for (int j = 0; j < BLD; ++j)
-            *reinterpret_cast<f32x4*>(b + (b_k0 + b_kstep * j) * BN + b_n4 * 4) = rb[j];
+            *reinterpret_cast<f32x4*>(b + (r0 + 32 * j) * LDA + a_c4 * 4) = rb[j];
     };
 
     f32x16 acc[MR][NR];
@@ -117,25 +114,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
         const int buf = s & 1;
         if (s + 1 < S) gload(s + 1);
         const float* Ab = As + buf * BM * LDA + (wm * WM + l31) * LDA + 4 * hl;
-        const float* Bb = Bs + buf * BK * BN + (4 * hl) * BN + wn * WN + l31;
+        const float* Bb = Bs + buf * BN * LDA + (wn * WN + l31) * LDA + 4 * hl;
+        // fragments of k-group q+1 are fetched while the 4*MR*NR MFMAs of group q issue (register double buffer)
+        f32x4 af[2][MR], bf[2][NR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) af[0][mr] = *reinterpret_cast<const f32x4*>(Ab + mr * 32 * LDA);
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) bf[0][nr] = *reinterpret_cast<const f32x4*>(Bb + nr * 32 * LDA);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 av[MR];
+            if (q < 3) {
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) av[mr] = *reinterpret_cast<const f32x4*>(Ab + mr * 32 * LDA + 8 * q);
+                for (int mr = 0; mr < MR; ++mr)
+                    af[(q + 1) & 1][mr] = *reinterpret_cast<const f32x4*>(Ab + mr * 32 * LDA + 8 * (q + 1));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float bv[NR];
+                for (int nr = 0; nr < NR; ++nr)
+                    bf[(q + 1) & 1][nr] = *reinterpret_cast<const f32x4*>(Bb + nr * 32 * LDA + 8 * (q + 1));
+            }
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) bv[nr] = Bb[(8 * q + j) * BN + nr * 32];
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
                     for (int mr = 0; mr < MR; ++mr)
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][j], bv[nr], acc[mr][nr], 0, 0, 0);
-            }
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][mr][j], bf[q & 1][nr][j],
+                                                                          acc[mr][nr], 0, 0, 0);
+            // the other LDS buffer was released by the barrier that ended slice s-1: stage slice s+1 into it
+            // half-way through this slice's MFMAs (its global loads were issued ~2k cycles ago)
+            if (q == 1 && s + 1 < S) lstore(buf ^ 1);
         }
-        if (s + 1 < S) lstore(buf ^ 1);
         __syncthreads();
     }
 
@@ -187,23 +194,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
     }
 }
 
-// wp[(tap*Cp + c)*Kp + k] = w[(k*C + c)*9 + tap], zero in the padding (Cp, Kp = C, K rounded up to 32)
+// wp[(tap*Kp + k)*Cp + c] = w[(k*C + c)*9 + tap], zero in the padding (Cp, Kp = C, K rounded up to 32):
+// one k-contiguous (here: input-channel-contiguous) row per output channel, like the A tile's pixel rows
 __global__ void pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K, int Cp, int Kp) {
-    const long n = (long)9 * Cp * Kp;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kp);
-        const long t = i / Kp;
-        const int c = (int)(t % Cp), tap = (int)(t / Cp);
-        wp[i] = (c < C && k < K) ? w[((long)k * C + c) * 9 + tap] : 0.f;
-    }
-}
-// dgrad view: dX = conv3x3(dY, Wd) with Wd[(8-tap)][k][c] = w[k][c][tap]  (tap flip + in/out transpose), padded
-__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K, int Cp, int Kp) {
     const long n = (long)9 * Cp * Kp;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % Cp);
         const long t = i / Cp;
-        const int k = (int)(t % Kp), tapf = (int)(t / Kp);
+        const int k = (int)(t % Kp), tap = (int)(t / Kp);
+        wp[i] = (c < C && k < K) ? w[((long)k * C + c) * 9 + tap] : 0.f;
+    }
+}
+// dgrad view: dX = conv3x3(dY, Wd); the GEMM's output channel is c and its reduction index is k:
+// wp[((8-tap)*Cp + c)*Kp + k] = w[(k*C + c)*9 + tap]  (tap flip + in/out transpose), padded
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, int K, int Cp, int Kp) {
+    const long n = (long)9 * Cp * Kp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const long t = i / Kp;
+        const int c = (int)(t % Cp), tapf = (int)(t / Cp);
         wp[i] = (c < C && k < K) ? w[((long)k * C + c) * 9 + (8 - tapf)] : 0.f;
     }
 }
