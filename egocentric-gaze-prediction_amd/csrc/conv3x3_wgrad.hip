@@ -119,6 +119,116 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 9-tap fused variant (the default for the SP shapes): one block owns a 64(c) x 64(k) tile for ALL nine taps.
+// A stage is a row segment of L pixels; its 3 x (L+2) input halo and its L dY rows are staged in LDS once and
+// feed 9 MFMAs per k-step (one per tap, reading the halo at the tap's shift), so x and dY are fetched from
+// L2/HBM once per tile instead of nine times and the arithmetic intensity per staged byte is 4.5x higher.
+// Each wave keeps 9 accumulators (144 VGPRs) for its 32 x 32 corner of the tile.
+template <bool UPS, int L>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, int segs_per_split) {
+    constexpr int HP = L + 2;                         // halo pixels per row
+    constexpr int NX = (3 * HP * 16 + 255) / 256;     // float4 halo loads per thread
+    constexpr int ND = (L * 16 + 255) / 256;          // float4 dY loads per thread
+    __shared__ __attribute__((aligned(16))) float Xh[2 * 3 * HP * 64];
+    __shared__ __attribute__((aligned(16))) float Ds[2 * L * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wk = wave & 1, hl = lane >> 5, l31 = lane & 31;
+    const int tk = K / 64;
+    const int c0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
+    const int spr = W / L;                            // segments per image row
+    const long nseg = (long)B * H * spr;
+    const long g0 = (long)blockIdx.y * segs_per_split;
+    const long g1 = (g0 + segs_per_split < nseg) ? (g0 + segs_per_split) : nseg;
+    const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
+
+    f32x4 rx[NX], rd[ND];
+    auto gload = [&](long g) {
+        const int xs = (int)(g % spr) * L;
+        const long t = g / spr;
+        const int yy = (int)(t % H);
+        const long b = t / H;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            const int pos = i >> 4, c4 = i & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pos < 3 * HP) {
+                const int r = pos / HP, px = pos - r * HP;
+                const int iy = yy + r - 1, ix = xs + px - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+                    v = *reinterpret_cast<const f32x4*>(x + ((b * Hs + sy) * (long)Ws + sx) * C + c0 + c4 * 4);
+                }
+            }
+            rx[j] = v;
+        }
+        const long m0 = (b * H + yy) * (long)W + xs;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j;
+            const int pp = i >> 4, k4 = i & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pp < L) v = *reinterpret_cast<const f32x4*>(dy + (m0 + pp) * K + k0 + k4 * 4);
+            rd[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            if (i < 3 * HP * 16) *reinterpret_cast<f32x4*>(Xh + buf * 3 * HP * 64 + i * 4) = rx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j;
+            if (i < L * 16) *reinterpret_cast<f32x4*>(Ds + buf * L * 64 + i * 4) = rd[j];
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (g0 < g1) {
+        gload(g0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (long g = g0; g < g1; ++g) {
+        const int buf = (int)((g - g0) & 1);
+        if (g + 1 < g1) gload(g + 1);
+        const float* Xb = Xh + buf * 3 * HP * 64 + hl * 64 + wc * 32 + l31;
+        const float* Db = Ds + buf * L * 64 + hl * 64 + wk * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < L / 2; ++t) {
+            const float bv = Db[(2 * t) * 64];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float av = Xb[((tap / 3) * HP + 2 * t + (tap % 3)) * 64];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+            }
+        }
+        if (g + 1 < g1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* out = part + ((long)blockIdx.y * 9 + tap) * C * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wc * 32 + egz_acc_row(r, lane);
+            const int k = k0 + wk * 32 + l31;
+            out[(long)c * K + k] = acc[tap][r];
+        }
+    }
+}
+
 // Narrow layers (late_fusion: C = 32, K = 32 / 8): one 32(c) x 32(k) MFMA tile per block; the four waves split
 // each 32-pixel stage four ways (intra-block split-K) and are summed through LDS at the end.  Channel counts
 // that are not multiples of 32 are masked on load / store.
@@ -220,6 +330,24 @@ int pick_splits(long M, int C, int K, int BT) {
     return (int)s;
 }
 
+// segment length of the 9-tap fused kernel (0 = not applicable -> per-tap kernel)
+int pick_seg(int W, int C, int K, int flags) {
+    if (flags & 0x800) return 0;                      // force the per-tap kernel (A/B benchmarking)
+    if (C % 64 != 0 || K % 64 != 0) return 0;
+    if (W % 32 == 0) return 32;
+    if (W % 28 == 0) return 28;
+    if (W % 14 == 0) return 14;
+    return 0;
+}
+int pick_splits9(long nseg, int C, int K) {
+    const long tiles = (long)(C / 64) * (K / 64);
+    long s = (1024 + tiles - 1) / tiles;              // ~4 blocks per CU
+    const long smax = (nseg + 7) / 8;                 // at least 8 segments per split
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
 int pick_bt(int C, int K, int flags) {
     if (C % 64 != 0 || K % 64 != 0) return 32;
     if (flags & 0x100) return 64;
@@ -229,6 +357,8 @@ int pick_bt(int C, int K, int flags) {
 }  // namespace
 
 EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags) {
+    const int L = pick_seg(W, C, K, flags);
+    if (L) return (size_t)pick_splits9((long)B * H * (W / L), C, K) * 9 * C * K * sizeof(float);
     const int bt = pick_bt(C, K, flags);
     const int S = pick_splits((long)B * H * W, C, K, bt);
     return (size_t)S * 9 * C * K * sizeof(float);
@@ -243,12 +373,30 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     const bool ups = flags & 1;
     EGZ_CHECK_ARG(!ups || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_wgrad: upsampled output must be even");
     const long M = (long)B * H * W;
+    float* part = static_cast<float*>(workspace);
+    const long nred = (long)9 * C * K;
+    const int gred = egz_cdiv(nred, 256) > 4096 ? 4096 : egz_cdiv(nred, 256);
+    const int L = pick_seg(W, C, K, flags);
+    if (L) {
+        const long nseg = (long)B * H * (W / L);
+        const int S = pick_splits9(nseg, C, K);
+        EGZ_CHECK_ARG(ws_bytes >= (size_t)S * 9 * C * K * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+        const int sps = (int)((nseg + S - 1) / S);
+        dim3 grid((C / 64) * (K / 64), S);
+#define EGZ_W9(U, LL) hipLaunchKernelGGL((conv3x3_wgrad9_kernel<U, LL>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, sps)
+        if (ups) { if (L == 32) EGZ_W9(true, 32); else if (L == 28) EGZ_W9(true, 28); else EGZ_W9(true, 14); }
+        else     { if (L == 32) EGZ_W9(false, 32); else if (L == 28) EGZ_W9(false, 28); else EGZ_W9(false, 14); }
+#undef EGZ_W9
+        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap)");
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gred), dim3(256), 0, st, part, dw, C, K, S);
+        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce)");
+        return 0;
+    }
     const int bt = pick_bt(C, K, flags);
     const int S = pick_splits(M, C, K, bt);
     EGZ_CHECK_ARG(ws_bytes >= (size_t)S * 9 * C * K * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
     long pps = (M + S - 1) / S;
     pps = (pps + PK - 1) / PK * PK;
-    float* part = static_cast<float*>(workspace);
     dim3 grid(((C + bt - 1) / bt) * ((K + bt - 1) / bt) * 9, S);
     if (bt == 32) {
         if (ups) hipLaunchKernelGGL(conv3x3_wgrad32_kernel<true>, grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);

@@ -74,6 +74,9 @@ def test_conv3x3_upsample_fused(B, Hh, Ww, C, K):
 @pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [
     (2, 12, 12, 64, 64, False), (1, 14, 14, 128, 256, False), (2, 10, 6, 192, 64, False),
     (2, 12, 12, 64, 128, True), (1, 8, 8, 128, 128, True),
+    # geometries of the 9-tap fused wgrad kernel (row segments of 32 / 28 / 14 pixels)
+    (2, 28, 28, 64, 64, False), (1, 32, 32, 64, 128, False), (1, 28, 28, 128, 64, True), (3, 6, 28, 64, 64, False),
+    (1, 16, 64, 64, 64, True), (2, 14, 14, 192, 128, False), (1, 28, 56, 64, 64, False),
 ])
 def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     """dgrad (same kernel, tap-flipped transposed weights), wgrad (split-K MFMA), bias grad, upsample bwd."""

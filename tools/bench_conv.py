@@ -1,0 +1,89 @@
+"""Micro-benchmark of the MFMA conv kernels on the SP layer shapes (B=32): forward / dgrad / wgrad, HIP-event timed.
+Usage: python tools/bench_conv.py [--iters N] [--only substring] [--batch B]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import egaze_amd  # noqa
+import egaze_amd.hipops as H
+
+PEAK = 157.3
+# (name, Cin, Cout, H(out), ups)
+SHAPES = [
+    ("enc3   64->64  @224", 64, 64, 224, False),
+    ("enc7   64->128 @112", 64, 128, 112, False),
+    ("enc10 128->128 @112", 128, 128, 112, False),
+    ("enc14 128->256 @56 ", 128, 256, 56, False),
+    ("enc17 256->256 @56 ", 256, 256, 56, False),
+    ("enc24 256->512 @28 ", 256, 512, 28, False),
+    ("enc27 512->512 @28 ", 512, 512, 28, False),
+    ("enc34 512->512 @14 ", 512, 512, 14, False),
+    ("dec12 512->256 @56u", 512, 256, 56, True),
+    ("dec19 256->128 @112u", 256, 128, 112, True),
+    ("dec24 128->64  @224u", 128, 64, 224, True),
+    ("dec26  64->64  @224", 64, 64, 224, False),
+]
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--tile", type=lambda v: int(v, 0), default=0)
+    ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--wflag", type=lambda v: int(v, 0), default=0, help="0x800 = per-tap wgrad kernel")
+    a = ap.parse_args()
+    dev = "cuda:0"
+    B = a.batch
+    tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
+    for name, C, K, Hh, ups in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        hin = Hh // 2 if ups else Hh
+        x = torch.randn(B, hin, hin, C, device=dev)
+        w = torch.randn(K, C, 3, 3, device=dev) * 0.05
+        bias = torch.randn(K, device=dev)
+        dy = torch.randn(B, Hh, Hh, K, device=dev)
+        flops = 2.0 * B * Hh * Hh * K * 9 * C
+        wp, wd = H.packed_weight(w, "fwd"), H.packed_weight(w, "dgrad")
+        res = []
+        if "fwd" in a.what:
+            t = timeit(lambda: H.conv3x3_fwd(x, wp, bias, K, ups=ups, epi=H.EPI_BIAS_RELU if ups else H.EPI_BIAS_STATS,
+                                             tile_flag=a.tile), a.iters)
+            res.append(("fwd", t))
+        if "dgrad" in a.what:
+            t = timeit(lambda: H.conv3x3_fwd(dy, wd, None, C, ups=False, epi=H.EPI_BIAS, tile_flag=a.tile), a.iters)
+            res.append(("dgrad", t))
+        if "wgrad" in a.what:
+            t = timeit(lambda: H.conv3x3_wgrad(x, dy, ups=ups, variant_flag=a.wflag), a.iters)
+            res.append(("wgrad", t))
+        line = f"{name}  {flops/1e9:7.1f} GF"
+        for k, t in res:
+            tf = flops / (t * 1e-3) / 1e12
+            tot[k][0] += flops
+            tot[k][1] += t
+            line += f" | {k} {t*1e3:7.0f} us {tf:6.1f} TF {100*tf/PEAK:4.1f}%"
+        print(line, flush=True)
+    for k, (f, t) in tot.items():
+        if t > 0:
+            print(f"TOTAL {k}: {t:.2f} ms, {f/(t*1e-3)/1e12:.1f} TF ({100*f/(t*1e-3)/1e12/PEAK:.1f}% of f32 MFMA peak)")
+
+
+if __name__ == "__main__":
+    main()
