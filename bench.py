@@ -126,9 +126,17 @@ def main():
     roofline = None
     breakdown = None
     if rank == 0 and not args.no_roofline:
+        # per-kernel HIP-event timing needs the kernels serialised: switch the multi-stream overlap off for this
+        # one extra (untimed) step so that an event pair brackets exactly one kernel family's launches
+        from egaze_amd import streams
+        was = streams.ENABLED
+        streams.ENABLED = False
+        step()
+        torch.cuda.synchronize()
         H.PROF.start()
         step()
         prof = H.PROF.stop()
+        streams.ENABLED = was
         ig = prof.get("egz_conv3x3_fwd", {"calls": 0, "ms": 0.0, "flops": 0.0})
         if ig["ms"] > 0:
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12

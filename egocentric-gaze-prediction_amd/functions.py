@@ -16,6 +16,7 @@ from __future__ import annotations
 import torch
 
 from . import hipops as H
+from .streams import fork
 
 
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
@@ -76,12 +77,14 @@ class ConvBNReLUPool(torch.autograd.Function):
         dx = dw = db = None
         if ng[2]:
             db = _zero_bias_grad(dy, K)
-        if ng[1]:
-            dw = H.conv_first_wgrad(xin, dy) if first else H.conv3x3_wgrad(xin, dy)
+        with fork("wgrad") as f:                # weight gradient || data gradient (both only read dy)
+            if ng[1]:
+                dw = H.conv_first_wgrad(xin, dy) if first else H.conv3x3_wgrad(xin, dy)
         if ng[0]:
             if first:
                 raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
             dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C))
+        f.join(dw)
         return (dx, dw, db, dgamma if ng[3] else None, dbeta if ng[4] else None, None, None, None, None, None,
                 None, None)
 
@@ -107,11 +110,13 @@ class ConvReLU(torch.autograd.Function):
             dy, db = H.relu_bwd_bias(y, to_nhwc(dout))
         else:
             dy = H.relu_bwd(y, to_nhwc(dout))
-        if ng[1]:
-            dw = H.conv3x3_wgrad(xin, dy, ups=ups)
+        with fork("wgrad") as f:
+            if ng[1]:
+                dw = H.conv3x3_wgrad(xin, dy, ups=ups)
         if ng[0]:
             dxu = H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C)
             dx = from_nhwc(H.upsample2x_bwd(dxu) if ups else dxu)
+        f.join(dw)
         return dx, dw, db, None
 
 
@@ -146,12 +151,14 @@ class FusionBlock(torch.autograd.Function):
         dfs = dft = dw = db = None
         if ng[3]:
             db = _zero_bias_grad(dy2, K)
-        if ng[2]:
-            dw = H.conv3x3_wgrad(x2, dy2).view(weight.shape)
+        with fork("wgrad") as f:
+            if ng[2]:
+                dw = H.conv3x3_wgrad(x2, dy2).view(weight.shape)
         if ng[0] or ng[1]:
             dx2 = H.conv3x3_dgrad(dy2, H.packed_weight(weight, "dgrad"), C)
             B = dx2.shape[0] // 2
             dfs, dft = from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
+        f.join(dw)
         return (dfs, dft, dw, db, dgamma if ng[4] else None, dbeta if ng[5] else None, None, None, None, None,
                 None)
 

@@ -95,8 +95,9 @@ _WS = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Stream-ordered scratch (one buffer per device, grown on demand; the C-ABI never allocates)."""
-    key = torch.device(device).index or 0
+    """Stream-ordered scratch (one buffer per device AND stream, grown on demand; the C-ABI never allocates).
+    Keyed by stream because kernels on different HIP streams run concurrently (streams.py)."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)

@@ -7,7 +7,10 @@ post-ReLU (B,512,14,14) activation.
 """
 import torch.nn as nn
 
+import torch
+
 from ..functions import FusionBlock
+from ..streams import fork
 from ..utils import FusedSequential, init_like_reference
 
 # models/model_SP.py:13-31 as (Cin, Cout) 3x3+ReLU blocks and 'U' = nearest x2 upsample; a 1x1 head follows
@@ -36,8 +39,12 @@ class model_SP(nn.Module):
         self._initialize_weights()
 
     def forward(self, x_s, x_t):
+        with fork("encoder_t") as f:                     # the two encoders are independent: two HIP streams
+            if f.enabled:
+                x_t.record_stream(torch.cuda.current_stream())
+            x_t = self.features_t(x_t)
         x_s = self.features_s(x_s)                       # (B,512,h,w) channels_last; hooks fire here
-        x_t = self.features_t(x_t)
+        f.join(x_t)
         bn = self.bn
         if bn.training and bn.track_running_stats:
             bn.num_batches_tracked += 1

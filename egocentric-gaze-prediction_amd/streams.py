@@ -1,0 +1,56 @@
+"""HIP-stream level concurrency for the SP step (instead of a tracing compiler / graph rewriter).
+
+The layer chain is serial, but two kinds of work are independent and are issued on separate HIP streams so that the
+workgroup tail of one kernel (e.g. 784 tiles over 512 resident slots) is filled by the next kernel's blocks:
+  * forward: the RGB encoder and the flow encoder (models/model_SP.py:36-37) -- and, since autograd replays a node on
+    the stream its forward ran on, their backward passes too;
+  * backward: the weight gradient and the data gradient of the same convolution (both consume dy).
+Ordering is expressed with stream waits only (no host synchronisation).  EGAZE_STREAMS=0 disables it (A/B runs).
+"""
+import os
+
+import torch
+
+ENABLED = os.environ.get("EGAZE_STREAMS", "1") != "0"
+_SIDE = {}
+
+
+def side_stream(kind: str) -> torch.cuda.Stream:
+    """A persistent helper stream per (current stream, kind)."""
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream, kind)
+    st = _SIDE.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=cur.device)
+        _SIDE[key] = st
+    return st
+
+
+class fork:
+    """``with fork('wgrad') as f: ...`` runs the body on a side stream that first waits for the current stream;
+    ``f.join(*tensors)`` makes the current stream wait for it and hands the tensors over to the current stream."""
+
+    def __init__(self, kind: str):
+        self.enabled = ENABLED and torch.cuda.is_available()
+        self.kind = kind
+
+    def __enter__(self):
+        if self.enabled:
+            self.cur = torch.cuda.current_stream()
+            self.side = side_stream(self.kind)
+            self.side.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.enabled:
+            self.cur.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.cur)
