@@ -15,14 +15,13 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;   // 36 floats: 16-B aligned rows, conflict-free ds_read_b128
 
 enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
 
-template <int BN, bool UPS, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
+template <int BM, int BN, bool UPS, int EPI>
+__global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp) {
     // C / K: real channel counts (strides of x / y); Cp / Kp: the padded extents of the packed weights.
@@ -32,6 +31,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
     constexpr int WM = BM / WAVES_M;           // m-extent per wave
     constexpr int WN = BN / WAVES_N;           // n-extent per wave
     constexpr int BLD = BN / 32;               // float4 B loads per thread per slice (4, 2, 1)
+    constexpr int ALD = BM / 32;               // float4 A loads per thread per slice (4, 2)
 
     // A: [pixel row][k], B: [output channel row][k]; both k-contiguous with the same padded row stride so both
     // MFMA operands are fetched with conflict-free ds_read_b128 (4 consecutive k of the lane's half per read)
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
 
     // ---- per-thread rows (fixed for the whole K loop): 4 A rows (pixels) and BLD B rows (output channels)
     const int a_c4 = tid & 7, r0 = tid >> 3;
-    int a_y[4], a_x[4];
-    long a_img[4];
+    int a_y[ALD], a_x[ALD];
+    long a_img[ALD];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < ALD; ++j) {
         const long m = m0 + r0 + 32 * j;
         if (m < M) {
             const long b = m / HW;
@@ -68,13 +68,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
         }
     }
 
-    f32x4 ra[4], rb[BLD];
+    f32x4 ra[ALD], rb[BLD];
     auto gload = [&](int s) {
         const int cblk = s / 9, tap = s - cblk * 9;
         const int c0 = cblk * BK;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < ALD; ++j) {
             const int iy = a_y[j] + dy, ix = a_x[j] + dx;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && (c0 + a_c4 * 4 < C);
             const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_kernel(
         float* a = As + buf * BM * LDA;
         float* b = Bs + buf * BN * LDA;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < ALD; ++j)
             *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDA + a_c4 * 4) = ra[j];
 #pragma unroll
         for (int j = 0; j < BLD; ++j)
@@ -217,41 +217,58 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict
     }
 }
 
-template <int BN, bool UPS, int EPI>
+template <int BM, int BN, bool UPS, int EPI>
 int launch_igemm(const float* x, const float* wp, const float* bias, float* y, double* stat, int B, int H,
                  int W, int C, int K, hipStream_t st) {
     const long M = (long)B * H * W;
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
     const int grid = egz_cdiv(M, BM) * (Kp / BN);
-    hipLaunchKernelGGL((conv3x3_igemm_kernel<BN, UPS, EPI>), dim3(grid), dim3(256), 0, st, x, wp, bias, y,
+    hipLaunchKernelGGL((conv3x3_igemm_kernel<BM, BN, UPS, EPI>), dim3(grid), dim3(256), 0, st, x, wp, bias, y,
                        stat, B, H, W, C, K, Cp, Kp);
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd");
     return 0;
 }
 
-template <int BN, bool UPS>
+template <int BM, int BN, bool UPS>
 int dispatch_epi(int epi, const float* x, const float* wp, const float* bias, float* y, double* stat, int B,
                  int H, int W, int C, int K, hipStream_t st) {
     switch (epi) {
-        case EPI_BIAS: return launch_igemm<BN, UPS, EPI_BIAS>(x, wp, bias, y, stat, B, H, W, C, K, st);
-        case EPI_BIAS_RELU: return launch_igemm<BN, UPS, EPI_BIAS_RELU>(x, wp, bias, y, stat, B, H, W, C, K, st);
-        default: return launch_igemm<BN, UPS, EPI_BIAS_STATS>(x, wp, bias, y, stat, B, H, W, C, K, st);
+        case EPI_BIAS: return launch_igemm<BM, BN, UPS, EPI_BIAS>(x, wp, bias, y, stat, B, H, W, C, K, st);
+        case EPI_BIAS_RELU: return launch_igemm<BM, BN, UPS, EPI_BIAS_RELU>(x, wp, bias, y, stat, B, H, W, C, K, st);
+        default: return launch_igemm<BM, BN, UPS, EPI_BIAS_STATS>(x, wp, bias, y, stat, B, H, W, C, K, st);
     }
 }
 
-int pick_bn(long M, int K, int flags) {
-    if (K % 64 != 0) return 32;       // late-fusion widths (32, 8): one 32-wide n-tile, 4 waves along m
-    if (flags & 0x100) return 64;
-    if (flags & 0x200) return 128;
-    if (K % 128 != 0) return 64;
-    // under ~1.5 waves of 128x128 tiles the 64-wide tile fills the 256 CUs better
-    const long blocks128 = ((M + BM - 1) / BM) * (K / 128);
-    return blocks128 < 384 ? 64 : 128;
+// Tile choice.  Every CU hosts `occ` blocks (LDS-limited: 2 for the 128-row tiles, 4 for 64x64); a launch takes
+// ceil(blocks / (256*occ)) waves of co-resident blocks, each wave costing occ * (tile area) of MFMA time on a CU.
+// Pick the tile with the smallest such makespan (the 28^2 / 56^2 layers have 784 / 1568 tiles of 128x128 for 512
+// slots: 23 % of the second wave would idle), scaled by the measured in-kernel efficiency of each tile shape.
+struct Tile { int bm, bn; };
+Tile pick_tile(long M, int K, int flags) {
+    if (K % 64 != 0) return {128, 32};   // late-fusion widths (32, 8): one 32-wide n-tile, 4 waves along m
+    if (flags & 0x400) return {64, 64};
+    if (flags & 0x100) return {128, 64};
+    if (flags & 0x200) return {128, K % 128 == 0 ? 128 : 64};
+    const Tile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
+    const int occ[3] = {2, 2, 4};
+    const double eff[3] = {1.00, 0.95, 0.90};
+    double best = 1e30;
+    Tile pick = {128, 64};
+    for (int i = 0; i < 3; ++i) {
+        if (K % cand[i].bn != 0) continue;
+        const long blocks = ((M + cand[i].bm - 1) / cand[i].bm) * (K / cand[i].bn);
+        const long waves = (blocks + 256L * occ[i] - 1) / (256L * occ[i]);
+        const double cost = (double)waves * occ[i] * cand[i].bm * cand[i].bn / eff[i];
+        if (cost < best) { best = cost; pick = cand[i]; }
+    }
+    return pick;
 }
 
 }  // namespace
 
-EGZ_API int egz_conv3x3_stat_rows(int B, int H, int W) { return egz_cdiv((long)B * H * W, BM); }
+EGZ_API int egz_conv3x3_stat_rows(int B, int H, int W, int K, int flags) {
+    return egz_cdiv((long)B * H * W, pick_tile((long)B * H * W, K, flags).bm);
+}
 
 EGZ_API size_t egz_pack_w3x3_elems(int C, int K) {
     return (size_t)9 * ((C + 31) / 32 * 32) * ((K + 31) / 32 * 32);
@@ -279,7 +296,7 @@ EGZ_API int egz_pack_w3x3_dgrad(const float* w, float* wp, int C, int K, hipStre
 
 // flags: bit0 = input is nearest-x2 upsampled on the fly (x is [B][H/2][W/2][C]);
 //        bits 4-5 = epilogue (0 bias, 1 bias+relu, 2 bias + BN stat partials);
-//        0x100 / 0x200 force the 64 / 128 wide n-tile (benchmarking).
+//        0x100 / 0x200 / 0x400 force the 128x64 / 128x128 / 64x64 tile (benchmarking).
 EGZ_API int egz_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* y, double* stat_partial,
                             int B, int H, int W, int C, int K, int flags, hipStream_t st) {
     EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd: null pointer");
@@ -292,13 +309,13 @@ EGZ_API int egz_conv3x3_fwd(const float* x, const float* wp, const float* bias, 
     const int epi = (flags >> 4) & 3;
     EGZ_CHECK_ARG(epi <= 2, "egz_conv3x3_fwd: bad epilogue %d", epi);
     EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd: stats epilogue needs stat_partial");
-    const int bn = pick_bn((long)B * H * W, K, flags);
-    if (bn == 32)
-        return ups ? dispatch_epi<32, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
-                   : dispatch_epi<32, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st);
-    if (bn == 128)
-        return ups ? dispatch_epi<128, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
-                   : dispatch_epi<128, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st);
-    return ups ? dispatch_epi<64, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
-               : dispatch_epi<64, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st);
+    const Tile t = pick_tile((long)B * H * W, K, flags);
+#define EGZ_DISPATCH(BM_, BN_)                                                                                  \
+    return ups ? dispatch_epi<BM_, BN_, true>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)            \
+               : dispatch_epi<BM_, BN_, false>(epi, x, wp, bias, y, stat_partial, B, H, W, C, K, st)
+    if (t.bn == 32) { EGZ_DISPATCH(128, 32); }
+    if (t.bm == 64) { EGZ_DISPATCH(64, 64); }
+    if (t.bn == 64) { EGZ_DISPATCH(128, 64); }
+    EGZ_DISPATCH(128, 128);
+#undef EGZ_DISPATCH
 }

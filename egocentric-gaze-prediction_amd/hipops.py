@@ -162,10 +162,10 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     H, W = (2 * Hin, 2 * Win) if ups else (Hin, Win)
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
     stat = None
-    if epi == EPI_BIAS_STATS:
-        rows = LIB.egz_conv3x3_stat_rows(B, H, W)
-        stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
     flags = (1 if ups else 0) | (epi << 4) | tile_flag
+    if epi == EPI_BIAS_STATS:
+        rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
+        stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
     PROF.note_flops("egz_conv3x3_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K, flags,
                               _stream()), "egz_conv3x3_fwd")
