@@ -239,29 +239,17 @@ int dispatch_epi(int epi, const float* x, const float* wp, const float* bias, fl
     }
 }
 
-// Tile choice.  Every CU hosts `occ` blocks (LDS-limited: 2 for the 128-row tiles, 4 for 64x64); a launch takes
-// ceil(blocks / (256*occ)) waves of co-resident blocks, each wave costing occ * (tile area) of MFMA time on a CU.
-// Pick the tile with the smallest such makespan (the 28^2 / 56^2 layers have 784 / 1568 tiles of 128x128 for 512
-// slots: 23 % of the second wave would idle), scaled by the measured in-kernel efficiency of each tile shape.
+// Tile choice.  Measured on MI355X over all SP layer shapes at B=32 (tools/bench_conv.py, profiles/): the 64x64
+// tile at 4 blocks/CU (16 waves/CU, 37 KB LDS each) beats 128x128 / 128x64 at 2 blocks/CU on every shape but two
+// (within 3 %): with 256 CUs the coarse tiles leave up to 23 % of the last wave of blocks idle (784 or 1568 tiles for
+// 512 slots) and a lone wave per SIMD only reaches ~45 % MFMA issue, while 4 waves/SIMD keep the pipe fed.
 struct Tile { int bm, bn; };
 Tile pick_tile(long M, int K, int flags) {
+    (void)M;
     if (K % 64 != 0) return {128, 32};   // late-fusion widths (32, 8): one 32-wide n-tile, 4 waves along m
-    if (flags & 0x400) return {64, 64};
     if (flags & 0x100) return {128, 64};
     if (flags & 0x200) return {128, K % 128 == 0 ? 128 : 64};
-    const Tile cand[3] = {{128, 128}, {128, 64}, {64, 64}};
-    const int occ[3] = {2, 2, 4};
-    const double eff[3] = {1.00, 0.95, 0.90};
-    double best = 1e30;
-    Tile pick = {128, 64};
-    for (int i = 0; i < 3; ++i) {
-        if (K % cand[i].bn != 0) continue;
-        const long blocks = ((M + cand[i].bm - 1) / cand[i].bm) * (K / cand[i].bn);
-        const long waves = (blocks + 256L * occ[i] - 1) / (256L * occ[i]);
-        const double cost = (double)waves * occ[i] * cand[i].bm * cand[i].bn / eff[i];
-        if (cost < best) { best = cost; pick = cand[i]; }
-    }
-    return pick;
+    return {64, 64};
 }
 
 }  // namespace
