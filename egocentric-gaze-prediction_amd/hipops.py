@@ -16,6 +16,8 @@ import torch
 from ._lib import LIB as _RAW_LIB, check
 
 EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_STATS = 0, 1, 2
+import os as _os
+_TILE_FLAG = int(_os.environ.get("EGAZE_TILE", "0"), 0)     # A/B knob: 0x100 / 0x200 force the 128-row tiles
 
 
 class _Profiler:
@@ -162,7 +164,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     H, W = (2 * Hin, 2 * Win) if ups else (Hin, Win)
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
     stat = None
-    flags = (1 if ups else 0) | (epi << 4) | tile_flag
+    flags = (1 if ups else 0) | (epi << 4) | (tile_flag or _TILE_FLAG)
     if epi == EPI_BIAS_STATS:
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
