@@ -239,17 +239,20 @@ int dispatch_epi(int epi, const float* x, const float* wp, const float* bias, fl
     }
 }
 
-// Tile choice.  Measured on MI355X over all SP layer shapes at B=32 (tools/bench_conv.py, profiles/): the 64x64
-// tile at 4 blocks/CU (16 waves/CU, 37 KB LDS each) beats 128x128 / 128x64 at 2 blocks/CU on every shape but two
-// (within 3 %): with 256 CUs the coarse tiles leave up to 23 % of the last wave of blocks idle (784 or 1568 tiles for
-// 512 slots) and a lone wave per SIMD only reaches ~45 % MFMA issue, while 4 waves/SIMD keep the pipe fed.
+// Tile choice, from measurements on MI355X at B=32 (tools/bench_conv.py; whole-step A/B in bench.py):
+//   * Cout = 64 layers (224^2): the 64x64 tile at 4 blocks/CU wins by 6-15 % (a 128x64 block has half the MFMA
+//     work per staged byte and only 18 K-slices to amortise its prologue / epilogue over);
+//   * Cout >= 128: in isolation 64x64 is 1-5 % faster (finer tail: 784 / 1568 coarse tiles leave up to 23 % of the
+//     last wave of 512 slots idle), but inside the training step -- where the flow / RGB encoders and wgrad || dgrad
+//     overlap on separate HIP streams and fill those tails -- the 128x128 tile is 1.5 % faster end to end.
 struct Tile { int bm, bn; };
 Tile pick_tile(long M, int K, int flags) {
     (void)M;
     if (K % 64 != 0) return {128, 32};   // late-fusion widths (32, 8): one 32-wide n-tile, 4 waves along m
+    if (flags & 0x400) return {64, 64};
     if (flags & 0x100) return {128, 64};
     if (flags & 0x200) return {128, K % 128 == 0 ? 128 : 64};
-    return {64, 64};
+    return (K % 128 == 0) ? Tile{128, 128} : Tile{64, 64};
 }
 
 }  // namespace
