@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU (BASELINE: 32)")
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-at", action="store_true", help="leave the AT (lstmnet T=16, B=32) training step out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -94,12 +95,37 @@ def main():
     batch = synthetic.sp_batch(args.batch, args.size, dev, seed=100 + rank)
     input_s, input_t, target = batch["image"], batch["flow"], batch["gt"]
 
+    # AT module (BASELINE config 4 shape): lstmnet over T=16 steps of 512-vectors, batch 32, explicit (h, c)
+    use_at = not args.no_at
+    if use_at:
+        from egaze_amd.models.LSTMnet import lstmnet
+        from egaze_amd.functions import MSELoss
+        T_AT = 16
+        lstm = lstmnet().to(dev)
+        lstm.train()
+        opt_at = FusedAdam(lstm.parameters(), lr=1e-4)          # AT.py:84
+        if world > 1:
+            dp.attach(opt_at)
+        atb = synthetic.at_batch(T_AT, args.batch, dev, seed=200 + rank)
+        at_in, at_tgt = atb["input"], torch.tanh(atb["gt"])
+        h0 = torch.zeros(2, args.batch, 512, device=dev)
+        c0 = torch.zeros(2, args.batch, 512, device=dev)
+        opt_at.zero_grad()
+
     def step():
+        # SP: the body of SP.trainSP's loop (SP.py:132-138)
         output = model(input_s, input_t)
         loss = criterion(output, target.view(output.size()))
         loss.backward()
         optimizer.step()
         optimizer.zero_grad()
+        if use_at:
+            # AT: forward + MSE + backward + Adam of the attention-transition LSTM (AT.py:138-145 at T=16, B=32)
+            pred, _ = lstm(at_in, (h0, c0))
+            l2 = MSELoss.apply(pred, at_tgt)
+            l2.backward()
+            opt_at.step()
+            opt_at.zero_grad()
         return loss
 
     optimizer.zero_grad()
@@ -164,7 +190,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"SP two-stream (RGB + 10-pair flow stack) forward + floss + backward + Adam, "
                                    f"batch {args.batch}/GPU, {args.size}x{args.size}, train-mode BN, all "
-                                   f"46.5M params trainable (--sp_resume 0)",
+                                   f"46.5M params trainable (--sp_resume 0)"
+                                   + (f"; + AT lstmnet forward + MSE + backward + Adam over T=16, B={args.batch} "
+                                      f"512-vectors per step" if use_at else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "precision": "exact f32 MFMA (v_mfma_f32_32x32x2_f32)"},
             "roofline": roofline, "cpu_baseline": cpu,

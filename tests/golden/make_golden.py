@@ -275,10 +275,58 @@ def gen_metrics_and_glue():
     save("metrics_glue.npz", **arrs)
 
 
+def gen_config1():
+    """BASELINE config 1: run_spatialstream.py plumbing on one synthetic 224x224x3 image, CPU.  The script parses
+    argv and runs at import, so only its class / function definitions are extracted (ast) and executed."""
+    import ast
+    import contextlib
+    import io
+    import math
+    import torch.nn as nn
+    import utils as rutils
+    from models.late_fusion import late_fusion
+    from scipy import ndimage
+    src = open(os.path.join(REF, "run_spatialstream.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef))]
+    ns = {"nn": nn, "math": math, "np": np, "torch": torch}
+    ns.update({k: getattr(rutils, k) for k in dir(rutils) if not k.startswith("_")})
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "run_spatialstream_defs", "exec"), ns)
+    model = ns["VGG"](rutils.make_layers(rutils.cfg["D"], 3))
+    load_synth(model, seed=4, head_gain=0.25)
+    model.eval()
+    lf = late_fusion()
+    load_synth(lf, seed=3, head_gain=0.5)
+    lf.eval()
+    rs = np.random.RandomState(21)
+    im_u8 = rs.randint(0, 256, (224, 224, 3)).astype(np.uint8)          # "cv2.imread + resize" result (BGR)
+    im = ns["totensor"](im_u8)
+    with torch.no_grad():
+        out, feat = model(im)
+    imq = ns["toim"](out)
+    predicted = ndimage.center_of_mass(imq)
+    with contextlib.redirect_stdout(io.StringIO()):
+        vec = ns["crop_feature1"](feat, predicted, 3)
+    vec = vec.contiguous().view(vec.size(0), vec.size(1), -1)
+    vec = torch.mean(vec, 2).squeeze()
+    weighted = ns["get_weighted"](vec, feat)
+    weighted = torch.nn.functional.interpolate(weighted, scale_factor=16, mode="bilinear")   # F.upsample default
+    with torch.no_grad():
+        fin = lf(out, weighted)
+    save("config1.npz", out=out.numpy(), feat_sum=feat.double().sum(dim=(2, 3)).numpy(), imq=imq,
+         predicted=np.array(predicted), vec=vec.numpy(), weighted=weighted.numpy(), fin=fin.numpy(),
+         fin_u8=ns["toim"](fin), n_params=np.array(sum(p.numel() for p in model.parameters())))
+    print("config1 out range", out.min().item(), out.max().item(), "fin range", fin.min().item(), fin.max().item())
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":
+        gen_config1()
+        sys.exit(0)
     gen_floss()
     gen_lstm()
     gen_late_fusion()
     gen_metrics_and_glue()
     gen_model_sp(32, 2, "s32", head_gain=0.25)
     gen_model_sp(224, 2, "s224", head_gain=0.25)
+    gen_config1()

@@ -113,3 +113,25 @@ def test_late_fusion_grads_vs_fp64():
     print("LF HIP vs fp64: median %.2e max %.2e | CPU fp32: median %.2e max %.2e" %
           (np.median(eh), max(eh), np.median(ec), max(ec)))
     assert np.median(eh) < max(10 * np.median(ec), 1e-4) and max(eh) < 5e-2
+
+
+def test_config1_run_spatialstream_on_hip():
+    """BASELINE config 1 through the HIP path: VGG (3-conv-at-14 decoder) + plumbing + late_fusion(out, weighted)."""
+    from egaze_amd.run_spatialstream import VGG, predict
+    from egaze_amd.models.late_fusion import late_fusion
+    from egaze_amd.utils import make_layers, cfg
+    gold = np.load(os.path.join(GOLDEN, "config1.npz"))
+    model = VGG(make_layers(cfg['D'], 3))
+    assert list(model.state_dict()) == list(O.spatial_vgg_shapes())
+    model.load_state_dict(synth.synth_state_dict(O.spatial_vgg_shapes(), seed=4, head_gain=0.25))
+    model.to(DEV).eval()
+    lf = build().eval()
+    im_u8 = np.random.RandomState(21).randint(0, 256, (224, 224, 3)).astype(np.uint8)
+    r = predict(model, lf, im_u8, DEV)
+    assert rel(r["out"].cpu().numpy(), gold["out"]) < 1e-4
+    assert rel(r["feat"].double().sum(dim=(2, 3)).cpu().numpy(), gold["feat_sum"]) < 1e-4
+    assert np.abs(r["imq"].astype(int) - gold["imq"].astype(int)).max() <= 1        # uint8 truncation boundary
+    assert np.allclose(r["predicted"], gold["predicted"], atol=0.05)
+    assert rel(r["vec"].cpu().numpy(), gold["vec"]) < 1e-4
+    assert rel(r["weighted"].cpu().numpy(), gold["weighted"]) < 1e-4
+    assert rel(r["fin"].cpu().numpy(), gold["fin"]) < 1e-4

@@ -185,3 +185,23 @@ def test_metrics_and_glue():
     assert np.array_equal(cf.numpy(), gold["crop_feature"])
     w = cf.contiguous().view(2, 512, -1).mean(2)
     assert rel(O.get_weighted(w[0], feat[0:1]).numpy(), gold["get_weighted"]) < 1e-6
+
+
+def test_config1_run_spatialstream_plumbing():
+    """BASELINE config 1 (run_spatialstream.py on CPU): every stage of the plumbing against the reference."""
+    gold = g("config1.npz")
+    shapes = O.spatial_vgg_shapes()
+    assert sum(int(np.prod(v)) for k, v in shapes.items()
+               if not ("running" in k or "tracked" in k)) == int(gold["n_params"]) == 31795457
+    sd = synth.synth_state_dict(shapes, seed=4, head_gain=0.25)
+    sd_lf = synth.synth_state_dict(O.lf_shapes(), seed=3, head_gain=0.5)
+    im_u8 = np.random.RandomState(21).randint(0, 256, (224, 224, 3)).astype(np.uint8)
+    with torch.no_grad():
+        r = O.config1_pipeline(sd, sd_lf, im_u8)
+    assert rel(r["out"].numpy(), gold["out"]) < 1e-5
+    assert rel(r["feat"].double().sum(dim=(2, 3)).numpy(), gold["feat_sum"]) < 1e-5
+    assert np.array_equal(r["imq"], gold["imq"])
+    assert np.allclose(r["predicted"], gold["predicted"], rtol=1e-12)
+    assert rel(r["vec"].numpy(), gold["vec"]) < 1e-5
+    assert rel(r["weighted"].numpy(), gold["weighted"]) < 1e-5
+    assert rel(r["fin"].numpy(), gold["fin"]) < 1e-5
