@@ -22,7 +22,10 @@ SIGNATURES = {
     "egz_version": (c_char_p, []),
     "egz_last_error": (c_char_p, []),
     # --- 3x3 conv, implicit GEMM on f32 MFMA
-    "egz_pack_w3x3_elems": (c_size_t, [c_int, c_int]),
+    "egz_pack_w3x3_elems": (c_size_t, [c_int, c_int, c_int]),
+    "egz_pack_w3x3_ups_fwd": (c_int, [P, P, c_int, c_int, S]),
+    "egz_pack_w3x3_ups_dgrad": (c_int, [P, P, c_int, c_int, S]),
+    "egz_conv3x3_ups_dgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, S]),
     "egz_pack_w3x3_fwd": (c_int, [P, P, c_int, c_int, S]),
     "egz_pack_w3x3_dgrad": (c_int, [P, P, c_int, c_int, S]),
     "egz_conv3x3_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),

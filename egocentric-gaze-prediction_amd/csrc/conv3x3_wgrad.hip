@@ -307,8 +307,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad32_kernel(
     }
 }
 
-// dw[(k*C + c)*9 + tap] = sum_s part[s][tap][c][k]   (fixed order -> deterministic)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int C, int K, int S) {
+// Split-K reduction, fixed order (deterministic, no atomics).  Many splits (up to 1024 for the one-tile 64x64
+// layers) are first folded 32 at a time by a 2-D grid (every thread sums 32 rows with 4 independent accumulators);
+// the final pass sums the <= 32 remaining rows and transposes into the reference layout:
+//   dw[(k*C + c)*9 + tap] = sum_s part[s][tap][c][k]
+constexpr int RG = 32;
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const float* __restrict__ part, float* __restrict__ part2,
+                                                         long n, int S) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s0 = blockIdx.y * RG, s1 = (s0 + RG < S) ? s0 + RG : S;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int sp = s0;
+    for (; sp + 3 < s1; sp += 4) {
+        a0 += part[(long)sp * n + i];
+        a1 += part[(long)(sp + 1) * n + i];
+        a2 += part[(long)(sp + 2) * n + i];
+        a3 += part[(long)(sp + 3) * n + i];
+    }
+    for (; sp < s1; ++sp) a0 += part[(long)sp * n + i];
+    part2[(long)blockIdx.y * n + i] = (a0 + a1) + (a2 + a3);
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int C, int K, int S) {
     const long n = (long)9 * C * K;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         // i enumerates (tap, c, k) with k fastest -> coalesced reads of the partials
@@ -319,6 +340,24 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
         for (int sp = 0; sp < S; ++sp) s += part[(long)sp * n + i];
         dw[((long)k * C + c) * 9 + tap] = s;
     }
+}
+// workspace layout: [S][n] partial tiles, then [ceil(S/RG)][n] folded partials when S > RG
+size_t wgrad_ws_floats(int S, long n) { return (size_t)S * n + (S > RG ? (size_t)((S + RG - 1) / RG) * n : 0); }
+int wgrad_reduce(float* part, float* dw, int C, int K, int S, hipStream_t st) {
+    const long n = (long)9 * C * K;
+    const float* src = part;
+    int rows = S;
+    if (S > RG) {
+        float* part2 = part + (size_t)S * n;
+        rows = (S + RG - 1) / RG;
+        hipLaunchKernelGGL(wgrad_fold_kernel, dim3(egz_cdiv(n, 256), rows), dim3(256), 0, st, part, part2, n, S);
+        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(fold)");
+        src = part2;
+    }
+    const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, src, dw, C, K, rows);
+    EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce)");
+    return 0;
 }
 
 int pick_splits(long M, int C, int K, int BT) {
@@ -358,10 +397,11 @@ int pick_bt(int C, int K, int flags) {
 
 EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags) {
     const int L = pick_seg(W, C, K, flags);
-    if (L) return (size_t)pick_splits9((long)B * H * (W / L), C, K) * 9 * C * K * sizeof(float);
+    const long n = (long)9 * C * K;
+    if (L) return wgrad_ws_floats(pick_splits9((long)B * H * (W / L), C, K), n) * sizeof(float);
     const int bt = pick_bt(C, K, flags);
     const int S = pick_splits((long)B * H * W, C, K, bt);
-    return (size_t)S * 9 * C * K * sizeof(float);
+    return wgrad_ws_floats(S, n) * sizeof(float);
 }
 
 // flags: bit0 = the conv input was the nearest-x2 upsampling of x ([B][H/2][W/2][C]); 0x100 forces 64 tiles.
@@ -375,12 +415,11 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     const long M = (long)B * H * W;
     float* part = static_cast<float*>(workspace);
     const long nred = (long)9 * C * K;
-    const int gred = egz_cdiv(nred, 256) > 4096 ? 4096 : egz_cdiv(nred, 256);
     const int L = pick_seg(W, C, K, flags);
     if (L) {
         const long nseg = (long)B * H * (W / L);
         const int S = pick_splits9(nseg, C, K);
-        EGZ_CHECK_ARG(ws_bytes >= (size_t)S * 9 * C * K * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+        EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int sps = (int)((nseg + S - 1) / S);
         dim3 grid((C / 64) * (K / 64), S);
 #define EGZ_W9(U, LL) hipLaunchKernelGGL((conv3x3_wgrad9_kernel<U, LL>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, sps)
@@ -388,13 +427,11 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         else     { if (L == 32) EGZ_W9(false, 32); else if (L == 28) EGZ_W9(false, 28); else EGZ_W9(false, 14); }
 #undef EGZ_W9
         EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap)");
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(gred), dim3(256), 0, st, part, dw, C, K, S);
-        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce)");
-        return 0;
+        return wgrad_reduce(part, dw, C, K, S, st);
     }
     const int bt = pick_bt(C, K, flags);
     const int S = pick_splits(M, C, K, bt);
-    EGZ_CHECK_ARG(ws_bytes >= (size_t)S * 9 * C * K * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+    EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
     long pps = (M + S - 1) / S;
     pps = (pps + PK - 1) / PK * PK;
     dim3 grid(((C + bt - 1) / bt) * ((K + bt - 1) / bt) * 9, S);
@@ -409,9 +446,5 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         else     hipLaunchKernelGGL((conv3x3_wgrad_kernel<64, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
     }
     EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad");
-    const long n = (long)9 * C * K;
-    const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, part, dw, C, K, S);
-    EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce)");
-    return 0;
+    return wgrad_reduce(part, dw, C, K, S, st);
 }

@@ -94,8 +94,9 @@ class ConvReLU(torch.autograd.Function):
     def forward(ctx, x, weight, bias, ups):
         K, C = weight.shape[0], weight.shape[1]
         xin = to_nhwc(x)
-        y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd"), bias.detach() if bias is not None else None, K,
-                             ups=ups, epi=H.EPI_BIAS_RELU)
+        y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "ups_fwd" if ups else "fwd"),
+                             bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
+                             epi=H.EPI_BIAS_RELU)
         ctx.save_for_backward(xin, y, weight)
         ctx.cfg = (ups, C, K)
         return from_nhwc(y)
@@ -114,8 +115,10 @@ class ConvReLU(torch.autograd.Function):
             if ng[1]:
                 dw = H.conv3x3_wgrad(xin, dy, ups=ups)
         if ng[0]:
-            dxu = H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C)
-            dx = from_nhwc(H.upsample2x_bwd(dxu) if ups else dxu)
+            if ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
+                dx = from_nhwc(H.conv3x3_ups_dgrad(dy, H.packed_weight(weight, "ups_dgrad"), C))
+            else:
+                dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C))
         f.join(dw)
         return dx, dw, db, None
 

@@ -132,13 +132,18 @@ def _uid(w: torch.Tensor) -> int:
     return uid
 
 
+_PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0), "dgrad": ("egz_pack_w3x3_dgrad", 0),
+            "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1)}
+
+
 def _drop_packed(uid: int):
-    _PACKED.pop((uid, "fwd"), None)
-    _PACKED.pop((uid, "dgrad"), None)
+    for kind in _PACK_FN:
+        _PACKED.pop((uid, kind), None)
 
 
 def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
-    """(Cout, Cin, [1,] 3, 3) -> [9][Cin][Cout] ('fwd') or tap-flipped [9][Cout][Cin] ('dgrad').
+    """(Cout, Cin, [1,] 3, 3) -> the kernels' private packed layout: 'fwd' / 'dgrad' (9 taps) or, for a conv that
+    follows a nearest x2 upsample, 'ups_fwd' (4 phases x 2x2 pre-summed taps) / 'ups_dgrad' (4x4 stride-2 taps).
     Pass the parameter object itself (not a detached alias) so the cache can follow its identity."""
     _req(w, "weight")
     K, C = w.shape[0], w.shape[1]
@@ -147,24 +152,27 @@ def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
     hit = _PACKED.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    buf = hit[1] if hit is not None else torch.empty(LIB.egz_pack_w3x3_elems(C, K), dtype=torch.float32,
+    fname, ekind = _PACK_FN[kind]
+    buf = hit[1] if hit is not None else torch.empty(LIB.egz_pack_w3x3_elems(C, K, ekind), dtype=torch.float32,
                                                      device=w.device)
-    fn = LIB.egz_pack_w3x3_fwd if kind == "fwd" else LIB.egz_pack_w3x3_dgrad
-    check(fn(w.data_ptr(), buf.data_ptr(), C, K, _stream()), "pack_w3x3")
+    check(getattr(LIB, fname)(w.data_ptr(), buf.data_ptr(), C, K, _stream()), fname)
     _PACKED[key] = (tag, buf)
     return buf
 
 
 # ----------------------------------------------------------------------------- convolutions
-def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups: bool = False,
+def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
                 epi: int = EPI_BIAS, tile_flag: int = 0):
-    """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups."""
+    """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups.
+    ups: False | 'fold' (3x3 taps on the virtual upsampled image, wp = 'fwd' packing) | 'phase' or True (four 2x2
+    phase convolutions on the low-res input, 4/9 of the MACs, wp = 'ups_fwd' packing)."""
     _req(x, "x")
     B, Hin, Win, C = x.shape
     H, W = (2 * Hin, 2 * Win) if ups else (Hin, Win)
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
     stat = None
-    flags = (1 if ups else 0) | (epi << 4) | (tile_flag or _TILE_FLAG)
+    uflag = 0 if not ups else (1 if ups == "fold" else 3)
+    flags = uflag | (epi << 4) | (tile_flag or _TILE_FLAG)
     if epi == EPI_BIAS_STATS:
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
@@ -178,6 +186,17 @@ def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int) -> torch.Ten
     """dy: (B,H,W,K) -> dx (B,H,W,C) (for an upsampled conv this is the gradient of the upsampled input)."""
     y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS)
     return y
+
+
+def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int) -> torch.Tensor:
+    """Data gradient of [upsample x2 -> conv3x3] w.r.t. the LOW-res input: dy (B,H,W,K) -> dx (B,H/2,W/2,C)."""
+    _req(dy, "dy")
+    B, H, W, K = dy.shape
+    dx = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=dy.device)
+    PROF.note_flops("egz_conv3x3_ups_dgrad", 2.0 * B * H * W * K * 9 * C)     # algorithmic (reference) FLOPs
+    check(LIB.egz_conv3x3_ups_dgrad(dy.data_ptr(), wp_ups_dgrad.data_ptr(), dx.data_ptr(), B, H, W, C, K,
+                                    _TILE_FLAG, _stream()), "egz_conv3x3_ups_dgrad")
+    return dx
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0) -> torch.Tensor:

@@ -35,17 +35,25 @@ const char* egz_last_error(void);
  *      Implicit GEMM on v_mfma_f32_32x32x2_f32.  Weights are re-packed on the device first:
  *      fwd  : wp[tap][Cout_pad][Cin_pad]         dgrad: wp[8-tap][Cin_pad][Cout_pad]   (pad = round up to 32, zeros;
  *      one reduction-index-contiguous row per output channel of the GEMM -- private layout, may change) */
-size_t egz_pack_w3x3_elems(int C, int K);
+size_t egz_pack_w3x3_elems(int C, int K, int kind /* 0: fwd / dgrad, 1: ups_fwd / ups_dgrad */);
 int egz_pack_w3x3_fwd(const float* w, float* wp, int C, int K, hipStream_t stream);
 int egz_pack_w3x3_dgrad(const float* w, float* wp, int C, int K, hipStream_t stream);
+/* nn.Upsample(scale_factor=2) followed by the conv (models/model_SP.py:16-17,20-21,24-25,27-28): per output phase the
+ * 3x3 taps collapse to 2x2 pre-summed taps on the low-res input (4/9 of the MACs); ups_dgrad is its transpose. */
+int egz_pack_w3x3_ups_fwd(const float* w, float* wp, int C, int K, hipStream_t stream);
+int egz_pack_w3x3_ups_dgrad(const float* w, float* wp, int C, int K, hipStream_t stream);
 /* rows of the BatchNorm statistic partials written by the stats epilogue: stat_partial is [rows][2][K] fp64 */
 int egz_conv3x3_stat_rows(int B, int H, int W, int K, int flags);
 /* y[B][H][W][K] = conv3x3(x) + bias.  H, W are OUTPUT dims.  flags: bit0 = x is [B][H/2][W/2][C] and is nearest-x2
- * upsampled on the fly (nn.Upsample(scale_factor=2), models/model_SP.py:16,20,24,27); bits 4-5 epilogue: 0 bias,
+ * upsampled on the fly (nn.Upsample(scale_factor=2), models/model_SP.py:16,20,24,27); bit1 (with bit0) = use the
+ * phase-decomposed form (weights from egz_pack_w3x3_ups_fwd); bits 4-5 epilogue: 0 bias,
  * 1 bias+ReLU, 2 bias + per-channel (sum, sumsq) partials for train-mode BatchNorm; 0x100 / 0x200 / 0x400 force the
  * 128x64 / 128x128 / 64x64 tile (same flags must be given to egz_conv3x3_stat_rows).  Called with dgrad-packed weights (and K = Cin) it computes the data gradient. */
 int egz_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* y, double* stat_partial, int B, int H,
                     int W, int C, int K, int flags, hipStream_t stream);
+/* data gradient of [upsample x2 -> conv] w.r.t. the low-res input: dy [B][H][W][K] -> dx [B][H/2][W/2][C] */
+int egz_conv3x3_ups_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int C, int K, int flags,
+                          hipStream_t stream);
 /* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
 size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,

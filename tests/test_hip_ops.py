@@ -59,16 +59,25 @@ def test_conv3x3_fwd(B, Hh, Ww, C, K, tile, epi):
         assert rel(s[1], (ref.double() ** 2).sum(dim=(0, 2, 3))) < 1e-5
 
 
-@pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 6, 6, 64, 64), (1, 7, 5, 128, 128)])
-def test_conv3x3_upsample_fused(B, Hh, Ww, C, K):
+@pytest.mark.parametrize("mode", ["fold", "phase"])
+@pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 6, 6, 64, 64), (1, 7, 5, 128, 128), (3, 9, 4, 64, 256)])
+def test_conv3x3_upsample_fused(B, Hh, Ww, C, K, mode):
+    """[nearest x2 upsample -> conv3x3 -> ReLU] without materialising the upsampled tensor: folded gather (9 taps on
+    the virtual image) and the phase decomposition (four 2x2 convs with pre-summed weights, 4/9 of the MACs)."""
     h = H()
     x = rnd(B, C, Hh, Ww, seed=4)
     w = rnd(K, C, 3, 3, seed=5, scale=(2.0 / (9 * C)) ** 0.5)
     b = rnd(K, seed=6, scale=0.1)
-    ref = F.relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1))
-    y, _ = h.conv3x3_fwd(nhwc(x), h.packed_weight(w.to(DEV), "fwd"), b.to(DEV), K, ups=True, epi=1)
+    pre = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    wd = w.to(DEV)
+    wp = h.packed_weight(wd, "fwd" if mode == "fold" else "ups_fwd")
+    y, _ = h.conv3x3_fwd(nhwc(x), wp, b.to(DEV), K, ups=mode, epi=1)
     assert tuple(y.shape) == (B, 2 * Hh, 2 * Ww, K)
-    assert rel(nchw(y), ref) < 2e-5
+    assert rel(nchw(y), F.relu(pre)) < 2e-5
+    y2, stat = h.conv3x3_fwd(nhwc(x), wp, b.to(DEV), K, ups=mode, epi=2)
+    assert rel(nchw(y2), pre) < 2e-5
+    assert rel(stat.sum(0)[0].cpu(), pre.double().sum(dim=(0, 2, 3))) < 1e-5
+    assert rel(stat.sum(0)[1].cpu(), (pre.double() ** 2).sum(dim=(0, 2, 3))) < 1e-5
 
 
 @pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [
@@ -89,9 +98,12 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
     F.conv2d(xin, w, b, padding=1).backward(dy)
     dyd = nhwc(dy)
-    dxu = h.conv3x3_dgrad(dyd, h.packed_weight(w.detach().to(DEV), "dgrad"), C)
+    wdev = w.detach().to(DEV)
+    dxu = h.conv3x3_dgrad(dyd, h.packed_weight(wdev, "dgrad"), C)
     dx = h.upsample2x_bwd(dxu) if ups else dxu
     assert rel(nchw(dx), x.grad) < 2e-5
+    if ups:      # fused form: 4x4 / stride-2 gather straight to the low-res gradient
+        assert rel(nchw(h.conv3x3_ups_dgrad(dyd, h.packed_weight(wdev, "ups_dgrad"), C)), x.grad) < 2e-5
     dw = h.conv3x3_wgrad(nhwc(x.detach()), dyd, ups=ups)
     assert rel(dw.cpu(), w.grad) < 2e-5
     assert rel(h.colsum(dyd).cpu(), b.grad) < 1e-5
