@@ -63,6 +63,11 @@ class GradReducer:
     def _launch(self, b: int):
         start, end, _ = self.buckets[b]
         self._launched[b] = True
+        if self.flat_grad.is_cuda:
+            # a bucket may hold gradients accumulated on different HIP streams (the two encoders and the
+            # wgrad helper streams run concurrently, streams.py): order all of them before the collective
+            from . import streams
+            streams.join_all_into_current()
         self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True))
 

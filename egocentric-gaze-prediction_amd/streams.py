@@ -54,3 +54,17 @@ class fork:
             for t in tensors:
                 if t is not None:
                     t.record_stream(self.cur)
+
+
+def join_all_into_current():
+    """Make the current stream wait for every helper stream created so far (used before a gradient bucket that may
+    hold gradients produced on several streams is handed to RCCL)."""
+    if not torch.cuda.is_available():
+        return
+    cur = torch.cuda.current_stream()
+    for st in _SIDE.values():
+        if st.device == cur.device and st.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(st)
+    default = torch.cuda.default_stream(cur.device)
+    if default.cuda_stream != cur.cuda_stream:
+        cur.wait_stream(default)
