@@ -173,12 +173,19 @@ def main():
         for entry in ("egz_conv3x3_fwd", "egz_conv3x3_ups_dgrad"):       # both launch conv3x3_igemm_kernel
             for k2 in ig:
                 ig[k2] += prof.get(entry, {}).get(k2, 0)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_igemm.json")
+        if os.path.exists(tpath):
+            # HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+            # this same command (tools/pmc_traffic.py; gfx950 FETCH half-count corrected) -- PMC cannot be sampled
+            # from inside the process, so the committed profile is quoted
+            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         if ig["ms"] > 0:
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             roofline = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad launches; "
                                   "FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it)",
                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                         "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
                         "algorithmic_flop_per_step": ig["flops"]}
         tot = sum(v["ms"] for v in prof.values())
