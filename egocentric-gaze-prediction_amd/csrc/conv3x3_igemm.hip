@@ -9,7 +9,7 @@
 //   block tile BM(m) x BN(n) in {128x128, 128x64, 64x64, 128x32}, K-slice = one tap x 32 channels,
 //   4 waves (64 lanes), each wave MR x NR MFMA 32x32 tiles; A = [pixel][k] and B = [out-channel][k] tiles in LDS,
 //   both k-contiguous with a 36-float row stride so both operands are fetched with conflict-free ds_read_b128;
-//   LDS double-buffered, register-staged global loads (issue slice s+1 -> MFMAs of slice s -> ds_write mid-slice),
+//   LDS double-buffered, register-staged global loads running two slices ahead (two register sets),
 //   fragment reads register-double-buffered against the MFMAs.
 //   Channel counts that are not multiples of 32 are zero-padded in the packed weights and masked in x / y.
 //
@@ -23,6 +23,7 @@
 //               hi-res dY (16 taps on a quarter of the pixels = 4/9 of the MACs); replaces dgrad + 2x2-sum
 // Epilogues: bias, bias+ReLU, bias + per-channel sum / sum-of-squares partials (fp64) for train-mode BatchNorm.
 #include "egz_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -88,8 +89,12 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
         if (a_c4 == 0) Ro[r0 + 32 * j] = off;
     }
 
-    f32x4 ra[ALD], rb[BLD];
-    auto gload = [&](int s) {
+    // two register sets: the global loads run TWO slices ahead of the MFMAs (slice s+2 is in flight while slice
+    // s+1 is being staged into LDS and slice s is multiplied), so a wave that is alone on its SIMD -- the tail of
+    // a launch -- still hides the full HBM latency
+    f32x4 ra[2][ALD], rb[2][BLD];
+    auto gload = [&](int s, auto SETC) {
+        constexpr int SET = decltype(SETC)::value;
         const int cblk = s / NTAP, tap = s - cblk * NTAP;
         const int c0 = cblk * BK;
         int dy, dx;
@@ -118,23 +123,24 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
             const bool ok = (unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb && (c0 + a_c4 * 4 < C);
             const int sy = (MODE == UPS_FOLD) ? (iy >> 1) : iy, sx = (MODE == UPS_FOLD) ? (ix >> 1) : ix;
             const float* p = x + ((a_img[j] + (long)sy * Wg + sx) * C + c0 + a_c4 * 4);
-            ra[j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[SET][j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int j = 0; j < BLD; ++j) {
             const float* p = wp + ((long)((phase * NTAP + tap) * Kp + n0 + r0 + 32 * j) * Cp + c0 + a_c4 * 4);
-            rb[j] = *reinterpret_cast<const f32x4*>(p);
+            rb[SET][j] = *reinterpret_cast<const f32x4*>(p);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, auto SETC) {
+        constexpr int SET = decltype(SETC)::value;
         float* a = As + buf * BM * LDA;
         float* b = Bs + buf * BN * LDA;
 #pragma unroll
         for (int j = 0; j < ALD; ++j)
-            *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDA + a_c4 * 4) = ra[j];
+            *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDA + a_c4 * 4) = ra[SET][j];
 #pragma unroll
         for (int j = 0; j < BLD; ++j)
-            *reinterpret_cast<f32x4*>(b + (r0 + 32 * j) * LDA + a_c4 * 4) = rb[j];
+            *reinterpret_cast<f32x4*>(b + (r0 + 32 * j) * LDA + a_c4 * 4) = rb[SET][j];
     };
 
     f32x16 acc[MR][NR];
@@ -146,12 +152,18 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int S = (Cp / BK) * NTAP;
-    gload(0);
-    lstore(0);
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    gload(0, Set0{});
+    lstore(0, Set0{});
+    if (S > 1) gload(1, Set1{});
     __syncthreads();
-    for (int s = 0; s < S; ++s) {
+    // one slice: MFMAs on LDS buffer s&1; slice s+1 (register set CUR^1) is staged mid-way into the other LDS
+    // buffer; slice s+2 is requested from HBM/L2 into the register set that slice s just vacated (CUR)
+    auto slice = [&](int s, auto CURC) {
+        constexpr int CUR = decltype(CURC)::value;
         const int buf = s & 1;
-        if (s + 1 < S) gload(s + 1);
+        if (s + 2 < S) gload(s + 2, std::integral_constant<int, CUR>{});
         const float* Ab = As + buf * BM * LDA + (wm * WM + l31) * LDA + 4 * hl;
         const float* Bb = Bs + buf * BN * LDA + (wn * WN + l31) * LDA + 4 * hl;
         // fragments of k-group q+1 are fetched while the 4*MR*NR MFMAs of group q issue (register double buffer)
@@ -178,11 +190,14 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
                     for (int mr = 0; mr < MR; ++mr)
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][mr][j], bf[q & 1][nr][j],
                                                                           acc[mr][nr], 0, 0, 0);
-            // the other LDS buffer was released by the barrier that ended slice s-1: stage slice s+1 into it
-            // half-way through this slice's MFMAs (its global loads were issued ~2k cycles ago)
-            if (q == 1 && s + 1 < S) lstore(buf ^ 1);
+            // the other LDS buffer was released by the barrier that ended slice s-1
+            if (q == 1 && s + 1 < S) lstore(buf ^ 1, std::integral_constant<int, CUR ^ 1>{});
         }
         __syncthreads();
+    };
+    for (int s = 0; s < S; s += 2) {
+        slice(s, Set0{});
+        if (s + 1 < S) slice(s + 1, Set1{});
     }
 
     // ---- epilogue: bias (+ReLU) (+BN statistic partials), NHWC store
