@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
     // s+1 is being staged into LDS and slice s is multiplied), so a wave that is alone on its SIMD -- the tail of
     // a launch -- still hides the full HBM latency
     f32x4 ra[2][ALD], rb[2][BLD];
-    auto gload = [&](int s, auto SETC) {
+    auto gload_a = [&](int s, auto SETC) {
         constexpr int SET = decltype(SETC)::value;
         const int cblk = s / NTAP, tap = s - cblk * NTAP;
         const int c0 = cblk * BK;
@@ -125,11 +125,20 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
             const float* p = x + ((a_img[j] + (long)sy * Wg + sx) * C + c0 + a_c4 * 4);
             ra[SET][j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto gload_b = [&](int s, auto SETC) {
+        constexpr int SET = decltype(SETC)::value;
+        const int cblk = s / NTAP, tap = s - cblk * NTAP;
+        const int c0 = cblk * BK;
 #pragma unroll
         for (int j = 0; j < BLD; ++j) {
             const float* p = wp + ((long)((phase * NTAP + tap) * Kp + n0 + r0 + 32 * j) * Cp + c0 + a_c4 * 4);
             rb[SET][j] = *reinterpret_cast<const f32x4*>(p);
         }
+    };
+    auto gload = [&](int s, auto SETC) {
+        gload_a(s, SETC);
+        gload_b(s, SETC);
     };
     auto lstore = [&](int buf, auto SETC) {
         constexpr int SET = decltype(SETC)::value;
@@ -163,7 +172,11 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
     auto slice = [&](int s, auto CURC) {
         constexpr int CUR = decltype(CURC)::value;
         const int buf = s & 1;
-        if (s + 2 < S) gload(s + 2, std::integral_constant<int, CUR>{});
+        // Branch-free body (one basic block, so the scheduler can sink the address arithmetic of the prefetch into
+        // the shadow of the MFMAs instead of running it up front while the matrix pipe idles -- which is what a
+        // wave that is alone on its SIMD would pay every slice).  Past the last slices the prefetch re-reads the
+        // last slice (clamped index) and the staged copy is never consumed.
+        const int sp = (s + 2 < S) ? s + 2 : S - 1;
         const float* Ab = As + buf * BM * LDA + (wm * WM + l31) * LDA + 4 * hl;
         const float* Bb = Bs + buf * BN * LDA + (wn * WN + l31) * LDA + 4 * hl;
         // fragments of k-group q+1 are fetched while the 4*MR*NR MFMAs of group q issue (register double buffer)
@@ -190,8 +203,10 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
                     for (int mr = 0; mr < MR; ++mr)
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][mr][j], bf[q & 1][nr][j],
                                                                           acc[mr][nr], 0, 0, 0);
-            // the other LDS buffer was released by the barrier that ended slice s-1
-            if (q == 1 && s + 1 < S) lstore(buf ^ 1, std::integral_constant<int, CUR ^ 1>{});
+            if (q == 0) gload_a(sp, std::integral_constant<int, CUR>{});       // slice s+2 -> the set slice s vacated
+            if (q == 1) gload_b(sp, std::integral_constant<int, CUR>{});
+            // the other LDS buffer was released by the barrier that ended slice s-1: stage slice s+1 (set CUR^1)
+            if (q == 2) lstore(buf ^ 1, std::integral_constant<int, CUR ^ 1>{});
         }
         __syncthreads();
     };
