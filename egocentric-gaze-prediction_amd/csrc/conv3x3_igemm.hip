@@ -167,24 +167,30 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
     lstore(0, Set0{});
     if (S > 1) gload(1, Set1{});
     __syncthreads();
-    // one slice: MFMAs on LDS buffer s&1; slice s+1 (register set CUR^1) is staged mid-way into the other LDS
-    // buffer; slice s+2 is requested from HBM/L2 into the register set that slice s just vacated (CUR)
-    auto slice = [&](int s, auto CURC) {
-        constexpr int CUR = decltype(CURC)::value;
-        const int buf = s & 1;
-        // Branch-free body (one basic block, so the scheduler can sink the address arithmetic of the prefetch into
-        // the shadow of the MFMAs instead of running it up front while the matrix pipe idles -- which is what a
-        // wave that is alone on its SIMD would pay every slice).  Past the last slices the prefetch re-reads the
-        // last slice (clamped index) and the staged copy is never consumed.
-        const int sp = (s + 2 < S) ? s + 2 : S - 1;
-        const float* Ab = As + buf * BM * LDA + (wm * WM + l31) * LDA + 4 * hl;
-        const float* Bb = Bs + buf * BN * LDA + (wn * WN + l31) * LDA + 4 * hl;
-        // fragments of k-group q+1 are fetched while the 4*MR*NR MFMAs of group q issue (register double buffer)
-        f32x4 af[2][MR], bf[2][NR];
+    // Fragment registers persist across slices: group q lives in set q&1, and the q=0 fragments of slice s+1 are
+    // fetched during the q=3 MFMAs of slice s, so the matrix pipe never drains at a slice boundary.
+    f32x4 af[2][MR], bf[2][NR];
+    {
+        const float* Ab = As + (wm * WM + l31) * LDA + 4 * hl;
+        const float* Bb = Bs + (wn * WN + l31) * LDA + 4 * hl;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) af[0][mr] = *reinterpret_cast<const f32x4*>(Ab + mr * 32 * LDA);
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) bf[0][nr] = *reinterpret_cast<const f32x4*>(Bb + nr * 32 * LDA);
+    }
+    // One slice = 4 k-groups of 4*MR*NR MFMAs on LDS buffer s&1.  Interleaved in their shadow (branch-free, one basic
+    // block): the address arithmetic + issue of the global loads of slice s+2 (into the register set slice s
+    // vacated), the staging of slice s+1 into the other LDS buffer, ONE barrier right after that staging (RAW for
+    // slice s+1; WAR is safe because every read of buffer s&1 was issued before this barrier of the same slice),
+    // and the first fragments of slice s+1.  Past the end the prefetches re-read the last slice (clamped index).
+    auto slice = [&](int s, auto CURC) {
+        constexpr int CUR = decltype(CURC)::value;
+        const int buf = s & 1;
+        const int sp = (s + 2 < S) ? s + 2 : S - 1;
+        const float* Ab = As + buf * BM * LDA + (wm * WM + l31) * LDA + 4 * hl;
+        const float* Bb = Bs + buf * BN * LDA + (wn * WN + l31) * LDA + 4 * hl;
+        const float* An = As + (buf ^ 1) * BM * LDA + (wm * WM + l31) * LDA + 4 * hl;
+        const float* Bn = Bs + (buf ^ 1) * BN * LDA + (wn * WN + l31) * LDA + 4 * hl;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (q < 3) {
@@ -194,6 +200,11 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
                     bf[(q + 1) & 1][nr] = *reinterpret_cast<const f32x4*>(Bb + nr * 32 * LDA + 8 * (q + 1));
+            } else {
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) af[0][mr] = *reinterpret_cast<const f32x4*>(An + mr * 32 * LDA);
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) bf[0][nr] = *reinterpret_cast<const f32x4*>(Bn + nr * 32 * LDA);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -203,17 +214,19 @@ __global__ __launch_bounds__(256, (BM == 64) ? 4 : 2) void conv3x3_igemm_kernel(
                     for (int mr = 0; mr < MR; ++mr)
                         acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][mr][j], bf[q & 1][nr][j],
                                                                           acc[mr][nr], 0, 0, 0);
-            if (q == 0) gload_a(sp, std::integral_constant<int, CUR>{});       // slice s+2 -> the set slice s vacated
+            if (q == 0) gload_a(sp, std::integral_constant<int, CUR>{});
             if (q == 1) gload_b(sp, std::integral_constant<int, CUR>{});
-            // the other LDS buffer was released by the barrier that ended slice s-1: stage slice s+1 (set CUR^1)
-            if (q == 2) lstore(buf ^ 1, std::integral_constant<int, CUR ^ 1>{});
+            if (q == 2) {
+                lstore(buf ^ 1, std::integral_constant<int, CUR ^ 1>{});
+                __syncthreads();
+            }
         }
-        __syncthreads();
     };
     for (int s = 0; s < S; s += 2) {
         slice(s, Set0{});
         if (s + 1 < S) slice(s + 1, Set1{});
     }
+    __syncthreads();      // all fragment reads done before the epilogue reuses As
 
     // ---- epilogue: bias (+ReLU) (+BN statistic partials), NHWC store
     double* red = reinterpret_cast<double*>(As);   // [WAVES_M][2 (sum, sumsq)][BN]
