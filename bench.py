@@ -157,9 +157,10 @@ def main():
 
     roofline = None
     breakdown = None
-    if rank == 0 and not args.no_roofline:
-        # per-kernel HIP-event timing needs the kernels serialised: switch the multi-stream overlap off for this
-        # one extra (untimed) step so that an event pair brackets exactly one kernel family's launches
+    if not args.no_roofline:
+        # Every rank runs these two extra (untimed) steps -- the gradient all-reduce inside step() is a collective --
+        # but only rank 0 reports.  Per-kernel HIP-event timing needs the kernels serialised: the multi-stream
+        # overlap is switched off so that an event pair brackets exactly one kernel family's launches.
         from egaze_amd import streams
         was = streams.ENABLED
         streams.ENABLED = False
@@ -182,8 +183,10 @@ def main():
             traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
         if ig["ms"] > 0:
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad launches; "
-                                  "FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it)",
+            roofline = {"bound": "mfma",
+                        "kernel": "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
+                                  "launches; FLOPs are the reference's algorithmic count, the upsample-fused launches "
+                                  "execute 4/9 of it)",
                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                         "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],

@@ -47,12 +47,19 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--tile", type=lambda v: int(v, 0), default=0)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--shape", action="append", default=[], help="extra shape C,K,H,B (plain conv)")
     ap.add_argument("--wflag", type=lambda v: int(v, 0), default=0, help="0x800 = per-tap wgrad kernel")
     a = ap.parse_args()
     dev = "cuda:0"
     B = a.batch
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
-    for name, C, K, Hh, ups in SHAPES:
+    shapes = [(n, c, k, h, u, B) for n, c, k, h, u in SHAPES]
+    if a.shape:
+        shapes = []
+        for sh in a.shape:
+            c, k, h, b = (int(v) for v in sh.split(","))
+            shapes.append((f"custom {c}->{k} @{h} B{b}", c, k, h, False, b))
+    for name, C, K, Hh, ups, B in shapes:
         if a.only and a.only not in name:
             continue
         hin = Hh // 2 if ups else Hh
