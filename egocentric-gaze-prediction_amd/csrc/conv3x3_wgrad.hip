@@ -229,6 +229,141 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of [nearest x2 upsample -> conv3x3] in phase form (the transpose of the UPS_PHASE forward of
+// conv3x3_igemm.hip): for each output phase (py,px) the 3x3 taps collapse to 2x2 taps on the LOW-res input, so
+//   dWeff[py][px][a][b][c][k] = sum_{b,y,x} X[y+a+py-1][x+b+px-1][c] * dY[2y+py][2x+px][k]
+// (16 accumulations over a quarter of the pixels = 4/9 of the MACs of the folded form) and
+//   dW[r][s] = sum over the (py,a) with r in R(py,a) and the (px,b) with s in R(px,b) of dWeff[py][px][a][b].
+// One block = one 64(c) x 64(k) tile of ONE phase (blockIdx.z), 4 accumulators per wave; a stage is a segment of L
+// low-res pixels: 2 x (L+1) input halo + L strided dY rows in LDS.
+template <int L>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, int segs_per_split) {
+    constexpr int HP = L + 1;
+    constexpr int NX = (2 * HP * 16 + 255) / 256;
+    constexpr int ND = (L * 16 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float Xh[2 * 2 * HP * 64];
+    __shared__ __attribute__((aligned(16))) float Ds[2 * L * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wk = wave & 1, hl = lane >> 5, l31 = lane & 31;
+    const int tk = K / 64;
+    const int c0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
+    const int phase = blockIdx.z, py = phase >> 1, px = phase & 1;
+    const int Hl = H >> 1, Wl = W >> 1;               // low-res dims (H, W are the hi-res conv output dims)
+    const int spr = Wl / L;
+    const long nseg = (long)B * Hl * spr;
+    const long g0 = (long)blockIdx.y * segs_per_split;
+    const long g1 = (g0 + segs_per_split < nseg) ? (g0 + segs_per_split) : nseg;
+
+    f32x4 rx[NX], rd[ND];
+    auto gload = [&](long g) {
+        const int xs = (int)(g % spr) * L;
+        const long t = g / spr;
+        const int yy = (int)(t % Hl);
+        const long b = t / Hl;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            const int pos = i >> 4, c4 = i & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pos < 2 * HP) {
+                const int a = pos / HP, pxi = pos - a * HP;
+                const int iy = yy + a + py - 1, ix = xs + pxi + px - 1;
+                if ((unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl)
+                    v = *reinterpret_cast<const f32x4*>(x + ((b * Hl + iy) * (long)Wl + ix) * C + c0 + c4 * 4);
+            }
+            rx[j] = v;
+        }
+        const long m0 = (b * H + 2 * yy + py) * (long)W + 2 * xs + px;      // hi-res pixel of segment pixel 0
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j;
+            const int pp = i >> 4, k4 = i & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pp < L) v = *reinterpret_cast<const f32x4*>(dy + (m0 + 2 * pp) * K + k0 + k4 * 4);
+            rd[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            if (i < 2 * HP * 16) *reinterpret_cast<f32x4*>(Xh + buf * 2 * HP * 64 + i * 4) = rx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j;
+            if (i < L * 16) *reinterpret_cast<f32x4*>(Ds + buf * L * 64 + i * 4) = rd[j];
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (g0 < g1) {
+        gload(g0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (long g = g0; g < g1; ++g) {
+        const int buf = (int)((g - g0) & 1);
+        if (g + 1 < g1) gload(g + 1);
+        const float* Xb = Xh + buf * 2 * HP * 64 + hl * 64 + wc * 32 + l31;
+        const float* Db = Ds + buf * L * 64 + hl * 64 + wk * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < L / 2; ++t) {
+            const float bv = Db[(2 * t) * 64];
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) {
+                const float av = Xb[((tap >> 1) * HP + 2 * t + (tap & 1)) * 64];
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[tap], 0, 0, 0);
+            }
+        }
+        if (g + 1 < g1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+        float* out = part + ((long)blockIdx.y * 16 + phase * 4 + tap) * C * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wc * 32 + egz_acc_row(r, lane);
+            const int k = k0 + wk * 32 + l31;
+            out[(long)c * K + k] = acc[tap][r];
+        }
+    }
+}
+
+// dw[k][c][r][s] = sum_rows sum_{(py,a) : r in R(py,a)} sum_{(px,b) : s in R(px,b)} part[row][py*2+px][a*2+b][c][k]
+//   R(0,0)={0}, R(0,1)={1,2}, R(1,0)={0,1}, R(1,1)={2}  =>  r=0: (0,0),(1,0);  r=1: (0,1),(1,0);  r=2: (0,1),(1,1)
+__global__ __launch_bounds__(256) void wgrad_reduce_ups_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                               int C, int K, int rows) {
+    const long ck = (long)C * K, n = 16 * ck;
+    const int PA[3][2][2] = {{{0, 0}, {1, 0}}, {{0, 1}, {1, 0}}, {{0, 1}, {1, 1}}};   // [r][which] -> (p, a)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 9 * ck; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const long t = i / K;
+        const int c = (int)(t % C), tap = (int)(t / C);
+        const int r = tap / 3, q = tap % 3;
+        float s = 0.f;
+        for (int row = 0; row < rows; ++row)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int py = PA[r][u][0], a = PA[r][u][1], px = PA[q][v][0], b = PA[q][v][1];
+                    s += part[(long)row * n + ((py * 2 + px) * 4 + a * 2 + b) * ck + (long)c * K + k];
+                }
+        dw[((long)k * C + c) * 9 + tap] = s;
+    }
+}
+
 // Narrow layers (late_fusion: C = 32, K = 32 / 8): one 32(c) x 32(k) MFMA tile per block; the four waves split
 // each 32-pixel stage four ways (intra-block split-K) and are summed through LDS at the end.  Channel counts
 // that are not multiples of 32 are masked on load / store.
@@ -369,6 +504,24 @@ int pick_splits(long M, int C, int K, int BT) {
     return (int)s;
 }
 
+// segment length of the upsample-phase kernel on the LOW-res row (0 = not applicable)
+int pick_seg_ups(int W, int C, int K, int flags) {
+    if ((flags & 0x1800) || C % 64 != 0 || K % 64 != 0 || W % 2) return 0;   // 0x1000: force the folded 9-tap form
+    const int Wl = W / 2;
+    if (Wl % 32 == 0) return 32;
+    if (Wl % 28 == 0) return 28;
+    if (Wl % 14 == 0) return 14;
+    return 0;
+}
+int pick_splits_ups(long nseg, int C, int K) {
+    const long tiles = (long)(C / 64) * (K / 64) * 4;
+    long s = (1024 + tiles - 1) / tiles;
+    const long smax = (nseg + 7) / 8;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
 // segment length of the 9-tap fused kernel (0 = not applicable -> per-tap kernel)
 int pick_seg(int W, int C, int K, int flags) {
     if (flags & 0x800) return 0;                      // force the per-tap kernel (A/B benchmarking)
@@ -398,13 +551,18 @@ int pick_bt(int C, int K, int flags) {
 EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags) {
     const int L = pick_seg(W, C, K, flags);
     const long n = (long)9 * C * K;
+    if (flags & 1) {
+        const int Lu = pick_seg_ups(W, C, K, flags);
+        if (Lu) return wgrad_ws_floats(pick_splits_ups((long)B * (H / 2) * (W / 2 / Lu), C, K), 16L * C * K) * sizeof(float);
+    }
     if (L) return wgrad_ws_floats(pick_splits9((long)B * H * (W / L), C, K), n) * sizeof(float);
     const int bt = pick_bt(C, K, flags);
     const int S = pick_splits((long)B * H * W, C, K, bt);
     return wgrad_ws_floats(S, n) * sizeof(float);
 }
 
-// flags: bit0 = the conv input was the nearest-x2 upsampling of x ([B][H/2][W/2][C]); 0x100 forces 64 tiles.
+// flags: bit0 = the conv input was the nearest-x2 upsampling of x ([B][H/2][W/2][C]); 0x100 forces 64 tiles;
+//        0x800 forces the per-tap kernel, 0x1000 the folded 9-tap form of an upsampled conv (A/B benchmarking).
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
 EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
                               int flags, void* workspace, size_t ws_bytes, hipStream_t st) {
@@ -415,6 +573,32 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     const long M = (long)B * H * W;
     float* part = static_cast<float*>(workspace);
     const long nred = (long)9 * C * K;
+    const int Lu = ups ? pick_seg_ups(W, C, K, flags) : 0;
+    if (Lu) {      // phase-decomposed upsample: 16 (phase, tap) partial tiles per split, 4/9 of the MACs
+        const long n16 = 16L * C * K;
+        const long nseg = (long)B * (H / 2) * (W / 2 / Lu);
+        const int S = pick_splits_ups(nseg, C, K);
+        EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, n16) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+        const int sps = (int)((nseg + S - 1) / S);
+        dim3 grid((C / 64) * (K / 64), S, 4);
+        if (Lu == 32)      hipLaunchKernelGGL(conv3x3_wgrad_ups_kernel<32>, grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, sps);
+        else if (Lu == 28) hipLaunchKernelGGL(conv3x3_wgrad_ups_kernel<28>, grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, sps);
+        else               hipLaunchKernelGGL(conv3x3_wgrad_ups_kernel<14>, grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, sps);
+        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(ups-phase)");
+        const float* src = part;
+        int rows = S;
+        if (S > RG) {
+            float* part2 = part + (size_t)S * n16;
+            rows = (S + RG - 1) / RG;
+            hipLaunchKernelGGL(wgrad_fold_kernel, dim3(egz_cdiv(n16, 256), rows), dim3(256), 0, st, part, part2, n16, S);
+            EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(fold)");
+            src = part2;
+        }
+        const int g = egz_cdiv(nred, 256) > 4096 ? 4096 : egz_cdiv(nred, 256);
+        hipLaunchKernelGGL(wgrad_reduce_ups_kernel, dim3(g), dim3(256), 0, st, src, dw, C, K, rows);
+        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce-ups)");
+        return 0;
+    }
     const int L = pick_seg(W, C, K, flags);
     if (L) {
         const long nseg = (long)B * H * (W / L);

@@ -86,6 +86,7 @@ def test_conv3x3_upsample_fused(B, Hh, Ww, C, K, mode):
     # geometries of the 9-tap fused wgrad kernel (row segments of 32 / 28 / 14 pixels)
     (2, 28, 28, 64, 64, False), (1, 32, 32, 64, 128, False), (1, 28, 28, 128, 64, True), (3, 6, 28, 64, 64, False),
     (1, 16, 64, 64, 64, True), (2, 14, 14, 192, 128, False), (1, 28, 56, 64, 64, False),
+    (1, 56, 56, 64, 64, True), (2, 6, 56, 128, 64, True),        # phase-decomposed upsample wgrad, L = 28
 ])
 def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     """dgrad (same kernel, tap-flipped transposed weights), wgrad (split-K MFMA), bias grad, upsample bwd."""
