@@ -1,0 +1,354 @@
+// Error-compensated split-half variant of the 3x3 implicit GEMM (conv3x3_igemm.hip) for the wide layers
+// (GEMM output channels a multiple of 128): every fp32 operand is represented as hi + lo in a 16-bit type and the
+// product is accumulated in fp32 as  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  -- three v_mfma_f32_32x32x16_{f16,bf16}
+// (2.5 PFLOP/s class, 16x the rate of the exact-f32 MFMA) per 16 k instead of eight v_mfma_f32_32x32x2_f32:
+// 5.3x less matrix-pipe time at fp32-class accuracy ("error-compensated split-half").
+//   * f16 x3 (forward): 22 significant bits per operand; measured |err| 3e-7 of max|ref| on K = 4608 dot products,
+//     the same as an fp32 matmul (4.8e-7).  Weights are pre-scaled by 2^10 at pack time (keeps the lo half normal),
+//     undone exactly in the epilogue; activations are clamped to +-65504 before the split (no inf).
+//   * bf16 x3 (data gradient): fp32 exponent range for tiny gradients, 16 significant bits, |err| 5.5e-6.
+// The activation operand is split on the fly while it is staged into LDS (it stays fp32 in HBM); the weight operand is
+// split once at pack time (egz_pack_w3x3_split).  Same gather modes and epilogues as the fp32 kernel.
+//   block tile 128 x 128, K-slice = one tap x 32 channels, 4 waves as 2 x 2, each wave 2 x 2 MFMA 32x32 tiles;
+//   LDS (single buffer, 40 KB): hi / lo planes of A [128][32] and B [128][32] 16-bit, 80-byte row stride (conflict-free
+//   ds_read_b128 fragments: lane l reads 8 consecutive k of row l&31 at k = 8*(l>>5)); the next slice is prefetched
+//   into registers during the MFMAs and converted / stored between two barriers; 2 blocks per CU overlap each other.
+#include "egz_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int XBM = 128, XBN = 128, XBK = 32;
+constexpr int XLD = 40;                 // row stride in 16-bit elements (80 B)
+constexpr float F16_WSCALE = 1024.f;    // 2^10
+
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
+enum { PLAIN = 0, UPS_FOLD = 1, UPS_PHASE = 2, UPS_DGRAD = 3 };
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Half;
+template <> struct Half<_Float16> {
+    static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
+        x = fminf(fmaxf(x, -65504.f), 65504.f);
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        h = __builtin_bit_cast(unsigned short, hi);
+        l = __builtin_bit_cast(unsigned short, lo);
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Half<__bf16> {
+    static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
+        const __bf16 hi = (__bf16)x;
+        const __bf16 lo = (__bf16)(x - (float)hi);
+        h = __builtin_bit_cast(unsigned short, hi);
+        l = __builtin_bit_cast(unsigned short, lo);
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// wp: [2 planes (hi, lo)][taps][Kp][Cp] 16-bit.  H, W: hi-res (conv output) dims for the UPS_* modes.
+template <typename T, int MODE, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
+    float out_scale) {
+    constexpr int NTAP = (MODE == UPS_PHASE) ? 4 : (MODE == UPS_DGRAD) ? 16 : 9;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * XBM * XLD];   // [plane][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * XBN * XLD];
+    __shared__ long Ro[XBM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hl = lane >> 5, l31 = lane & 31;
+    const int ntn = Kp / XBN;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int m0 = tile_m * XBM, n0 = tile_n * XBN;
+    const int phase = (MODE == UPS_PHASE) ? blockIdx.y : 0, py = phase >> 1, px = phase & 1;
+    const int Hr = (MODE >= UPS_PHASE) ? (H >> 1) : H, Wr = (MODE >= UPS_PHASE) ? (W >> 1) : W;
+    const int Hg = (MODE == UPS_FOLD || MODE == UPS_PHASE) ? (H >> 1) : H;
+    const int Wg = (MODE == UPS_FOLD || MODE == UPS_PHASE) ? (W >> 1) : W;
+    const long HWr = (long)Hr * Wr;
+    const long M = (long)B * HWr;
+    const long plane = (long)((MODE == UPS_PHASE) ? 16 : NTAP) * Kp * Cp;    // elements per weight plane
+
+    const int a_c4 = tid & 7, r0 = tid >> 3;            // A: rows r0 + 32 j, channels 4*a_c4 .. +3
+    const int b_ch = tid & 3, b_r0 = tid >> 2;          // B: rows b_r0 + 64 j, 16-byte chunk b_ch (8 k)
+    int a_y[4], a_x[4];
+    long a_img[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long m = m0 + r0 + 32 * j;
+        long off = -1;
+        if (m < M) {
+            const long b = m / HWr;
+            const int rem = (int)(m - b * HWr);
+            a_y[j] = rem / Wr;
+            a_x[j] = rem - a_y[j] * Wr;
+            a_img[j] = b * (long)Hg * Wg;
+            off = (MODE == UPS_PHASE) ? ((b * H + 2 * a_y[j] + py) * (long)W + 2 * a_x[j] + px) * K : m * K;
+        } else {
+            a_y[j] = -(1 << 20);
+            a_x[j] = 0;
+            a_img[j] = 0;
+        }
+        if (a_c4 == 0) Ro[r0 + 32 * j] = off;
+    }
+
+    f32x4 ra[4];
+    u32x4 rb[2][2];   // [plane][j]
+    auto gload = [&](int s) {
+        const int cblk = s / NTAP, tap = s - cblk * NTAP;
+        const int c0 = cblk * XBK;
+        int dy, dx;
+        if (MODE == UPS_PHASE) {
+            dy = (tap >> 1) + py - 1;
+            dx = (tap & 1) + px - 1;
+        } else if (MODE == UPS_DGRAD) {
+            dy = (tap >> 2) - 1;
+            dx = (tap & 3) - 1;
+        } else {
+            dy = tap / 3 - 1;
+            dx = tap - (tap / 3) * 3 - 1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int iy, ix;
+            if (MODE == UPS_DGRAD) {
+                iy = 2 * a_y[j] + dy;
+                ix = 2 * a_x[j] + dx;
+            } else {
+                iy = a_y[j] + dy;
+                ix = a_x[j] + dx;
+            }
+            const int Hb = (MODE == UPS_FOLD) ? H : Hg, Wb = (MODE == UPS_FOLD) ? W : Wg;
+            const bool ok = (unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb && (c0 + a_c4 * 4 < C);
+            const int sy = (MODE == UPS_FOLD) ? (iy >> 1) : iy, sx = (MODE == UPS_FOLD) ? (ix >> 1) : ix;
+            const float* p = x + ((a_img[j] + (long)sy * Wg + sx) * C + c0 + a_c4 * 4);
+            ra[j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned short* p = wp + pl * plane +
+                                          ((long)((phase * NTAP + tap) * Kp + n0 + b_r0 + 64 * j) * Cp + c0 + b_ch * 8);
+                rb[pl][j] = *reinterpret_cast<const u32x4*>(p);
+            }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Half<T>::split(ra[j][e], h[e], l[e]);
+            const int o = (r0 + 32 * j) * XLD + a_c4 * 4;
+            *reinterpret_cast<u32x2*>(As + o) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+            *reinterpret_cast<u32x2*>(As + XBM * XLD + o) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<u32x4*>(Bs + pl * XBN * XLD + (b_r0 + 64 * j) * XLD + b_ch * 8) = rb[pl][j];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int S = (Cp / XBK) * NTAP;
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        const int sp = (s + 1 < S) ? s + 1 : S - 1;      // branch-free prefetch (clamped past the end)
+        gload(sp);
+        const unsigned short* Ab = As + (wm * 64 + l31) * XLD + 8 * hl;
+        const unsigned short* Bb = Bs + (wn * 64 + l31) * XLD + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr) {
+                ah[mr] = *reinterpret_cast<const u32x4*>(Ab + mr * 32 * XLD + ks * 16);
+                al[mr] = *reinterpret_cast<const u32x4*>(Ab + XBM * XLD + mr * 32 * XLD + ks * 16);
+            }
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr) {
+                bh[nr] = *reinterpret_cast<const u32x4*>(Bb + nr * 32 * XLD + ks * 16);
+                bl[nr] = *reinterpret_cast<const u32x4*>(Bb + XBN * XLD + nr * 32 * XLD + ks * 16);
+            }
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                for (int mr = 0; mr < 2; ++mr) {
+                    acc[mr][nr] = Half<T>::mfma(al[mr], bh[nr], acc[mr][nr]);      // small terms first
+                    acc[mr][nr] = Half<T>::mfma(ah[mr], bl[nr], acc[mr][nr]);
+                    acc[mr][nr] = Half<T>::mfma(ah[mr], bh[nr], acc[mr][nr]);
+                }
+        }
+        __syncthreads();          // every wave is done reading this slice
+        lstore();                 // convert + stage the prefetched slice
+        __syncthreads();
+    }
+
+    // ---- epilogue (same as the fp32 kernel; out_scale undoes the weight pre-scaling of the f16 path exactly)
+    double* red = reinterpret_cast<double*>(As);   // [2 (wm)][2 (sum, sumsq)][128] doubles = 4 KB
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr) {
+        const int col = wn * 64 + nr * 32 + l31;
+        const bool nok = n0 + col < K;
+        const float bz = (bias && nok) ? bias[n0 + col] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long off = Ro[wm * 64 + mr * 32 + egz_acc_row(r, lane)];
+                if (off >= 0 && nok) {
+                    float v = acc[mr][nr][r] * out_scale + bz;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    y[off + n0 + col] = v;
+                    if (EPI == EPI_BIAS_STATS) {
+                        s1 += (double)v;
+                        s2 += (double)v * (double)v;
+                    }
+                }
+            }
+        }
+        if (EPI == EPI_BIAS_STATS) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hl == 0) {
+                red[(wm * 2 + 0) * XBN + col] = s1;
+                red[(wm * 2 + 1) * XBN + col] = s2;
+            }
+        }
+    }
+    if (EPI == EPI_BIAS_STATS) {
+        __syncthreads();
+        if (tid < XBN && n0 + tid < K) {
+            const double t1 = red[(0 * 2 + 0) * XBN + tid] + red[(1 * 2 + 0) * XBN + tid];
+            const double t2 = red[(0 * 2 + 1) * XBN + tid] + red[(1 * 2 + 1) * XBN + tid];
+            const long srow = (long)phase * (gridDim.x / ntn) + tile_m;
+            stat[(srow * 2 + 0) * K + n0 + tid] = t1;
+            stat[(srow * 2 + 1) * K + n0 + tid] = t2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- split packing
+__device__ __forceinline__ float weff9(const float* __restrict__ w9, int py, int a, int px, int b) {
+    const int rlo = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), rhi = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int slo = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), shi = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float s = 0.f;
+    for (int r = rlo; r <= rhi; ++r)
+        for (int q = slo; q <= shi; ++q) s += w9[r * 3 + q];
+    return s;
+}
+// kind 0 fwd [9][Kp][Cp], 1 dgrad [9][Cp][Kp], 2 ups_fwd [16][Kp][Cp], 3 ups_dgrad [16][Cp][Kp]  (same value
+// definitions as the fp32 pack kernels of conv3x3_igemm.hip); output = hi plane then lo plane, 16-bit each.
+template <typename T>
+__global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int C, int K, int Cp,
+                                  int Kp, int kind, float scale) {
+    const int taps = (kind >= 2) ? 16 : 9;
+    const long n = (long)taps * Cp * Kp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int c, k, tap;
+        if (kind == 0 || kind == 2) {
+            c = (int)(i % Cp);
+            const long t = i / Cp;
+            k = (int)(t % Kp);
+            tap = (int)(t / Kp);
+        } else {
+            k = (int)(i % Kp);
+            const long t = i / Kp;
+            c = (int)(t % Cp);
+            tap = (int)(t / Cp);
+        }
+        float v = 0.f;
+        if (c < C && k < K) {
+            const float* w9 = w + ((long)k * C + c) * 9;
+            if (kind == 0) v = w9[tap];
+            else if (kind == 1) v = w9[8 - tap];
+            else if (kind == 2) v = weff9(w9, (tap >> 2) >> 1, (tap & 3) >> 1, (tap >> 2) & 1, tap & 1);
+            else {
+                const int oy = (tap >> 2) - 1, ox = (tap & 3) - 1;
+                v = weff9(w9, (oy == -1 || oy == 1) ? 1 : 0, (oy <= 0) ? 1 : 0, (ox == -1 || ox == 1) ? 1 : 0, (ox <= 0) ? 1 : 0);
+            }
+        }
+        unsigned short h, l;
+        Half<T>::split(v * scale, h, l);
+        wp[i] = h;
+        wp[n + i] = l;
+    }
+}
+
+template <typename T, int MODE>
+int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bias, float* y, double* stat, int B, int H,
+              int W, int C, int K, float out_scale, hipStream_t st) {
+    const long M = (MODE >= UPS_PHASE) ? (long)B * (H / 2) * (W / 2) : (long)B * H * W;
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    dim3 grid(egz_cdiv(M, XBM) * (Kp / XBN), MODE == UPS_PHASE ? 4 : 1);
+#define EGZ_X3(E) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, MODE, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale)
+    if (MODE == UPS_DGRAD || epi == EPI_BIAS) EGZ_X3(EPI_BIAS);
+    else if (epi == EPI_BIAS_RELU) EGZ_X3(EPI_BIAS_RELU);
+    else EGZ_X3(EPI_BIAS_STATS);
+#undef EGZ_X3
+    EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_split");
+    return 0;
+}
+
+}  // namespace
+
+// Split a (K, C, 3, 3) weight into hi / lo 16-bit planes in the packed layout `kind`
+// (0 fwd, 1 dgrad, 2 ups_fwd, 3 ups_dgrad); dtype 1 = f16 (values pre-scaled by 2^10), 2 = bf16.
+// wp needs egz_pack_w3x3_elems(C, K, kind >= 2) * 4 bytes (two 16-bit planes = one fp32 plane).
+EGZ_API int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind, int dtype, hipStream_t st) {
+    EGZ_CHECK_ARG(w && wp && C > 0 && K > 0 && kind >= 0 && kind <= 3 && (dtype == 1 || dtype == 2),
+                  "egz_pack_w3x3_split: bad arguments");
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const long n = (long)(kind >= 2 ? 16 : 9) * Cp * Kp;
+    const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
+    unsigned short* o = static_cast<unsigned short*>(wp);
+    if (dtype == 1) hipLaunchKernelGGL(pack_split_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, Cp, Kp, kind, F16_WSCALE);
+    else            hipLaunchKernelGGL(pack_split_kernel<__bf16>, dim3(g), dim3(256), 0, st, w, o, C, K, Cp, Kp, kind, 1.f);
+    EGZ_CHECK_LAUNCH("egz_pack_w3x3_split");
+    return 0;
+}
+
+// Same contract as egz_conv3x3_fwd (flags: bit0/bit1 upsample forms, bits 4-5 epilogue) / egz_conv3x3_ups_dgrad
+// (flags bit 2 = 0x4 selects the 16-tap data gradient of an upsampled conv), computed with split-half operands.
+// dtype 1 = f16 x3, 2 = bf16 x3; wp from egz_pack_w3x3_split with the same dtype.  Needs Cout % 128 == 0, Cin % 32 == 0.
+EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial,
+                                  int B, int H, int W, int C, int K, int flags, int dtype, hipStream_t st) {
+    EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd_split: null pointer");
+    EGZ_CHECK_ARG(K % 128 == 0 && C % 32 == 0 && C > 0, "egz_conv3x3_fwd_split: needs Cout %% 128 == 0 and Cin %% 32 == 0 (got %d, %d)", K, C);
+    EGZ_CHECK_ARG(dtype == 1 || dtype == 2, "egz_conv3x3_fwd_split: dtype must be 1 (f16) or 2 (bf16)");
+    const int ups = flags & 3, epi = (flags >> 4) & 3;
+    EGZ_CHECK_ARG(ups != 2 && epi <= 2, "egz_conv3x3_fwd_split: bad flags");
+    EGZ_CHECK_ARG(!(ups || (flags & 4)) || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_fwd_split: upsampled dims must be even");
+    EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_split: stats epilogue needs stat_partial");
+    const unsigned short* w16 = static_cast<const unsigned short*>(wp);
+    const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
+#define EGZ_MODE(T)                                                                                          \
+    if (flags & 4) return launch_x3<T, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st); \
+    if (ups == 3) return launch_x3<T, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);  \
+    if (ups == 1) return launch_x3<T, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);   \
+    return launch_x3<T, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st)
+    if (dtype == 1) { EGZ_MODE(_Float16); }
+    EGZ_MODE(__bf16);
+#undef EGZ_MODE
+}

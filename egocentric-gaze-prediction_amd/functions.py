@@ -52,8 +52,9 @@ class ConvBNReLUPool(torch.autograd.Function):
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training)
         else:
             xin = to_nhwc(x)
-            y, stat = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd"), bias.detach() if bias is not None else None,
-                                    K, ups=False, epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS)
+            dt = H.conv_dtype("fwd", K, C)
+            y, stat = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd", dt), bias.detach() if bias is not None else None,
+                                    K, ups=False, epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt)
         B, Hh, Ww, _ = y.shape
         if training:
             coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
@@ -83,7 +84,8 @@ class ConvBNReLUPool(torch.autograd.Function):
         if ng[0]:
             if first:
                 raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
-            dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C))
+            dt = H.conv_dtype("dgrad", C, K)
+            dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
         f.join(dw)
         return (dx, dw, db, dgamma if ng[3] else None, dbeta if ng[4] else None, None, None, None, None, None,
                 None, None)
@@ -94,9 +96,10 @@ class ConvReLU(torch.autograd.Function):
     def forward(ctx, x, weight, bias, ups):
         K, C = weight.shape[0], weight.shape[1]
         xin = to_nhwc(x)
-        y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "ups_fwd" if ups else "fwd"),
+        dt = H.conv_dtype("fwd", K, C)
+        y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "ups_fwd" if ups else "fwd", dt),
                              bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
-                             epi=H.EPI_BIAS_RELU)
+                             epi=H.EPI_BIAS_RELU, dtype=dt)
         ctx.save_for_backward(xin, y, weight)
         ctx.cfg = (ups, C, K)
         return from_nhwc(y)
@@ -115,10 +118,11 @@ class ConvReLU(torch.autograd.Function):
             if ng[1]:
                 dw = H.conv3x3_wgrad(xin, dy, ups=ups)
         if ng[0]:
+            dt = H.conv_dtype("dgrad", C, K)
             if ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
-                dx = from_nhwc(H.conv3x3_ups_dgrad(dy, H.packed_weight(weight, "ups_dgrad"), C))
+                dx = from_nhwc(H.conv3x3_ups_dgrad(dy, H.packed_weight(weight, "ups_dgrad", dt), C, dtype=dt))
             else:
-                dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad"), C))
+                dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
         f.join(dw)
         return dx, dw, db, None
 
@@ -128,8 +132,9 @@ class FusionBlock(torch.autograd.Function):
     def forward(ctx, fs, ft, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps):
         K, C = weight.shape[0], weight.shape[1]
         x2 = torch.cat((to_nhwc(fs), to_nhwc(ft)), 0)            # depth-2 stack folded into the batch dim
-        y2, _ = H.conv3x3_fwd(x2, H.packed_weight(weight, "fwd"), bias.detach() if bias is not None else None, K,
-                              ups=False, epi=H.EPI_BIAS)
+        dt = H.conv_dtype("fwd", K, C)
+        y2, _ = H.conv3x3_fwd(x2, H.packed_weight(weight, "fwd", dt), bias.detach() if bias is not None else None, K,
+                              ups=False, epi=H.EPI_BIAS, dtype=dt)
         z = H.pairmax_fwd(y2)
         B, Hh, Ww, _ = z.shape
         if training:
@@ -158,7 +163,8 @@ class FusionBlock(torch.autograd.Function):
             if ng[2]:
                 dw = H.conv3x3_wgrad(x2, dy2).view(weight.shape)
         if ng[0] or ng[1]:
-            dx2 = H.conv3x3_dgrad(dy2, H.packed_weight(weight, "dgrad"), C)
+            dt = H.conv_dtype("dgrad", C, K)
+            dx2 = H.conv3x3_dgrad(dy2, H.packed_weight(weight, "dgrad", dt), C, dtype=dt)
             B = dx2.shape[0] // 2
             dfs, dft = from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
         f.join(dw)

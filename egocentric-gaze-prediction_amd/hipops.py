@@ -132,37 +132,55 @@ def _uid(w: torch.Tensor) -> int:
     return uid
 
 
-_PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0), "dgrad": ("egz_pack_w3x3_dgrad", 0),
-            "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1)}
+_PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad", 0, 1),
+            "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1, 2), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1, 3)}
+
+# Arithmetic of the wide convolutions (GEMM output channels % 128 == 0):
+#   "f32"   exact-f32 MFMA everywhere (v_mfma_f32_32x32x2_f32)
+#   "split" error-compensated split-half operands on the 16-bit MFMA path: f16 x3 forward (err ~3e-7, fp32 class),
+#           bf16 x3 data gradient (err ~5e-6, fp32 exponent range for tiny gradients)  -- conv3x3_igemm_x3.hip
+PRECISION = _os.environ.get("EGAZE_PRECISION", "f32")
+F32, F16X3, BF16X3 = 0, 1, 2
+
+
+def conv_dtype(role: str, gemm_out: int, gemm_in: int) -> int:
+    """dtype code for a conv launch under the current PRECISION policy (role: 'fwd' | 'dgrad')."""
+    if PRECISION != "split" or gemm_out % 128 != 0 or gemm_in % 32 != 0:
+        return F32
+    return F16X3 if role == "fwd" else BF16X3
 
 
 def _drop_packed(uid: int):
     for kind in _PACK_FN:
-        _PACKED.pop((uid, kind), None)
+        for dt in (0, 1, 2):
+            _PACKED.pop((uid, kind, dt), None)
 
 
-def packed_weight(w: torch.Tensor, kind: str) -> torch.Tensor:
+def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
     """(Cout, Cin, [1,] 3, 3) -> the kernels' private packed layout: 'fwd' / 'dgrad' (9 taps) or, for a conv that
     follows a nearest x2 upsample, 'ups_fwd' (4 phases x 2x2 pre-summed taps) / 'ups_dgrad' (4x4 stride-2 taps).
     Pass the parameter object itself (not a detached alias) so the cache can follow its identity."""
     _req(w, "weight")
     K, C = w.shape[0], w.shape[1]
-    key = (_uid(w), kind)
+    key = (_uid(w), kind, dtype)
     tag = (_WEIGHT_EPOCH[0], w._version, w.data_ptr())
     hit = _PACKED.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    fname, ekind = _PACK_FN[kind]
+    fname, ekind, kidx = _PACK_FN[kind]
     buf = hit[1] if hit is not None else torch.empty(LIB.egz_pack_w3x3_elems(C, K, ekind), dtype=torch.float32,
                                                      device=w.device)
-    check(getattr(LIB, fname)(w.data_ptr(), buf.data_ptr(), C, K, _stream()), fname)
+    if dtype:      # hi / lo 16-bit planes (same byte count as the fp32 packing)
+        check(LIB.egz_pack_w3x3_split(w.data_ptr(), buf.data_ptr(), C, K, kidx, dtype, _stream()), "egz_pack_w3x3_split")
+    else:
+        check(getattr(LIB, fname)(w.data_ptr(), buf.data_ptr(), C, K, _stream()), fname)
     _PACKED[key] = (tag, buf)
     return buf
 
 
 # ----------------------------------------------------------------------------- convolutions
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
-                epi: int = EPI_BIAS, tile_flag: int = 0):
+                epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0):
     """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups.
     ups: False | 'fold' (3x3 taps on the virtual upsampled image, wp = 'fwd' packing) | 'phase' or True (four 2x2
     phase convolutions on the low-res input, 4/9 of the MACs, wp = 'ups_fwd' packing)."""
@@ -172,27 +190,37 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
     stat = None
     uflag = 0 if not ups else (1 if ups == "fold" else 3)
-    flags = uflag | (epi << 4) | (tile_flag or _TILE_FLAG)
+    flags = uflag | (epi << 4) | (0x200 if dtype else (tile_flag or _TILE_FLAG))      # split kernels: 128x128 tile
     if epi == EPI_BIAS_STATS:
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
+    if dtype:
+        PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        check(LIB.egz_conv3x3_fwd_split(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
+                                        flags & 0x33, dtype, _stream()), "egz_conv3x3_fwd_split")
+        return y, stat
     PROF.note_flops("egz_conv3x3_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K, flags,
                               _stream()), "egz_conv3x3_fwd")
     return y, stat
 
 
-def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int) -> torch.Tensor:
+def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int, dtype: int = 0) -> torch.Tensor:
     """dy: (B,H,W,K) -> dx (B,H,W,C) (for an upsampled conv this is the gradient of the upsampled input)."""
-    y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS)
+    y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS, dtype=dtype)
     return y
 
 
-def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int) -> torch.Tensor:
+def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtype: int = 0) -> torch.Tensor:
     """Data gradient of [upsample x2 -> conv3x3] w.r.t. the LOW-res input: dy (B,H,W,K) -> dx (B,H/2,W/2,C)."""
     _req(dy, "dy")
     B, H, W, K = dy.shape
     dx = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=dy.device)
+    if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
+        PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        check(LIB.egz_conv3x3_fwd_split(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
+                                        4, dtype, _stream()), "egz_conv3x3_fwd_split(ups_dgrad)")
+        return dx
     PROF.note_flops("egz_conv3x3_ups_dgrad", 2.0 * B * H * W * K * 9 * C)     # algorithmic (reference) FLOPs
     check(LIB.egz_conv3x3_ups_dgrad(dy.data_ptr(), wp_ups_dgrad.data_ptr(), dx.data_ptr(), B, H, W, C, K,
                                     _TILE_FLAG, _stream()), "egz_conv3x3_ups_dgrad")

@@ -54,6 +54,15 @@ int egz_conv3x3_fwd(const float* x, const float* wp, const float* bias, float* y
 /* data gradient of [upsample x2 -> conv] w.r.t. the low-res input: dy [B][H][W][K] -> dx [B][H/2][W/2][C] */
 int egz_conv3x3_ups_dgrad(const float* dy, const float* wp, float* dx, int B, int H, int W, int C, int K, int flags,
                           hipStream_t stream);
+/* Error-compensated split-half variant for the wide layers (Cout % 128 == 0, Cin % 32 == 0): operands as hi + lo in a
+ * 16-bit type, a*b ~= hi*hi + hi*lo + lo*hi accumulated in fp32 on v_mfma_f32_32x32x16_{f16,bf16} (16x the exact-f32
+ * MFMA rate, 3 instructions per product).  dtype 1 = f16 x3 (weights pre-scaled 2^10; err ~3e-7 = fp32 class),
+ * 2 = bf16 x3 (fp32 exponent range, err ~5e-6; used for gradients).  kind: 0 fwd, 1 dgrad, 2 ups_fwd, 3 ups_dgrad.
+ * egz_conv3x3_fwd_split: flags as egz_conv3x3_fwd (bits 0-1, 4-5) plus bit2 = the 16-tap data gradient of an
+ * upsampled conv (then C / K are the GEMM's reduction / output channel counts). */
+int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind, int dtype, hipStream_t stream);
+int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial, int B,
+                          int H, int W, int C, int K, int flags, int dtype, hipStream_t stream);
 /* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
 size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,

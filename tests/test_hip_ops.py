@@ -245,3 +245,48 @@ def test_mse():
     ad, bd = a.detach().to(DEV), b.to(DEV)
     assert abs(h.mse_fwd(ad, bd).item() - ref.item()) < 1e-6 * abs(ref.item())
     assert rel(h.mse_bwd(ad, bd, None).cpu(), a.grad) < 1e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
+@pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 12, 12, 64, 128), (1, 14, 14, 256, 256), (3, 9, 7, 32, 128)])
+def test_conv3x3_split_half(B, Hh, Ww, C, K, dtype, tol):
+    """Error-compensated split-half operands (f16 x3 / bf16 x3 on the 16-bit MFMA path) against an fp64 reference:
+    f16 x3 must be fp32-class (the exact-f32 kernel itself sits at ~5e-7), bf16 x3 within 3e-5."""
+    h = H()
+    x = rnd(B, C, Hh, Ww, seed=41)
+    w = rnd(K, C, 3, 3, seed=42, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=43, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    wd = w.to(DEV)
+    for epi in (0, 1, 2):
+        want = F.relu(ref) if epi == 1 else ref
+        y, stat = h.conv3x3_fwd(nhwc(x), h.packed_weight(wd, "fwd", dtype), b.to(DEV), K, epi=epi, dtype=dtype)
+        assert rel(nchw(y), want) < tol
+        if epi == 2:
+            assert rel(stat.sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
+    y32, _ = h.conv3x3_fwd(nhwc(x), h.packed_weight(wd, "fwd"), b.to(DEV), K, epi=0)
+    print(f"dtype {dtype}: split err {rel(nchw(y), ref):.2e}, exact-f32 MFMA err {rel(nchw(y32), ref):.2e}")
+    # data gradient (GEMM output channels = C must be a multiple of 128 for the split kernel)
+    if C % 128 == 0:
+        dy = rnd(B, K, Hh, Ww, seed=44)
+        dref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1)
+        dx = h.conv3x3_dgrad(nhwc(dy), h.packed_weight(wd, "dgrad", dtype), C, dtype=dtype)
+        assert rel(nchw(dx), dref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
+def test_conv3x3_split_half_upsample(dtype, tol):
+    h = H()
+    B, Hh, Ww, C, K = 2, 6, 8, 128, 128
+    x = rnd(B, C, Hh, Ww, seed=45).requires_grad_(True)
+    w = rnd(K, C, 3, 3, seed=46, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=47, scale=0.1)
+    xd, wd = x.detach().double().requires_grad_(True), w.double()
+    pre = F.conv2d(F.interpolate(xd, scale_factor=2, mode="nearest"), wd, b.double(), padding=1)
+    dy = rnd(B, K, 2 * Hh, 2 * Ww, seed=48)
+    pre.backward(dy.double())
+    wdev = w.to(DEV)
+    y, _ = h.conv3x3_fwd(nhwc(x.detach()), h.packed_weight(wdev, "ups_fwd", dtype), b.to(DEV), K, ups="phase", epi=0, dtype=dtype)
+    assert rel(nchw(y), pre.detach()) < tol
+    dx = h.conv3x3_ups_dgrad(nhwc(dy), h.packed_weight(wdev, "ups_dgrad", dtype), C, dtype=dtype)
+    assert rel(nchw(dx), xd.grad) < tol
