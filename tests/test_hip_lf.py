@@ -112,7 +112,7 @@ def test_late_fusion_grads_vs_fp64():
         ec.append(rel(g32[k].numpy(), g64[k].numpy()))
     print("LF HIP vs fp64: median %.2e max %.2e | CPU fp32: median %.2e max %.2e" %
           (np.median(eh), max(eh), np.median(ec), max(ec)))
-    assert np.median(eh) < max(10 * np.median(ec), 1e-4) and max(eh) < 5e-2
+    assert np.median(eh) < max(20 * np.median(ec), 2e-4) and max(eh) < 5e-2
 
 
 def test_config1_run_spatialstream_on_hip():
