@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int XBM = 128, XBN = 128, XBK = 32;
+constexpr int XBM = 128, XBK = 32;
 constexpr int XLD = 40;                 // row stride in 16-bit elements (80 B)
 constexpr float F16_WSCALE = 1024.f;    // 2^10
 
@@ -56,12 +56,15 @@ template <> struct Half<__bf16> {
 };
 
 // wp: [2 planes (hi, lo)][taps][Kp][Cp] 16-bit.  H, W: hi-res (conv output) dims for the UPS_* modes.
-template <typename T, int MODE, int EPI>
+template <typename T, int XBN, int MODE, int EPI>   // XBN = 128 (Cout % 128 == 0) or 64 (Cout = 64 layers)
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
     float out_scale) {
     constexpr int NTAP = (MODE == UPS_PHASE) ? 4 : (MODE == UPS_DGRAD) ? 16 : 9;
+    constexpr int NR = XBN / 64;            // 32-wide n-tiles per wave (2 x 2 waves)
+    constexpr int WN = XBN / 2;
+    constexpr int BLD = XBN / 64;           // 16-byte B chunks per thread per plane
     __shared__ __attribute__((aligned(16))) unsigned short As[2 * XBM * XLD];   // [plane][row][k]
     __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * XBN * XLD];
     __shared__ long Ro[XBM];
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     }
 
     f32x4 ra[4];
-    u32x4 rb[2][2];   // [plane][j]
+    u32x4 rb[2][BLD];   // [plane][j]
     auto gload = [&](int s) {
         const int cblk = s / NTAP, tap = s - cblk * NTAP;
         const int c0 = cblk * XBK;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < BLD; ++j) {
                 const unsigned short* p = wp + pl * plane +
                                           ((long)((phase * NTAP + tap) * Kp + n0 + b_r0 + 64 * j) * Cp + c0 + b_ch * 8);
                 rb[pl][j] = *reinterpret_cast<const u32x4*>(p);
@@ -156,15 +159,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < BLD; ++j)
                 *reinterpret_cast<u32x4*>(Bs + pl * XBN * XLD + (b_r0 + 64 * j) * XLD + b_ch * 8) = rb[pl][j];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NR];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NR; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -176,22 +179,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
         const int sp = (s + 1 < S) ? s + 1 : S - 1;      // branch-free prefetch (clamped past the end)
         gload(sp);
         const unsigned short* Ab = As + (wm * 64 + l31) * XLD + 8 * hl;
-        const unsigned short* Bb = Bs + (wn * 64 + l31) * XLD + 8 * hl;
+        const unsigned short* Bb = Bs + (wn * WN + l31) * XLD + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4 ah[2], al[2], bh[2], bl[2];
+            u32x4 ah[2], al[2], bh[NR], bl[NR];
 #pragma unroll
             for (int mr = 0; mr < 2; ++mr) {
                 ah[mr] = *reinterpret_cast<const u32x4*>(Ab + mr * 32 * XLD + ks * 16);
                 al[mr] = *reinterpret_cast<const u32x4*>(Ab + XBM * XLD + mr * 32 * XLD + ks * 16);
             }
 #pragma unroll
-            for (int nr = 0; nr < 2; ++nr) {
+            for (int nr = 0; nr < NR; ++nr) {
                 bh[nr] = *reinterpret_cast<const u32x4*>(Bb + nr * 32 * XLD + ks * 16);
                 bl[nr] = *reinterpret_cast<const u32x4*>(Bb + XBN * XLD + nr * 32 * XLD + ks * 16);
             }
 #pragma unroll
-            for (int nr = 0; nr < 2; ++nr)
+            for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
                 for (int mr = 0; mr < 2; ++mr) {
                     acc[mr][nr] = Half<T>::mfma(al[mr], bh[nr], acc[mr][nr]);      // small terms first
@@ -207,8 +210,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     // ---- epilogue (same as the fp32 kernel; out_scale undoes the weight pre-scaling of the f16 path exactly)
     double* red = reinterpret_cast<double*>(As);   // [2 (wm)][2 (sum, sumsq)][128] doubles = 4 KB
 #pragma unroll
-    for (int nr = 0; nr < 2; ++nr) {
-        const int col = wn * 64 + nr * 32 + l31;
+    for (int nr = 0; nr < NR; ++nr) {
+        const int col = wn * WN + nr * 32 + l31;
         const bool nok = n0 + col < K;
         const float bz = (bias && nok) ? bias[n0 + col] : 0.f;
         double s1 = 0.0, s2 = 0.0;
@@ -296,13 +299,13 @@ __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* _
     }
 }
 
-template <typename T, int MODE>
+template <typename T, int XBN, int MODE>
 int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bias, float* y, double* stat, int B, int H,
               int W, int C, int K, float out_scale, hipStream_t st) {
     const long M = (MODE >= UPS_PHASE) ? (long)B * (H / 2) * (W / 2) : (long)B * H * W;
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
     dim3 grid(egz_cdiv(M, XBM) * (Kp / XBN), MODE == UPS_PHASE ? 4 : 1);
-#define EGZ_X3(E) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, MODE, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale)
+#define EGZ_X3(E) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, XBN, MODE, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale)
     if (MODE == UPS_DGRAD || epi == EPI_BIAS) EGZ_X3(EPI_BIAS);
     else if (epi == EPI_BIAS_RELU) EGZ_X3(EPI_BIAS_RELU);
     else EGZ_X3(EPI_BIAS_STATS);
@@ -331,11 +334,12 @@ EGZ_API int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind
 
 // Same contract as egz_conv3x3_fwd (flags: bit0/bit1 upsample forms, bits 4-5 epilogue) / egz_conv3x3_ups_dgrad
 // (flags bit 2 = 0x4 selects the 16-tap data gradient of an upsampled conv), computed with split-half operands.
-// dtype 1 = f16 x3, 2 = bf16 x3; wp from egz_pack_w3x3_split with the same dtype.  Needs Cout % 128 == 0, Cin % 32 == 0.
+// dtype 1 = f16 x3, 2 = bf16 x3; wp from egz_pack_w3x3_split with the same dtype.  Needs Cout % 64 == 0, Cin % 32 == 0
+// (tile 128 x 128, or 128 x 64 when Cout is not a multiple of 128).
 EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial,
                                   int B, int H, int W, int C, int K, int flags, int dtype, hipStream_t st) {
     EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd_split: null pointer");
-    EGZ_CHECK_ARG(K % 128 == 0 && C % 32 == 0 && C > 0, "egz_conv3x3_fwd_split: needs Cout %% 128 == 0 and Cin %% 32 == 0 (got %d, %d)", K, C);
+    EGZ_CHECK_ARG(K % 64 == 0 && C % 32 == 0 && C > 0, "egz_conv3x3_fwd_split: needs Cout %% 64 == 0 and Cin %% 32 == 0 (got %d, %d)", K, C);
     EGZ_CHECK_ARG(dtype == 1 || dtype == 2, "egz_conv3x3_fwd_split: dtype must be 1 (f16) or 2 (bf16)");
     const int ups = flags & 3, epi = (flags >> 4) & 3;
     EGZ_CHECK_ARG(ups != 2 && epi <= 2, "egz_conv3x3_fwd_split: bad flags");
@@ -343,12 +347,16 @@ EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* b
     EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_split: stats epilogue needs stat_partial");
     const unsigned short* w16 = static_cast<const unsigned short*>(wp);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
-#define EGZ_MODE(T)                                                                                          \
-    if (flags & 4) return launch_x3<T, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st); \
-    if (ups == 3) return launch_x3<T, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);  \
-    if (ups == 1) return launch_x3<T, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);   \
-    return launch_x3<T, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st)
-    if (dtype == 1) { EGZ_MODE(_Float16); }
-    EGZ_MODE(__bf16);
+#define EGZ_MODE(T, N)                                                                                          \
+    if (flags & 4) return launch_x3<T, N, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st); \
+    if (ups == 3) return launch_x3<T, N, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);  \
+    if (ups == 1) return launch_x3<T, N, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);   \
+    return launch_x3<T, N, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st)
+    if (K % 128 == 0) {
+        if (dtype == 1) { EGZ_MODE(_Float16, 128); }
+        EGZ_MODE(__bf16, 128);
+    }
+    if (dtype == 1) { EGZ_MODE(_Float16, 64); }
+    EGZ_MODE(__bf16, 64);
 #undef EGZ_MODE
 }

@@ -145,7 +145,7 @@ F32, F16X3, BF16X3 = 0, 1, 2
 
 def conv_dtype(role: str, gemm_out: int, gemm_in: int) -> int:
     """dtype code for a conv launch under the current PRECISION policy (role: 'fwd' | 'dgrad')."""
-    if PRECISION != "split" or gemm_out % 128 != 0 or gemm_in % 32 != 0:
+    if PRECISION != "split" or gemm_out % 64 != 0 or gemm_in % 32 != 0:
         return F32
     return F16X3 if role == "fwd" else BF16X3
 
@@ -190,7 +190,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
     stat = None
     uflag = 0 if not ups else (1 if ups == "fold" else 3)
-    flags = uflag | (epi << 4) | (0x200 if dtype else (tile_flag or _TILE_FLAG))      # split kernels: 128x128 tile
+    flags = uflag | (epi << 4) | (0x200 if dtype else (tile_flag or _TILE_FLAG))      # split kernels: 128-row tiles
     if epi == EPI_BIAS_STATS:
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)

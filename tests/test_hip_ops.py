@@ -248,7 +248,8 @@ def test_mse():
 
 
 @pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
-@pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 12, 12, 64, 128), (1, 14, 14, 256, 256), (3, 9, 7, 32, 128)])
+@pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 12, 12, 64, 128), (1, 14, 14, 256, 256), (3, 9, 7, 32, 128),
+                                        (2, 10, 12, 64, 64), (1, 8, 8, 128, 64)])
 def test_conv3x3_split_half(B, Hh, Ww, C, K, dtype, tol):
     """Error-compensated split-half operands (f16 x3 / bf16 x3 on the 16-bit MFMA path) against an fp64 reference:
     f16 x3 must be fp32-class (the exact-f32 kernel itself sits at ~5e-7), bf16 x3 within 3e-5."""
@@ -267,7 +268,7 @@ def test_conv3x3_split_half(B, Hh, Ww, C, K, dtype, tol):
     y32, _ = h.conv3x3_fwd(nhwc(x), h.packed_weight(wd, "fwd"), b.to(DEV), K, epi=0)
     print(f"dtype {dtype}: split err {rel(nchw(y), ref):.2e}, exact-f32 MFMA err {rel(nchw(y32), ref):.2e}")
     # data gradient (GEMM output channels = C must be a multiple of 128 for the split kernel)
-    if C % 128 == 0:
+    if C % 64 == 0:
         dy = rnd(B, K, Hh, Ww, seed=44)
         dref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1)
         dx = h.conv3x3_dgrad(nhwc(dy), h.packed_weight(wd, "dgrad", dtype), C, dtype=dtype)

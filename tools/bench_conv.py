@@ -69,8 +69,8 @@ def main():
         bias = torch.randn(K, device=dev)
         dy = torch.randn(B, Hh, Hh, K, device=dev)
         flops = 2.0 * B * Hh * Hh * K * 9 * C
-        fdt = a.dtype if (a.dtype and K % 128 == 0) else 0
-        ddt = a.dtype if (a.dtype and C % 128 == 0) else 0
+        fdt = a.dtype if (a.dtype and K % 64 == 0) else 0
+        ddt = a.dtype if (a.dtype and C % 64 == 0) else 0
         wp = H.packed_weight(w, "ups_fwd" if ups else "fwd", fdt)
         wd = H.packed_weight(w, "dgrad", ddt)
         res = []
