@@ -136,10 +136,11 @@ _PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad",
             "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1, 2), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1, 3)}
 
 # Arithmetic of the wide convolutions (GEMM output channels % 128 == 0):
-#   "f32"   exact-f32 MFMA everywhere (v_mfma_f32_32x32x2_f32)
-#   "split" error-compensated split-half operands on the 16-bit MFMA path: f16 x3 forward (err ~3e-7, fp32 class),
-#           bf16 x3 data gradient (err ~5e-6, fp32 exponent range for tiny gradients)  -- conv3x3_igemm_x3.hip
-PRECISION = _os.environ.get("EGAZE_PRECISION", "f32")
+#   "split" (default) error-compensated split-half operands on the 16-bit MFMA path: f16 x3 forward (measured err
+#           5e-7 of max|ref| per layer vs 8.6e-7 for the exact-f32 MFMA kernel), bf16 x3 data gradient (err ~5e-6,
+#           fp32 exponent range for tiny gradients)  -- conv3x3_igemm_x3.hip.  Weight gradients stay exact-f32.
+#   "f32"   exact-f32 MFMA everywhere (v_mfma_f32_32x32x2_f32); EGAZE_PRECISION=f32 selects it.
+PRECISION = _os.environ.get("EGAZE_PRECISION", "split")
 F32, F16X3, BF16X3 = 0, 1, 2
 
 
