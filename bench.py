@@ -178,7 +178,7 @@ def main():
             for k2 in ig:
                 ig[k2] += prof.get(entry, {}).get(k2, 0)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_igemm.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_igemm_x3.json" if split else "r01_pmc_traffic_igemm.json")
         if os.path.exists(tpath):
             # HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
             # this same command (tools/pmc_traffic.py; gfx950 FETCH half-count corrected) -- PMC cannot be sampled

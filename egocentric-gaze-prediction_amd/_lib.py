@@ -90,6 +90,10 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension is mandatory (no CPU fallback). "
             "Build it with `python __graft_entry__.py` or `csrc/build.sh`.")
+    # torch first: it ships its own libamdhip64.so.7 + HSA runtime, and the process must hold exactly one HIP
+    # runtime -- the one that owns the tensors' device memory.  Loading this library first would bind the system
+    # runtime instead and every launch would fail with "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
