@@ -230,6 +230,181 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Split-half (bf16 x3) form of the 9-tap fused kernel: x and dY stay fp32 in HBM and are split into bf16 hi + lo
+// halves while they are staged into LDS; every product is  x*dy ~= xh*dh + xh*dl + xl*dh  on
+// v_mfma_f32_32x32x16_bf16 (16x the rate of the exact-f32 MFMA, 3 per 16 pixels instead of 8), fp32 accumulate.
+// The reduction dimension of this GEMM is the PIXEL, but both operands are channel-contiguous in HBM and in LDS
+// ([pixel][channel]); the 16-bit MFMA wants 8 consecutive reduction elements per lane, i.e. the transposed image.
+// gfx950's ds_read_b64_tr_b16 does that transpose inside the LDS read: each 16-lane group hands in sixteen 8-byte
+// addresses (4 pixels x 4 chunks of 4 channels) and lane t gets the 4 pixels of channel t.  Per-lane addresses make
+// the pixel -> halo mapping free, so the stage is a 2-D patch of R x WD pixels (R * WD = 32) with an (R+2) x (WD+2)
+// halo, the nine taps are immediate offsets off ONE per-lane base address, and row widths that are not a
+// multiple of 16 (28, 14) run as masked WD = 32 / 16 patches (zero dY beyond the row end).
+//   LDS image: [plane hi/lo][channel half][halo pixel][32 ch] bf16 -- a wave only touches the 64-byte rows of its own
+//   channel half, and the four pixel rows a 16-lane group reads tile one 256-byte bank row exactly.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+#define EGZ_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ void bf16_split4(const f32x4 v, u32x2_t& hi, u32x2_t& lo) {
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 a = (__bf16)v[e];
+        const __bf16 b = (__bf16)(v[e] - (float)a);
+        h[e] = __builtin_bit_cast(unsigned short, a);
+        l[e] = __builtin_bit_cast(unsigned short, b);
+    }
+    hi[0] = h[0] | ((unsigned)h[1] << 16); hi[1] = h[2] | ((unsigned)h[3] << 16);
+    lo[0] = l[0] | ((unsigned)l[1] << 16); lo[1] = l[2] | ((unsigned)l[3] << 16);
+}
+
+template <bool UPS, int R, int WD>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, int patches_per_split) {
+    static_assert(R * WD == 32 && (WD == 32 || WD == 16 || WD == 8), "patch = 32 pixels");
+    constexpr int NP = R * WD, KS = NP / 16;
+    constexpr int HPW = WD + 2, NH = (R + 2) * HPW;            // halo row width / halo pixels
+    constexpr int XH = NH * 32 + ((NH & 1) ? 0 : 32);          // channel-half stride (elements): bytes % 128 == 64
+    constexpr int DH = NP * 32 + 32;
+    constexpr int XB = 4 * XH, DB = 4 * DH;                    // per-buffer strides ([plane][half])
+    constexpr int NX = (NH * 16 + 255) / 256;                  // float4 halo loads per thread
+    constexpr int ND = (NP * 16) / 256;                        // float4 dY loads per thread (2)
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[2 * XB];
+    __shared__ __attribute__((aligned(16))) unsigned short Ds[2 * DB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wk = wave & 1, l31 = lane & 31;
+    const int tk = K / 64;
+    const int c0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
+    const int cpr = (W + WD - 1) / WD, rpi = (H + R - 1) / R;  // patches per row / patch rows per image
+    const long npatch = (long)B * rpi * cpr;
+    const long g0 = (long)blockIdx.y * patches_per_split;
+    const long g1 = (g0 + patches_per_split < npatch) ? (g0 + patches_per_split) : npatch;
+    const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
+
+    f32x4 rx[NX], rd[ND];
+    auto gload = [&](long g) {
+        const int x0 = (int)(g % cpr) * WD;
+        const long t = g / cpr;
+        const int y0 = (int)(t % rpi) * R;
+        const long b = t / rpi;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            const int pos = i >> 4, c4 = i & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pos < NH) {
+                const int hr = pos / HPW, hx = pos - hr * HPW;
+                const int iy = y0 + hr - 1, ix = x0 + hx - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const int sy = UPS ? (iy >> 1) : iy, sx = UPS ? (ix >> 1) : ix;
+                    v = *reinterpret_cast<const f32x4*>(x + ((b * Hs + sy) * (long)Ws + sx) * C + c0 + c4 * 4);
+                }
+            }
+            rx[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j;
+            const int pp = i >> 4, k4 = i & 15;
+            const int yy = y0 + pp / WD, xx = x0 + pp % WD;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (yy < H && xx < W) v = *reinterpret_cast<const f32x4*>(dy + ((b * H + yy) * (long)W + xx) * K + k0 + k4 * 4);
+            rd[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            const int pos = i >> 4, c4 = i & 15;
+            if (pos < NH) {
+                u32x2_t hi, lo;
+                bf16_split4(rx[j], hi, lo);
+                unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
+                *reinterpret_cast<u32x2_t*>(d) = hi;
+                *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j;
+            const int pp = i >> 4, k4 = i & 15;
+            u32x2_t hi, lo;
+            bf16_split4(rd[j], hi, lo);
+            unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
+            *reinterpret_cast<u32x2_t*>(d) = hi;
+            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
+        }
+    };
+
+    // transpose-read addressing: 16-lane group g = lane >> 4 covers channels 16 * (g & 1) .. +15 of the wave's half and
+    // reduction elements 8 * (g >> 1) .. +7 (two reads of 4 pixels); lane u of the group hands in pixel (u >> 2),
+    // channel chunk (u & 3)
+    const int u = lane & 15, hh = lane >> 5;
+    const int chan = 16 * ((lane >> 4) & 1) + 4 * (u & 3);
+    const int lp = 8 * hh + (u >> 2);                                  // pixel of the 16-pixel chunk (first read)
+    const int xlane = (WD >= 16) ? lp : (hh * HPW + (u >> 2));          // halo position of that pixel (tap 0,0)
+    const EGZ_LDS unsigned short* Xl = (const EGZ_LDS unsigned short*)(Xs) + wc * XH + xlane * 32 + chan;
+    const EGZ_LDS unsigned short* Dl = (const EGZ_LDS unsigned short*)(Ds) + wk * DH + lp * 32 + chan;
+    auto xoff = [&](int ks, int q, int tap) -> int {                   // compile-time after unrolling
+        const int base = (WD == 32) ? (16 * ks + 4 * q) : (WD == 16) ? (ks * HPW + 4 * q) : (2 * ks * HPW + 4 * q);
+        return (base + (tap / 3) * HPW + (tap % 3)) * 32;
+    };
+    auto frag = [&](const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) -> bf16x8_t {
+        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p0);
+        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p1);
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (g0 < g1) {
+        gload(g0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (long g = g0; g < g1; ++g) {
+        const int buf = (int)((g - g0) & 1);
+        if (g + 1 < g1) gload(g + 1);
+        const EGZ_LDS unsigned short* Xb = Xl + buf * XB;
+        const EGZ_LDS unsigned short* Db = Dl + buf * DB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t dh = frag(Db + (16 * ks) * 32, Db + (16 * ks + 4) * 32);
+            const bf16x8_t dl = frag(Db + 2 * DH + (16 * ks) * 32, Db + 2 * DH + (16 * ks + 4) * 32);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const bf16x8_t xh = frag(Xb + xoff(ks, 0, tap), Xb + xoff(ks, 1, tap));
+                const bf16x8_t xl = frag(Xb + 2 * XH + xoff(ks, 0, tap), Xb + 2 * XH + xoff(ks, 1, tap));
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, dh, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, dl, acc[tap], 0, 0, 0);
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, dh, acc[tap], 0, 0, 0);
+            }
+        }
+        if (g + 1 < g1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* out = part + ((long)blockIdx.y * 9 + tap) * C * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wc * 32 + egz_acc_row(r, lane);
+            const int k = k0 + wk * 32 + l31;
+            out[(long)c * K + k] = acc[tap][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient of [nearest x2 upsample -> conv3x3] in phase form (the transpose of the UPS_PHASE forward of
 // conv3x3_igemm.hip): for each output phase (py,px) the 3x3 taps collapse to 2x2 taps on the LOW-res input, so
 //   dWeff[py][px][a][b][c][k] = sum_{b,y,x} X[y+a+py-1][x+b+px-1][c] * dY[2y+py][2x+px][k]
@@ -540,6 +715,16 @@ int pick_splits9(long nseg, int C, int K) {
     return (int)s;
 }
 
+// split-half 9-tap kernel (flags 0x2000): patch width (0 = not applicable); rows narrower than the patch are masked
+int pick_patch_x3(int W, int C, int K, int flags) {
+    if (!(flags & 0x2000) || (flags & 0x800) || C % 64 != 0 || K % 64 != 0) return 0;
+    if (W % 32 == 0 || (W > 16 && W < 32)) return 32;
+    if (W % 16 == 0 || (W > 8 && W < 16)) return 16;
+    if (W % 8 == 0) return 8;
+    return 0;
+}
+long npatch_x3(int B, int H, int W, int WD) { return (long)B * ((H + 32 / WD - 1) / (32 / WD)) * ((W + WD - 1) / WD); }
+
 int pick_bt(int C, int K, int flags) {
     if (C % 64 != 0 || K % 64 != 0) return 32;
     if (flags & 0x100) return 64;
@@ -551,6 +736,8 @@ int pick_bt(int C, int K, int flags) {
 EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags) {
     const int L = pick_seg(W, C, K, flags);
     const long n = (long)9 * C * K;
+    if (const int WD = pick_patch_x3(W, C, K, flags))
+        return wgrad_ws_floats(pick_splits9(npatch_x3(B, H, W, WD), C, K), n) * sizeof(float);
     if (flags & 1) {
         const int Lu = pick_seg_ups(W, C, K, flags);
         if (Lu) return wgrad_ws_floats(pick_splits_ups((long)B * (H / 2) * (W / 2 / Lu), C, K), 16L * C * K) * sizeof(float);
@@ -562,7 +749,8 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 }
 
 // flags: bit0 = the conv input was the nearest-x2 upsampling of x ([B][H/2][W/2][C]); 0x100 forces 64 tiles;
-//        0x800 forces the per-tap kernel, 0x1000 the folded 9-tap form of an upsampled conv (A/B benchmarking).
+//        0x800 forces the per-tap kernel, 0x1000 the folded 9-tap form of an upsampled conv (A/B benchmarking);
+//        0x2000 = split-half bf16 x3 arithmetic on the 16-bit MFMA path (C, K multiples of 64; else exact f32).
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
 EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
                               int flags, void* workspace, size_t ws_bytes, hipStream_t st) {
@@ -573,6 +761,19 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     const long M = (long)B * H * W;
     float* part = static_cast<float*>(workspace);
     const long nred = (long)9 * C * K;
+    if (const int WD = pick_patch_x3(W, C, K, flags)) {   // split-half bf16 x3 on the 16-bit MFMA path
+        const long np = npatch_x3(B, H, W, WD);
+        const int S = pick_splits9(np, C, K);
+        EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+        const int pps = (int)((np + S - 1) / S);
+        dim3 grid((C / 64) * (K / 64), S);
+#define EGZ_W9X(U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps)
+        if (ups) { if (WD == 32) EGZ_W9X(true, 1, 32); else if (WD == 16) EGZ_W9X(true, 2, 16); else EGZ_W9X(true, 4, 8); }
+        else     { if (WD == 32) EGZ_W9X(false, 1, 32); else if (WD == 16) EGZ_W9X(false, 2, 16); else EGZ_W9X(false, 4, 8); }
+#undef EGZ_W9X
+        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap split)");
+        return wgrad_reduce(part, dw, C, K, S, st);
+    }
     const int Lu = ups ? pick_seg_ups(W, C, K, flags) : 0;
     if (Lu) {      // phase-decomposed upsample: 16 (phase, tap) partial tiles per split, 4/9 of the MACs
         const long n16 = 16L * C * K;

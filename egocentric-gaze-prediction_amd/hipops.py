@@ -228,12 +228,18 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
     return dx
 
 
-def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0) -> torch.Tensor:
+WGRAD_SPLIT = 0x2000       # egz_conv3x3_wgrad flag: bf16 x3 split-half arithmetic (C, K multiples of 64)
+
+
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0,
+                  precision: Optional[str] = None) -> torch.Tensor:
     _req(x, "x"); _req(dy, "dy")
     B, H, W, K = dy.shape
     C = x.shape[3]
     dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
     flags = (1 if ups else 0) | variant_flag
+    if (precision or PRECISION) == "split":
+        flags |= WGRAD_SPLIT
     nb = LIB.egz_conv3x3_wgrad_ws_bytes(B, H, W, C, K, flags)
     ws = workspace(nb, x.device)
     PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * C)

@@ -110,6 +110,31 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     assert rel(h.colsum(dyd).cpu(), b.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [
+    (2, 8, 32, 64, 64, False), (1, 5, 64, 128, 64, False), (2, 28, 28, 64, 128, False), (3, 6, 28, 64, 64, True),
+    (2, 6, 16, 64, 64, False), (1, 9, 48, 64, 64, False), (2, 14, 14, 128, 64, False), (1, 14, 14, 64, 64, True),
+    (1, 12, 12, 64, 64, False), (2, 8, 56, 64, 64, False), (1, 6, 24, 64, 128, True), (2, 7, 8, 64, 64, False),
+    (1, 56, 56, 64, 64, True),
+])
+def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups):
+    """bf16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes): patch geometries 1x32 / 2x16 / 4x8,
+    masked narrow rows (28 in 32, 14 and 12 in 16), odd row counts, upsample-fused gather.  Compared with the fp64
+    weight gradient; the exact-f32 kernel is held to the same bound for reference."""
+    h = H()
+    hin, win = (Hh // 2, Ww // 2) if ups else (Hh, Ww)
+    x = rnd(B, C, hin, win, seed=21)
+    dy = rnd(B, K, Hh, Ww, seed=22)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    w = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin.double(), w, None, padding=1).backward(dy.double())
+    dw_split = h.conv3x3_wgrad(nhwc(x), nhwc(dy), ups=ups, precision="split")
+    dw_f32 = h.conv3x3_wgrad(nhwc(x), nhwc(dy), ups=ups, precision="f32")
+    e_split, e_f32 = rel(dw_split.cpu().double(), w.grad), rel(dw_f32.cpu().double(), w.grad)
+    print(f"wgrad err vs fp64: split {e_split:.2e}  f32 {e_f32:.2e}")
+    assert e_f32 < 1e-5
+    assert e_split < 2e-5
+
+
 @pytest.mark.parametrize("C", [3, 20])
 @pytest.mark.parametrize("B,Hh,Ww", [(2, 16, 16), (1, 13, 21)])
 def test_conv_first(C, B, Hh, Ww):
