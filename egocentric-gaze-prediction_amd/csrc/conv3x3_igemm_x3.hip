@@ -21,6 +21,10 @@ namespace {
 constexpr int XBM = 128, XBK = 32;
 constexpr int XLD = 40;                 // row stride in 16-bit elements (80 B)
 constexpr float F16_WSCALE = 1024.f;    // 2^10
+#ifndef EGZ_X3_NSET
+#define EGZ_X3_NSET 1
+#endif
+constexpr int NSET = EGZ_X3_NSET;       // staging register sets = prefetch distance in K-slices
 
 enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
 enum { PLAIN = 0, UPS_FOLD = 1, UPS_PHASE = 2, UPS_DGRAD = 3 };
@@ -33,7 +37,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct Half;
 template <> struct Half<_Float16> {
     static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
-        x = fminf(fmaxf(x, -65504.f), 65504.f);
+        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
         const _Float16 hi = (_Float16)x;
         const _Float16 lo = (_Float16)(x - (float)hi);
         h = __builtin_bit_cast(unsigned short, hi);
@@ -57,10 +61,12 @@ template <> struct Half<__bf16> {
 
 // wp: [2 planes (hi, lo)][taps][Kp][Cp] 16-bit.  H, W: hi-res (conv output) dims for the UPS_* modes.
 template <typename T, int XBN, int MODE, int EPI>   // XBN = 128 (Cout % 128 == 0) or 64 (Cout = 64 layers)
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
+__global__ __launch_bounds__(256, (EGZ_X3_NSET > 1) ? 2 : 3) void conv3x3_igemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
-    float out_scale) {
+    float out_scale, int mt, int tile_base, int nsplit, int pass, float* __restrict__ ws) {
+    // pass 0: whole tile (all K-slices + epilogue).  pass 1: split-K part blockIdx.y of nsplit -> raw accumulators to ws.
+    // pass 2: sum the nsplit partials of the tile in a fixed order, then the normal epilogue (launch_x3: tail tiles).
     constexpr int NTAP = (MODE == UPS_PHASE) ? 4 : (MODE == UPS_DGRAD) ? 16 : 9;
     constexpr int NR = XBN / 64;            // 32-wide n-tiles per wave (2 x 2 waves)
     constexpr int WN = XBN / 2;
@@ -72,9 +78,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, hl = lane >> 5, l31 = lane & 31;
     const int ntn = Kp / XBN;
-    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int gb = blockIdx.x + tile_base, tpp = mt * ntn;       // global tile id over [phase][tile_m][tile_n]
+    const int phase = (MODE == UPS_PHASE) ? gb / tpp : 0, py = phase >> 1, px = phase & 1;
+    const int tl = gb - phase * tpp;
+    const int tile_n = tl % ntn, tile_m = tl / ntn;
     const int m0 = tile_m * XBM, n0 = tile_n * XBN;
-    const int phase = (MODE == UPS_PHASE) ? blockIdx.y : 0, py = phase >> 1, px = phase & 1;
     const int Hr = (MODE >= UPS_PHASE) ? (H >> 1) : H, Wr = (MODE >= UPS_PHASE) ? (W >> 1) : W;
     const int Hg = (MODE == UPS_FOLD || MODE == UPS_PHASE) ? (H >> 1) : H;
     const int Wg = (MODE == UPS_FOLD || MODE == UPS_PHASE) ? (W >> 1) : W;
@@ -105,9 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
         if (a_c4 == 0) Ro[r0 + 32 * j] = off;
     }
 
-    f32x4 ra[4];
-    u32x4 rb[2][BLD];   // [plane][j]
-    auto gload = [&](int s) {
+    f32x4 ra[NSET][4];
+    u32x4 rb[NSET][2][BLD];   // [set][plane][j]
+    auto gload = [&](int s, const int set) {
         const int cblk = s / NTAP, tap = s - cblk * NTAP;
         const int c0 = cblk * XBK;
         int dy, dx;
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
             const bool ok = (unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb && (c0 + a_c4 * 4 < C);
             const int sy = (MODE == UPS_FOLD) ? (iy >> 1) : iy, sx = (MODE == UPS_FOLD) ? (ix >> 1) : ix;
             const float* p = x + ((a_img[j] + (long)sy * Wg + sx) * C + c0 + a_c4 * 4);
-            ra[j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ra[set][j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
@@ -143,15 +151,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
             for (int j = 0; j < BLD; ++j) {
                 const unsigned short* p = wp + pl * plane +
                                           ((long)((phase * NTAP + tap) * Kp + n0 + b_r0 + 64 * j) * Cp + c0 + b_ch * 8);
-                rb[pl][j] = *reinterpret_cast<const u32x4*>(p);
+                rb[set][pl][j] = *reinterpret_cast<const u32x4*>(p);
             }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](const int set) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned short h[4], l[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Half<T>::split(ra[j][e], h[e], l[e]);
+            for (int e = 0; e < 4; ++e) Half<T>::split(ra[set][j][e], h[e], l[e]);
             const int o = (r0 + 32 * j) * XLD + a_c4 * 4;
             *reinterpret_cast<u32x2*>(As + o) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
             *reinterpret_cast<u32x2*>(As + XBM * XLD + o) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int j = 0; j < BLD; ++j)
-                *reinterpret_cast<u32x4*>(Bs + pl * XBN * XLD + (b_r0 + 64 * j) * XLD + b_ch * 8) = rb[pl][j];
+                *reinterpret_cast<u32x4*>(Bs + pl * XBN * XLD + (b_r0 + 64 * j) * XLD + b_ch * 8) = rb[set][pl][j];
     };
 
     f32x16 acc[2][NR];
@@ -172,12 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int S = (Cp / XBK) * NTAP;
-    gload(0);
-    lstore();
-    __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        const int sp = (s + 1 < S) ? s + 1 : S - 1;      // branch-free prefetch (clamped past the end)
-        gload(sp);
+    auto compute = [&]() {
         const unsigned short* Ab = As + (wm * 64 + l31) * XLD + 8 * hl;
         const unsigned short* Bb = Bs + (wn * WN + l31) * XLD + 8 * hl;
 #pragma unroll
@@ -193,18 +196,63 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
                 bh[nr] = *reinterpret_cast<const u32x4*>(Bb + nr * 32 * XLD + ks * 16);
                 bl[nr] = *reinterpret_cast<const u32x4*>(Bb + XBN * XLD + nr * 32 * XLD + ks * 16);
             }
+            // small terms first; the three products of one accumulator are NR * 2 MFMAs apart (no dependent back-to-back)
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
+            for (int term = 0; term < 3; ++term)
 #pragma unroll
-                for (int mr = 0; mr < 2; ++mr) {
-                    acc[mr][nr] = Half<T>::mfma(al[mr], bh[nr], acc[mr][nr]);      // small terms first
-                    acc[mr][nr] = Half<T>::mfma(ah[mr], bl[nr], acc[mr][nr]);
-                    acc[mr][nr] = Half<T>::mfma(ah[mr], bh[nr], acc[mr][nr]);
-                }
+                for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                    for (int mr = 0; mr < 2; ++mr)
+                        acc[mr][nr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl[nr] : bh[nr], acc[mr][nr]);
         }
-        __syncthreads();          // every wave is done reading this slice
-        lstore();                 // convert + stage the prefetched slice
+    };
+    // register ring: set u holds slice (s + u) until it is staged, then is refilled with slice (s + u + NSET), so every
+    // global load has NSET slice-times to land
+    int s_lo = 0, s_hi = S;
+    if (pass == 1) {
+        s_lo = (int)((long)S * blockIdx.y / nsplit);
+        s_hi = (int)((long)S * (blockIdx.y + 1) / nsplit);
+    }
+    if (pass != 2) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) gload(s_lo + u < s_hi ? s_lo + u : s_hi - 1, u);
+        lstore(0);
         __syncthreads();
+        for (int s = s_lo; s < s_hi; s += NSET) {
+#pragma unroll
+            for (int u = 0; u < NSET; ++u) {
+                if (s + u < s_hi) {
+                    const int sp = (s + u + NSET < s_hi) ? s + u + NSET : s_hi - 1;   // branch-free prefetch (clamped)
+                    gload(sp, u);
+                    compute();
+                    __syncthreads();              // every wave is done reading this slice
+                    lstore((u + 1) % NSET);       // convert + stage slice s + u + 1
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
+        __syncthreads();                          // Ro
+    }
+    if (pass) {      // raw accumulators, thread-major: element ((mr * NR + nr) * 16 + r) * 256 + tid -> coalesced both ways
+        float* wt = ws + (long)blockIdx.x * nsplit * (XBM * XBN);
+        if (pass == 1) {
+            wt += (long)blockIdx.y * (XBM * XBN);
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) wt[((mr * NR + nr) * 16 + r) * 256 + tid] = acc[mr][nr][r];
+            return;
+        }
+        for (int sp = 0; sp < nsplit; ++sp, wt += XBM * XBN)
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mr][nr][r] += wt[((mr * NR + nr) * 16 + r) * 256 + tid];
     }
 
     // ---- epilogue (same as the fp32 kernel; out_scale undoes the weight pre-scaling of the f16 path exactly)
@@ -245,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
         if (tid < XBN && n0 + tid < K) {
             const double t1 = red[(0 * 2 + 0) * XBN + tid] + red[(1 * 2 + 0) * XBN + tid];
             const double t2 = red[(0 * 2 + 1) * XBN + tid] + red[(1 * 2 + 1) * XBN + tid];
-            const long srow = (long)phase * (gridDim.x / ntn) + tile_m;
+            const long srow = (long)phase * mt + tile_m;
             stat[(srow * 2 + 0) * K + n0 + tid] = t1;
             stat[(srow * 2 + 1) * K + n0 + tid] = t2;
         }
@@ -299,17 +347,72 @@ __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* _
     }
 }
 
+// Tile schedule.  Every block of this kernel does the same work, so a launch runs in rounds of R = (resident blocks per
+// CU) x (CUs) tiles; the SP shapes give 196 / 784 / 1568 / 3136 tiles -- just over 1 / 1 / 2 / 4 rounds of 768 -- so a plain
+// launch spends up to half its time in a nearly empty last round.  The tiles beyond the last full round are instead run
+// split-K (each tile's K-slices divided over nsplit blocks so the remainder still fills the chip), as raw partial
+// accumulators through the workspace, and a third tiny launch sums them in a fixed order and applies the epilogue.
+struct X3Plan { int mt, ntn, nph, total, main, tail, nsplit; };
+int x3_slots() {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 0;
+        slots = 3 * (cus > 0 ? cus : 256);      // __launch_bounds__(256, 3): 168 VGPRs, 42 KB LDS
+    }
+    return slots;
+}
+X3Plan x3_plan(long M, int Cp, int Kp, int XBN, int mode, int flags) {
+    X3Plan p;
+    p.mt = egz_cdiv(M, XBM);
+    p.ntn = Kp / XBN;
+    p.nph = (mode == UPS_PHASE) ? 4 : 1;
+    p.total = p.mt * p.ntn * p.nph;
+    p.main = p.total;
+    p.tail = 0;
+    p.nsplit = 1;
+    const int ntap = (mode == UPS_PHASE) ? 4 : (mode == UPS_DGRAD) ? 16 : 9;
+    const int nslices = (Cp / XBK) * ntap, R = x3_slots();
+    const int rem = p.total % R;
+    if (!(flags & 0x8000) && EGZ_X3_NSET == 1 && rem != 0 && rem * 10 < R * 7) {
+        int ns = R / rem;
+        if (ns > 16) ns = 16;
+        if (ns > nslices / 2) ns = nslices / 2;
+        if (ns >= 2) {
+            p.main = p.total - rem;
+            p.tail = rem;
+            p.nsplit = ns;
+        }
+    }
+    return p;
+}
+int x3_mode(int flags) { return (flags & 4) ? UPS_DGRAD : ((flags & 3) == 3) ? UPS_PHASE : ((flags & 3) == 1) ? UPS_FOLD : PLAIN; }
+long x3_rows(int mode, int B, int H, int W) { return (mode >= UPS_PHASE) ? (long)B * (H / 2) * (W / 2) : (long)B * H * W; }
+
 template <typename T, int XBN, int MODE>
 int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bias, float* y, double* stat, int B, int H,
-              int W, int C, int K, float out_scale, hipStream_t st) {
-    const long M = (MODE >= UPS_PHASE) ? (long)B * (H / 2) * (W / 2) : (long)B * H * W;
+              int W, int C, int K, float out_scale, int flags, float* ws, size_t ws_bytes, hipStream_t st) {
+    const long M = x3_rows(MODE, B, H, W);
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
-    dim3 grid(egz_cdiv(M, XBM) * (Kp / XBN), MODE == UPS_PHASE ? 4 : 1);
-#define EGZ_X3(E) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, XBN, MODE, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale)
+    const X3Plan p = x3_plan(M, Cp, Kp, XBN, MODE, flags);
+    EGZ_CHECK_ARG(!p.tail || (ws && ws_bytes >= (size_t)p.tail * p.nsplit * XBM * XBN * sizeof(float)),
+                  "egz_conv3x3_fwd_split: workspace too small (%zu bytes; see egz_conv3x3_fwd_split_ws_bytes)", ws_bytes);
+#define EGZ_X3L(E, GRID, BASE, NS, PASS) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, XBN, MODE, E>), GRID, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, p.mt, BASE, NS, PASS, ws)
+#define EGZ_X3(E)                                                                  \
+    do {                                                                           \
+        if (p.main) EGZ_X3L(E, dim3(p.main), 0, 1, 0);                             \
+        if (p.tail) {                                                              \
+            EGZ_X3L(E, dim3(p.tail, p.nsplit), p.main, p.nsplit, 1);               \
+            EGZ_X3L(E, dim3(p.tail), p.main, p.nsplit, 2);                         \
+        }                                                                          \
+    } while (0)
     if (MODE == UPS_DGRAD || epi == EPI_BIAS) EGZ_X3(EPI_BIAS);
     else if (epi == EPI_BIAS_RELU) EGZ_X3(EPI_BIAS_RELU);
     else EGZ_X3(EPI_BIAS_STATS);
 #undef EGZ_X3
+#undef EGZ_X3L
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_split");
     return 0;
 }
@@ -336,8 +439,18 @@ EGZ_API int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind
 // (flags bit 2 = 0x4 selects the 16-tap data gradient of an upsampled conv), computed with split-half operands.
 // dtype 1 = f16 x3, 2 = bf16 x3; wp from egz_pack_w3x3_split with the same dtype.  Needs Cout % 64 == 0, Cin % 32 == 0
 // (tile 128 x 128, or 128 x 64 when Cout is not a multiple of 128).
+// Workspace bytes egz_conv3x3_fwd_split needs for these arguments (0 when the tile count fills whole rounds).
+EGZ_API size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K, int flags) {
+    if (K % 64 != 0 || C % 32 != 0 || C <= 0) return 0;
+    const int mode = x3_mode(flags), XBN = (K % 128 == 0) ? 128 : 64;
+    const X3Plan p = x3_plan(x3_rows(mode, B, H, W), (C + 31) / 32 * 32, (K + 31) / 32 * 32, XBN, mode, flags);
+    return (size_t)p.tail * p.nsplit * XBM * XBN * sizeof(float);
+}
+
+// flags bit 15 (0x8000): plain single launch (no split-K tail), for A/B measurements.
 EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial,
-                                  int B, int H, int W, int C, int K, int flags, int dtype, hipStream_t st) {
+                                  int B, int H, int W, int C, int K, int flags, int dtype, void* workspace,
+                                  size_t ws_bytes, hipStream_t st) {
     EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd_split: null pointer");
     EGZ_CHECK_ARG(K % 64 == 0 && C % 32 == 0 && C > 0, "egz_conv3x3_fwd_split: needs Cout %% 64 == 0 and Cin %% 32 == 0 (got %d, %d)", K, C);
     EGZ_CHECK_ARG(dtype == 1 || dtype == 2, "egz_conv3x3_fwd_split: dtype must be 1 (f16) or 2 (bf16)");
@@ -347,11 +460,12 @@ EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* b
     EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_split: stats epilogue needs stat_partial");
     const unsigned short* w16 = static_cast<const unsigned short*>(wp);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
+    float* ws = static_cast<float*>(workspace);
 #define EGZ_MODE(T, N)                                                                                          \
-    if (flags & 4) return launch_x3<T, N, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st); \
-    if (ups == 3) return launch_x3<T, N, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);  \
-    if (ups == 1) return launch_x3<T, N, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st);   \
-    return launch_x3<T, N, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, st)
+    if (flags & 4) return launch_x3<T, N, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st); \
+    if (ups == 3) return launch_x3<T, N, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st);  \
+    if (ups == 1) return launch_x3<T, N, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st);   \
+    return launch_x3<T, N, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st)
     if (K % 128 == 0) {
         if (dtype == 1) { EGZ_MODE(_Float16, 128); }
         EGZ_MODE(__bf16, 128);

@@ -380,13 +380,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8_t dh = frag(Db + (16 * ks) * 32, Db + (16 * ks + 4) * 32);
             const bf16x8_t dl = frag(Db + 2 * DH + (16 * ks) * 32, Db + 2 * DH + (16 * ks + 4) * 32);
+            // taps in groups of three: the three products of one accumulator are issued three MFMAs apart
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const bf16x8_t xh = frag(Xb + xoff(ks, 0, tap), Xb + xoff(ks, 1, tap));
-                const bf16x8_t xl = frag(Xb + 2 * XH + xoff(ks, 0, tap), Xb + 2 * XH + xoff(ks, 1, tap));
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, dh, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, dl, acc[tap], 0, 0, 0);
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, dh, acc[tap], 0, 0, 0);
+            for (int tr = 0; tr < 3; ++tr) {
+                bf16x8_t xh[3], xl[3];
+#pragma unroll
+                for (int ts = 0; ts < 3; ++ts) {
+                    const int tap = tr * 3 + ts;
+                    xh[ts] = frag(Xb + xoff(ks, 0, tap), Xb + xoff(ks, 1, tap));
+                    xl[ts] = frag(Xb + 2 * XH + xoff(ks, 0, tap), Xb + 2 * XH + xoff(ks, 1, tap));
+                }
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int ts = 0; ts < 3; ++ts)
+                        acc[tr * 3 + ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts], 0, 0, 0);
             }
         }
         if (g + 1 < g1) lstore(buf ^ 1);
@@ -706,9 +715,9 @@ int pick_seg(int W, int C, int K, int flags) {
     if (W % 14 == 0) return 14;
     return 0;
 }
-int pick_splits9(long nseg, int C, int K) {
+int pick_splits9(long nseg, int C, int K, int target = 1024) {
     const long tiles = (long)(C / 64) * (K / 64);
-    long s = (1024 + tiles - 1) / tiles;              // ~4 blocks per CU
+    long s = (target + tiles - 1) / tiles;            // 1024: ~4 blocks per CU (two rounds of 2 resident)
     const long smax = (nseg + 7) / 8;                 // at least 8 segments per split
     if (s > smax) s = smax;
     if (s < 1) s = 1;
@@ -723,6 +732,10 @@ int pick_patch_x3(int W, int C, int K, int flags) {
     if (W % 8 == 0) return 8;
     return 0;
 }
+#ifndef EGZ_X3_BLOCKS
+#define EGZ_X3_BLOCKS 512
+#endif
+constexpr int X3_BLOCKS = EGZ_X3_BLOCKS;   // blocks per launch of the split-half kernel: one round of 2 resident blocks per CU
 long npatch_x3(int B, int H, int W, int WD) { return (long)B * ((H + 32 / WD - 1) / (32 / WD)) * ((W + WD - 1) / WD); }
 
 int pick_bt(int C, int K, int flags) {
@@ -737,7 +750,7 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
     const int L = pick_seg(W, C, K, flags);
     const long n = (long)9 * C * K;
     if (const int WD = pick_patch_x3(W, C, K, flags))
-        return wgrad_ws_floats(pick_splits9(npatch_x3(B, H, W, WD), C, K), n) * sizeof(float);
+        return wgrad_ws_floats(pick_splits9(npatch_x3(B, H, W, WD), C, K, X3_BLOCKS), n) * sizeof(float);
     if (flags & 1) {
         const int Lu = pick_seg_ups(W, C, K, flags);
         if (Lu) return wgrad_ws_floats(pick_splits_ups((long)B * (H / 2) * (W / 2 / Lu), C, K), 16L * C * K) * sizeof(float);
@@ -763,7 +776,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     const long nred = (long)9 * C * K;
     if (const int WD = pick_patch_x3(W, C, K, flags)) {   // split-half bf16 x3 on the 16-bit MFMA path
         const long np = npatch_x3(B, H, W, WD);
-        const int S = pick_splits9(np, C, K);
+        const int S = pick_splits9(np, C, K, X3_BLOCKS);
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int pps = (int)((np + S - 1) / S);
         dim3 grid((C / 64) * (K / 64), S);

@@ -197,8 +197,11 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
     if dtype:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        sflags = (flags & 0x33) | (tile_flag & 0x8000)      # 0x8000: no split-K tail (A/B measurements)
+        nb = LIB.egz_conv3x3_fwd_split_ws_bytes(B, H, W, C, K, sflags)
+        ws = workspace(nb, x.device) if nb else None
         check(LIB.egz_conv3x3_fwd_split(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                        flags & 0x33, dtype, _stream()), "egz_conv3x3_fwd_split")
+                                        sflags, dtype, _p(ws), nb, _stream()), "egz_conv3x3_fwd_split")
         return y, stat
     PROF.note_flops("egz_conv3x3_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K, flags,
@@ -219,8 +222,10 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
     dx = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=dy.device)
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        nb = LIB.egz_conv3x3_fwd_split_ws_bytes(B, H, W, K, C, 4)
+        ws = workspace(nb, dy.device) if nb else None
         check(LIB.egz_conv3x3_fwd_split(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                        4, dtype, _stream()), "egz_conv3x3_fwd_split(ups_dgrad)")
+                                        4, dtype, _p(ws), nb, _stream()), "egz_conv3x3_fwd_split(ups_dgrad)")
         return dx
     PROF.note_flops("egz_conv3x3_ups_dgrad", 2.0 * B * H * W * K * 9 * C)     # algorithmic (reference) FLOPs
     check(LIB.egz_conv3x3_ups_dgrad(dy.data_ptr(), wp_ups_dgrad.data_ptr(), dx.data_ptr(), B, H, W, C, K,

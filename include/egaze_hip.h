@@ -61,8 +61,12 @@ int egz_conv3x3_ups_dgrad(const float* dy, const float* wp, float* dx, int B, in
  * egz_conv3x3_fwd_split: flags as egz_conv3x3_fwd (bits 0-1, 4-5) plus bit2 = the 16-tap data gradient of an
  * upsampled conv (then C / K are the GEMM's reduction / output channel counts). */
 int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind, int dtype, hipStream_t stream);
+/* Tile schedule of egz_conv3x3_fwd_split: tiles beyond the last full round of resident blocks are run split-K through
+ * `workspace` (raw partial accumulators) and reduced in a fixed order -> egz_conv3x3_fwd_split_ws_bytes (0 = no tail). */
+size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial, int B,
-                          int H, int W, int C, int K, int flags, int dtype, hipStream_t stream);
+                          int H, int W, int C, int K, int flags, int dtype, void* workspace, size_t ws_bytes,
+                          hipStream_t stream);
 /* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
 size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,

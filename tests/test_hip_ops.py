@@ -300,6 +300,37 @@ def test_conv3x3_split_half(B, Hh, Ww, C, K, dtype, tol):
         assert rel(nchw(dx), dref) < tol
 
 
+@pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [
+    (1, 129, 384, 32, 256, False),     # 774 tiles = one full round of 768 + 6 tail tiles split 16 ways
+    (1, 96, 200, 64, 128, False),      # 150 tiles < one round: every tile split 5 ways
+    (2, 56, 58, 32, 64, True),         # phase-decomposed upsample, 4 x 26 tiles of 128 x 64
+])
+def test_conv3x3_split_tail_schedule(B, Hh, Ww, C, K, ups):
+    """Split-K tail of the split-half implicit GEMM (main round + split tail + fixed-order fixup) against the plain
+    single launch (flag 0x8000) of the same kernel: same values up to fp32 summation order, same BN statistics."""
+    h = H()
+    x = rnd(B, C, Hh // 2 if ups else Hh, Ww // 2 if ups else Ww, seed=51)
+    w = rnd(K, C, 3, 3, seed=52, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
+    b = rnd(K, seed=53, scale=0.1).to(DEV)
+    xd = nhwc(x)
+    for dtype in (1, 2):
+        wp = h.packed_weight(w, "ups_fwd" if ups else "fwd", dtype)
+        for epi in (1, 2):
+            y0, s0 = h.conv3x3_fwd(xd, wp, b, K, ups="phase" if ups else False, epi=epi, dtype=dtype, tile_flag=0x8000)
+            y1, s1 = h.conv3x3_fwd(xd, wp, b, K, ups="phase" if ups else False, epi=epi, dtype=dtype)
+            assert rel(y1, y0) < 2e-6
+            if epi == 2:
+                assert s0.shape == s1.shape
+                assert rel(s1.sum(0), s0.sum(0)) < 1e-6
+    # the transposed (data-gradient) role on the same schedule
+    dy = nhwc(rnd(B, K, Hh, Ww, seed=54))
+    if C % 64 == 0 and not ups:
+        wd = h.packed_weight(w, "dgrad", 2)
+        d0, _ = h.conv3x3_fwd(dy, wd, None, C, epi=0, dtype=2, tile_flag=0x8000)
+        d1, _ = h.conv3x3_fwd(dy, wd, None, C, epi=0, dtype=2)
+        assert rel(d1, d0) < 2e-6
+
+
 @pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
 def test_conv3x3_split_half_upsample(dtype, tol):
     h = H()
