@@ -19,12 +19,14 @@
 namespace {
 
 constexpr int XBM = 128, XBK = 32;
-constexpr int XLD = 40;                 // row stride in 16-bit elements (80 B)
+constexpr int XLD = 32;                 // row stride in 16-bit elements: 64 B, no padding -- the four 16-byte chunks
+                                        // of a row are XOR-swizzled with (row >> 2) & 3, which makes the ds_read_b128
+                                        // fragment reads conflict-free in every 16-lane service group
 constexpr float F16_WSCALE = 1024.f;    // 2^10
-#ifndef EGZ_X3_NSET
-#define EGZ_X3_NSET 1
+#ifndef EGZ_X3_SCHED
+#define EGZ_X3_SCHED 1
 #endif
-constexpr int NSET = EGZ_X3_NSET;       // staging register sets = prefetch distance in K-slices
+constexpr int NSET = 2;                 // staging register sets (slice s+1 being converted, slice s+2 in flight)
 
 enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
 enum { PLAIN = 0, UPS_FOLD = 1, UPS_PHASE = 2, UPS_DGRAD = 3 };
@@ -34,6 +36,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <typename T> struct Half;
 template <> struct Half<_Float16> {
     static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
@@ -42,6 +48,18 @@ template <> struct Half<_Float16> {
         const _Float16 lo = (_Float16)(x - (float)hi);
         h = __builtin_bit_cast(unsigned short, hi);
         l = __builtin_bit_cast(unsigned short, lo);
+    }
+    // 4 floats -> packed hi / lo halves in 3 VALU per float: hi = v_cvt_pkrtz (round toward zero: the residual is then
+    // exact in fp32 and an out-of-range input saturates hi instead of producing inf), lo = RNE of the residual, so the
+    // pair carries 22 significant bits with an unbiased error.  |x| > 65504 is outside the f16 x3 domain (lo overflows).
+    static __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * e], v[2 * e + 1]));
+            const f16x2 l = __builtin_convertvector(f32x2{v[2 * e] - (float)h[0], v[2 * e + 1] - (float)h[1]}, f16x2);
+            hi[e] = __builtin_bit_cast(unsigned, h);
+            lo[e] = __builtin_bit_cast(unsigned, l);
+        }
     }
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -54,6 +72,17 @@ template <> struct Half<__bf16> {
         h = __builtin_bit_cast(unsigned short, hi);
         l = __builtin_bit_cast(unsigned short, lo);
     }
+    // v_cvt_pk_bf16_f32 (RNE), two bit ops to widen the halves back, one packed subtract, v_cvt_pk_bf16_f32: 2.5 VALU / float
+    static __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f32x2 x = {v[2 * e], v[2 * e + 1]};
+            const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+            const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+            hi[e] = hu;
+            lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, bf16x2));
+        }
+    }
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
@@ -61,7 +90,7 @@ template <> struct Half<__bf16> {
 
 // wp: [2 planes (hi, lo)][taps][Kp][Cp] 16-bit.  H, W: hi-res (conv output) dims for the UPS_* modes.
 template <typename T, int XBN, int MODE, int EPI>   // XBN = 128 (Cout % 128 == 0) or 64 (Cout = 64 layers)
-__global__ __launch_bounds__(256, (EGZ_X3_NSET > 1) ? 2 : 3) void conv3x3_igemm_x3_kernel(
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
     float out_scale, int mt, int tile_base, int nsplit, int pass, float* __restrict__ ws) {
@@ -71,8 +100,9 @@ __global__ __launch_bounds__(256, (EGZ_X3_NSET > 1) ? 2 : 3) void conv3x3_igemm_
     constexpr int NR = XBN / 64;            // 32-wide n-tiles per wave (2 x 2 waves)
     constexpr int WN = XBN / 2;
     constexpr int BLD = XBN / 64;           // 16-byte B chunks per thread per plane
-    __shared__ __attribute__((aligned(16))) unsigned short As[2 * XBM * XLD];   // [plane][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * XBN * XLD];
+    constexpr int ABUF = 2 * XBM * XLD, BBUF = 2 * XBN * XLD;                    // elements per LDS buffer
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * ABUF];         // [buffer][plane][row][k swizzled]
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BBUF];
     __shared__ long Ro[XBM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,6 +142,37 @@ __global__ __launch_bounds__(256, (EGZ_X3_NSET > 1) ? 2 : 3) void conv3x3_igemm_
         }
         if (a_c4 == 0) Ro[r0 + 32 * j] = off;
     }
+    // Operand fetch through buffer loads (all modes but UPS_FOLD, whose >> 1 gather is not affine in the tap): per row a
+    // 32-bit byte offset and a bit mask of the taps whose source pixel exists are fixed for the whole tile; per slice the
+    // tap / channel-block displacement is one scalar offset for all lanes, and a row whose tap falls outside the image
+    // gets offset 0xFFFFFFFF, which the buffer bounds check turns into zeros.  ~3 VALU per row per slice instead of ~14.
+    // The resource base sits (Wg + 1) * C floats before x so that scalar displacements are never negative.
+    constexpr bool BUFA = (MODE != UPS_FOLD);
+    const unsigned a_bias = (unsigned)(Wg + 1) * (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(x)) - a_bias, 0,
+        (int)((unsigned)B * Hg * Wg * C * 4u + a_bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(wp), 0, (int)(4 * plane), 0x00020000);
+    unsigned a_vo[4], a_mask[4], b_vo[2][BLD];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int by = (MODE == UPS_DGRAD) ? 2 * a_y[j] : a_y[j], bx = (MODE == UPS_DGRAD) ? 2 * a_x[j] : a_x[j];
+        a_vo[j] = (unsigned)(((a_img[j] + (long)by * Wg + bx) * C + a_c4 * 4) * 4);
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const int dy = (MODE == UPS_PHASE) ? (t >> 1) + py - 1 : (MODE == UPS_DGRAD) ? (t >> 2) - 1 : t / 3 - 1;
+            const int dx = (MODE == UPS_PHASE) ? (t & 1) + px - 1 : (MODE == UPS_DGRAD) ? (t & 3) - 1 : t % 3 - 1;
+            mk |= ((unsigned)(by + dy) < (unsigned)Hg && (unsigned)(bx + dx) < (unsigned)Wg) ? (1u << t) : 0u;
+        }
+        a_mask[j] = mk;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int j = 0; j < BLD; ++j)
+            b_vo[pl][j] = (unsigned)((pl * plane + (long)(n0 + b_r0 + 64 * j) * Cp + b_ch * 8) * 2);
 
     f32x4 ra[NSET][4];
     u32x4 rb[NSET][2][BLD];   // [set][plane][j]
@@ -129,46 +190,55 @@ __global__ __launch_bounds__(256, (EGZ_X3_NSET > 1) ? 2 : 3) void conv3x3_igemm_
             dy = tap / 3 - 1;
             dx = tap - (tap / 3) * 3 - 1;
         }
+        if constexpr (BUFA) {
+            const unsigned so_a = (unsigned)(((dy * Wg + dx) * C + c0) * 4) + a_bias;
+            const unsigned so_b = (unsigned)((((long)(phase * NTAP + tap) * Kp) * Cp + c0) * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int iy, ix;
-            if (MODE == UPS_DGRAD) {
-                iy = 2 * a_y[j] + dy;
-                ix = 2 * a_x[j] + dx;
-            } else {
-                iy = a_y[j] + dy;
-                ix = a_x[j] + dx;
+            for (int j = 0; j < 4; ++j) {
+                const unsigned vo = a_vo[j] | (((a_mask[j] >> tap) & 1u) - 1u);      // valid ? offset : 0xFFFFFFFF
+                ra[set][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, vo, so_a, 0));
             }
-            const int Hb = (MODE == UPS_FOLD) ? H : Hg, Wb = (MODE == UPS_FOLD) ? W : Wg;
-            const bool ok = (unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb && (c0 + a_c4 * 4 < C);
-            const int sy = (MODE == UPS_FOLD) ? (iy >> 1) : iy, sx = (MODE == UPS_FOLD) ? (ix >> 1) : ix;
-            const float* p = x + ((a_img[j] + (long)sy * Wg + sx) * C + c0 + a_c4 * 4);
-            ra[set][j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < BLD; ++j)
+                    rb[set][pl][j] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo[pl][j], so_b, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = a_y[j] + dy, ix = a_x[j] + dx;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const float* p = x + ((a_img[j] + (long)(iy >> 1) * Wg + (ix >> 1)) * C + c0 + a_c4 * 4);
+                ra[set][j] = ok ? *reinterpret_cast<const f32x4*>(p) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < BLD; ++j) {
+                    const unsigned short* p = wp + pl * plane +
+                                              ((long)((phase * NTAP + tap) * Kp + n0 + b_r0 + 64 * j) * Cp + c0 + b_ch * 8);
+                    rb[set][pl][j] = *reinterpret_cast<const u32x4*>(p);
+                }
         }
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int j = 0; j < BLD; ++j) {
-                const unsigned short* p = wp + pl * plane +
-                                          ((long)((phase * NTAP + tap) * Kp + n0 + b_r0 + 64 * j) * Cp + c0 + b_ch * 8);
-                rb[set][pl][j] = *reinterpret_cast<const u32x4*>(p);
-            }
     };
-    auto lstore = [&](const int set) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned short h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) Half<T>::split(ra[set][j][e], h[e], l[e]);
-            const int o = (r0 + 32 * j) * XLD + a_c4 * 4;
-            *reinterpret_cast<u32x2*>(As + o) = u32x2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-            *reinterpret_cast<u32x2*>(As + XBM * XLD + o) = u32x2{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
-        }
+    // LDS staging of register set `set` into buffer `buf`, in five pieces (four A rows with their hi/lo conversion, then
+    // the pre-split B chunks) so the main loop can spread them between the MFMAs of the slice being multiplied
+    const int a_sw = (r0 >> 2) & 3, b_sw = (b_r0 >> 2) & 3;     // (row >> 2) & 3 of every row this thread stages
+    const int a_off = r0 * XLD + (((a_c4 >> 1) ^ a_sw) << 3) + (a_c4 & 1) * 4;
+    const int b_off = b_r0 * XLD + ((b_ch ^ b_sw) << 3);
+    auto lstore_a = [&](const int set, const int buf, const int j) {
+        u32x2 hi, lo;
+        Half<T>::split4(ra[set][j], hi, lo);
+        unsigned short* d = As + buf * ABUF + a_off + 32 * j * XLD;
+        *reinterpret_cast<u32x2*>(d) = hi;
+        *reinterpret_cast<u32x2*>(d + XBM * XLD) = lo;
+    };
+    auto lstore_b = [&](const int set, const int buf) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int j = 0; j < BLD; ++j)
-                *reinterpret_cast<u32x4*>(Bs + pl * XBN * XLD + (b_r0 + 64 * j) * XLD + b_ch * 8) = rb[set][pl][j];
+                *reinterpret_cast<u32x4*>(Bs + buf * BBUF + pl * XBN * XLD + b_off + 64 * j * XLD) = rb[set][pl][j];
     };
 
     f32x16 acc[2][NR];
@@ -180,53 +250,76 @@ __global__ __launch_bounds__(256, (EGZ_X3_NSET > 1) ? 2 : 3) void conv3x3_igemm_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int S = (Cp / XBK) * NTAP;
-    auto compute = [&]() {
-        const unsigned short* Ab = As + (wm * 64 + l31) * XLD + 8 * hl;
-        const unsigned short* Bb = Bs + (wn * WN + l31) * XLD + 8 * hl;
+    // one K-slice: 2 k-steps x (fragment reads, 3 * 2 * NR MFMAs).  The conversion + staging of the NEXT slice (register
+    // set `set` -> LDS buffer buf ^ 1) is issued between the MFMAs, whose 32-cycle matrix-pipe occupancy leaves ~7 issue
+    // slots each: the VALU / LDS-write work disappears into that shadow instead of forming a phase of its own.
+    const int f_sw = (l31 >> 2) & 3;
+    const int fo0 = ((hl ^ f_sw) << 3), fo1 = fo0 ^ 16;          // swizzled chunk of k-step 0 / 1 for this lane
+    auto slice = [&](const int buf, const int set, const bool stage) {
+        const unsigned short* Ab = As + buf * ABUF + (wm * 64 + l31) * XLD;
+        const unsigned short* Bb = Bs + buf * BBUF + (wn * WN + l31) * XLD;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? fo1 : fo0;
             u32x4 ah[2], al[2], bh[NR], bl[NR];
 #pragma unroll
             for (int mr = 0; mr < 2; ++mr) {
-                ah[mr] = *reinterpret_cast<const u32x4*>(Ab + mr * 32 * XLD + ks * 16);
-                al[mr] = *reinterpret_cast<const u32x4*>(Ab + XBM * XLD + mr * 32 * XLD + ks * 16);
+                ah[mr] = *reinterpret_cast<const u32x4*>(Ab + mr * 32 * XLD + fo);
+                al[mr] = *reinterpret_cast<const u32x4*>(Ab + XBM * XLD + mr * 32 * XLD + fo);
             }
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
-                bh[nr] = *reinterpret_cast<const u32x4*>(Bb + nr * 32 * XLD + ks * 16);
-                bl[nr] = *reinterpret_cast<const u32x4*>(Bb + XBN * XLD + nr * 32 * XLD + ks * 16);
+                bh[nr] = *reinterpret_cast<const u32x4*>(Bb + nr * 32 * XLD + fo);
+                bl[nr] = *reinterpret_cast<const u32x4*>(Bb + XBN * XLD + nr * 32 * XLD + fo);
             }
-            // small terms first; the three products of one accumulator are NR * 2 MFMAs apart (no dependent back-to-back)
+            // small terms first; the three products of one accumulator are 2 * NR MFMAs apart (no dependent back-to-back)
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < 3; ++term) {
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
                     for (int mr = 0; mr < 2; ++mr)
                         acc[mr][nr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl[nr] : bh[nr], acc[mr][nr]);
+                if (stage) {
+                    if (term < 2) lstore_a(set, buf ^ 1, ks * 2 + term);
+                    else if (ks == 1) lstore_b(set, buf ^ 1);
+                }
+            }
+#if EGZ_X3_SCHED
+            // pin the interleave: one MFMA, then a few VALU (conversion) and an LDS write
+#pragma unroll
+            for (int i = 0; i < 6 * NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+#endif
         }
     };
-    // register ring: set u holds slice (s + u) until it is staged, then is refilled with slice (s + u + NSET), so every
-    // global load has NSET slice-times to land
+    // software pipeline over the K-slices [s_lo, s_hi): LDS is double buffered, registers hold two slices.  In iteration s
+    // the MFMAs read buffer s & 1 while slice s + 1 (loaded during iteration s - 1) is converted into the other buffer
+    // and slice s + 2 is fetched from L2 / HBM; one barrier per slice.
     int s_lo = 0, s_hi = S;
     if (pass == 1) {
         s_lo = (int)((long)S * blockIdx.y / nsplit);
         s_hi = (int)((long)S * (blockIdx.y + 1) / nsplit);
     }
     if (pass != 2) {
+        gload(s_lo, 0);
+        gload(s_lo + 1 < s_hi ? s_lo + 1 : s_hi - 1, 1);
 #pragma unroll
-        for (int u = 0; u < NSET; ++u) gload(s_lo + u < s_hi ? s_lo + u : s_hi - 1, u);
-        lstore(0);
+        for (int j = 0; j < 4; ++j) lstore_a(0, 0, j);
+        lstore_b(0, 0);
         __syncthreads();
-        for (int s = s_lo; s < s_hi; s += NSET) {
+        for (int s = s_lo; s < s_hi; s += 2) {
 #pragma unroll
-            for (int u = 0; u < NSET; ++u) {
-                if (s + u < s_hi) {
-                    const int sp = (s + u + NSET < s_hi) ? s + u + NSET : s_hi - 1;   // branch-free prefetch (clamped)
+            for (int u = 0; u < 2; ++u) {
+                if (s + u < s_hi) {      // block-uniform
+                    const int sp = (s + u + 2 < s_hi) ? s + u + 2 : s_hi - 1;   // branch-free prefetch (clamped past the end)
+                    // set u held slice s + u, staged during the previous iteration -> free for slice s + u + 2;
+                    // set u ^ 1 holds slice s + u + 1 -> staged into buffer (u ^ 1) now
                     gload(sp, u);
-                    compute();
-                    __syncthreads();              // every wave is done reading this slice
-                    lstore((u + 1) % NSET);       // convert + stage slice s + u + 1
+                    slice(u, u ^ 1, true);
                     __syncthreads();
                 }
             }
@@ -246,7 +339,17 @@ __global__ __launch_bounds__(256, (EGZ_X3_NSET > 1) ? 2 : 3) void conv3x3_igemm_
                     for (int r = 0; r < 16; ++r) wt[((mr * NR + nr) * 16 + r) * 256 + tid] = acc[mr][nr][r];
             return;
         }
-        for (int sp = 0; sp < nsplit; ++sp, wt += XBM * XBN)
+        for (int sp = 0; sp + 1 < nsplit; sp += 2, wt += 2 * XBM * XBN)     // pairs: twice the loads in flight
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = ((mr * NR + nr) * 16 + r) * 256 + tid;
+                        acc[mr][nr][r] = (acc[mr][nr][r] + wt[o]) + wt[XBM * XBN + o];
+                    }
+        if (nsplit & 1)
 #pragma unroll
             for (int mr = 0; mr < 2; ++mr)
 #pragma unroll
@@ -353,16 +456,16 @@ __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* _
 // split-K (each tile's K-slices divided over nsplit blocks so the remainder still fills the chip), as raw partial
 // accumulators through the workspace, and a third tiny launch sums them in a fixed order and applies the epilogue.
 struct X3Plan { int mt, ntn, nph, total, main, tail, nsplit; };
-int x3_slots() {
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 0;
+int x3_slots(int XBN) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 0;
-        slots = 3 * (cus > 0 ? cus : 256);      // __launch_bounds__(256, 3): 168 VGPRs, 42 KB LDS
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
     }
-    return slots;
+    // resident blocks per CU: 128 x 128 tile = 204 VGPRs / 65 KB LDS -> 2; 128 x 64 tile = 129 VGPRs / 49 KB LDS -> 3
+    return (XBN == 128 ? 2 : 3) * cus;
 }
 X3Plan x3_plan(long M, int Cp, int Kp, int XBN, int mode, int flags) {
     X3Plan p;
@@ -374,9 +477,9 @@ X3Plan x3_plan(long M, int Cp, int Kp, int XBN, int mode, int flags) {
     p.tail = 0;
     p.nsplit = 1;
     const int ntap = (mode == UPS_PHASE) ? 4 : (mode == UPS_DGRAD) ? 16 : 9;
-    const int nslices = (Cp / XBK) * ntap, R = x3_slots();
+    const int nslices = (Cp / XBK) * ntap, R = x3_slots(XBN);
     const int rem = p.total % R;
-    if (!(flags & 0x8000) && EGZ_X3_NSET == 1 && rem != 0 && rem * 10 < R * 7) {
+    if (!(flags & 0x8000) && rem != 0 && rem * 4 <= R) {
         int ns = R / rem;
         if (ns > 16) ns = 16;
         if (ns > nslices / 2) ns = nslices / 2;

@@ -301,8 +301,8 @@ def test_conv3x3_split_half(B, Hh, Ww, C, K, dtype, tol):
 
 
 @pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [
-    (1, 129, 384, 32, 256, False),     # 774 tiles = one full round of 768 + 6 tail tiles split 16 ways
-    (1, 96, 200, 64, 128, False),      # 150 tiles < one round: every tile split 5 ways
+    (1, 148, 224, 32, 256, False),     # 518 tiles = one full round of 512 + 6 tail tiles split 9 ways
+    (1, 64, 100, 64, 128, False),      # 50 tiles < one round: every tile split 9 ways
     (2, 56, 58, 32, 64, True),         # phase-decomposed upsample, 4 x 26 tiles of 128 x 64
 ])
 def test_conv3x3_split_tail_schedule(B, Hh, Ww, C, K, ups):
