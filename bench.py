@@ -90,7 +90,7 @@ def main():
     from egaze_amd.utils import make_layers, cfg
     from egaze_amd.floss import floss
     from egaze_amd.optim import FusedAdam
-    from egaze_amd import dp, synthetic
+    from egaze_amd import dp, streams, synthetic
 
     torch.manual_seed(1234)
     model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20)).to(dev)   # random init (no weights offline)
@@ -119,6 +119,23 @@ def main():
         c0 = torch.zeros(2, args.batch, 512, device=dev)
         opt_at.zero_grad()
 
+    def at_step():
+        # AT: forward + MSE + backward + Adam of the attention-transition LSTM (AT.py:138-145 at T=16, B=32)
+        pred, _ = lstm(at_in, (h0, c0))
+        l2 = MSELoss.apply(pred, at_tgt)
+        l2.backward()
+        opt_at.step()
+        opt_at.zero_grad()
+
+    # The AT module is a separate model on separate inputs (the reference trains it from extracted features, AT.py):
+    # its ~200 small, launch-latency-bound kernels are issued on their own HIP stream and run in the shadow of the SP
+    # step's large kernels.  Stream order keeps AT step k+1 behind AT step k; the timed region ends with a device-wide
+    # synchronize, so every AT step is complete inside it.  EGAZE_STREAMS=0 serialises it again.
+    at_stream = None
+    if use_at and streams.ENABLED:
+        at_stream = streams.side_stream("at")
+        at_stream.wait_stream(torch.cuda.current_stream())
+
     def step():
         # SP: the body of SP.trainSP's loop (SP.py:132-138)
         output = model(input_s, input_t)
@@ -127,12 +144,11 @@ def main():
         optimizer.step()
         optimizer.zero_grad()
         if use_at:
-            # AT: forward + MSE + backward + Adam of the attention-transition LSTM (AT.py:138-145 at T=16, B=32)
-            pred, _ = lstm(at_in, (h0, c0))
-            l2 = MSELoss.apply(pred, at_tgt)
-            l2.backward()
-            opt_at.step()
-            opt_at.zero_grad()
+            if at_stream is not None and streams.ENABLED:
+                with torch.cuda.stream(at_stream):
+                    at_step()
+            else:
+                at_step()
         return loss
 
     optimizer.zero_grad()

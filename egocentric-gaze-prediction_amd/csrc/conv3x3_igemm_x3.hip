@@ -451,10 +451,12 @@ __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* _
 }
 
 // Tile schedule.  Every block of this kernel does the same work, so a launch runs in rounds of R = (resident blocks per
-// CU) x (CUs) tiles; the SP shapes give 196 / 784 / 1568 / 3136 tiles -- just over 1 / 1 / 2 / 4 rounds of 768 -- so a plain
-// launch spends up to half its time in a nearly empty last round.  The tiles beyond the last full round are instead run
-// split-K (each tile's K-slices divided over nsplit blocks so the remainder still fills the chip), as raw partial
-// accumulators through the workspace, and a third tiny launch sums them in a fixed order and applies the epilogue.
+// CU) x (CUs) tiles; the SP shapes give 196 / 784 / 1568 / 3136 tiles, i.e. 0.4 / 1.5 / 3.06 / 6.1 rounds of 512.  With
+// flag 0x4000 the tiles beyond the last full round (when they fill at most a quarter of a round) are run split-K -- each
+// tile's K-slices divided over nsplit blocks -- as raw partial accumulators through the workspace, and a third small
+// launch sums them in a fixed order and applies the epilogue.  Measured on MI355X this does NOT pay for the SP shapes
+// (the blocks of a thin last round run ~1.7x faster than co-resident ones, while the fixup pass reads nsplit x 64 KB per
+// tile from few CUs): enc7 263 vs 240 us, enc10 433 vs 415 us.  The default is therefore the plain single launch.
 struct X3Plan { int mt, ntn, nph, total, main, tail, nsplit; };
 int x3_slots(int XBN) {
     static int cus = 0;
@@ -479,7 +481,7 @@ X3Plan x3_plan(long M, int Cp, int Kp, int XBN, int mode, int flags) {
     const int ntap = (mode == UPS_PHASE) ? 4 : (mode == UPS_DGRAD) ? 16 : 9;
     const int nslices = (Cp / XBK) * ntap, R = x3_slots(XBN);
     const int rem = p.total % R;
-    if (!(flags & 0x8000) && rem != 0 && rem * 4 <= R) {
+    if ((flags & 0x4000) && rem != 0 && rem * 4 <= R) {
         int ns = R / rem;
         if (ns > 16) ns = 16;
         if (ns > nslices / 2) ns = nslices / 2;
@@ -550,7 +552,8 @@ EGZ_API size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K,
     return (size_t)p.tail * p.nsplit * XBM * XBN * sizeof(float);
 }
 
-// flags bit 15 (0x8000): plain single launch (no split-K tail), for A/B measurements.
+// flags bit 14 (0x4000): run the tiles beyond the last full round split-K (see x3_plan; measured slower than the plain
+// launch on MI355X for the SP shapes -- lone tail blocks already run ~1.7x faster -- so it is opt-in).
 EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial,
                                   int B, int H, int W, int C, int K, int flags, int dtype, void* workspace,
                                   size_t ws_bytes, hipStream_t st) {

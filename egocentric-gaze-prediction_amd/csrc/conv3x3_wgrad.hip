@@ -247,17 +247,20 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 #define EGZ_LDS __attribute__((address_space(3)))
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// 4 floats -> packed bf16 hi / lo halves: v_cvt_pk_bf16_f32 (RNE), two bit ops to widen the halves back, one packed
+// subtract, v_cvt_pk_bf16_f32 of the residuals -- 2.5 VALU per float
 __device__ __forceinline__ void bf16_split4(const f32x4 v, u32x2_t& hi, u32x2_t& lo) {
-    unsigned short h[4], l[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 a = (__bf16)v[e];
-        const __bf16 b = (__bf16)(v[e] - (float)a);
-        h[e] = __builtin_bit_cast(unsigned short, a);
-        l[e] = __builtin_bit_cast(unsigned short, b);
+    for (int e = 0; e < 2; ++e) {
+        const f32x2_t x = {v[2 * e], v[2 * e + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+        const f32x2_t hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+        hi[e] = hu;
+        lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, bf16x2_t));
     }
-    hi[0] = h[0] | ((unsigned)h[1] << 16); hi[1] = h[2] | ((unsigned)h[3] << 16);
-    lo[0] = l[0] | ((unsigned)l[1] << 16); lo[1] = l[2] | ((unsigned)l[3] << 16);
 }
 
 template <bool UPS, int R, int WD>
@@ -285,12 +288,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     const long g1 = (g0 + patches_per_split < npatch) ? (g0 + patches_per_split) : npatch;
     const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
 
+    // Operand fetch (direct conv): buffer loads.  A thread's halo slot (hr, hx) and dY pixel (py, px) never change, so its
+    // byte offsets relative to the patch origin are fixed; the origin is one scalar offset per stage, and a slot outside
+    // the image gets offset 0xFFFFFFFF, which the buffer bounds check turns into zeros (~5 VALU per load instead of ~20).
+    // The x resource starts (W + 1) * C floats early so the (-1, -1) halo corner keeps lane offsets non-negative.
+    const unsigned x_bias = (unsigned)(W + 1) * (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(x)) - x_bias, 0, (int)((unsigned)B * H * W * C * 4u + x_bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dy), 0, (int)((unsigned)B * H * W * K * 4u), 0x00020000);
+    unsigned x_vo[NX], x_rc[NX], d_vo[ND], d_rc[ND];      // byte offsets; (row << 8 | col) of the slot inside the patch
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int i = tid + 256 * j, pos = i >> 4, c4 = i & 15;
+        const int hr = pos / HPW, hx = pos - hr * HPW;
+        x_vo[j] = (pos < NH) ? (unsigned)((hr * W + hx) * C * 4 + c4 * 16) : 0xFFFFFFFFu;
+        x_rc[j] = (unsigned)(hr << 8 | hx);
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int i = tid + 256 * j, pp = i >> 4, k4 = i & 15;
+        d_vo[j] = (unsigned)(((pp / WD) * W + pp % WD) * K * 4 + k4 * 16);
+        d_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
+    }
+
     f32x4 rx[NX], rd[ND];
     auto gload = [&](long g) {
         const int x0 = (int)(g % cpr) * WD;
         const long t = g / cpr;
         const int y0 = (int)(t % rpi) * R;
         const long b = t / rpi;
+        if constexpr (!UPS) {
+            // valid halo rows hr in [rlo, rhi], cols hx in [clo, chi]  (source pixel = (y0 + hr - 1, x0 + hx - 1))
+            const unsigned rlo = (y0 == 0) ? 1u : 0u, rn = (unsigned)((H - y0 < R + 1) ? (H - y0) : (R + 1)) - rlo;
+            const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((W - x0 < WD + 1) ? (W - x0) : (WD + 1)) - clo;
+            const unsigned so_x = (unsigned)((((b * H + y0) * W + x0) * C + c0) * 4);     // + x_bias - x_bias
+            const unsigned so_d = (unsigned)((((b * H + y0) * W + x0) * K + k0) * 4);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const bool ok = ((x_rc[j] >> 8) - rlo <= rn) && ((x_rc[j] & 255u) - clo <= cn);
+                rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? x_vo[j] : 0xFFFFFFFFu, so_x, 0));
+            }
+            const unsigned rmax = (unsigned)(H - y0), cmax = (unsigned)(W - x0);              // py < rmax, px < cmax
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const bool ok = ((d_rc[j] >> 8) < rmax) && ((d_rc[j] & 255u) < cmax);
+                rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, ok ? d_vo[j] : 0xFFFFFFFFu, so_d, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int i = tid + 256 * j;

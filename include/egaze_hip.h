@@ -61,8 +61,9 @@ int egz_conv3x3_ups_dgrad(const float* dy, const float* wp, float* dx, int B, in
  * egz_conv3x3_fwd_split: flags as egz_conv3x3_fwd (bits 0-1, 4-5) plus bit2 = the 16-tap data gradient of an
  * upsampled conv (then C / K are the GEMM's reduction / output channel counts). */
 int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind, int dtype, hipStream_t stream);
-/* Tile schedule of egz_conv3x3_fwd_split: tiles beyond the last full round of resident blocks are run split-K through
- * `workspace` (raw partial accumulators) and reduced in a fixed order -> egz_conv3x3_fwd_split_ws_bytes (0 = no tail). */
+/* Optional tile schedule of egz_conv3x3_fwd_split (flags bit 14 = 0x4000): tiles beyond the last full round of resident
+ * blocks are run split-K through `workspace` (raw partial accumulators) and reduced in a fixed order;
+ * egz_conv3x3_fwd_split_ws_bytes gives the workspace size (0 without the flag: workspace may then be NULL). */
 size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial, int B,
                           int H, int W, int C, int K, int flags, int dtype, void* workspace, size_t ws_bytes,
