@@ -106,10 +106,15 @@ def test_model_sp_train_step(tag, size):
     keys = [k[5:] for k in gold.files if k.startswith("gsum/")]
     assert set(keys) == set(grads.keys())
     floor = 1e-5 * max(gold["gsum/" + k][0] for k in keys)
+    # Gradient norms.  At 224 x 224 the fp32 reference itself is this far from the exact (fp64) gradient of the same
+    # step: norms up to 2.3e-3, element-wise L2 0.6 % (median) -- ReLU / max-pool decisions on |z| ~ 1e-7 elements
+    # flip with the summation order and each flip moves an early-layer gradient by O(1) of one entry
+    # (tests/report_grad_accuracy.py: CPU fp32 2.3e-3, HIP exact-f32 1.5e-3, HIP split-half 3.6e-3 max norm deviation).
+    # The bound is therefore 2x the reference's own deviation, not its rounding error.
     for k in keys:
         want = gold["gsum/" + k][0]
         got = grads[k].double().norm().item()
-        assert abs(got - want) <= 2e-3 * want + floor, (k, got, want)
+        assert abs(got - want) <= 5e-3 * want + floor, (k, got, want)
     # Element-wise gradients: see robust_close(); test_model_sp_grads_vs_fp64 bounds the arithmetic error
     # itself (2e-5 on every tensor against an fp64 run of the same step).
     for k in [f[5:] for f in gold.files if f.startswith("grad/")]:
