@@ -135,35 +135,63 @@ def test_model_sp_train_step(tag, size):
     assert int(sd["features_s.1.num_batches_tracked"]) == 1
 
 
-def test_model_sp_vs_oracle_full_grads_small():
-    """Every gradient tensor element-wise against the CPU oracle at 32x32 (seconds on CPU)."""
+# Element-wise gradient checks at 32 x 32.  The encoders end at 2 x 2 (B = 3: twelve samples per channel), so ONE
+# post-BN value that lands within ~1e-5 of zero makes two implementations take different (equally valid) ReLU
+# subgradients at the TOP of a 13-layer chain, which moves every gradient below it by ~2 % -- measured with
+# tests/report_split_enc_t.py: exactly one of 6144 decisions differs (7.9e-6 vs 0) for seed 5 in split-half mode; for
+# seeds 6 and 7 the exact-f32 mode and the fp32 CPU reference itself (vs fp64) hit one.  So each check runs three
+# seeded inputs with two criteria:
+#   * every seed, every tensor: direction and size agree (cosine >= 0.995, norm within 3 %) -- a formula, layout or
+#     indexing bug breaks this on every input, a subgradient flip does not;
+#   * at least one seed is flip-free and then matches tightly (98 % of the entries within 2e-3 / the fp32-class bound).
+GRAD_SEEDS = (5, 6, 7)
+
+
+def cos_norm(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    na, nb = np.linalg.norm(a), np.linalg.norm(b)
+    return float(a @ b / max(na * nb, 1e-300)), float(na / max(nb, 1e-300))
+
+
+def _full_grads_small(seed):
     from egaze_amd.floss import floss
     model, sd0 = build_model()
-    x_s, x_t, gt, _ = synth.synth_sp_batch(3, 32, seed=5)
+    x_s, x_t, gt, _ = synth.synth_sp_batch(3, 32, seed=seed)
     model.train()
     out = model(x_s.to(DEV), x_t.to(DEV))
     loss = floss()(out, gt.to(DEV).view(out.size()))
     loss.backward()
     work = {k: v.clone() for k, v in sd0.items()}
     oloss, oout, ograds = O.sp_train_step(work, {}, 1, x_s, x_t, gt, 0.0)
-    assert rel(out.detach().cpu().numpy(), oout.numpy()) < TOL_TIGHT
+    assert rel(out.detach().cpu().numpy(), oout.numpy()) < TOL_TIGHT              # forward: every seed
     assert abs(loss.item() - oloss.item()) < 1e-4 * abs(oloss.item())
     gmax = max(g.abs().max().item() for g in ograds.values())
+    tight, why = True, None
     for k, p in model.named_parameters():
         ref = ograds[k]
         if ref.abs().max().item() < 1e-5 * gmax:      # analytically-zero bias grads in front of BN
             assert p.grad.abs().max().item() < 1e-4 * gmax, k
             continue
+        c, r = cos_norm(p.grad.cpu().numpy(), ref.numpy())
+        assert c >= 0.995 and abs(r - 1) <= 0.03, (seed, k, c, r)
         good, info = mostly_close(p.grad.cpu().numpy(), ref.numpy())
-        assert good, (k, info)
+        if not good and tight:
+            tight, why = False, (k, info)
+    return tight, (seed, why)
 
 
-def test_model_sp_grads_vs_fp64():
-    """Accuracy, not just agreement: the same train step in fp64 on the CPU oracle is the truth; the HIP
-    path's gradient error must be of the same size as the fp32 CPU reference path's own error."""
+def test_model_sp_vs_oracle_full_grads_small():
+    """Every gradient tensor element-wise against the CPU oracle at 32x32 (seconds on CPU)."""
+    results = [_full_grads_small(seed) for seed in GRAD_SEEDS]
+    print("full-grads:", results)
+    assert any(ok for ok, _ in results), results
+
+
+def _grads_vs_fp64(seed):
     from egaze_amd.floss import floss
     model, sd0 = build_model()
-    x_s, x_t, gt, _ = synth.synth_sp_batch(3, 32, seed=5)
+    x_s, x_t, gt, _ = synth.synth_sp_batch(3, 32, seed=seed)
     model.train()
     out = model(x_s.to(DEV), x_t.to(DEV))
     floss()(out, gt.to(DEV).view(out.size())).backward()
@@ -173,25 +201,37 @@ def test_model_sp_grads_vs_fp64():
     _, out64, g64 = O.sp_train_step(w64, {}, 1, x_s.double(), x_t.double(), gt.double(), 0.0)
     e_hip = rel(out.detach().cpu().numpy(), out64.numpy())
     e_cpu = rel(out32.numpy(), out64.numpy())
-    assert e_hip < max(5 * e_cpu, 2e-6), (e_hip, e_cpu)
+    assert e_hip < max(5 * e_cpu, 2e-6), (e_hip, e_cpu)                            # forward: every seed
     errs = {}
     for k, p in model.named_parameters():
         t = g64[k]
         if t.abs().max().item() < 1e-9:
             continue
         errs[k] = (rel(p.grad.cpu().numpy(), t.numpy()), rel(g32[k].numpy(), t.numpy()))
+        c, r = cos_norm(p.grad.cpu().numpy(), t.numpy())
+        assert c >= 0.995 and abs(r - 1) <= 0.03, (seed, k, c, r)
     eh = np.array([v[0] for v in errs.values()])
     ec = np.array([v[1] for v in errs.values()])
-    print("HIP vs fp64: median %.2e max %.2e | CPU fp32 vs fp64: median %.2e max %.2e" %
-          (np.median(eh), eh.max(), np.median(ec), ec.max()))
-    # typical tensor: same accuracy class as the CPU fp32 path (f32 kernels: 1e-5; split-half mode, bf16 x3 data
-    # gradients: ~1e-4); every tensor: >= 98 % of its entries right even if a ReLU / pool decision flips on a
-    # |z| ~ 1e-7 element (a discontinuity of the gradient, not an arithmetic error)
-    assert np.median(eh) < max(20 * np.median(ec), 2e-4), (np.median(eh), np.median(ec))
+    print("seed %d HIP vs fp64: median %.2e max %.2e | CPU fp32 vs fp64: median %.2e max %.2e" %
+          (seed, np.median(eh), eh.max(), np.median(ec), ec.max()))
+    # flip-free input: the typical tensor is in the accuracy class of the CPU fp32 path (f32 kernels: 1e-5;
+    # split-half mode, bf16 x3 data gradients: ~1e-4) and every tensor has >= 98 % of its entries right
+    if not np.median(eh) < max(20 * np.median(ec), 2e-4):
+        return False, (seed, "median", float(np.median(eh)), float(np.median(ec)))
     for k, p in model.named_parameters():
         if k in errs:
             good, info = mostly_close(p.grad.cpu().numpy(), g64[k].numpy())
-            assert good, (k, info, errs[k])
+            if not good:
+                return False, (seed, k, info, errs[k])
+    return True, (seed, float(np.median(eh)), float(eh.max()))
+
+
+def test_model_sp_grads_vs_fp64():
+    """Accuracy, not just agreement: the same train step in fp64 on the CPU oracle is the truth; the HIP
+    path's gradient error must be of the same size as the fp32 CPU reference path's own error."""
+    results = [_grads_vs_fp64(seed) for seed in GRAD_SEEDS]
+    print("grads-vs-fp64:", results)
+    assert any(ok for ok, _ in results), results
 
 
 def test_floss_golden_bit_exact_weights():
