@@ -403,6 +403,305 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Halo-tile variant of the plain (stride 1, pad 1) 3x3 implicit GEMM.  The kernel above fetches and converts every
+// activation element once per tap and per n-tile; here the 128 output pixels of a tile are a compact set -- a raster run
+// of 128 consecutive pixels (W <= 56) or an 8 x 16 patch (W % 16 == 0, H % 8 == 0) -- whose input halo (run +- (W + 1)
+// pixels = 130 + 2W slots, or 10 x 18 pixels in a 10 x 20 grid) is fetched, split into hi / lo halves and written to LDS
+// ONCE per 32-channel block; the nine taps then read their fragments from that one image at shifted addresses.  Per
+// K-slice that is 6.4x (patch) / 4.8-8x (run) fewer activation loads and conversions, and no per-slice address work:
+// the 18 fragment addresses (2 row groups x 9 taps) are computed once per tile and live in registers.
+//   * out-of-image halo slots are filled with zeros by the buffer bounds check, so a patch needs no tap masks at all;
+//     in a raster run a tap that wraps around a row end or an image border reads the all-zero slot 255 instead;
+//   * LDS A image: [plane hi/lo][256 slots][32 ch] 16-bit, 64-byte rows, 16-byte chunks XOR-swizzled with (col >> 2) & 3
+//     where col = the slot (run) or the halo column (patch, row pitch 20): conflict-free ds_read_b128 for 32 consecutive
+//     slots at any start offset and for two 16-runs one grid row apart (brute-forced over the gfx950 service groups);
+//   * B (pre-split weights) as in the kernel above: one tap x 32 channels per slice, double buffered, two register sets;
+//     one barrier per slice, two more per channel block around the A restaging (single A buffer: 33 + 32 KB LDS, 2 blocks/CU).
+constexpr int HSLOTS = 256, HZERO = 255, HPITCH = 20;
+
+template <typename T, int XBN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3h_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
+    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
+    float out_scale, int mt, int patch) {
+    constexpr int NR = XBN / 64, WN = XBN / 2, BLD = XBN / 64;
+    constexpr int APL = HSLOTS * XLD;                       // elements per A plane
+    constexpr int BBUF = 2 * XBN * XLD;
+    constexpr int NJ = HSLOTS / 32;                         // halo slots per thread (8 threads x 4 channels per slot)
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[2 * APL];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * BBUF];
+    __shared__ long Ro[XBM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, hl = lane >> 5, l31 = lane & 31;
+    const int ntn = Kp / XBN;
+    const int tile_n = blockIdx.x % ntn, tile_m = blockIdx.x / ntn;
+    const int n0 = tile_n * XBN;
+    const long HW = (long)H * W, M = (long)B * HW;
+    const long plane = (long)9 * Kp * Cp;
+    // tile origin: raster run = flat pixel m0; patch = image b0, top-left (y0, x0)
+    const long m0 = (long)tile_m * XBM;
+    const int pw = W >> 4, ppi = (H >> 3) * pw;             // patches per row / per image (patch geometry only)
+    const int b0 = patch ? tile_m / ppi : 0;
+    const int y0 = patch ? ((tile_m - b0 * ppi) / pw) * 8 : 0, x0 = patch ? ((tile_m - b0 * ppi) % pw) * 16 : 0;
+
+    // output offsets of the 128 tile rows
+    if (tid < XBM) {
+        long off = -1;
+        if (patch) {
+            off = (((long)b0 * H + y0 + (tid >> 4)) * W + x0 + (tid & 15)) * K;
+        } else if (m0 + tid < M) {
+            off = (m0 + tid) * K;
+        }
+        Ro[tid] = off;
+    }
+
+    // ---- A halo staging map: slot q = (tid >> 3) + 32 j holds 4 channels (tid & 7) of one input pixel
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(wp), 0, (int)(4 * plane), 0x00020000);
+    const int a_c4 = tid & 7;
+    unsigned a_vo[NJ];
+    int a_lds[NJ];                                          // element offset of the slot's 8-byte piece in a plane
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = (tid >> 3) + 32 * j;
+        long pix = -1;
+        int col = q;
+        if (patch) {
+            const int hy = q / HPITCH, hx = q - hy * HPITCH;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            col = hx;
+            if (hy < 10 && hx < 18 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                pix = ((long)b0 * H + iy) * W + ix;
+        } else {
+            const long g = m0 - W - 1 + q;
+            if (q < XBM + 2 * W + 2 && g >= 0 && g < M) pix = g;
+        }
+        a_vo[j] = (pix >= 0) ? (unsigned)((pix * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
+        a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
+    }
+    // ---- B: the pre-split weight slice goes HBM/L2 -> LDS directly (buffer_load ... lds, 1 KB = 16 rows x 64 B per wave
+    // instruction, no VGPRs, no ds_write).  The LDS image is lane-linear, so the chunk swizzle is applied on the global
+    // side: lane (row r = lane >> 2, position p = lane & 3) fetches chunk p ^ ((r >> 2) & 3) of its row.
+    constexpr int NPIECE = 2 * (XBN / 16) / 4;              // 1 KB pieces per wave per slice (planes x row blocks / waves)
+    unsigned b_vo[NPIECE];
+    int b_lds[NPIECE];                                       // element offset of the piece inside a B buffer
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) {
+        const int pi = wave + 4 * k, pl = pi / (XBN / 16), rb16 = pi % (XBN / 16);
+        const int r = lane >> 2, p = lane & 3;
+        b_vo[k] = (unsigned)((pl * plane + (long)(n0 + rb16 * 16 + r) * Cp + ((p ^ ((r >> 2) & 3)) << 3)) * 2);
+        b_lds[k] = pl * XBN * XLD + rb16 * 16 * XLD;
+    }
+
+    // ---- fragment addresses: lane row i = wm * 64 + mr * 32 + l31, tap t -> byte address of the k-step-0 chunk in plane 0
+    int fa[2][9];
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr) {
+        const int i = wm * 64 + mr * 32 + l31;
+        int py = 0, px = 0;
+        bool rowok = true;
+        if (!patch) {
+            const long m = m0 + i;
+            rowok = m < M;
+            const int rem = (int)(m % HW);
+            py = rem / W;
+            px = rem - py * W;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            int slot, col;
+            if (patch) {
+                slot = ((i >> 4) + 1 + dy) * HPITCH + (i & 15) + 1 + dx;
+                col = (i & 15) + 1 + dx;
+            } else {
+                const bool ok = rowok && (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W;
+                slot = ok ? i + W + 1 + dy * W + dx : HZERO;
+                col = slot;
+            }
+            fa[mr][t] = (slot * XLD + ((hl ^ ((col >> 2) & 3)) << 3)) * 2;
+        }
+    }
+    const int fb = ((wn * WN + l31) * XLD + ((hl ^ ((l31 >> 2) & 3)) << 3)) * 2;     // B fragment, k-step 0, plane 0
+
+    f32x4 ra[NJ];
+    auto gload_a = [&](int cblk) {
+        const unsigned so = (unsigned)(cblk * XBK * 4);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[j], so, 0));
+    };
+    auto lstore_a = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            u32x2 hi, lo;
+            Half<T>::split4(ra[j], hi, lo);
+            *reinterpret_cast<u32x2*>(Ah + a_lds[j]) = hi;
+            *reinterpret_cast<u32x2*>(Ah + APL + a_lds[j]) = lo;
+        }
+    };
+    auto dma_b = [&](int s, const int buf) {             // slice s = cblk * 9 + tap -> B buffer buf
+        const int cblk = s / 9, tap = s - cblk * 9;
+        const unsigned so = (unsigned)((((long)tap * Kp) * Cp + cblk * XBK) * 2);
+#if defined(__HIP_DEVICE_COMPILE__)      // the host pass of hipcc rejects the LDS-DMA builtin (and then drops the kernel stub)
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                b_rs, (__attribute__((address_space(3))) void*)(Bs + buf * BBUF + b_lds[k]), 16, b_vo[k], so, 0, 0);
+#else
+        (void)so;
+#endif
+    };
+
+    f32x16 acc[2][NR];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const char* Ab = reinterpret_cast<const char*>(Ah);
+    const char* Bb = reinterpret_cast<const char*>(Bs);
+    // Fragment pipeline.  An LDS read needs ~130 cycles to land and a k-step is only 12 MFMAs (384 cycles), so fragments
+    // are fetched one k-step ahead: k-step 1 of the slice before the MFMAs of k-step 0, the A fragments of the next tap
+    // (same halo image, no hazard) before the MFMAs of k-step 1, the B fragments of the next slice right after the barrier.
+    // sched_barrier(0) pins those points (hipcc otherwise sinks each read next to its use and every wave stalls ~6 x 100
+    // cycles per slice: MFMA pipe 54 % busy).
+    u32x4 ah0[2], al0[2], bh0[NR], bl0[NR];               // k-step 0 fragments of the slice about to run
+    auto read_a0 = [&](const int t) {
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+            ah0[mr] = *reinterpret_cast<const u32x4*>(Ab + fa[mr][t]);
+            al0[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + fa[mr][t]);
+        }
+    };
+    auto read_b0 = [&](const int buf) {
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int b = fb + buf * BBUF * 2 + nr * 32 * XLD * 2;
+            bh0[nr] = *reinterpret_cast<const u32x4*>(Bb + b);
+            bl0[nr] = *reinterpret_cast<const u32x4*>(Bb + XBN * XLD * 2 + b);
+        }
+    };
+    // one K-slice (tap t of the staged channel block) on B buffer `buf`
+    auto slice = [&](const int t, const int buf, const bool next_a) {
+        u32x4 ah1[2], al1[2], bh1[NR], bl1[NR];
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+            const int a = fa[mr][t] ^ 32;
+            ah1[mr] = *reinterpret_cast<const u32x4*>(Ab + a);
+            al1[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + a);
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int b = (fb ^ 32) + buf * BBUF * 2 + nr * 32 * XLD * 2;
+            bh1[nr] = *reinterpret_cast<const u32x4*>(Bb + b);
+            bl1[nr] = *reinterpret_cast<const u32x4*>(Bb + XBN * XLD * 2 + b);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int mr = 0; mr < 2; ++mr)
+                    acc[mr][nr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bl0[nr] : bh0[nr], acc[mr][nr]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (next_a) read_a0(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int mr = 0; mr < 2; ++mr)
+                    acc[mr][nr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bl1[nr] : bh1[nr], acc[mr][nr]);
+    };
+
+    const int ncb = Cp / XBK, S = ncb * 9;
+    gload_a(0);
+    dma_b(0, 0);
+    lstore_a();
+    __builtin_amdgcn_s_waitcnt(0);                            // vmcnt(0): this wave's B pieces have landed
+    __syncthreads();
+    read_a0(0);
+    read_b0(0);
+    // Two channel blocks per trip so that the B buffer index is compile-time: slice s uses buffer s & 1, and 9 taps per
+    // block flip the parity.  The DMA of slice s + 1 is issued at the top of slice s (its buffer was last read in slice
+    // s - 1, all waves are past that barrier) and has the 24 MFMAs of the slice to land.
+    for (int cb = 0; cb < ncb; cb += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = cb + h;
+            if (c < ncb) {                                   // block-uniform
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int s = c * 9 + t, par = (h + t) & 1;          // s & 1 == par (cb is even)
+                    dma_b(s + 1 < S ? s + 1 : S - 1, par ^ 1);
+                    if (t == 6 && c + 1 < ncb) gload_a(c + 1);            // lands during slices 6..8
+                    slice(t, par, t < 8);
+                    __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) (+ lgkmcnt(0)): B pieces of slice s + 1 in LDS
+                    __syncthreads();
+                    read_b0(par ^ 1);                         // next slice's B, k-step 0
+                }
+                if (c + 1 < ncb) {                            // restage the halo image for the next channel block
+                    lstore_a();
+                    __syncthreads();
+                }
+                read_a0(0);
+            }
+        }
+    }
+
+    // ---- epilogue (as conv3x3_igemm_x3_kernel)
+    double* red = reinterpret_cast<double*>(Ah);
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int col = wn * WN + nr * 32 + l31;
+        const bool nok = n0 + col < K;
+        const float bz = (bias && nok) ? bias[n0 + col] : 0.f;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long off = Ro[wm * 64 + mr * 32 + egz_acc_row(r, lane)];
+                if (off >= 0 && nok) {
+                    float v = acc[mr][nr][r] * out_scale + bz;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    y[off + n0 + col] = v;
+                    if (EPI == EPI_BIAS_STATS) {
+                        s1 += (double)v;
+                        s2 += (double)v * (double)v;
+                    }
+                }
+            }
+        }
+        if (EPI == EPI_BIAS_STATS) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hl == 0) {
+                red[(wm * 2 + 0) * XBN + col] = s1;
+                red[(wm * 2 + 1) * XBN + col] = s2;
+            }
+        }
+    }
+    if (EPI == EPI_BIAS_STATS) {
+        __syncthreads();
+        if (tid < XBN && n0 + tid < K) {
+            const double t1 = red[(0 * 2 + 0) * XBN + tid] + red[(1 * 2 + 0) * XBN + tid];
+            const double t2 = red[(0 * 2 + 1) * XBN + tid] + red[(1 * 2 + 1) * XBN + tid];
+            stat[((long)tile_m * 2 + 0) * K + n0 + tid] = t1;
+            stat[((long)tile_m * 2 + 1) * K + n0 + tid] = t2;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- split packing
 __device__ __forceinline__ float weff9(const float* __restrict__ w9, int py, int a, int px, int b) {
     const int rlo = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), rhi = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
@@ -501,6 +800,21 @@ int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bi
               int W, int C, int K, float out_scale, int flags, float* ws, size_t ws_bytes, hipStream_t st) {
     const long M = x3_rows(MODE, B, H, W);
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    if constexpr (MODE == PLAIN) {
+        // halo-tile kernel: 8 x 16 patches, or raster runs for narrow images; flag 0x2000 forces the per-tap gather kernel
+        const bool patch = (W % 16 == 0) && (H % 8 == 0);
+        if (!(flags & 0x2000) && (patch || (W <= 56 && XBM + 2 * W + 2 <= HZERO))) {
+            const int mt = egz_cdiv(M, XBM);
+            dim3 grid(mt * (Kp / XBN));
+#define EGZ_X3H(E) hipLaunchKernelGGL((conv3x3_igemm_x3h_kernel<T, XBN, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, patch ? 1 : 0)
+            if (epi == EPI_BIAS) EGZ_X3H(EPI_BIAS);
+            else if (epi == EPI_BIAS_RELU) EGZ_X3H(EPI_BIAS_RELU);
+            else EGZ_X3H(EPI_BIAS_STATS);
+#undef EGZ_X3H
+            EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_split(halo)");
+            return 0;
+        }
+    }
     const X3Plan p = x3_plan(M, Cp, Kp, XBN, MODE, flags);
     EGZ_CHECK_ARG(!p.tail || (ws && ws_bytes >= (size_t)p.tail * p.nsplit * XBM * XBN * sizeof(float)),
                   "egz_conv3x3_fwd_split: workspace too small (%zu bytes; see egz_conv3x3_fwd_split_ws_bytes)", ws_bytes);

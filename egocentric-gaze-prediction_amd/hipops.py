@@ -197,7 +197,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
     if dtype:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
-        sflags = (flags & 0x33) | (tile_flag & 0x4000)      # 0x4000: split-K tail schedule (opt-in, see csrc)
+        sflags = (flags & 0x33) | (tile_flag & 0x6000)      # 0x4000: split-K tail schedule, 0x2000: no halo-tile kernel
         nb = LIB.egz_conv3x3_fwd_split_ws_bytes(B, H, W, C, K, sflags)
         ws = workspace(nb, x.device) if nb else None
         check(LIB.egz_conv3x3_fwd_split(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,

@@ -274,7 +274,11 @@ def test_mse():
 
 @pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
 @pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 12, 12, 64, 128), (1, 14, 14, 256, 256), (3, 9, 7, 32, 128),
-                                        (2, 10, 12, 64, 64), (1, 8, 8, 128, 64)])
+                                        (2, 10, 12, 64, 64), (1, 8, 8, 128, 64),
+                                        # halo-tile kernel geometries: 8 x 16 patches (W % 16 == 0, H % 8 == 0) ...
+                                        (2, 16, 32, 64, 128), (1, 8, 16, 64, 64), (3, 24, 48, 32, 128),
+                                        # ... and raster runs crossing row ends / image borders (28, 56 wide; ragged M)
+                                        (3, 28, 28, 64, 128), (1, 20, 56, 96, 64), (5, 5, 3, 64, 64)])
 def test_conv3x3_split_half(B, Hh, Ww, C, K, dtype, tol):
     """Error-compensated split-half operands (f16 x3 / bf16 x3 on the 16-bit MFMA path) against an fp64 reference:
     f16 x3 must be fp32-class (the exact-f32 kernel itself sits at ~5e-7), bf16 x3 within 3e-5."""
@@ -290,6 +294,8 @@ def test_conv3x3_split_half(B, Hh, Ww, C, K, dtype, tol):
         assert rel(nchw(y), want) < tol
         if epi == 2:
             assert rel(stat.sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
+    yg, sg = h.conv3x3_fwd(nhwc(x), h.packed_weight(wd, "fwd", dtype), b.to(DEV), K, epi=2, dtype=dtype, tile_flag=0x2000)
+    assert rel(y, yg) < 2e-6 and rel(stat.sum(0), sg.sum(0)) < 1e-6       # halo-tile vs per-tap gather kernel
     y32, _ = h.conv3x3_fwd(nhwc(x), h.packed_weight(wd, "fwd"), b.to(DEV), K, epi=0)
     print(f"dtype {dtype}: split err {rel(nchw(y), ref):.2e}, exact-f32 MFMA err {rel(nchw(y32), ref):.2e}")
     # data gradient (GEMM output channels = C must be a multiple of 128 for the split kernel)
