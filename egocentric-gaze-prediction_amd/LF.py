@@ -66,7 +66,7 @@ class LF():
             feat = sample['feat'].float().to(self.device)
             out = self.model(feat, im)                       # channel 0 = AT map, channel 1 = SP map (LF.py:90)
             loss = self.criterion(out, gt)
-            aae1, auc1, _ = computeAAEAUC(out.detach().cpu().numpy().squeeze(), gt.cpu().numpy().squeeze())
+            aae1, auc1, _ = computeAAEAUC(out.detach(), gt)          # device kernel, maps stay in HBM (LF.py:92-94)
             auc.update(auc1)
             aae.update(aae1)
             losses.update(loss.item())

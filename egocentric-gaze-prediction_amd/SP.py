@@ -143,7 +143,7 @@ class SP():
                 losses.update(loss.item(), input_s.size(0))
                 batch_time.update(time.time() - end)
                 end = time.time()
-                aae1, auc1, _ = computeAAEAUC(output.cpu().numpy().squeeze(), target.cpu().numpy().squeeze())
+                aae1, auc1, _ = computeAAEAUC(output, target)          # device kernel (SP.py:170-174)
                 auc.update(auc1)
                 aae.update(aae1)
                 if (i + 1) % 1000 == 0:

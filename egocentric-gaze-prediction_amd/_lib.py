@@ -77,6 +77,7 @@ SIGNATURES = {
     "egz_tanh_bwd": (c_int, [P, P, P, c_long, S]),
     "egz_add": (c_int, [P, P, P, c_long, S]),
     # --- optimizer
+    "egz_aae_auc": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_double, P, S]),
     "egz_adam_step": (c_int, [P, P, P, P, c_long, c_double, c_double, c_double, c_double, c_int, c_double, S]),
 }
 

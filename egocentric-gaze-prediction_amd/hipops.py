@@ -537,3 +537,34 @@ def add(a, b):
     out = torch.empty_like(a)
     check(LIB.egz_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "egz_add")
     return out
+
+
+# ----------------------------------------------------------------------------- validation metric (utils.computeAAEAUC)
+_GAUSS_W = {}
+
+
+def _gauss_weights(device, sigma: float = 14.0, truncate: float = 4.0):
+    """The 1-D kernel exactly as scipy.ndimage builds it (_gaussian_kernel1d, order 0): radius = int(truncate*sigma+.5)."""
+    key = (torch.device(device).index or 0, sigma, truncate)
+    hit = _GAUSS_W.get(key)
+    if hit is None:
+        import numpy as np
+        radius = int(truncate * sigma + 0.5)
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        phi = phi / phi.sum()
+        hit = (torch.from_numpy(phi).to(device), radius)
+        _GAUSS_W[key] = hit
+    return hit
+
+
+def aae_auc(out: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    """out, gt: (B, 224, 224) fp32 on the GPU -> (B, 6) float64: AAE deg, fp count, gaze row/col, centroid row/col."""
+    import math
+    _req(out, "output"); _req(gt, "target")
+    B, Hh, Ww = out.shape
+    gw, radius = _gauss_weights(out.device)
+    res = torch.empty((B, 6), dtype=torch.float64, device=out.device)
+    check(LIB.egz_aae_auc(out.data_ptr(), gt.data_ptr(), B, Hh, Ww, gw.data_ptr(), radius, 112 / math.tan(math.pi / 6),
+                          res.data_ptr(), _stream()), "egz_aae_auc")
+    return res

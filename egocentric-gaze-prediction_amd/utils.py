@@ -206,9 +206,33 @@ def _aae_auc_one(out_sq, tar_sq, npix):
     return angle, 1 - float(fp) / npix, [i, j]
 
 
+def _aae_auc_device(output, target):
+    """GPU tensors in, same return values: the maps stay in HBM, one kernel per batch (csrc/metrics.hip), 6 doubles
+    per sample come back.  Shapes as the reference's callers produce them after ``.squeeze()``: (B,224,224) or (224,224)."""
+    from . import hipops as H
+    o = output.detach().to(torch.float32).squeeze()
+    t = target.detach().to(torch.float32).squeeze()
+    single = o.ndim == 2
+    if single:
+        o, t = o.unsqueeze(0), t.unsqueeze(0)
+    res = H.aae_auc(o.contiguous(), t.contiguous()).cpu().numpy()
+    npix_h, npix_w = o.shape[1], o.shape[2]
+    gp = [[int(r[2]), int(r[3])] for r in res]
+    if single:
+        return float(res[0, 0]), 1 - float(res[0, 1]) / (npix_h * npix_w), gp
+    aae = [float(r[0]) for r in res]
+    auc = [1 - float(r[1]) / npix_w / npix_h for r in res]
+    return np.mean(aae), np.mean(auc), gp
+
+
 def computeAAEAUC(output, target):
     """utils.computeAAEAUC (utils.py:96-140): AAE (deg, 60-degree field of view over 224 px) and the
-    single-threshold AUC proxy, on the host like the reference (validation metric, not on the fwd/bwd path)."""
+    single-threshold AUC proxy.  numpy arrays (what the reference's callers pass) are evaluated on the host with
+    scipy like the reference; CUDA tensors (what this package's drivers pass) go through the device kernel."""
+    if isinstance(output, torch.Tensor) and output.is_cuda and tuple(output.shape[-2:]) == (224, 224):
+        return _aae_auc_device(output, target)          # the metric's constants (224, 112) are the reference's
+    if isinstance(output, torch.Tensor):
+        output, target = output.detach().cpu().numpy().squeeze(), target.detach().cpu().numpy().squeeze()
     if output.ndim == 3:
         aae, auc, gp = [], [], []
         for b in range(output.shape[0]):

@@ -156,6 +156,13 @@ int egz_add(const float* a, const float* b, float* out, long n, hipStream_t stre
 int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                   double eps, int step, double grad_scale, hipStream_t stream);
 
+/* utils.computeAAEAUC (utils.py:96-140) per sample on the device: res (B,6) doubles = (AAE deg, fp = #{z > z[gp]}, gaze row,
+ * gaze col, centroid row, centroid col); gw = the 2R+1 weights of scipy's gaussian kernel (sigma 14, R = 56),
+ * dist = 112 / tan(pi/6).  224 x 224 maps only, like the reference.  Called by LF.trainLate / SP.testSP every batch
+ * (LF.py:92-94, SP.py:170-174) instead of a device-to-host copy of both maps + 148 ms of scipy per 32 frames. */
+int egz_aae_auc(const float* out, const float* gt, int B, int H, int W, const double* gw, int R, double dist,
+                double* res, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+"""GPU parity of the device computeAAEAUC (csrc/metrics.hip) with the reference's host metric (utils.py:96-140):
+the golden fixture generated from the reference, the scipy-based oracle on border / tie cases, and the drivers' entry."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import egaze_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+
+
+def test_aae_auc_golden_fixture():
+    from egaze_amd.utils import computeAAEAUC
+    gold = np.load(os.path.join(GOLDEN, "metrics_glue.npz"))
+    rs = np.random.RandomState(11)
+    gt = synth.synth_gt(3, 224, rs)[:, 0]
+    pred = synth.synth_gt(3, 224, rs)[:, 0] * 0.8 + rs.uniform(0, 0.05, (3, 224, 224)).astype(np.float32)
+    aae, auc, gp = computeAAEAUC(_dev(pred), _dev(gt))                       # batch branch (utils.py:100-121)
+    assert abs(aae - gold["batch_aae_auc"][0]) < 1e-6 and abs(auc - gold["batch_aae_auc"][1]) < 1e-12
+    assert np.array_equal(np.array(gp), gold["batch_gp"])
+    aae1, auc1, gp1 = computeAAEAUC(_dev(pred[1]), _dev(gt[1]))              # single-image branch (:122-140)
+    assert abs(aae1 - gold["single_aae_auc"][0]) < 1e-6 and abs(auc1 - gold["single_aae_auc"][1]) < 1e-12
+    assert np.array_equal(np.array(gp1), gold["single_gp"])
+    # the (B,1,H,W) tensors the drivers hand over squeeze to the same thing
+    aae2, auc2, _ = computeAAEAUC(_dev(pred)[:, None], _dev(gt)[:, None])
+    assert aae2 == aae and auc2 == auc
+
+
+def test_aae_auc_borders_and_ties_vs_oracle():
+    """Centroids whose filtered delta is reflected at the image border (direct + mirrored taps overlap), the flat and
+    multi-peak targets (first arg-max), and an exact count check: fp is an integer and must be identical."""
+    import egaze_amd.hipops as H
+    rs = np.random.RandomState(3)
+    preds, gts = [], []
+    for (ci, cj) in [(0, 0), (223, 223), (3, 219), (40, 60), (111, 112), (55, 56), (57, 166), (200, 10), (1, 100)]:
+        p = np.full((224, 224), 1e-6, np.float32)
+        p[max(ci - 1, 0):ci + 2, max(cj - 1, 0):cj + 2] += rs.uniform(0.5, 1.0)
+        preds.append(p)
+        gts.append(synth.synth_gt(1, 224, rs)[0, 0])
+    flat = np.full((224, 224), 0.25, np.float32)                              # all-equal target: arg-max = (0, 0)
+    two = np.zeros((224, 224), np.float32); two[200, 30] = 0.7; two[10, 20] = 0.7   # ties: first in row-major order
+    preds += [synth.synth_gt(1, 224, rs)[0, 0], synth.synth_gt(1, 224, rs)[0, 0]]
+    gts += [flat, two]
+    pred, gt = np.stack(preds), np.stack(gts)
+    res = H.aae_auc(_dev(pred), _dev(gt)).cpu().numpy()
+    for b in range(len(preds)):
+        a, auc, gp = O.compute_aae_auc(pred[b], gt[b])
+        fp_ref = round((1 - auc) * 224 * 224)
+        assert [int(res[b, 2]), int(res[b, 3])] == list(gp[0]), b
+        assert int(res[b, 1]) == fp_ref, (b, res[b], fp_ref)
+        # the reference divides by a float32 numpy sum (1 ulp = 8e-8 relative): up to ~2e-5 px of centroid, ~2e-6 deg
+        assert abs(res[b, 0] - a) < 1e-5, (b, res[b, 0], a)
+    assert [int(res[-2, 2]), int(res[-2, 3])] == [0, 0] and [int(res[-1, 2]), int(res[-1, 3])] == [10, 20]
+
+
+def test_aae_auc_rejects_other_sizes():
+    import egaze_amd.hipops as H
+    from egaze_amd._lib import EgazeHipError
+    x = torch.rand(2, 112, 112, device=DEV)
+    with pytest.raises(EgazeHipError):
+        H.aae_auc(x, x)
