@@ -13,6 +13,7 @@ import torch.nn as nn
 from torch.utils.data import DataLoader
 
 from .data._io import imwrite, resize
+from .data.STdatas import stage_batch
 from .functions import MSELoss
 from .models.LSTMnet import lstmnet
 from .models.model_SP import model_SP
@@ -50,8 +51,23 @@ def crop_align_feature(feature, maxind, size):
     return torch.cat(out, 0)
 
 
+def crop_mean_weight(feature, maxind, size):
+    """chn_weight = spatial mean of crop_feature(feature, maxind, size) (AT.py:25-39 + :229) in one kernel
+    (egz_crop_mean) when the map lives on the GPU."""
+    if feature.is_cuda:
+        from . import hipops as H
+        from .functions import to_nhwc
+        return H.crop_mean(to_nhwc(feature), [list(map(int, m)) for m in maxind], size, 16)
+    c = crop_feature(feature, maxind, size).contiguous()
+    return c.view(c.size(0), c.size(1), -1).mean(2)
+
+
 def get_weighted(chn_weight, feature):
     """Channel-weighted sum of the (1,512,14,14) map, min-max normalised (AT.py:58-66)."""
+    if feature.is_cuda and feature.size(0) == 1:
+        from . import hipops as H
+        from .functions import to_nhwc
+        return H.weighted_minmax(to_nhwc(feature), chn_weight.reshape(1, -1).contiguous().float())
     feature = torch.sum(feature * chn_weight.view(1, 512, 1, 1), 1)
     feature = feature - torch.min(feature)
     return feature / torch.max(feature)
@@ -152,9 +168,7 @@ class AT():
             for i, sample in _progress(enumerate(st_loader)):
                 currname = sample['imname'][0]
                 fixsac = sample['fixsac']
-                input_s = sample['image'].float().to(self.device)
-                input_t = sample['flow'].float().to(self.device)
-                target = sample['gt'].float().to(self.device)
+                input_s, input_t, target = stage_batch(sample, self.device)
                 del features_blobs[:]
                 output = self.model(input_s, input_t)                 # (1,1,224,224)
                 feature_s = features_blobs[0]                          # (1,512,14,14)
@@ -162,9 +176,11 @@ class AT():
                 imwrite(os.path.join(pred_folder, currname), outim)
                 # computeAAEAUC's third value is the GROUND-TRUTH arg-max, used as the "predicted" gaze point
                 _, _, pred_gp = computeAAEAUC(outim, target.cpu().numpy().squeeze())
-                crop = crop_align_feature if self.align else crop_feature
-                cfeature = crop(feature_s, pred_gp, self.crop_size).contiguous()
-                chn_weight = cfeature.view(cfeature.size(0), cfeature.size(1), -1).mean(2)      # (1,512)
+                if self.align:
+                    cfeature = crop_align_feature(feature_s, pred_gp, self.crop_size).contiguous()
+                    chn_weight = cfeature.view(cfeature.size(0), cfeature.size(1), -1).mean(2)  # (1,512)
+                else:
+                    chn_weight = crop_mean_weight(feature_s, pred_gp, self.crop_size)           # (1,512)
                 if int(fixsac) != 1:
                     hidden = repackage_hidden(hidden)
                     chn_weight, hidden = self.lstm(chn_weight.unsqueeze(0), hidden)

@@ -14,6 +14,7 @@ from . import dp
 from .floss import BCELoss, floss
 from .models.model_SP import model_SP
 from .optim import FusedAdam
+from .data.STdatas import stage_batch
 from .utils import (AverageMeter, cfg, change_key_names, computeAAEAUC, make_layers, plot_loss, save_checkpoint)
 
 VGG16_BN_URL = 'https://download.pytorch.org/models/vgg16_bn-6c64b313.pth'
@@ -104,9 +105,7 @@ class SP():
         print('SP module init done!')
 
     def _batch(self, sample):
-        input_s = sample['image'].float().to(self.device, non_blocking=True)
-        input_t = sample['flow'].float().to(self.device, non_blocking=True)
-        target = sample['gt'].float().to(self.device, non_blocking=True)
+        input_s, input_t, target = stage_batch(sample, self.device)     # u8 -> normalised fp32 on the device if raw
         return input_s, input_t, target
 
     def trainSP(self):

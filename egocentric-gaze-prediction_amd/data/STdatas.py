@@ -26,9 +26,28 @@ def build_temporal_list(imgPath, gtPath, listFolders, listGtFiles):
     return imgx, imgy
 
 
+IMAGE_MEAN, IMAGE_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)      # applied to BGR-ordered channels (:51-55)
+FLOW_MEAN, FLOW_STD = (0.5,) * 20, (0.5,) * 20                             # (:59-68)
+
+
+def stage_batch(sample, device):
+    """('image', 'flow', 'gt') of a collated sample as normalised fp32 tensors on ``device``.  A dataset built with
+    ``raw_u8=True`` hands over bytes: they cross PCIe at a quarter of the fp32 size and are normalised by
+    ``egz_u8_normalize`` with the reference's own three fp32 operations (bit-exact with the host expression below)."""
+    if sample['image'].dtype == torch.uint8:
+        from .. import hipops as H
+        put = lambda t: t.contiguous().to(device, non_blocking=True)
+        return (H.u8_normalize(put(sample['image']), IMAGE_MEAN, IMAGE_STD),
+                H.u8_normalize(put(sample['flow']), FLOW_MEAN, FLOW_STD),
+                H.u8_normalize(put(sample['gt']), (0.0,), (1.0,)))
+    return (sample['image'].float().to(device, non_blocking=True), sample['flow'].float().to(device, non_blocking=True),
+            sample['gt'].float().to(device, non_blocking=True))
+
+
 class STDataset(Dataset):
     def __init__(self, imgPath, imgPath_s, gtPath, listFolders, listTrainFiles, listGtFiles, listfixsacTrain,
-                 fixsacPath):
+                 fixsacPath, raw_u8=False):
+        self.raw_u8 = raw_u8
         self.listFolders, self.listGtFiles = listFolders, listGtFiles
         self.imgPath, self.imgPath_s, self.gtPath = imgPath, imgPath_s, gtPath
         self.listTrainFiles = listTrainFiles
@@ -44,6 +63,14 @@ class STDataset(Dataset):
 
     def __getitem__(self, index):
         im = torch.from_numpy(imread(os.path.join(self.imgPath_s, self.listTrainFiles[index])).transpose((2, 0, 1)).copy())
+        if self.raw_u8:            # bytes out; stage_batch() normalises on the device
+            planes = []
+            for fx, fy in zip(self.imgx[index], self.imgy[index]):
+                planes.append(torch.from_numpy(imread(fx, gray=True)))
+                planes.append(torch.from_numpy(imread(fy, gray=True)))
+            gt = torch.from_numpy(imread(os.path.join(self.gtPath, self.listGtFiles[index]), gray=True))
+            return {'image': im, 'flow': torch.stack(planes), 'gt': gt.unsqueeze(0),
+                    'fixsac': torch.FloatTensor([self.fixsac[index]]), 'imname': self.listTrainFiles[index]}
         im = (im.float().div(255) - _MEAN) / _STD
         planes = []
         for fx, fy in zip(self.imgx[index], self.imgy[index]):

@@ -74,9 +74,9 @@ def main(argv=None):
     listTrainFiles, listValFiles = _split(args.imagePath, args.val_name)
     print('num of val samples: ', len(listValFiles))
     STTrainData = STDataset(args.flowPath, args.imagePath, args.gtPath, listFolders, listTrainFiles, listGtFiles,
-                            listfixsacTrain, args.fixsacPath)
+                            listfixsacTrain, args.fixsacPath, raw_u8=True)      # bytes over PCIe, normalised on the GPU
     STValData = STDataset(args.flowPath, args.imagePath, args.gtPath, listFolders, listValFiles, listValGtFiles,
-                          listfixsacVal, args.fixsacPath)
+                          listfixsacVal, args.fixsacPath, raw_u8=True)
     os.makedirs(args.save_path, exist_ok=True)
     if args.train_sp:
         sp = SP(lr=args.lr, loss_save=args.sp_save_img, save_name=args.save_sp, save_path=args.save_path,

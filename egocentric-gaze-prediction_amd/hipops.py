@@ -568,3 +568,47 @@ def aae_auc(out: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     check(LIB.egz_aae_auc(out.data_ptr(), gt.data_ptr(), B, Hh, Ww, gw.data_ptr(), radius, 112 / math.tan(math.pi / 6),
                           res.data_ptr(), _stream()), "egz_aae_auc")
     return res
+
+
+# ----------------------------------------------------------------------------- input pipeline / AT glue
+_NORM_CONST = {}
+
+
+def u8_normalize(src: torch.Tensor, mean, std) -> torch.Tensor:
+    """src: uint8 (..., C, H, W) on the GPU -> fp32 (u8 / 255 - mean[c]) / std[c] (bit-exact with the torch expression)."""
+    if src.dtype != torch.uint8 or not src.is_cuda or not src.is_contiguous():
+        raise ValueError("u8_normalize: contiguous CUDA uint8 tensor expected")
+    C, plane = src.shape[-3], src.shape[-2] * src.shape[-1]
+    key = (src.device.index or 0, tuple(float(v) for v in mean), tuple(float(v) for v in std))
+    hit = _NORM_CONST.get(key)
+    if hit is None:
+        hit = (torch.tensor(key[1], dtype=torch.float32, device=src.device),
+               torch.tensor(key[2], dtype=torch.float32, device=src.device))
+        _NORM_CONST[key] = hit
+    if hit[0].numel() != C:
+        raise ValueError(f"u8_normalize: {C} channels but {hit[0].numel()} mean / std values")
+    dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(LIB.egz_u8_normalize(src.data_ptr(), dst.data_ptr(), src.numel(), plane, C, hit[0].data_ptr(),
+                               hit[1].data_ptr(), _stream()), "egz_u8_normalize")
+    return dst
+
+
+def crop_mean(feat_nhwc: torch.Tensor, gp, size: int, cell: int = 16) -> torch.Tensor:
+    """feat_nhwc: (B,H,W,C) fp32; gp: B gaze points (row, col) in input pixels -> chn_weight (B, C)."""
+    _req(feat_nhwc, "feature")
+    B, Hh, Ww, C = feat_nhwc.shape
+    g = torch.as_tensor(gp, dtype=torch.int32).reshape(B, 2).to(feat_nhwc.device)
+    out = torch.empty((B, C), dtype=torch.float32, device=feat_nhwc.device)
+    check(LIB.egz_crop_mean(feat_nhwc.data_ptr(), g.data_ptr(), out.data_ptr(), B, Hh, Ww, C, int(size), int(cell),
+                            _stream()), "egz_crop_mean")
+    return out
+
+
+def weighted_minmax(feat_nhwc: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """feat_nhwc: (B,H,W,C), w: (B,C) -> (B,H,W): channel-weighted sum, min-max normalised per image."""
+    _req(feat_nhwc, "feature"); _req(w, "chn_weight")
+    B, Hh, Ww, C = feat_nhwc.shape
+    out = torch.empty((B, Hh, Ww), dtype=torch.float32, device=feat_nhwc.device)
+    check(LIB.egz_weighted_minmax(feat_nhwc.data_ptr(), w.data_ptr(), out.data_ptr(), B, Hh * Ww, C, _stream()),
+          "egz_weighted_minmax")
+    return out

@@ -163,6 +163,16 @@ int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double l
 int egz_aae_auc(const float* out, const float* gt, int B, int H, int W, const double* gw, int R, double dist,
                 double* res, hipStream_t stream);
 
+/* Input pipeline on the device (data/STdatas.py:50-68, data/lateDataset.py:22-33): uint8 planes [...][C][plane] ->
+ * (u8 / 255 - mean[c]) / std[c] in fp32, the reference's three correctly-rounded operations (bit-exact). */
+int egz_u8_normalize(const unsigned char* src, float* dst, long n, long plane, int C, const float* mean,
+                     const float* std, hipStream_t stream);
+/* AT extraction glue (AT.py:25-39,58-66,229; extractLSTMw.py:81-90): chn_weight = mean of the size x size window of the
+ * channels-last (B,H,W,C) feature map around gaze_point / cell; weighted map = min-max normalised sum_c feat * w. */
+int egz_crop_mean(const float* feat, const int* gp, float* out, int B, int H, int W, int C, int size, int cell,
+                  hipStream_t stream);
+int egz_weighted_minmax(const float* feat, const float* w, float* out, int B, int HW, int C, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,3 +68,46 @@ def test_aae_auc_rejects_other_sizes():
     x = torch.rand(2, 112, 112, device=DEV)
     with pytest.raises(EgazeHipError):
         H.aae_auc(x, x)
+
+
+def test_u8_normalize_bit_exact():
+    """Device input pipeline (data/STdatas.py:50-68): same three fp32 operations as the reference's torch expression."""
+    import egaze_amd.hipops as H
+    from egaze_amd.data.STdatas import IMAGE_MEAN, IMAGE_STD, FLOW_MEAN, FLOW_STD, stage_batch
+    rs = np.random.RandomState(4)
+    im = torch.from_numpy(rs.randint(0, 256, (3, 3, 32, 20)).astype(np.uint8))
+    fl = torch.from_numpy(rs.randint(0, 256, (3, 20, 32, 20)).astype(np.uint8))
+    gt = torch.from_numpy(rs.randint(0, 256, (3, 1, 32, 20)).astype(np.uint8))
+    mean = torch.tensor(IMAGE_MEAN).view(3, 1, 1); std = torch.tensor(IMAGE_STD).view(3, 1, 1)
+    ref_im = (im.float().div(255) - mean) / std
+    ref_fl = (fl.float().div(255) - 0.5) / 0.5
+    ref_gt = gt.float().div(255)
+    a, b, c = stage_batch({'image': im, 'flow': fl, 'gt': gt}, DEV)
+    assert torch.equal(a.cpu(), ref_im) and torch.equal(b.cpu(), ref_fl) and torch.equal(c.cpu(), ref_gt)
+    a2, b2, c2 = stage_batch({'image': ref_im, 'flow': ref_fl, 'gt': ref_gt}, DEV)       # already-normalised samples pass through
+    assert torch.equal(a2.cpu(), ref_im) and torch.equal(c2.cpu(), ref_gt)
+    with pytest.raises(ValueError):
+        H.u8_normalize(im.to(DEV), (0.5,), (0.5,))
+
+
+def test_at_glue_kernels_vs_oracle():
+    """AT.crop_feature + spatial mean and AT.get_weighted (AT.py:25-39,58-66,229) on the device vs the oracle."""
+    from egaze_amd.AT import crop_mean_weight, get_weighted
+    gold = np.load(os.path.join(GOLDEN, "metrics_glue.npz"))
+    krs = np.random.RandomState(12)
+    krs.standard_normal((64, 3, 3, 3)); [krs.standard_normal((4,)) for _ in range(1, 30)]     # same stream as the fixture
+    feat = torch.from_numpy(np.abs(krs.standard_normal((2, 512, 14, 14))).astype(np.float32))
+    gp = [[5, 220], [117, 60]]
+    fd = feat.to(DEV).contiguous(memory_format=torch.channels_last)
+    w = crop_mean_weight(fd, gp, 3)
+    ref_crop = torch.from_numpy(gold["crop_feature"])
+    ref_w = ref_crop.contiguous().view(2, 512, -1).mean(2)
+    assert (w.cpu() - ref_w).abs().max().item() < 1e-6 * ref_w.abs().max().item()
+    for size, pts in [(1, [[0, 0], [223, 223]]), (2, [[100, 37], [16, 208]]), (5, [[3, 3], [222, 111]])]:
+        ow = O.crop_feature(feat, pts, size).contiguous().view(2, 512, -1).mean(2)
+        assert (crop_mean_weight(fd, pts, size).cpu() - ow).abs().max().item() < 1e-6 * ow.abs().max().item()
+    got = get_weighted(w[0], fd[0:1])
+    assert tuple(got.shape) == (1, 14, 14)
+    ref = gold["get_weighted"]
+    assert np.abs(got.cpu().numpy() - ref).max() < 2e-6
+    assert float(got.min()) == 0.0 and float(got.max()) == 1.0

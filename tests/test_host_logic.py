@@ -88,3 +88,35 @@ def test_host_glue_against_golden():
     h = (torch.ones(2, requires_grad=True) * 2, torch.ones(2, requires_grad=True) * 3)
     d = repackage_hidden(h)
     assert not d[0].requires_grad and repackage_hidden(None) is None
+
+
+def test_stdataset_raw_u8_contract(tmp_path):
+    """data/STdatas.py mirror on files: the raw_u8 samples (bytes for the device input pipeline) normalise on the host to
+    exactly the reference-contract samples; flow window looks 10 frames back; fixsac is dilated by one frame."""
+    from PIL import Image
+    from egaze_amd.data.STdatas import STDataset, IMAGE_MEAN, IMAGE_STD
+    rs = np.random.RandomState(0)
+    folder = "Ahmad_American"
+    (tmp_path / "flow" / folder).mkdir(parents=True)
+    (tmp_path / "img").mkdir(); (tmp_path / "gt").mkdir(); (tmp_path / "fs").mkdir()
+    for n in range(1, 13):
+        for ax in "xy":
+            Image.fromarray(rs.randint(0, 256, (16, 12)).astype(np.uint8)).save(str(tmp_path / "flow" / folder / f"flow_{ax}_{n:05d}.jpg"))
+    names, gts = [], []
+    for n in (11, 12):
+        nm = f"{folder}_img_{n:05d}.png"; g = f"{folder}_gt_{n:05d}.png"
+        Image.fromarray(rs.randint(0, 256, (16, 12, 3)).astype(np.uint8)).save(str(tmp_path / "img" / nm))
+        Image.fromarray(rs.randint(0, 256, (16, 12)).astype(np.uint8)).save(str(tmp_path / "gt" / (folder + "_000000_" + f"{n:05d}.png")))
+        names.append(nm); gts.append(folder + "_000000_" + f"{n:05d}.png")
+    np.savetxt(str(tmp_path / "fs" / "a.txt"), np.array([0.0, 1.0]))
+    args = (str(tmp_path / "flow"), str(tmp_path / "img"), str(tmp_path / "gt"), [folder], names, gts, ["a.txt"], str(tmp_path / "fs"))
+    ref, raw = STDataset(*args), STDataset(*args, raw_u8=True)
+    for i in range(2):
+        a, b = ref[i], raw[i]
+        assert b['image'].dtype == torch.uint8 and b['flow'].dtype == torch.uint8 and b['gt'].dtype == torch.uint8
+        assert tuple(b['flow'].shape) == (20, 16, 12) and tuple(b['image'].shape) == (3, 16, 12)
+        mean = torch.tensor(IMAGE_MEAN).view(3, 1, 1); std = torch.tensor(IMAGE_STD).view(3, 1, 1)
+        assert torch.equal((b['image'].float().div(255) - mean) / std, a['image'])
+        assert torch.equal((b['flow'].float().div(255) - 0.5) / 0.5, a['flow'])
+        assert torch.equal(b['gt'].float().div(255), a['gt'])
+        assert float(a['fixsac']) == 1.0                       # [0, 1] dilated by [1, 1, 1] -> [1, 1]
