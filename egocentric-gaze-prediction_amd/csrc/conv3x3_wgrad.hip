@@ -460,6 +460,184 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Split-half weight gradient of [nearest x2 upsample -> conv3x3] in phase form (4/9 of the MACs of the folded 9-tap form):
+//   dWeff[py][px][a][b][c][k] = sum_{b,y,x} X[y+a+py-1][x+b+px-1][c] * dY[2y+py][2x+px][k]      (LOW-res y, x)
+// One block = one 64(c) x 64(k) tile of BOTH column phases of one row phase py (blockIdx.z): 8 accumulators per wave
+// (px, a, b).  A stage is an R x WD patch of low-res pixels: its (R+1) x (WD+2) input halo and the two stride-2 dY
+// sub-grids (px = 0, 1) are split into bf16 hi / lo and staged once; the A fragment at halo column offset px + b is
+// shared by the two (px, b) pairs that reach it.  Same LDS image / ds_read_b64_tr_b16 addressing as
+// conv3x3_wgrad9_x3_kernel; partial tiles in the [split][16 phase-taps][C][K] layout of wgrad_reduce_ups_kernel.
+template <int R, int WD>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, int patches_per_split) {
+    static_assert(R * WD == 32 && (WD == 32 || WD == 16 || WD == 8), "patch = 32 low-res pixels");
+    constexpr int NP = R * WD, KS = NP / 16;
+    constexpr int HPW = WD + 2, NH = (R + 1) * HPW;
+    constexpr int XH = NH * 32 + ((NH & 1) ? 0 : 32);          // channel-half stride (elements): bytes % 128 == 64
+    constexpr int DH = 2 * NP * 32 + 32;                       // both column phases: slot = px * NP + pixel
+    constexpr int XB = 4 * XH, DB = 4 * DH;
+    constexpr int NX = (NH * 16 + 255) / 256;
+    constexpr int ND = (2 * NP * 16) / 256;                    // 4
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[2 * XB];
+    __shared__ __attribute__((aligned(16))) unsigned short Ds[2 * DB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wc = wave >> 1, wk = wave & 1, l31 = lane & 31;
+    const int tk = K / 64;
+    const int c0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
+    const int py = blockIdx.z;
+    const int Hl = H >> 1, Wl = W >> 1;                        // low-res dims (H, W: the conv's hi-res output dims)
+    const int cpr = (Wl + WD - 1) / WD, rpi = (Hl + R - 1) / R;
+    const long npatch = (long)B * rpi * cpr;
+    const long g0 = (long)blockIdx.y * patches_per_split;
+    const long g1 = (g0 + patches_per_split < npatch) ? (g0 + patches_per_split) : npatch;
+
+    const unsigned x_bias = (unsigned)(Wl + 1) * (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(x)) - x_bias, 0, (int)((unsigned)B * Hl * Wl * C * 4u + x_bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dy), 0, (int)((unsigned)B * H * W * K * 4u), 0x00020000);
+    unsigned x_vo[NX], x_rc[NX], d_vo[ND], d_rc[ND];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int i = tid + 256 * j, pos = i >> 4, c4 = i & 15;
+        const int hr = pos / HPW, hx = pos - hr * HPW;
+        x_vo[j] = (pos < NH) ? (unsigned)((hr * Wl + hx) * C * 4 + c4 * 16) : 0xFFFFFFFFu;
+        x_rc[j] = (unsigned)(hr << 8 | hx);
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int i = tid + 256 * j, slot = i >> 4, k4 = i & 15;
+        const int px = slot / NP, pp = slot - px * NP, ry = pp / WD, rx = pp % WD;
+        d_vo[j] = (unsigned)(((2 * ry) * W + 2 * rx + px) * K * 4 + k4 * 16);
+        d_rc[j] = (unsigned)(ry << 8 | rx);
+    }
+
+    f32x4 rx_[NX], rd[ND];
+    auto gload = [&](long g) {
+        const int x0 = (int)(g % cpr) * WD;
+        const long t = g / cpr;
+        const int y0 = (int)(t % rpi) * R;
+        const long b = t / rpi;
+        // halo row hr <-> low-res row y0 + py - 1 + hr, halo col hx <-> x0 - 1 + hx
+        const int ytop = y0 + py;                                            // low-res row of hr = 1
+        const unsigned rlo = (ytop == 0) ? 1u : 0u, rn = (unsigned)((Hl - ytop < R) ? (Hl - ytop) : R) - rlo;
+        const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((Wl - x0 < WD + 1) ? (Wl - x0) : (WD + 1)) - clo;
+        const unsigned so_x = (unsigned)((((b * Hl + ytop) * Wl + x0) * C + c0) * 4);
+        const unsigned so_d = (unsigned)((((b * H + 2 * y0 + py) * W + 2 * x0) * K + k0) * 4);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const bool ok = ((x_rc[j] >> 8) - rlo <= rn) && ((x_rc[j] & 255u) - clo <= cn);
+            rx_[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? x_vo[j] : 0xFFFFFFFFu, so_x, 0));
+        }
+        const unsigned rmax = (unsigned)(Hl - y0), cmax = (unsigned)(Wl - x0);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const bool ok = ((d_rc[j] >> 8) < rmax) && ((d_rc[j] & 255u) < cmax);
+            rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, ok ? d_vo[j] : 0xFFFFFFFFu, so_d, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j;
+            const int pos = i >> 4, c4 = i & 15;
+            if (pos < NH) {
+                u32x2_t hi, lo;
+                bf16_split4(rx_[j], hi, lo);
+                unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
+                *reinterpret_cast<u32x2_t*>(d) = hi;
+                *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j;
+            const int slot = i >> 4, k4 = i & 15;
+            u32x2_t hi, lo;
+            bf16_split4(rd[j], hi, lo);
+            unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + slot * 32 + (k4 & 7) * 4;
+            *reinterpret_cast<u32x2_t*>(d) = hi;
+            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
+        }
+    };
+
+    const int u = lane & 15, hh = lane >> 5;
+    const int chan = 16 * ((lane >> 4) & 1) + 4 * (u & 3);
+    const int lp = 8 * hh + (u >> 2);
+    const int xlane = (WD >= 16) ? lp : (hh * HPW + (u >> 2));
+    const EGZ_LDS unsigned short* Xl = (const EGZ_LDS unsigned short*)(Xs) + wc * XH + xlane * 32 + chan;
+    const EGZ_LDS unsigned short* Dl = (const EGZ_LDS unsigned short*)(Ds) + wk * DH + lp * 32 + chan;
+    auto xoff = [&](int ks, int q, int a, int o) -> int {        // o = px + b: halo column offset
+        const int base = (WD == 32) ? (16 * ks + 4 * q) : (WD == 16) ? (ks * HPW + 4 * q) : (2 * ks * HPW + 4 * q);
+        return (base + a * HPW + o) * 32;
+    };
+    auto frag = [&](const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) -> bf16x8_t {
+        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p0);
+        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p1);
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    f32x16 acc[8];                                               // [px][a][b]
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (g0 < g1) {
+        gload(g0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (long g = g0; g < g1; ++g) {
+        const int buf = (int)((g - g0) & 1);
+        if (g + 1 < g1) gload(g + 1);
+        const EGZ_LDS unsigned short* Xb = Xl + buf * XB;
+        const EGZ_LDS unsigned short* Db = Dl + buf * DB;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8_t dh[2], dl[2];
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                dh[px] = frag(Db + (px * NP + 16 * ks) * 32, Db + (px * NP + 16 * ks + 4) * 32);
+                dl[px] = frag(Db + 2 * DH + (px * NP + 16 * ks) * 32, Db + 2 * DH + (px * NP + 16 * ks + 4) * 32);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                bf16x8_t xh[3], xl[3];
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    xh[o] = frag(Xb + xoff(ks, 0, a, o), Xb + xoff(ks, 1, a, o));
+                    xl[o] = frag(Xb + 2 * XH + xoff(ks, 0, a, o), Xb + 2 * XH + xoff(ks, 1, a, o));
+                }
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            acc[px * 4 + a * 2 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                term == 0 ? xl[px + b] : xh[px + b], term == 1 ? dl[px] : dh[px], acc[px * 4 + a * 2 + b], 0, 0, 0);
+            }
+        }
+        if (g + 1 < g1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int px = t >> 2, ab = t & 3;
+        float* out = part + ((long)blockIdx.y * 16 + (py * 2 + px) * 4 + ab) * C * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = c0 + wc * 32 + egz_acc_row(r, lane);
+            const int k = k0 + wk * 32 + l31;
+            out[(long)c * K + k] = acc[t][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient of [nearest x2 upsample -> conv3x3] in phase form (the transpose of the UPS_PHASE forward of
 // conv3x3_igemm.hip): for each output phase (py,px) the 3x3 taps collapse to 2x2 taps on the LOW-res input, so
 //   dWeff[py][px][a][b][c][k] = sum_{b,y,x} X[y+a+py-1][x+b+px-1][c] * dY[2y+py][2x+px][k]
@@ -795,6 +973,10 @@ int pick_bt(int C, int K, int flags) {
 EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags) {
     const int L = pick_seg(W, C, K, flags);
     const long n = (long)9 * C * K;
+    if ((flags & 1) && !(flags & 0x1000) && H % 2 == 0 && W % 2 == 0) {
+        if (const int WD = pick_patch_x3(W / 2, C, K, flags))       // phase form on the low-res grid, 16 partial tiles
+            return wgrad_ws_floats(pick_splits9(npatch_x3(B, H / 2, W / 2, WD), C, K, X3_BLOCKS / 2), 16L * C * K) * sizeof(float);
+    }
     if (const int WD = pick_patch_x3(W, C, K, flags))
         return wgrad_ws_floats(pick_splits9(npatch_x3(B, H, W, WD), C, K, X3_BLOCKS), n) * sizeof(float);
     if (flags & 1) {
@@ -820,6 +1002,33 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     const long M = (long)B * H * W;
     float* part = static_cast<float*>(workspace);
     const long nred = (long)9 * C * K;
+    if (ups && !(flags & 0x1000)) {
+        if (const int WD = pick_patch_x3(W / 2, C, K, flags)) {     // split-half phase form of an upsampled conv
+            const long n16 = 16L * C * K;
+            const long np = npatch_x3(B, H / 2, W / 2, WD);
+            const int S = pick_splits9(np, C, K, X3_BLOCKS / 2);    // two row-phase blocks per (tile, split)
+            EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, n16) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+            const int pps = (int)((np + S - 1) / S);
+            dim3 grid((C / 64) * (K / 64), S, 2);
+            if (WD == 32)      hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<1, 32>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+            else if (WD == 16) hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<2, 16>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+            else               hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<4, 8>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+            EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(ups-phase split)");
+            const float* src = part;
+            int rows = S;
+            if (S > RG) {
+                float* part2 = part + (size_t)S * n16;
+                rows = (S + RG - 1) / RG;
+                hipLaunchKernelGGL(wgrad_fold_kernel, dim3(egz_cdiv(n16, 256), rows), dim3(256), 0, st, part, part2, n16, S);
+                EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(fold)");
+                src = part2;
+            }
+            const int g = egz_cdiv(nred, 256) > 4096 ? 4096 : egz_cdiv(nred, 256);
+            hipLaunchKernelGGL(wgrad_reduce_ups_kernel, dim3(g), dim3(256), 0, st, src, dw, C, K, rows);
+            EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce-ups)");
+            return 0;
+        }
+    }
     if (const int WD = pick_patch_x3(W, C, K, flags)) {   // split-half bf16 x3 on the 16-bit MFMA path
         const long np = npatch_x3(B, H, W, WD);
         const int S = pick_splits9(np, C, K, X3_BLOCKS);

@@ -115,6 +115,8 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     (2, 6, 16, 64, 64, False), (1, 9, 48, 64, 64, False), (2, 14, 14, 128, 64, False), (1, 14, 14, 64, 64, True),
     (1, 12, 12, 64, 64, False), (2, 8, 56, 64, 64, False), (1, 6, 24, 64, 128, True), (2, 7, 8, 64, 64, False),
     (1, 56, 56, 64, 64, True),
+    # phase-form split-half wgrad of upsampled convs: low-res patches 2x16 / 1x32 / 4x8, masked rows and columns
+    (2, 16, 32, 64, 64, True), (1, 16, 64, 64, 128, True), (2, 16, 16, 128, 64, True), (1, 10, 48, 64, 64, True),
 ])
 def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups):
     """bf16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes): patch geometries 1x32 / 2x16 / 4x8,
