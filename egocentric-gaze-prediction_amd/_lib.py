@@ -31,6 +31,7 @@ SIGNATURES = {
     "egz_conv3x3_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, S]),
     "egz_pack_w3x3_split": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_pack_w3x3_split_multi": (c_int, [P, c_int, c_int, S]),
     "egz_conv3x3_fwd_split_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

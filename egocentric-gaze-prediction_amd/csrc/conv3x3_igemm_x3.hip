@@ -713,37 +713,71 @@ __device__ __forceinline__ float weff9(const float* __restrict__ w9, int py, int
 }
 // kind 0 fwd [9][Kp][Cp], 1 dgrad [9][Cp][Kp], 2 ups_fwd [16][Kp][Cp], 3 ups_dgrad [16][Cp][Kp]  (same value
 // definitions as the fp32 pack kernels of conv3x3_igemm.hip); output = hi plane then lo plane, 16-bit each.
+// value of packed element i of layout `kind` (0 fwd [9][Kp][Cp], 1 dgrad [9][Cp][Kp], 2 ups_fwd [16][Kp][Cp], 3 ups_dgrad [16][Cp][Kp])
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, long i, int C, int K, int Cp, int Kp, int kind) {
+    int c, k, tap;
+    if (kind == 0 || kind == 2) {
+        c = (int)(i % Cp);
+        const long t = i / Cp;
+        k = (int)(t % Kp);
+        tap = (int)(t / Kp);
+    } else {
+        k = (int)(i % Kp);
+        const long t = i / Kp;
+        c = (int)(t % Cp);
+        tap = (int)(t / Cp);
+    }
+    float v = 0.f;
+    if (c < C && k < K) {
+        const float* w9 = w + ((long)k * C + c) * 9;
+        if (kind == 0) v = w9[tap];
+        else if (kind == 1) v = w9[8 - tap];
+        else if (kind == 2) v = weff9(w9, (tap >> 2) >> 1, (tap & 3) >> 1, (tap >> 2) & 1, tap & 1);
+        else {
+            const int oy = (tap >> 2) - 1, ox = (tap & 3) - 1;
+            v = weff9(w9, (oy == -1 || oy == 1) ? 1 : 0, (oy <= 0) ? 1 : 0, (ox == -1 || ox == 1) ? 1 : 0, (ox <= 0) ? 1 : 0);
+        }
+    }
+    return v;
+}
+
 template <typename T>
 __global__ void pack_split_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int C, int K, int Cp,
                                   int Kp, int kind, float scale) {
     const int taps = (kind >= 2) ? 16 : 9;
     const long n = (long)taps * Cp * Kp;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        int c, k, tap;
-        if (kind == 0 || kind == 2) {
-            c = (int)(i % Cp);
-            const long t = i / Cp;
-            k = (int)(t % Kp);
-            tap = (int)(t / Kp);
-        } else {
-            k = (int)(i % Kp);
-            const long t = i / Kp;
-            c = (int)(t % Cp);
-            tap = (int)(t / Cp);
-        }
-        float v = 0.f;
-        if (c < C && k < K) {
-            const float* w9 = w + ((long)k * C + c) * 9;
-            if (kind == 0) v = w9[tap];
-            else if (kind == 1) v = w9[8 - tap];
-            else if (kind == 2) v = weff9(w9, (tap >> 2) >> 1, (tap & 3) >> 1, (tap >> 2) & 1, tap & 1);
-            else {
-                const int oy = (tap >> 2) - 1, ox = (tap & 3) - 1;
-                v = weff9(w9, (oy == -1 || oy == 1) ? 1 : 0, (oy <= 0) ? 1 : 0, (ox == -1 || ox == 1) ? 1 : 0, (ox <= 0) ? 1 : 0);
-            }
-        }
         unsigned short h, l;
-        Half<T>::split(v * scale, h, l);
+        Half<T>::split(pack_value(w, i, C, K, Cp, Kp, kind) * scale, h, l);
+        wp[i] = h;
+        wp[n + i] = l;
+    }
+}
+
+// All split packings of a model in ONE launch (after the optimizer step): 74 tiny launches per step become one.
+// table: n rows of 8 int64 = {w, wp, C, K, kind, dtype, nelem, first block}; a block packs PACK_PER_BLOCK elements of
+// the row that owns it (binary search over the first-block column).
+constexpr int PACK_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void pack_split_multi_kernel(const long* __restrict__ table, int nrows) {
+    int lo = 0, hi = nrows - 1;
+    while (lo < hi) {                       // last row whose first block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[8 * mid + 7] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* r = table + 8 * lo;
+    const float* w = reinterpret_cast<const float*>(r[0]);
+    unsigned short* wp = reinterpret_cast<unsigned short*>(r[1]);
+    const int C = (int)r[2], K = (int)r[3], kind = (int)r[4], dtype = (int)r[5];
+    const long n = r[6];
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const long base = ((long)blockIdx.x - r[7]) * PACK_PER_BLOCK;
+    for (int e = threadIdx.x; e < PACK_PER_BLOCK; e += 256) {
+        const long i = base + e;
+        if (i >= n) break;
+        const float v = pack_value(w, i, C, K, Cp, Kp, kind);
+        unsigned short h, l;
+        if (dtype == 1) Half<_Float16>::split(v * F16_WSCALE, h, l);
+        else            Half<__bf16>::split(v, h, l);
         wp[i] = h;
         wp[n + i] = l;
     }
@@ -858,6 +892,15 @@ EGZ_API int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind
 // (flags bit 2 = 0x4 selects the 16-tap data gradient of an upsampled conv), computed with split-half operands.
 // dtype 1 = f16 x3, 2 = bf16 x3; wp from egz_pack_w3x3_split with the same dtype.  Needs Cout % 64 == 0, Cin % 32 == 0
 // (tile 128 x 128, or 128 x 64 when Cout is not a multiple of 128).
+// Every split packing of a model in one launch.  table (device): nrows x 8 int64 = {w ptr, wp ptr, C, K, kind, dtype,
+// nelem = taps * Cp * Kp, first block}; rows ordered by first block; total_blocks = sum of ceil(nelem / 2048).
+EGZ_API int egz_pack_w3x3_split_multi(const void* table, int nrows, int total_blocks, hipStream_t st) {
+    EGZ_CHECK_ARG(table && nrows > 0 && total_blocks > 0, "egz_pack_w3x3_split_multi: bad arguments");
+    hipLaunchKernelGGL(pack_split_multi_kernel, dim3(total_blocks), dim3(256), 0, st, static_cast<const long*>(table), nrows);
+    EGZ_CHECK_LAUNCH("egz_pack_w3x3_split_multi");
+    return 0;
+}
+
 // Workspace bytes egz_conv3x3_fwd_split needs for these arguments (0 when the tile count fills whole rounds).
 EGZ_API size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K, int flags) {
     if (K % 64 != 0 || C % 32 != 0 || C <= 0) return 0;

@@ -113,8 +113,19 @@ _PACKED = {}
 
 
 def bump_weight_epoch():
-    """Called by the fused optimizer after it rewrote parameters behind torch's back."""
+    """Invalidate every packing (parameters were overwritten wholesale behind torch's back, e.g. a DP broadcast)."""
     _WEIGHT_EPOCH[0] += 1
+
+
+def touch_params(params):
+    """Called by the fused optimizer after it rewrote THESE parameters through its flat buffer (no torch version bump):
+    only their packings go stale -- a second optimizer (the AT module's) must not invalidate the SP model's."""
+    for p in params:
+        p._egz_epoch = getattr(p, "_egz_epoch", 0) + 1
+
+
+def _tag(w):
+    return (_WEIGHT_EPOCH[0], getattr(w, "_egz_epoch", 0), w._version, w.data_ptr())
 
 
 _UID = [0]
@@ -164,7 +175,7 @@ def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
     _req(w, "weight")
     K, C = w.shape[0], w.shape[1]
     key = (_uid(w), kind, dtype)
-    tag = (_WEIGHT_EPOCH[0], w._version, w.data_ptr())
+    tag = _tag(w)
     hit = _PACKED.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
@@ -175,8 +186,51 @@ def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
         check(LIB.egz_pack_w3x3_split(w.data_ptr(), buf.data_ptr(), C, K, kidx, dtype, _stream()), "egz_pack_w3x3_split")
     else:
         check(getattr(LIB, fname)(w.data_ptr(), buf.data_ptr(), C, K, _stream()), fname)
-    _PACKED[key] = (tag, buf)
+    _PACKED[key] = (tag, buf, weakref.ref(w))
     return buf
+
+
+_PACK_PER_BLOCK = 2048
+_MULTI_TABLES = {}
+
+
+def repack_params(params) -> int:
+    """Refresh EVERY cached split packing of these parameters in one launch (egz_pack_w3x3_split_multi) -- called by the
+    fused optimizer right after it rewrote them, instead of ~74 lazy per-layer pack launches during the next step.
+    Packings are only refreshed, never created: the first forward / backward builds them lazily.  Returns the row count."""
+    rows, entries = [], []
+    uids = {getattr(p, "_egz_uid", None) for p in params}
+    uids.discard(None)
+    for key, ent in _PACKED.items():
+        uid, kind, dtype = key
+        if uid not in uids or not dtype:
+            continue
+        w = ent[2]()
+        if w is None or not w.is_cuda:
+            continue
+        K, C = w.shape[0], w.shape[1]
+        Cp, Kp = (C + 31) // 32 * 32, (K + 31) // 32 * 32
+        kidx = _PACK_FN[kind][2]
+        rows.append((w.data_ptr(), ent[1].data_ptr(), C, K, kidx, dtype, (16 if kidx >= 2 else 9) * Cp * Kp))
+        entries.append((key, w))
+    if not rows:
+        return 0
+    sig = tuple(rows)
+    hit = _MULTI_TABLES.get(sig)
+    if hit is None:
+        first, table = 0, []
+        for r in rows:
+            table.append(list(r) + [first])
+            first += (r[6] + _PACK_PER_BLOCK - 1) // _PACK_PER_BLOCK
+        dev = entries[0][1].device
+        hit = (torch.tensor(table, dtype=torch.int64, device=dev), first)
+        _MULTI_TABLES.clear()                     # pointers are stable (flat parameter buffer): one live table
+        _MULTI_TABLES[sig] = hit
+    check(LIB.egz_pack_w3x3_split_multi(hit[0].data_ptr(), len(rows), hit[1], _stream()), "egz_pack_w3x3_split_multi")
+    for key, w in entries:
+        ent = _PACKED[key]
+        _PACKED[key] = (_tag(w), ent[1], ent[2])
+    return len(rows)
 
 
 # ----------------------------------------------------------------------------- convolutions

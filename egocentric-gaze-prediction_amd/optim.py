@@ -14,9 +14,17 @@ from __future__ import annotations
 
 from typing import Iterable, List
 
+import os
+
 import torch
 
 from . import hipops as H
+
+
+# One-launch refresh of all split packings after the step (hipops.repack_params).  Measured SLOWER than the lazy
+# per-layer packs (41.2 vs 40.3 ms/step): the single kernel sits alone at the end of the step, the 74 small lazy
+# launches hide behind the other streams' kernels.  Opt-in for A/B runs.
+_MULTIPACK = os.environ.get("EGAZE_MULTIPACK", "0") != "0"
 
 
 class FusedAdam:
@@ -71,7 +79,9 @@ class FusedAdam:
         self.step_count += 1
         H.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
                     self.eps, self.step_count, self.grad_scale)
-        H.bump_weight_epoch()
+        H.touch_params(self.params)
+        if _MULTIPACK:
+            H.repack_params(self.params)  # every cached split-half weight packing, one launch
 
     @property
     def param_groups(self):

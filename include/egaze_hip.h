@@ -61,6 +61,9 @@ int egz_conv3x3_ups_dgrad(const float* dy, const float* wp, float* dx, int B, in
  * egz_conv3x3_fwd_split: flags as egz_conv3x3_fwd (bits 0-1, 4-5) plus bit2 = the 16-tap data gradient of an
  * upsampled conv (then C / K are the GEMM's reduction / output channel counts). */
 int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind, int dtype, hipStream_t stream);
+/* All split packings of a model in one launch (after the optimizer step).  table (device memory): nrows x 8 int64 =
+ * {w, wp, C, K, kind, dtype, nelem = taps * Cp * Kp, first block}, rows ordered by first block, 2048 elements per block. */
+int egz_pack_w3x3_split_multi(const void* table, int nrows, int total_blocks, hipStream_t stream);
 /* Optional tile schedule of egz_conv3x3_fwd_split (flags bit 14 = 0x4000): tiles beyond the last full round of resident
  * blocks are run split-K through `workspace` (raw partial accumulators) and reduced in a fixed order;
  * egz_conv3x3_fwd_split_ws_bytes gives the workspace size (0 without the flag: workspace may then be NULL). */

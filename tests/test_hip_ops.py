@@ -356,3 +356,25 @@ def test_conv3x3_split_half_upsample(dtype, tol):
     assert rel(nchw(y), pre.detach()) < tol
     dx = h.conv3x3_ups_dgrad(nhwc(dy), h.packed_weight(wdev, "ups_dgrad", dtype), C, dtype=dtype)
     assert rel(nchw(dx), xd.grad) < tol
+
+
+def test_repack_params_multi_launch():
+    """One-launch refresh of all split packings (egz_pack_w3x3_split_multi) == the per-tensor pack kernels, for every
+    layout / dtype, and the cache treats the refreshed entries as current."""
+    h = H()
+    ws = [torch.nn.Parameter(rnd(64, 32, 3, 3, seed=61).to(DEV)), torch.nn.Parameter(rnd(128, 64, 3, 3, seed=62).to(DEV)),
+          torch.nn.Parameter(rnd(96, 160, 3, 3, seed=63).to(DEV))]
+    kinds = [("fwd", 1), ("dgrad", 2), ("ups_fwd", 1), ("ups_dgrad", 2), ("fwd", 2)]
+    for w in ws:
+        for kind, dt in kinds:
+            h.packed_weight(w, kind, dt)
+    with torch.no_grad():
+        for i, w in enumerate(ws):
+            w.data.copy_(rnd(*w.shape, seed=70 + i).to(DEV))         # in place, like the fused optimizer
+    h.touch_params(ws)
+    assert h.repack_params(ws) == len(ws) * len(kinds)
+    multi = {(i, kind, dt): h.packed_weight(w, kind, dt).clone() for i, w in enumerate(ws) for kind, dt in kinds}
+    h.bump_weight_epoch()                                             # force the per-tensor path
+    for i, w in enumerate(ws):
+        for kind, dt in kinds:
+            assert torch.equal(h.packed_weight(w, kind, dt), multi[(i, kind, dt)]), (i, kind, dt)
