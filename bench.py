@@ -204,9 +204,10 @@ def main():
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
             roofline = {"bound": "mfma",
-                        "kernel": ("conv3x3_igemm_x3_kernel (egz_conv3x3_fwd_split: all conv fwd + dgrad launches, "
-                                   "split-half f16x3 / bf16x3 operands on v_mfma_f32_32x32x16_{f16,bf16}; each algorithmic "
-                                   "MAC costs 3 MFMA MACs, priced against the dense 16-bit MFMA peak)" if split else
+                        "kernel": ("conv3x3_igemm_x3h_kernel + conv3x3_igemm_x3_kernel (egz_conv3x3_fwd_split: all conv fwd + dgrad "
+                                   "launches -- halo-tile kernel for plain convs, per-tap gather kernel for the upsample "
+                                   "forms; split-half f16x3 / bf16x3 operands on v_mfma_f32_32x32x16_{f16,bf16}; each "
+                                   "algorithmic MAC costs 3 MFMA MACs, priced against the dense 16-bit MFMA peak)" if split else
                                    "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
                                    "launches, exact-f32 MFMA)") +
                                   "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it",
@@ -232,7 +233,7 @@ def main():
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (conv fwd: f16x3 split-half MFMA, dgrad: bf16x3 split-half MFMA, fp32 accumulate; wgrad and "
+            "dtype": ("f32 (conv fwd: f16x3 split-half MFMA; dgrad and wgrad: bf16x3 split-half MFMA; fp32 accumulate; "
                       "everything else exact f32)" if H.PRECISION == "split" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"SP two-stream (RGB + 10-pair flow stack) forward + floss + backward + Adam, "
@@ -241,8 +242,8 @@ def main():
                                    + (f"; + AT lstmnet forward + MSE + backward + Adam over T=16, B={args.batch} "
                                       f"512-vectors per step" if use_at else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "precision": ("split-half f16x3 / bf16x3 MFMA for conv fwd / dgrad (fp32-class accuracy, "
-                                     "gaze map within 1e-5 of the reference), exact-f32 MFMA for wgrad"
+                       "precision": ("split-half f16x3 / bf16x3 MFMA for conv fwd / dgrad / wgrad (fp32-class accuracy, "
+                                     "gaze map within 1e-5 of the reference)"
                                      if H.PRECISION == "split" else "exact f32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "roofline": roofline, "cpu_baseline": cpu,
             "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
