@@ -378,3 +378,40 @@ def test_repack_params_multi_launch():
     for i, w in enumerate(ws):
         for kind, dt in kinds:
             assert torch.equal(h.packed_weight(w, kind, dt), multi[(i, kind, dt)]), (i, kind, dt)
+
+
+def test_split_kernels_shape_fuzz():
+    """Geometry dispatch fuzz: random (B, H, W, C, K) through every split-half kernel family (halo patch / halo raster run /
+    per-tap gather forward and data gradient, 9-tap and phase-form weight gradients, upsample forms) against the exact-f32
+    kernels of the same library.  Catches holes in the patch / run / mask selection rather than arithmetic."""
+    h = H()
+    rs = np.random.RandomState(2024)
+    chans = [32, 64, 96, 128, 192, 256]
+    for it in range(36):
+        B = int(rs.randint(1, 4))
+        Hh = int(rs.choice([2, 3, 4, 6, 7, 8, 9, 14, 16, 24, 28, 30, 32, 40, 56, 57]))
+        Ww = int(rs.choice([2, 3, 4, 6, 7, 8, 12, 14, 16, 24, 28, 32, 48, 56, 60, 64, 80]))
+        C, K = int(rs.choice(chans)), int(rs.choice([64, 128, 192, 256]))
+        ups = bool(it % 3 == 0)
+        x = torch.from_numpy(rs.standard_normal((B, Hh, Ww, C)).astype(np.float32)).to(DEV)
+        w = torch.from_numpy((rs.standard_normal((K, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32)).to(DEV)
+        b = torch.from_numpy(rs.standard_normal(K).astype(np.float32) * 0.1).to(DEV)
+        tag = (it, B, Hh, Ww, C, K, ups)
+        mode = "phase" if ups else False
+        Ho, Wo = (2 * Hh, 2 * Ww) if ups else (Hh, Ww)
+        y0, s0 = h.conv3x3_fwd(x, h.packed_weight(w, "ups_fwd" if ups else "fwd", 0), b, K, ups=mode, epi=2, dtype=0)
+        y1, s1 = h.conv3x3_fwd(x, h.packed_weight(w, "ups_fwd" if ups else "fwd", 1), b, K, ups=mode, epi=2, dtype=1)
+        assert rel(y1, y0) < 5e-6, tag
+        assert rel(s1.sum(0), s0.sum(0)) < 1e-5, tag
+        dy = torch.from_numpy(rs.standard_normal((B, Ho, Wo, K)).astype(np.float32)).to(DEV)
+        if C % 64 == 0:
+            if ups:
+                d0 = h.conv3x3_ups_dgrad(dy, h.packed_weight(w, "ups_dgrad", 0), C, dtype=0)
+                d1 = h.conv3x3_ups_dgrad(dy, h.packed_weight(w, "ups_dgrad", 2), C, dtype=2)
+            else:
+                d0 = h.conv3x3_dgrad(dy, h.packed_weight(w, "dgrad", 0), C, dtype=0)
+                d1 = h.conv3x3_dgrad(dy, h.packed_weight(w, "dgrad", 2), C, dtype=2)
+            assert rel(d1, d0) < 4e-5, tag
+            g0 = h.conv3x3_wgrad(x, dy, ups=ups, precision="f32")
+            g1 = h.conv3x3_wgrad(x, dy, ups=ups, precision="split")
+            assert rel(g1, g0) < 4e-5, tag
