@@ -921,6 +921,12 @@ EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* b
     EGZ_CHECK_ARG(ups != 2 && epi <= 2, "egz_conv3x3_fwd_split: bad flags");
     EGZ_CHECK_ARG(!(ups || (flags & 4)) || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_fwd_split: upsampled dims must be even");
     EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_split: stats epilogue needs stat_partial");
+    {   // the operand fetch uses 32-bit buffer offsets: the gathered tensor (+ its one-row bias) must stay below 4 GiB
+        const int hs = ((flags & 3) && !(flags & 4)) ? H / 2 : H, wsrc = ((flags & 3) && !(flags & 4)) ? W / 2 : W;
+        const unsigned long long bytes = 4ull * B * hs * wsrc * C + 4ull * (wsrc + 1) * C;
+        EGZ_CHECK_ARG(bytes < (1ull << 32), "egz_conv3x3_fwd_split: input of %llu bytes exceeds the 4 GiB buffer-offset range "
+                      "(use the exact-f32 kernels, EGAZE_PRECISION=f32, or a smaller per-GPU batch)", bytes);
+    }
     const unsigned short* w16 = static_cast<const unsigned short*>(wp);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
     float* ws = static_cast<float*>(workspace);

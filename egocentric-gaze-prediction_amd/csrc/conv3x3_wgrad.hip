@@ -971,6 +971,12 @@ int pick_bt(int C, int K, int flags) {
 }  // namespace
 
 EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags) {
+    if (flags & 0x2000) {   // same size rule as egz_conv3x3_wgrad
+        const bool ups = flags & 1;
+        const unsigned long long xb = 4ull * B * (ups ? H / 2 : H) * (ups ? W / 2 : W) * C + 4ull * (W + 1) * C;
+        const unsigned long long db = 4ull * B * H * W * K;
+        if (xb >= (1ull << 32) || db >= (1ull << 32)) flags &= ~0x2000;
+    }
     const int L = pick_seg(W, C, K, flags);
     const long n = (long)9 * C * K;
     if ((flags & 1) && !(flags & 0x1000) && H % 2 == 0 && W % 2 == 0) {
@@ -1000,6 +1006,11 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     const bool ups = flags & 1;
     EGZ_CHECK_ARG(!ups || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_wgrad: upsampled output must be even");
     const long M = (long)B * H * W;
+    if (flags & 0x2000) {   // split-half kernels fetch through 32-bit buffer offsets
+        const unsigned long long xb = 4ull * B * (ups ? H / 2 : H) * (ups ? W / 2 : W) * C + 4ull * (W + 1) * C;
+        const unsigned long long db = 4ull * B * H * W * K;
+        if (xb >= (1ull << 32) || db >= (1ull << 32)) flags &= ~0x2000;      // too large: exact-f32 kernels (64-bit addressing)
+    }
     float* part = static_cast<float*>(workspace);
     const long nred = (long)9 * C * K;
     if (ups && !(flags & 0x1000)) {

@@ -52,7 +52,7 @@ class ConvBNReLUPool(torch.autograd.Function):
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training)
         else:
             xin = to_nhwc(x)
-            dt = H.conv_dtype("fwd", K, C)
+            dt = H.conv_dtype("fwd", K, C, xin)
             y, stat = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd", dt), bias.detach() if bias is not None else None,
                                     K, ups=False, epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt)
         B, Hh, Ww, _ = y.shape
@@ -84,7 +84,7 @@ class ConvBNReLUPool(torch.autograd.Function):
         if ng[0]:
             if first:
                 raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
-            dt = H.conv_dtype("dgrad", C, K)
+            dt = H.conv_dtype("dgrad", C, K, dy)
             dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
         f.join(dw)
         return (dx, dw, db, dgamma if ng[3] else None, dbeta if ng[4] else None, None, None, None, None, None,
@@ -96,7 +96,7 @@ class ConvReLU(torch.autograd.Function):
     def forward(ctx, x, weight, bias, ups):
         K, C = weight.shape[0], weight.shape[1]
         xin = to_nhwc(x)
-        dt = H.conv_dtype("fwd", K, C)
+        dt = H.conv_dtype("fwd", K, C, xin)
         y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "ups_fwd" if ups else "fwd", dt),
                              bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
                              epi=H.EPI_BIAS_RELU, dtype=dt)
@@ -118,7 +118,7 @@ class ConvReLU(torch.autograd.Function):
             if ng[1]:
                 dw = H.conv3x3_wgrad(xin, dy, ups=ups)
         if ng[0]:
-            dt = H.conv_dtype("dgrad", C, K)
+            dt = H.conv_dtype("dgrad", C, K, dy)
             if ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
                 dx = from_nhwc(H.conv3x3_ups_dgrad(dy, H.packed_weight(weight, "ups_dgrad", dt), C, dtype=dt))
             else:
@@ -132,7 +132,7 @@ class FusionBlock(torch.autograd.Function):
     def forward(ctx, fs, ft, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps):
         K, C = weight.shape[0], weight.shape[1]
         x2 = torch.cat((to_nhwc(fs), to_nhwc(ft)), 0)            # depth-2 stack folded into the batch dim
-        dt = H.conv_dtype("fwd", K, C)
+        dt = H.conv_dtype("fwd", K, C, x2)
         y2, _ = H.conv3x3_fwd(x2, H.packed_weight(weight, "fwd", dt), bias.detach() if bias is not None else None, K,
                               ups=False, epi=H.EPI_BIAS, dtype=dt)
         z = H.pairmax_fwd(y2)
@@ -163,7 +163,7 @@ class FusionBlock(torch.autograd.Function):
             if ng[2]:
                 dw = H.conv3x3_wgrad(x2, dy2).view(weight.shape)
         if ng[0] or ng[1]:
-            dt = H.conv_dtype("dgrad", C, K)
+            dt = H.conv_dtype("dgrad", C, K, dy2)
             dx2 = H.conv3x3_dgrad(dy2, H.packed_weight(weight, "dgrad", dt), C, dtype=dt)
             B = dx2.shape[0] // 2
             dfs, dft = from_nhwc(dx2[:B]), from_nhwc(dx2[B:])

@@ -155,9 +155,15 @@ PRECISION = _os.environ.get("EGAZE_PRECISION", "split")
 F32, F16X3, BF16X3 = 0, 1, 2
 
 
-def conv_dtype(role: str, gemm_out: int, gemm_in: int) -> int:
-    """dtype code for a conv launch under the current PRECISION policy (role: 'fwd' | 'dgrad')."""
+_SPLIT_MAX_BYTES = (1 << 32) - (1 << 24)      # the split kernels fetch through 32-bit buffer offsets
+
+
+def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.Tensor] = None) -> int:
+    """dtype code for a conv launch under the current PRECISION policy (role: 'fwd' | 'dgrad').  ``operand`` = the gathered
+    activation / gradient tensor: one of 4 GiB or more (B >= 320 at 224 x 224 x 64) stays on the 64-bit-addressed f32 kernels."""
     if PRECISION != "split" or gemm_out % 64 != 0 or gemm_in % 32 != 0:
+        return F32
+    if operand is not None and operand.numel() * 4 >= _SPLIT_MAX_BYTES:
         return F32
     return F16X3 if role == "fwd" else BF16X3
 
