@@ -884,6 +884,30 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         dw[((long)k * C + c) * 9 + tap] = s;
     }
 }
+// Tiled form of the final pass for C % 8 == 0, K % 32 == 0: a block owns an 8(c) x 32(k) x 9-tap tile, reads the partials
+// coalesced along k (nine independent accumulators per thread, same row order as above -> identical sums), transposes
+// through LDS and writes dw[k][c0..c0+7][0..8] as 288-byte contiguous runs instead of 4-byte stores 36 bytes apart.
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                int C, int K, int S) {
+    __shared__ float tile[32 * 73];                    // [k][c * 9 + tap], row padded 72 -> 73
+    const long ck = (long)C * K, n = 9 * ck;
+    const int c0 = blockIdx.x * 8, k0 = blockIdx.y * 32;
+    const int kl = threadIdx.x & 31, cs = threadIdx.x >> 5;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    const float* p = part + (long)(c0 + cs) * K + k0 + kl;
+    for (int sp = 0; sp < S; ++sp, p += n)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += p[t * ck];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tile[kl * 73 + cs * 9 + t] = acc[t];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 72; e += 256) {
+        const int k = e / 72, r = e - k * 72;
+        dw[((long)(k0 + k) * C + c0) * 9 + r] = tile[k * 73 + r];
+    }
+}
 // workspace layout: [S][n] partial tiles, then [ceil(S/RG)][n] folded partials when S > RG
 size_t wgrad_ws_floats(int S, long n) { return (size_t)S * n + (S > RG ? (size_t)((S + RG - 1) / RG) * n : 0); }
 int wgrad_reduce(float* part, float* dw, int C, int K, int S, hipStream_t st) {
@@ -897,8 +921,12 @@ int wgrad_reduce(float* part, float* dw, int C, int K, int S, hipStream_t st) {
         EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(fold)");
         src = part2;
     }
-    const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, src, dw, C, K, rows);
+    if (C % 8 == 0 && K % 32 == 0) {
+        hipLaunchKernelGGL(wgrad_reduce_tile_kernel, dim3(C / 8, K / 32), dim3(256), 0, st, src, dw, C, K, rows);
+    } else {
+        const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, src, dw, C, K, rows);
+    }
     EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce)");
     return 0;
 }
