@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
 constexpr int HSLOTS = 256, HZERO = 255, HPITCH = 20;
 
 template <typename T, int XBN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3h_kernel(
+__global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
     float out_scale, int mt, int patch) {
