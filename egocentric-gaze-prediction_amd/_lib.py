@@ -33,9 +33,9 @@ SIGNATURES = {
     "egz_pack_w3x3_split": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "egz_pack_w3x3_split_multi": (c_int, [P, c_int, c_int, S]),
     "egz_conv3x3_fwd_split_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
+    "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
+    "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)
     "egz_conv_first_stat_rows": (c_int, [c_int, c_int, c_int]),
     "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
@@ -49,14 +49,16 @@ SIGNATURES = {
     "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
     "egz_bn_relu_pool_bwd_ws_bytes": (c_size_t, [c_int]),
     "egz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
-                                     c_size_t, S]),
+                                     c_size_t, P, S]),
     "egz_pairmax_fwd": (c_int, [P, P, c_long, S]),
-    "egz_pairmax_bwd": (c_int, [P, P, P, c_long, S]),
+    "egz_pairmax_bwd": (c_int, [P, P, P, c_long, P, S]),
+    "egz_absmax_elems": (c_int, []),
+    "egz_absmax": (c_int, [P, c_long, P, S]),
     "egz_channel_stats_rows": (c_int, []),
     "egz_channel_stats": (c_int, [P, c_long, c_int, P, S]),
     "egz_relu_bwd": (c_int, [P, P, P, c_long, S]),
     "egz_relu_bwd_bias_ws_bytes": (c_size_t, [c_int]),
-    "egz_relu_bwd_bias": (c_int, [P, P, P, P, c_long, c_int, P, c_size_t, S]),
+    "egz_relu_bwd_bias": (c_int, [P, P, P, P, c_long, c_int, P, c_size_t, P, S]),
     "egz_upsample2x_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "egz_colsum": (c_int, [P, c_long, c_int, P, P, c_size_t, S]),
     "egz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),

@@ -226,16 +226,62 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int npar
     mdzx[k] = (float)(s2 / count);
 }
 
+// max |v| of everything the launch wrote, without atomics (tens of thousands of device-scope atomics on one address cost
+// milliseconds): every block stores the bit pattern of its own maximum into absmax[1 + blockIdx.x] and a one-block
+// epilogue kernel folds the <= EGZ_ABSMAX_PARTIALS partials into absmax[0].  Bit patterns of non-negative floats order like
+// unsigned ints and max is exact and order independent: the result is deterministic.  No zero-initialisation is needed.
+constexpr int ABSMAX_PARTIALS = 8192;
+__device__ __forceinline__ void block_absmax_commit(float m, unsigned int* __restrict__ absmax) {
+    if (!absmax) return;                                  // uniform
+    __shared__ float s_am[16];
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_am[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, s_am[w]);
+        absmax[1 + blockIdx.x] = __float_as_uint(m);
+    }
+}
+__global__ __launch_bounds__(256) void absmax_final_kernel(unsigned int* __restrict__ absmax, int nblocks) {
+    __shared__ unsigned int s[256];
+    unsigned int m = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) m = max(m, absmax[1 + i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) s[threadIdx.x] = max(s[threadIdx.x], s[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) absmax[0] = s[0];
+}
+int absmax_finish(unsigned int* absmax, int nblocks, hipStream_t st, const char* what) {
+    if (!absmax) return 0;
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, absmax, nblocks);
+    EGZ_CHECK_LAUNCH(what);
+    return 0;
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n4, unsigned int* __restrict__ absmax) {
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    block_absmax_commit(m, absmax);
+}
+
 // ------------------------------------------------------------------ BN backward, pass 2: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ mdz, const float* __restrict__ mdzx,
-                                                           float* __restrict__ dy, int B, int H, int W, int K) {
+                                                           float* __restrict__ dy, int B, int H, int W, int K,
+                                                           unsigned int* __restrict__ absmax) {
     const int K4 = K >> 2;
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const long n = (long)B * Ho * Wo * K4;
+    float amx = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % K4);
         const long pix = i / K4;
@@ -255,6 +301,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 const float dz = z > 0.f ? g[e] : 0.f;
                 const float xh = (v[e] - mu[e]) * is[e];
                 r[e] = sc[e] * (dz - m1[e] - xh * m2[e]);
+                amx = fmaxf(amx, fabsf(r[e]));
             }
             *reinterpret_cast<f32x4*>(dy + pix * K + c4 * 4) = r;
         } else {
@@ -277,12 +324,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 for (int q = 0; q < 4; ++q) {
                     const float xh = (v[q][e] - mu[e]) * is[e];
                     r[q][e] = sc[e] * (dz[q] - m1[e] - xh * m2[e]);
+                    amx = fmaxf(amx, fabsf(r[q][e]));
                 }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dy + base + off[q]) = r[q];
         }
     }
+    block_absmax_commit(amx, absmax);
 }
 
 // ------------------------------------------------------------------ fusion: z = max(ys, yt) (ys wins ties)
@@ -297,7 +346,8 @@ __global__ __launch_bounds__(256) void pairmax_fwd_kernel(const float* __restric
     }
 }
 __global__ __launch_bounds__(256) void pairmax_bwd_kernel(const float* __restrict__ y2, const float* __restrict__ dz,
-                                                          float* __restrict__ dy2, long n4) {
+                                                          float* __restrict__ dy2, long n4, unsigned int* __restrict__ absmax) {
+    float amx = 0.f;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const f32x4 a = reinterpret_cast<const f32x4*>(y2)[i];
         const f32x4 b = reinterpret_cast<const f32x4*>(y2)[n4 + i];
@@ -308,10 +358,12 @@ __global__ __launch_bounds__(256) void pairmax_bwd_kernel(const float* __restric
             const bool first = a[e] >= b[e];
             ra[e] = first ? g[e] : 0.f;
             rb[e] = first ? 0.f : g[e];
+            amx = fmaxf(amx, fabsf(g[e]));
         }
         reinterpret_cast<f32x4*>(dy2)[i] = ra;
         reinterpret_cast<f32x4*>(dy2)[n4 + i] = rb;
     }
+    block_absmax_commit(amx, absmax);
 }
 
 // dy = dout * (out > 0)   (nn.ReLU backward; in place allowed)
@@ -330,12 +382,13 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 // dy = dout * (out > 0) plus per-channel partial sums of dy (the conv bias gradient), one pass
 __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restrict__ out, const float* __restrict__ dout,
                                                             float* __restrict__ dy, double* __restrict__ part,
-                                                            long rows, int K) {
+                                                            long rows, int K, unsigned int* __restrict__ absmax) {
     extern __shared__ double sred[];   // [rpb][K]
     const int K4 = K >> 2;
     const int rpb = blockDim.x / K4;
     const int c4 = threadIdx.x % K4, rr = threadIdx.x / K4;
     float s[4] = {0, 0, 0, 0};
+    float amx = 0.f;
     if (rr < rpb) {
         for (long r = (long)blockIdx.x * rpb + rr; r < rows; r += (long)gridDim.x * rpb) {
             const f32x4 o = *reinterpret_cast<const f32x4*>(out + r * K + c4 * 4);
@@ -345,12 +398,14 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(const float* __restr
             for (int e = 0; e < 4; ++e) {
                 v[e] = o[e] > 0.f ? g[e] : 0.f;
                 s[e] += v[e];
+                amx = fmaxf(amx, fabsf(v[e]));
             }
             *reinterpret_cast<f32x4*>(dy + r * K + c4 * 4) = v;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) sred[(long)rr * K + c4 * 4 + e] = (double)s[e];
     }
+    block_absmax_commit(amx, absmax);
     __syncthreads();
     for (int i = threadIdx.x; i < K; i += blockDim.x) {
         double t = 0.0;
@@ -504,7 +559,7 @@ EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {
 EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
                                  int B, int H, int W, int K, int pool, void* workspace, size_t ws_bytes,
-                                 hipStream_t st) {
+                                 unsigned int* absmax, hipStream_t st) {
     EGZ_CHECK_ARG(y && dout && scale && shift && mean && invstd && dy && workspace, "egz_bn_relu_pool_bwd: null pointer");
     EGZ_CHECK_ARG(K % 4 == 0 && K <= 1024, "egz_bn_relu_pool_bwd: K=%d must be a multiple of 4, <= 1024", K);
     EGZ_CHECK_ARG(!pool || (H % 2 == 0 && W % 2 == 0), "egz_bn_relu_pool_bwd: pooled map must be even");
@@ -536,10 +591,10 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
                        (double)B * H * W, dgamma, dbeta, mdz, mdzx);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(finalize)");
     const long n = npix * K4;
-    if (pool) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K);
-    else      hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K);
+    if (pool) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
+    else      hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(apply)");
-    return 0;
+    return absmax_finish(absmax, ew_grid(n), st, "egz_bn_relu_pool_bwd(absmax)");
 }
 
 
@@ -550,11 +605,22 @@ EGZ_API int egz_pairmax_fwd(const float* y2, float* z, long n, hipStream_t st) {
     EGZ_CHECK_LAUNCH("egz_pairmax_fwd");
     return 0;
 }
-EGZ_API int egz_pairmax_bwd(const float* y2, const float* dz, float* dy2, long n, hipStream_t st) {
+EGZ_API int egz_pairmax_bwd(const float* y2, const float* dz, float* dy2, long n, unsigned int* absmax, hipStream_t st) {
     EGZ_CHECK_ARG(y2 && dz && dy2 && n % 4 == 0, "egz_pairmax_bwd: bad arguments");
-    hipLaunchKernelGGL(pairmax_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, y2, dz, dy2, n / 4);
+    hipLaunchKernelGGL(pairmax_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, y2, dz, dy2, n / 4, absmax);
     EGZ_CHECK_LAUNCH("egz_pairmax_bwd");
-    return 0;
+    return absmax_finish(absmax, ew_grid(n / 4), st, "egz_pairmax_bwd(absmax)");
+}
+
+// absmax[0] = max |x| as the bit pattern of a float; absmax must hold egz_absmax_elems() uints (slot 0 + per-block
+// partials, no initialisation needed); n must be a multiple of 4.  The gradient producers above fold the same reduction
+// into their own pass; this entry point serves callers that hold a bare tensor.
+EGZ_API int egz_absmax_elems(void) { return 1 + ABSMAX_PARTIALS; }
+EGZ_API int egz_absmax(const float* x, long n, unsigned int* absmax, hipStream_t st) {
+    EGZ_CHECK_ARG(x && absmax && n > 0 && n % 4 == 0, "egz_absmax: bad arguments");
+    hipLaunchKernelGGL(absmax_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, x, n / 4, absmax);
+    EGZ_CHECK_LAUNCH("egz_absmax");
+    return absmax_finish(absmax, ew_grid(n / 4), st, "egz_absmax(final)");
 }
 
 // per-channel sum / sum-of-squares partials of an NHWC tensor [rows][K] in the conv-epilogue format, so that
@@ -607,7 +673,7 @@ EGZ_API size_t egz_relu_bwd_bias_ws_bytes(int K) { return ((size_t)BWD_BLOCKS + 
 
 // ReLU backward fused with the bias gradient of the conv that produced `out`: dy = dout*(out>0), db[k] = sum_rows dy.
 EGZ_API int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, float* db, long rows, int K,
-                              void* workspace, size_t ws_bytes, hipStream_t st) {
+                              void* workspace, size_t ws_bytes, unsigned int* absmax, hipStream_t st) {
     EGZ_CHECK_ARG(out && dout && dy && db && workspace, "egz_relu_bwd_bias: null pointer");
     EGZ_CHECK_ARG(K % 4 == 0 && K <= 1024, "egz_relu_bwd_bias: K=%d must be a multiple of 4, <= 1024", K);
     EGZ_CHECK_ARG(ws_bytes >= egz_relu_bwd_bias_ws_bytes(K), "egz_relu_bwd_bias: workspace too small");
@@ -619,7 +685,7 @@ EGZ_API int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, fl
     double* part = static_cast<double*>(workspace);
     double* part2 = part + (size_t)BWD_BLOCKS * K;
     hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(blocks), dim3(threads), (size_t)rpb * K * sizeof(double), st, out,
-                       dout, dy, part, rows, K);
+                       dout, dy, part, rows, K, absmax);
     EGZ_CHECK_LAUNCH("egz_relu_bwd_bias");
     const double* fin = part;
     int nfin = blocks;
@@ -631,7 +697,7 @@ EGZ_API int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, fl
     }
     hipLaunchKernelGGL(colsum_final_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K, db);
     EGZ_CHECK_LAUNCH("egz_relu_bwd_bias(final)");
-    return 0;
+    return absmax_finish(absmax, blocks, st, "egz_relu_bwd_bias(absmax)");
 }
 
 // dxu: [B][2H][2W][C] -> dx: [B][H][W][C]

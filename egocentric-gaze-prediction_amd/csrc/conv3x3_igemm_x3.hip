@@ -93,9 +93,12 @@ template <typename T, int XBN, int MODE, int EPI>   // XBN = 128 (Cout % 128 == 
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
-    float out_scale, int mt, int tile_base, int nsplit, int pass, float* __restrict__ ws) {
+    float out_scale, int mt, int tile_base, int nsplit, int pass, float* __restrict__ ws,
+    const unsigned int* __restrict__ a_absmax) {
     // pass 0: whole tile (all K-slices + epilogue).  pass 1: split-K part blockIdx.y of nsplit -> raw accumulators to ws.
     // pass 2: sum the nsplit partials of the tile in a fixed order, then the normal epilogue (launch_x3: tail tiles).
+    const float a_scale = absmax_scale(a_absmax);
+    out_scale /= a_scale;
     constexpr int NTAP = (MODE == UPS_PHASE) ? 4 : (MODE == UPS_DGRAD) ? 16 : 9;
     constexpr int NR = XBN / 64;            // 32-wide n-tiles per wave (2 x 2 waves)
     constexpr int WN = XBN / 2;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     const int b_off = b_r0 * XLD + ((b_ch ^ b_sw) << 3);
     auto lstore_a = [&](const int set, const int buf, const int j) {
         u32x2 hi, lo;
-        Half<T>::split4(ra[set][j], hi, lo);
+        Half<T>::split4(ra[set][j] * a_scale, hi, lo);
         unsigned short* d = As + buf * ABUF + a_off + 32 * j * XLD;
         *reinterpret_cast<u32x2*>(d) = hi;
         *reinterpret_cast<u32x2*>(d + XBM * XLD) = lo;
@@ -424,7 +427,9 @@ template <typename T, int XBN, int EPI>
 __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
-    float out_scale, int mt, int patch) {
+    float out_scale, int mt, int patch, const unsigned int* __restrict__ a_absmax) {
+    const float a_scale = absmax_scale(a_absmax);
+    out_scale /= a_scale;
     constexpr int NR = XBN / 64, WN = XBN / 2, BLD = XBN / 64;
     constexpr int APL = HSLOTS * XLD;                       // elements per A plane
     constexpr int BBUF = 2 * XBN * XLD;
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4(ra[j], hi, lo);
+            Half<T>::split4(ra[j] * a_scale, hi, lo);
             *reinterpret_cast<u32x2*>(Ah + a_lds[j]) = hi;
             *reinterpret_cast<u32x2*>(Ah + APL + a_lds[j]) = lo;
         }
@@ -831,7 +836,8 @@ long x3_rows(int mode, int B, int H, int W) { return (mode >= UPS_PHASE) ? (long
 
 template <typename T, int XBN, int MODE>
 int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bias, float* y, double* stat, int B, int H,
-              int W, int C, int K, float out_scale, int flags, float* ws, size_t ws_bytes, hipStream_t st) {
+              int W, int C, int K, float out_scale, int flags, float* ws, size_t ws_bytes, const unsigned int* a_absmax,
+              hipStream_t st) {
     const long M = x3_rows(MODE, B, H, W);
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
     if constexpr (MODE == PLAIN) {
@@ -840,7 +846,7 @@ int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bi
         if (!(flags & 0x2000) && (patch || (W <= 56 && XBM + 2 * W + 2 <= HZERO))) {
             const int mt = egz_cdiv(M, XBM);
             dim3 grid(mt * (Kp / XBN));
-#define EGZ_X3H(E) hipLaunchKernelGGL((conv3x3_igemm_x3h_kernel<T, XBN, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, patch ? 1 : 0)
+#define EGZ_X3H(E) hipLaunchKernelGGL((conv3x3_igemm_x3h_kernel<T, XBN, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, patch ? 1 : 0, a_absmax)
             if (epi == EPI_BIAS) EGZ_X3H(EPI_BIAS);
             else if (epi == EPI_BIAS_RELU) EGZ_X3H(EPI_BIAS_RELU);
             else EGZ_X3H(EPI_BIAS_STATS);
@@ -852,7 +858,7 @@ int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bi
     const X3Plan p = x3_plan(M, Cp, Kp, XBN, MODE, flags);
     EGZ_CHECK_ARG(!p.tail || (ws && ws_bytes >= (size_t)p.tail * p.nsplit * XBM * XBN * sizeof(float)),
                   "egz_conv3x3_fwd_split: workspace too small (%zu bytes; see egz_conv3x3_fwd_split_ws_bytes)", ws_bytes);
-#define EGZ_X3L(E, GRID, BASE, NS, PASS) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, XBN, MODE, E>), GRID, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, p.mt, BASE, NS, PASS, ws)
+#define EGZ_X3L(E, GRID, BASE, NS, PASS) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, XBN, MODE, E>), GRID, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, p.mt, BASE, NS, PASS, ws, a_absmax)
 #define EGZ_X3(E)                                                                  \
     do {                                                                           \
         if (p.main) EGZ_X3L(E, dim3(p.main), 0, 1, 0);                             \
@@ -909,11 +915,14 @@ EGZ_API size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K,
     return (size_t)p.tail * p.nsplit * XBM * XBN * sizeof(float);
 }
 
+// x_absmax (optional, device): max |x| as a float bit pattern (egz_absmax or a gradient producer).  When given, x is
+// multiplied by the power of two that brings that maximum into [2^12, 2^13) before the split and the result is divided by
+// it again -- this is what lets the f16 x3 form (22 bits) carry gradients whose magnitude is 1e-3 .. 1e-9.
 // flags bit 14 (0x4000): run the tiles beyond the last full round split-K (see x3_plan; measured slower than the plain
 // launch on MI355X for the SP shapes -- lone tail blocks already run ~1.7x faster -- so it is opt-in).
 EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial,
                                   int B, int H, int W, int C, int K, int flags, int dtype, void* workspace,
-                                  size_t ws_bytes, hipStream_t st) {
+                                  size_t ws_bytes, const unsigned int* x_absmax, hipStream_t st) {
     EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd_split: null pointer");
     EGZ_CHECK_ARG(K % 64 == 0 && C % 32 == 0 && C > 0, "egz_conv3x3_fwd_split: needs Cout %% 64 == 0 and Cin %% 32 == 0 (got %d, %d)", K, C);
     EGZ_CHECK_ARG(dtype == 1 || dtype == 2, "egz_conv3x3_fwd_split: dtype must be 1 (f16) or 2 (bf16)");
@@ -931,10 +940,10 @@ EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* b
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
     float* ws = static_cast<float*>(workspace);
 #define EGZ_MODE(T, N)                                                                                          \
-    if (flags & 4) return launch_x3<T, N, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st); \
-    if (ups == 3) return launch_x3<T, N, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st);  \
-    if (ups == 1) return launch_x3<T, N, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st);   \
-    return launch_x3<T, N, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, st)
+    if (flags & 4) return launch_x3<T, N, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st); \
+    if (ups == 3) return launch_x3<T, N, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st);  \
+    if (ups == 1) return launch_x3<T, N, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st);   \
+    return launch_x3<T, N, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st)
     if (K % 128 == 0) {
         if (dtype == 1) { EGZ_MODE(_Float16, 128); }
         EGZ_MODE(__bf16, 128);

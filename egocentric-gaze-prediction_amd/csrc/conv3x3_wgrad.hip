@@ -263,11 +263,56 @@ __device__ __forceinline__ void bf16_split4(const f32x4 v, u32x2_t& hi, u32x2_t&
     }
 }
 
-template <bool UPS, int R, int WD>
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x4_t __attribute__((ext_vector_type(4)));
+// 4 floats -> packed f16 hi / lo halves (22 significant bits): hi = v_cvt_pkrtz (exact residual, saturating), lo = RNE of
+// the residual -- the same split as the forward implicit GEMM.  The gradient operand is pre-multiplied by absmax_scale().
+__device__ __forceinline__ void f16_split4(const f32x4 v, u32x2_t& hi, u32x2_t& lo) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const f16x2_t h = __builtin_bit_cast(f16x2_t, __builtin_amdgcn_cvt_pkrtz(v[2 * e], v[2 * e + 1]));
+        const f16x2_t l = __builtin_convertvector(f32x2_t{v[2 * e] - (float)h[0], v[2 * e + 1] - (float)h[1]}, f16x2_t);
+        hi[e] = __builtin_bit_cast(unsigned, h);
+        lo[e] = __builtin_bit_cast(unsigned, l);
+    }
+}
+__device__ __forceinline__ f16x8_t tr_frag(const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) {
+    const f16x4_t a = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((EGZ_LDS fp16x4_t*)p0));
+    const f16x4_t b = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((EGZ_LDS fp16x4_t*)p1));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// 16-bit operand type of the split-half weight gradient: bf16 x3 (16 significant bits, fp32 exponent range, no scaling --
+// the default) or f16 x3 (22 bits; dY is multiplied by absmax_scale(*dy_absmax) before the split and the accumulators divided
+// by it at the end -- selected by passing dy_absmax).
+template <typename T> struct W16;
+template <> struct W16<__bf16> {
+    typedef bf16x8_t vec8;
+    static __device__ __forceinline__ void split4(const f32x4 v, u32x2_t& hi, u32x2_t& lo) { bf16_split4(v, hi, lo); }
+    static __device__ __forceinline__ vec8 frag(const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) {
+        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p0);
+        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p1);
+        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float scale(const unsigned int*) { return 1.f; }
+};
+template <> struct W16<_Float16> {
+    typedef f16x8_t vec8;
+    static __device__ __forceinline__ void split4(const f32x4 v, u32x2_t& hi, u32x2_t& lo) { f16_split4(v, hi, lo); }
+    static __device__ __forceinline__ vec8 frag(const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) { return tr_frag(p0, p1); }
+    static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ float scale(const unsigned int* am) { return absmax_scale(am); }
+};
+
+template <typename T, bool UPS, int R, int WD>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
-    int C, int K, int patches_per_split) {
+    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax) {
     static_assert(R * WD == 32 && (WD == 32 || WD == 16 || WD == 8), "patch = 32 pixels");
+    const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
     constexpr int NP = R * WD, KS = NP / 16;
     constexpr int HPW = WD + 2, NH = (R + 2) * HPW;            // halo row width / halo pixels
     constexpr int XH = NH * 32 + ((NH & 1) ? 0 : 32);          // channel-half stride (elements): bytes % 128 == 64
@@ -369,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                bf16_split4(rx[j], hi, lo);
+                W16<T>::split4(rx[j], hi, lo);
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
@@ -380,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const int i = tid + 256 * j;
             const int pp = i >> 4, k4 = i & 15;
             u32x2_t hi, lo;
-            bf16_split4(rd[j], hi, lo);
+            W16<T>::split4(rd[j] * d_scale, hi, lo);
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
             *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
@@ -400,12 +445,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         const int base = (WD == 32) ? (16 * ks + 4 * q) : (WD == 16) ? (ks * HPW + 4 * q) : (2 * ks * HPW + 4 * q);
         return (base + (tap / 3) * HPW + (tap % 3)) * 32;
     };
-    auto frag = [&](const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) -> bf16x8_t {
-        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p0);
-        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p1);
-        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -424,24 +463,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         const EGZ_LDS unsigned short* Db = Dl + buf * DB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t dh = frag(Db + (16 * ks) * 32, Db + (16 * ks + 4) * 32);
-            const bf16x8_t dl = frag(Db + 2 * DH + (16 * ks) * 32, Db + 2 * DH + (16 * ks + 4) * 32);
+            const typename W16<T>::vec8 dh = W16<T>::frag(Db + (16 * ks) * 32, Db + (16 * ks + 4) * 32);
+            const typename W16<T>::vec8 dl = W16<T>::frag(Db + 2 * DH + (16 * ks) * 32, Db + 2 * DH + (16 * ks + 4) * 32);
             // taps in groups of three: the three products of one accumulator are issued three MFMAs apart
 #pragma unroll
             for (int tr = 0; tr < 3; ++tr) {
-                bf16x8_t xh[3], xl[3];
+                typename W16<T>::vec8 xh[3], xl[3];
 #pragma unroll
                 for (int ts = 0; ts < 3; ++ts) {
                     const int tap = tr * 3 + ts;
-                    xh[ts] = frag(Xb + xoff(ks, 0, tap), Xb + xoff(ks, 1, tap));
-                    xl[ts] = frag(Xb + 2 * XH + xoff(ks, 0, tap), Xb + 2 * XH + xoff(ks, 1, tap));
+                    xh[ts] = W16<T>::frag(Xb + xoff(ks, 0, tap), Xb + xoff(ks, 1, tap));
+                    xl[ts] = W16<T>::frag(Xb + 2 * XH + xoff(ks, 0, tap), Xb + 2 * XH + xoff(ks, 1, tap));
                 }
 #pragma unroll
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
                     for (int ts = 0; ts < 3; ++ts)
-                        acc[tr * 3 + ts] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts], 0, 0, 0);
+                        acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
             }
         }
         if (g + 1 < g1) lstore(buf ^ 1);
@@ -454,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);
             const int k = k0 + wk * 32 + l31;
-            out[(long)c * K + k] = acc[tap][r];
+            out[(long)c * K + k] = acc[tap][r] * d_inv;
         }
     }
 }
@@ -467,11 +505,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 // sub-grids (px = 0, 1) are split into bf16 hi / lo and staged once; the A fragment at halo column offset px + b is
 // shared by the two (px, b) pairs that reach it.  Same LDS image / ds_read_b64_tr_b16 addressing as
 // conv3x3_wgrad9_x3_kernel; partial tiles in the [split][16 phase-taps][C][K] layout of wgrad_reduce_ups_kernel.
-template <int R, int WD>
+template <typename T, int R, int WD>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
-    int C, int K, int patches_per_split) {
+    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax) {
     static_assert(R * WD == 32 && (WD == 32 || WD == 16 || WD == 8), "patch = 32 low-res pixels");
+    const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
     constexpr int NP = R * WD, KS = NP / 16;
     constexpr int HPW = WD + 2, NH = (R + 1) * HPW;
     constexpr int XH = NH * 32 + ((NH & 1) ? 0 : 32);          // channel-half stride (elements): bytes % 128 == 64
@@ -545,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                bf16_split4(rx_[j], hi, lo);
+                W16<T>::split4(rx_[j], hi, lo);
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
@@ -556,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int i = tid + 256 * j;
             const int slot = i >> 4, k4 = i & 15;
             u32x2_t hi, lo;
-            bf16_split4(rd[j], hi, lo);
+            W16<T>::split4(rd[j] * d_scale, hi, lo);
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + slot * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
             *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
@@ -573,12 +612,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
         const int base = (WD == 32) ? (16 * ks + 4 * q) : (WD == 16) ? (ks * HPW + 4 * q) : (2 * ks * HPW + 4 * q);
         return (base + a * HPW + o) * 32;
     };
-    auto frag = [&](const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) -> bf16x8_t {
-        const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p0);
-        const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p1);
-        return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    };
-
     f32x16 acc[8];                                               // [px][a][b]
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -597,19 +630,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
         const EGZ_LDS unsigned short* Db = Dl + buf * DB;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8_t dh[2], dl[2];
+            typename W16<T>::vec8 dh[2], dl[2];
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
-                dh[px] = frag(Db + (px * NP + 16 * ks) * 32, Db + (px * NP + 16 * ks + 4) * 32);
-                dl[px] = frag(Db + 2 * DH + (px * NP + 16 * ks) * 32, Db + 2 * DH + (px * NP + 16 * ks + 4) * 32);
+                dh[px] = W16<T>::frag(Db + (px * NP + 16 * ks) * 32, Db + (px * NP + 16 * ks + 4) * 32);
+                dl[px] = W16<T>::frag(Db + 2 * DH + (px * NP + 16 * ks) * 32, Db + 2 * DH + (px * NP + 16 * ks + 4) * 32);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                bf16x8_t xh[3], xl[3];
+                typename W16<T>::vec8 xh[3], xl[3];
 #pragma unroll
                 for (int o = 0; o < 3; ++o) {
-                    xh[o] = frag(Xb + xoff(ks, 0, a, o), Xb + xoff(ks, 1, a, o));
-                    xl[o] = frag(Xb + 2 * XH + xoff(ks, 0, a, o), Xb + 2 * XH + xoff(ks, 1, a, o));
+                    xh[o] = W16<T>::frag(Xb + xoff(ks, 0, a, o), Xb + xoff(ks, 1, a, o));
+                    xl[o] = W16<T>::frag(Xb + 2 * XH + xoff(ks, 0, a, o), Xb + 2 * XH + xoff(ks, 1, a, o));
                 }
 #pragma unroll
                 for (int term = 0; term < 3; ++term)
@@ -617,8 +650,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
                     for (int px = 0; px < 2; ++px)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            acc[px * 4 + a * 2 + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                                term == 0 ? xl[px + b] : xh[px + b], term == 1 ? dl[px] : dh[px], acc[px * 4 + a * 2 + b], 0, 0, 0);
+                            acc[px * 4 + a * 2 + b] = W16<T>::mfma(term == 0 ? xl[px + b] : xh[px + b], term == 1 ? dl[px] : dh[px], acc[px * 4 + a * 2 + b]);
             }
         }
         if (g + 1 < g1) lstore(buf ^ 1);
@@ -632,7 +664,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);
             const int k = k0 + wk * 32 + l31;
-            out[(long)c * K + k] = acc[t][r];
+            out[(long)c * K + k] = acc[t][r] * d_inv;
         }
     }
 }
@@ -1025,10 +1057,12 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 
 // flags: bit0 = the conv input was the nearest-x2 upsampling of x ([B][H/2][W/2][C]); 0x100 forces 64 tiles;
 //        0x800 forces the per-tap kernel, 0x1000 the folded 9-tap form of an upsampled conv (A/B benchmarking);
-//        0x2000 = split-half bf16 x3 arithmetic on the 16-bit MFMA path (C, K multiples of 64; else exact f32).
+//        0x2000 = split-half arithmetic on the 16-bit MFMA path (C, K multiples of 64; else exact f32): bf16 x3 (16 bits,
+//        no scaling) when dy_absmax is NULL, f16 x3 (22 bits) with dy scaled by absmax_scale(*dy_absmax) when it is given.
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
 EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
-                              int flags, void* workspace, size_t ws_bytes, hipStream_t st) {
+                              int flags, void* workspace, size_t ws_bytes, const unsigned int* dy_absmax,
+                              hipStream_t st) {
     EGZ_CHECK_ARG(x && dy && dw && workspace, "egz_conv3x3_wgrad: null pointer");
     EGZ_CHECK_ARG(C % 4 == 0 && K % 4 == 0 && C > 0 && K > 0, "egz_conv3x3_wgrad: C=%d K=%d must be multiples of 4", C, K);
     const bool ups = flags & 1;
@@ -1049,9 +1083,10 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
             EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, n16) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
             const int pps = (int)((np + S - 1) / S);
             dim3 grid((C / 64) * (K / 64), S, 2);
-            if (WD == 32)      hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<1, 32>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
-            else if (WD == 16) hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<2, 16>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
-            else               hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<4, 8>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps);
+#define EGZ_WUX(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
+            if (dy_absmax) { if (WD == 32) EGZ_WUX(_Float16, 1, 32); else if (WD == 16) EGZ_WUX(_Float16, 2, 16); else EGZ_WUX(_Float16, 4, 8); }
+            else           { if (WD == 32) EGZ_WUX(__bf16, 1, 32); else if (WD == 16) EGZ_WUX(__bf16, 2, 16); else EGZ_WUX(__bf16, 4, 8); }
+#undef EGZ_WUX
             EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(ups-phase split)");
             const float* src = part;
             int rows = S;
@@ -1074,9 +1109,12 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int pps = (int)((np + S - 1) / S);
         dim3 grid((C / 64) * (K / 64), S);
-#define EGZ_W9X(U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps)
-        if (ups) { if (WD == 32) EGZ_W9X(true, 1, 32); else if (WD == 16) EGZ_W9X(true, 2, 16); else EGZ_W9X(true, 4, 8); }
-        else     { if (WD == 32) EGZ_W9X(false, 1, 32); else if (WD == 16) EGZ_W9X(false, 2, 16); else EGZ_W9X(false, 4, 8); }
+#define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
+#define EGZ_W9T(TT)                                                                                                    \
+        if (ups) { if (WD == 32) EGZ_W9X(TT, true, 1, 32); else if (WD == 16) EGZ_W9X(TT, true, 2, 16); else EGZ_W9X(TT, true, 4, 8); } \
+        else     { if (WD == 32) EGZ_W9X(TT, false, 1, 32); else if (WD == 16) EGZ_W9X(TT, false, 2, 16); else EGZ_W9X(TT, false, 4, 8); }
+        if (dy_absmax) { EGZ_W9T(_Float16) } else { EGZ_W9T(__bf16) }
+#undef EGZ_W9T
 #undef EGZ_W9X
         EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap split)");
         return wgrad_reduce(part, dw, C, K, S, st);

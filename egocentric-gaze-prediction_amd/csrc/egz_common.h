@@ -35,4 +35,19 @@ static inline int egz_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // 32x32 accumulator element `reg` of lane `lane` sits at row (reg&3)+8*(reg>>2)+4*(lane>>5),
 // column lane&31 (cdna_hip_programming.md section 3; dtype-independent on gfx950).
-__device__ __forceinline__ int egz_acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+__device__ __forceinline__ int egz_acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }// Power-of-two scale that brings a tensor whose max |value| is *absmax (float bit pattern, egz_absmax / the gradient
+// producers of bn_pool.hip) into [2^12, 2^13): gradients of 1e-3 .. 1e-9 become f16-representable with 22 significant
+// bits in the hi + lo pair.  Multiplying by it and dividing the accumulators by it afterwards is exact.
+__device__ __forceinline__ float absmax_scale(const unsigned int* __restrict__ absmax) {
+    if (!absmax) return 1.f;
+    const float am = __uint_as_float(*absmax);
+    if (!(am > 0.f) || !(am < INFINITY)) return 1.f;
+    int e;
+    frexpf(am, &e);
+    int se = 13 - e;
+    se = se > 100 ? 100 : (se < -100 ? -100 : se);
+    return ldexpf(1.f, se);
+}
+
+
+

@@ -152,6 +152,12 @@ _PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad",
 #           fp32 exponent range for tiny gradients)  -- conv3x3_igemm_x3.hip.  Weight gradients stay exact-f32.
 #   "f32"   exact-f32 MFMA everywhere (v_mfma_f32_32x32x2_f32); EGAZE_PRECISION=f32 selects it.
 PRECISION = _os.environ.get("EGAZE_PRECISION", "split")
+# Operand type of the split-half GRADIENT kernels (data and weight gradients):
+#   "bf16" (default) bf16 x3, 16 significant bits (5e-6 per layer), fp32 exponent range, no scaling;
+#   "f16"  f16 x3, 22 bits (3e-7 per layer, the exact-f32 kernels' own level): the gradient producers (BN / ReLU / fusion
+#          backward) also emit max |dy| and the conv backward scales dy by the matching power of two.  Measured ~2.5 %
+#          slower per step and no different at whole-model level (subgradient flips dominate), hence opt-in.
+GRAD_SPLIT = _os.environ.get("EGAZE_GRAD_SPLIT", "bf16")
 F32, F16X3, BF16X3 = 0, 1, 2
 
 
@@ -165,7 +171,7 @@ def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.T
         return F32
     if operand is not None and operand.numel() * 4 >= _SPLIT_MAX_BYTES:
         return F32
-    return F16X3 if role == "fwd" else BF16X3
+    return F16X3 if (role == "fwd" or GRAD_SPLIT == "f16") else BF16X3
 
 
 def _drop_packed(uid: int):
@@ -239,9 +245,37 @@ def repack_params(params) -> int:
     return len(rows)
 
 
+# ----------------------------------------------------------------------------- abs-max of gradient tensors
+_ABSMAX_ELEMS = [0]
+
+
+def _new_absmax(device) -> torch.Tensor:
+    """Abs-max buffer of a gradient tensor: slot 0 = max |x| as the bit pattern of a non-negative float, the other slots
+    are the per-block partials of the producing kernel (no initialisation needed, no atomics)."""
+    if not _ABSMAX_ELEMS[0]:
+        _ABSMAX_ELEMS[0] = int(LIB.egz_absmax_elems())
+    return torch.empty(_ABSMAX_ELEMS[0], dtype=torch.int32, device=device)
+
+
+def _want_absmax() -> bool:
+    return PRECISION == "split" and GRAD_SPLIT == "f16"
+
+
+def absmax_of(x: torch.Tensor) -> torch.Tensor:
+    """The abs-max scalar of a gradient tensor: the one its producer kernel attached (bn_relu_pool_bwd, relu_bwd_bias,
+    pairmax_bwd compute it in their own pass), else a standalone reduction (egz_absmax)."""
+    am = getattr(x, "_egz_absmax", None)
+    if am is None:
+        _req(x, "x")
+        am = _new_absmax(x.device)
+        check(LIB.egz_absmax(x.data_ptr(), x.numel(), am.data_ptr(), _stream()), "egz_absmax")
+        x._egz_absmax = am
+    return am
+
+
 # ----------------------------------------------------------------------------- convolutions
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
-                epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0):
+                epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None):
     """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups.
     ups: False | 'fold' (3x3 taps on the virtual upsampled image, wp = 'fwd' packing) | 'phase' or True (four 2x2
     phase convolutions on the low-res input, 4/9 of the MACs, wp = 'ups_fwd' packing)."""
@@ -261,7 +295,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         nb = LIB.egz_conv3x3_fwd_split_ws_bytes(B, H, W, C, K, sflags)
         ws = workspace(nb, x.device) if nb else None
         check(LIB.egz_conv3x3_fwd_split(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                        sflags, dtype, _p(ws), nb, _stream()), "egz_conv3x3_fwd_split")
+                                        sflags, dtype, _p(ws), nb, _p(absmax), _stream()), "egz_conv3x3_fwd_split")
         return y, stat
     PROF.note_flops("egz_conv3x3_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K, flags,
@@ -270,8 +304,10 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
 
 
 def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int, dtype: int = 0) -> torch.Tensor:
-    """dy: (B,H,W,K) -> dx (B,H,W,C) (for an upsampled conv this is the gradient of the upsampled input)."""
-    y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS, dtype=dtype)
+    """dy: (B,H,W,K) -> dx (B,H,W,C) (for an upsampled conv this is the gradient of the upsampled input).
+    dtype F16X3: dy is scaled by a power of two derived from its abs-max so that the f16 halves carry it."""
+    y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS, dtype=dtype,
+                       absmax=absmax_of(dy) if dtype == F16X3 else None)
     return y
 
 
@@ -284,8 +320,9 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         nb = LIB.egz_conv3x3_fwd_split_ws_bytes(B, H, W, K, C, 4)
         ws = workspace(nb, dy.device) if nb else None
+        am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_split(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                        4, dtype, _p(ws), nb, _stream()), "egz_conv3x3_fwd_split(ups_dgrad)")
+                                        4, dtype, _p(ws), nb, _p(am), _stream()), "egz_conv3x3_fwd_split(ups_dgrad)")
         return dx
     PROF.note_flops("egz_conv3x3_ups_dgrad", 2.0 * B * H * W * K * 9 * C)     # algorithmic (reference) FLOPs
     check(LIB.egz_conv3x3_ups_dgrad(dy.data_ptr(), wp_ups_dgrad.data_ptr(), dx.data_ptr(), B, H, W, C, K,
@@ -293,7 +330,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
     return dx
 
 
-WGRAD_SPLIT = 0x2000       # egz_conv3x3_wgrad flag: bf16 x3 split-half arithmetic (C, K multiples of 64)
+WGRAD_SPLIT = 0x2000       # egz_conv3x3_wgrad flag: split-half arithmetic (bf16 x3, or f16 x3 when dy_absmax is passed)
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0,
@@ -303,13 +340,17 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
     C = x.shape[3]
     dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
     flags = (1 if ups else 0) | variant_flag
-    if (precision or PRECISION) == "split":
+    am = None
+    prec = precision or PRECISION
+    if prec in ("split", "split_bf16", "split_f16"):
         flags |= WGRAD_SPLIT
+        if prec == "split_f16" or (prec == "split" and GRAD_SPLIT == "f16"):
+            am = absmax_of(dy)             # f16 x3 with dy scaled by its abs-max; bf16 x3 otherwise
     nb = LIB.egz_conv3x3_wgrad_ws_bytes(B, H, W, C, K, flags)
     ws = workspace(nb, x.device)
     PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, C, K, flags, ws.data_ptr(),
-                                ws.numel(), _stream()), "egz_conv3x3_wgrad")
+                                ws.numel(), _p(am), _stream()), "egz_conv3x3_wgrad")
     return dw
 
 
@@ -377,10 +418,13 @@ def bn_relu_pool_bwd(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, po
     dy = torch.empty_like(y)
     dgb = torch.empty((2, K), dtype=torch.float32, device=y.device)
     ws = workspace(LIB.egz_bn_relu_pool_bwd_ws_bytes(K), y.device)
+    am = _new_absmax(y.device) if _want_absmax() else None
     check(LIB.egz_bn_relu_pool_bwd(y.data_ptr(), dout.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
                                    coef[0].data_ptr(), coef[1].data_ptr(), dy.data_ptr(), dgb[0].data_ptr(),
-                                   dgb[1].data_ptr(), B, H, W, K, int(pool), ws.data_ptr(), ws.numel(), _stream()),
-          "egz_bn_relu_pool_bwd")
+                                   dgb[1].data_ptr(), B, H, W, K, int(pool), ws.data_ptr(), ws.numel(), _p(am),
+                                   _stream()), "egz_bn_relu_pool_bwd")
+    if am is not None:
+        dy._egz_absmax = am      # max |dy|, folded into the same pass: scales the f16 split of the conv backward
     return dy, dgb[0], dgb[1]
 
 
@@ -396,7 +440,11 @@ def pairmax_fwd(y2: torch.Tensor) -> torch.Tensor:
 def pairmax_bwd(y2: torch.Tensor, dz: torch.Tensor) -> torch.Tensor:
     _req(y2, "y2"); _req(dz, "dz")
     dy2 = torch.empty_like(y2)
-    check(LIB.egz_pairmax_bwd(y2.data_ptr(), dz.data_ptr(), dy2.data_ptr(), dz.numel(), _stream()), "egz_pairmax_bwd")
+    am = _new_absmax(y2.device) if _want_absmax() else None
+    check(LIB.egz_pairmax_bwd(y2.data_ptr(), dz.data_ptr(), dy2.data_ptr(), dz.numel(), _p(am), _stream()),
+          "egz_pairmax_bwd")
+    if am is not None:
+        dy2._egz_absmax = am
     return dy2
 
 
@@ -424,8 +472,11 @@ def relu_bwd_bias(out: torch.Tensor, dout: torch.Tensor):
     dy = torch.empty_like(dout)
     db = torch.empty((K,), dtype=torch.float32, device=out.device)
     ws = workspace(LIB.egz_relu_bwd_bias_ws_bytes(K), out.device)
+    am = _new_absmax(out.device) if _want_absmax() else None
     check(LIB.egz_relu_bwd_bias(out.data_ptr(), dout.data_ptr(), dy.data_ptr(), db.data_ptr(), rows, K,
-                                ws.data_ptr(), ws.numel(), _stream()), "egz_relu_bwd_bias")
+                                ws.data_ptr(), ws.numel(), _p(am), _stream()), "egz_relu_bwd_bias")
+    if am is not None:
+        dy._egz_absmax = am
     return dy, db
 
 

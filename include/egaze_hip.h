@@ -70,11 +70,11 @@ int egz_pack_w3x3_split_multi(const void* table, int nrows, int total_blocks, hi
 size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial, int B,
                           int H, int W, int C, int K, int flags, int dtype, void* workspace, size_t ws_bytes,
-                          hipStream_t stream);
+                          const unsigned int* x_absmax, hipStream_t stream);
 /* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
 size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,
-                      void* workspace, size_t ws_bytes, hipStream_t stream);
+                      void* workspace, size_t ws_bytes, const unsigned int* dy_absmax, hipStream_t stream);
 
 /* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
  *      per data/STdatas.py:50-73) and Conv2d(2,32) (models/late_fusion.py:10).  K in {64, 32}. */
@@ -100,12 +100,19 @@ int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift,
 size_t egz_bn_relu_pool_bwd_ws_bytes(int K);
 int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift, const float* mean,
                          const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int K,
-                         int pool, void* workspace, size_t ws_bytes, hipStream_t stream);
+                         int pool, void* workspace, size_t ws_bytes, unsigned int* absmax, hipStream_t stream);
+/* `absmax` of the three gradient producers (egz_bn_relu_pool_bwd, egz_pairmax_bwd, egz_relu_bwd_bias; optional): a buffer of
+ * egz_absmax_elems() uints, no initialisation needed.  Slot 0 receives max |dy| as the bit pattern of a float, computed in
+ * the same pass (per-block partials in the other slots + a one-block epilogue: no atomics, deterministic).  It is the scale
+ * source of the f16 x3 split-half data / weight gradients (egz_conv3x3_fwd_split x_absmax, egz_conv3x3_wgrad dy_absmax read
+ * slot 0); egz_absmax computes it for a bare tensor (n % 4 == 0). */
+int egz_absmax_elems(void);
+int egz_absmax(const float* x, long n, unsigned int* absmax, hipStream_t stream);
 
 /* ---- nn.MaxPool3d((2,1,1)) over the depth-2 stack == element-wise max of the two streams (model_SP.py:11,43);
  *      y2 = [2][n] (stream s, then t), the first stream wins ties like torch's pooling scan. */
 int egz_pairmax_fwd(const float* y2, float* z, long n, hipStream_t stream);
-int egz_pairmax_bwd(const float* y2, const float* dz, float* dy2, long n, hipStream_t stream);
+int egz_pairmax_bwd(const float* y2, const float* dz, float* dy2, long n, unsigned int* absmax, hipStream_t stream);
 /* per-channel (sum, sumsq) partials of an NHWC tensor, in the conv-epilogue format ([rows][2][K] fp64) */
 int egz_channel_stats_rows(void);
 int egz_channel_stats(const float* x, long rows, int K, double* stat_partial, hipStream_t stream);
@@ -115,7 +122,7 @@ int egz_channel_stats(const float* x, long rows, int K, double* stat_partial, hi
 int egz_relu_bwd(const float* out, const float* dout, float* dy, long n, hipStream_t stream);
 size_t egz_relu_bwd_bias_ws_bytes(int K);
 int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, float* db, long rows, int K, void* workspace,
-                      size_t ws_bytes, hipStream_t stream);
+                      size_t ws_bytes, unsigned int* absmax, hipStream_t stream);
 int egz_upsample2x_bwd(const float* dxu, float* dx, int B, int H, int W, int C, hipStream_t stream);
 int egz_colsum(const float* x, long rows, int K, float* out, void* workspace, size_t ws_bytes, hipStream_t stream);
 int egz_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);

@@ -119,7 +119,7 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     (2, 16, 32, 64, 64, True), (1, 16, 64, 64, 128, True), (2, 16, 16, 128, 64, True), (1, 10, 48, 64, 64, True),
 ])
 def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups):
-    """bf16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes): patch geometries 1x32 / 2x16 / 4x8,
+    """f16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes; dy scaled by its abs-max): patch geometries 1x32 / 2x16 / 4x8,
     masked narrow rows (28 in 32, 14 and 12 in 16), odd row counts, upsample-fused gather.  Compared with the fp64
     weight gradient; the exact-f32 kernel is held to the same bound for reference."""
     h = H()
@@ -129,12 +129,14 @@ def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups):
     xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
     w = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv2d(xin.double(), w, None, padding=1).backward(dy.double())
-    dw_split = h.conv3x3_wgrad(nhwc(x), nhwc(dy), ups=ups, precision="split")
+    dw_bf16 = h.conv3x3_wgrad(nhwc(x), nhwc(dy), ups=ups, precision="split_bf16")
+    dw_f16 = h.conv3x3_wgrad(nhwc(x), nhwc(dy), ups=ups, precision="split_f16")
     dw_f32 = h.conv3x3_wgrad(nhwc(x), nhwc(dy), ups=ups, precision="f32")
-    e_split, e_f32 = rel(dw_split.cpu().double(), w.grad), rel(dw_f32.cpu().double(), w.grad)
-    print(f"wgrad err vs fp64: split {e_split:.2e}  f32 {e_f32:.2e}")
+    e_bf16, e_f16, e_f32 = (rel(t.cpu().double(), w.grad) for t in (dw_bf16, dw_f16, dw_f32))
+    print(f"wgrad err vs fp64: bf16x3 {e_bf16:.2e}  f16x3 {e_f16:.2e}  f32 {e_f32:.2e}")
     assert e_f32 < 1e-5
-    assert e_split < 2e-5
+    assert e_bf16 < 2e-5
+    assert e_f16 < 2e-6
 
 
 @pytest.mark.parametrize("C", [3, 20])
@@ -411,7 +413,43 @@ def test_split_kernels_shape_fuzz():
             else:
                 d0 = h.conv3x3_dgrad(dy, h.packed_weight(w, "dgrad", 0), C, dtype=0)
                 d1 = h.conv3x3_dgrad(dy, h.packed_weight(w, "dgrad", 2), C, dtype=2)
+                d2 = h.conv3x3_dgrad(dy, h.packed_weight(w, "dgrad", 1), C, dtype=1)      # abs-max scaled f16 x3
+                assert rel(d2, d0) < 5e-6, tag
             assert rel(d1, d0) < 4e-5, tag
             g0 = h.conv3x3_wgrad(x, dy, ups=ups, precision="f32")
-            g1 = h.conv3x3_wgrad(x, dy, ups=ups, precision="split")
-            assert rel(g1, g0) < 4e-5, tag
+            g1 = h.conv3x3_wgrad(x, dy, ups=ups, precision="split_f16")
+            assert rel(g1, g0) < 5e-6, tag
+            g2 = h.conv3x3_wgrad(x, dy, ups=ups, precision="split_bf16")
+            assert rel(g2, g0) < 4e-5, tag
+
+
+@pytest.mark.parametrize("mag", [1.0, 3e-4, 1e-8, 7e-13, 2e5])
+def test_gradient_absmax_scaling(mag):
+    """f16 x3 data / weight gradients of a gradient tensor of ANY magnitude: the abs-max of dy (a producer's or
+    egz_absmax) picks a power-of-two scale, so 1e-8-sized gradients keep fp32-class accuracy (unscaled f16 would flush
+    them to zero, bf16 x3 carries 16 bits)."""
+    h = H()
+    B, Hh, Ww, C, K = 2, 16, 32, 64, 128
+    x = rnd(B, C, Hh, Ww, seed=81)
+    w = rnd(K, C, 3, 3, seed=82, scale=(2.0 / (9 * C)) ** 0.5)
+    dy = rnd(B, K, Hh, Ww, seed=83) * mag
+    dy[0, 3, 5, 7] = 40.0 * mag                                      # an outlier sets the scale
+    dref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1)
+    wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
+    dyd, wd = nhwc(dy), w.to(DEV)
+    am = h.absmax_of(dyd)
+    assert torch.equal(am[:1].view(torch.float32).cpu(), dy.abs().max().reshape(1))     # bit pattern of the exact max
+    dx = h.conv3x3_dgrad(dyd, h.packed_weight(wd, "dgrad", 1), C, dtype=1)
+    assert rel(nchw(dx), dref) < 2e-6
+    dw = h.conv3x3_wgrad(nhwc(x), dyd, precision="split_f16")
+    assert rel(dw.cpu(), wref) < 2e-6
+    assert rel(h.conv3x3_wgrad(nhwc(x), dyd, precision="split_bf16").cpu(), wref) < 2e-5
+    # a producer attaches the same scalar in its own pass
+    out = torch.rand(B, Hh, Ww, K, device=DEV) - 0.3
+    h.GRAD_SPLIT, keep = "f16", h.GRAD_SPLIT
+    try:
+        dy2, _ = h.relu_bwd_bias(out, dyd)
+    finally:
+        h.GRAD_SPLIT = keep
+    want = (dy2.abs().max()).reshape(1).cpu()
+    assert torch.equal(dy2._egz_absmax[:1].view(torch.float32).cpu(), want)
