@@ -62,6 +62,7 @@ SIGNATURES = {
     "egz_upsample2x_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "egz_colsum": (c_int, [P, c_long, c_int, P, P, c_size_t, S]),
     "egz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_nchw_to_nhwc_pad": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, S]),
     "egz_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     # --- head + losses
     "egz_conv1x1_sigmoid_fwd": (c_int, [P, P, P, P, P, c_long, c_int, S]),

@@ -449,7 +449,7 @@ __global__ void colsum_final_kernel(const double* __restrict__ part, int nparts,
 
 // layout transposes between the reference's NCHW tensors and the library's NHWC activations
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                           int B, int C, long HW) {
+                                                           int B, int C, long HW, int Cp) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const long p0 = (long)blockIdx.x * 32;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     for (int j = ty; j < 32; j += 8) {
         const long p = p0 + j;
         const int c = c0 + tx;
-        if (c < C && p < HW) out[((long)b * HW + p) * C + c] = tile[tx][j];
+        if (c < Cp && p < HW) out[((long)b * HW + p) * Cp + c] = tile[tx][j];      // channels C .. Cp-1 are zero padding
     }
 }
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -723,10 +723,20 @@ EGZ_API int egz_colsum(const float* x, long rows, int K, float* out, void* works
 EGZ_API int egz_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t st) {
     EGZ_CHECK_ARG(in && out, "egz_nchw_to_nhwc: null pointer");
     const long HW = (long)H * W;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(egz_cdiv(HW, 32), egz_cdiv(C, 32), B), dim3(256), 0, st, in, out, B, C, HW);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(egz_cdiv(HW, 32), egz_cdiv(C, 32), B), dim3(256), 0, st, in, out, B, C, HW, C);
     EGZ_CHECK_LAUNCH("egz_nchw_to_nhwc");
     return 0;
 }
+// Same transpose with the channel dimension zero-padded to Cp: (B, C, H, W) -> (B, H, W, Cp).  Lets the 20-channel flow
+// stack of the temporal encoder's first conv (SP.py:53) run on the split-half kernels, which want Cin % 32 == 0.
+EGZ_API int egz_nchw_to_nhwc_pad(const float* in, float* out, int B, int C, int H, int W, int Cp, hipStream_t st) {
+    EGZ_CHECK_ARG(in && out && Cp >= C && C > 0, "egz_nchw_to_nhwc_pad: bad arguments");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(egz_cdiv(HW, 32), egz_cdiv(Cp, 32), B), dim3(256), 0, st, in, out, B, C, HW, Cp);
+    EGZ_CHECK_LAUNCH("egz_nchw_to_nhwc_pad");
+    return 0;
+}
+
 EGZ_API int egz_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t st) {
     EGZ_CHECK_ARG(in && out, "egz_nhwc_to_nchw: null pointer");
     const long HW = (long)H * W;

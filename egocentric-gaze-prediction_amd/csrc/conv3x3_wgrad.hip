@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     for (int j = 0; j < NX; ++j) {
         const int i = tid + 256 * j, pos = i >> 4, c4 = i & 15;
         const int hr = pos / HPW, hx = pos - hr * HPW;
-        x_vo[j] = (pos < NH) ? (unsigned)((hr * W + hx) * C * 4 + c4 * 16) : 0xFFFFFFFFu;
+        x_vo[j] = (pos < NH && c0 + c4 * 4 < C) ? (unsigned)((hr * W + hx) * C * 4 + c4 * 16) : 0xFFFFFFFFu;   // C = 32: half tile
         x_rc[j] = (unsigned)(hr << 8 | hx);
     }
 #pragma unroll
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);
             const int k = k0 + wk * 32 + l31;
-            out[(long)c * K + k] = acc[tap][r] * d_inv;
+            if (c < C) out[(long)c * K + k] = acc[tap][r] * d_inv;
         }
     }
 }
@@ -1000,7 +1000,7 @@ int pick_seg(int W, int C, int K, int flags) {
     return 0;
 }
 int pick_splits9(long nseg, int C, int K, int target = 1024) {
-    const long tiles = (long)(C / 64) * (K / 64);
+    const long tiles = (long)((C + 63) / 64) * (K / 64);
     long s = (target + tiles - 1) / tiles;            // 1024: ~4 blocks per CU (two rounds of 2 resident)
     const long smax = (nseg + 7) / 8;                 // at least 8 segments per split
     if (s > smax) s = smax;
@@ -1010,7 +1010,8 @@ int pick_splits9(long nseg, int C, int K, int target = 1024) {
 
 // split-half 9-tap kernel (flags 0x2000): patch width (0 = not applicable); rows narrower than the patch are masked
 int pick_patch_x3(int W, int C, int K, int flags) {
-    if (!(flags & 0x2000) || (flags & 0x800) || C % 64 != 0 || K % 64 != 0) return 0;
+    if (!(flags & 0x2000) || (flags & 0x800) || C % 32 != 0 || K % 64 != 0) return 0;
+    if (C % 64 != 0 && ((flags & 1) || C != 32)) return 0;       // C = 32 (padded first conv): plain 9-tap form, half c-tile
     if (W % 32 == 0 || (W > 16 && W < 32)) return 32;
     if (W % 16 == 0 || (W > 8 && W < 16)) return 16;
     if (W % 8 == 0) return 8;
@@ -1108,7 +1109,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         const int S = pick_splits9(np, C, K, X3_BLOCKS);
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int pps = (int)((np + S - 1) / S);
-        dim3 grid((C / 64) * (K / 64), S);
+        dim3 grid(((C + 63) / 64) * (K / 64), S);
 #define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
 #define EGZ_W9T(TT)                                                                                                    \
         if (ups) { if (WD == 32) EGZ_W9X(TT, true, 1, 32); else if (WD == 16) EGZ_W9X(TT, true, 2, 16); else EGZ_W9X(TT, true, 4, 8); } \

@@ -42,12 +42,25 @@ def _zero_bias_grad(dy: torch.Tensor, K: int) -> torch.Tensor:
     return torch.zeros((K,), dtype=torch.float32, device=dy.device)
 
 
+def _first_conv_on_split(C: int, K: int) -> bool:
+    """First conv of a stack on the split-half kernels after padding Cin to 32: pays for the wide flow stack (C = 20),
+    not for RGB (C = 3, where 29 of 32 padded channels would be wasted work)."""
+    return H.PRECISION == "split" and 16 <= C <= 32 and K % 64 == 0
+
+
 class ConvBNReLUPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, pool,
                 first):
         K, C = weight.shape[0], weight.shape[1]
-        if first:
+        padded = first and _first_conv_on_split(C, K)
+        if padded:
+            # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
+            # for this one layer); the packed weight is padded the same way by the pack kernel
+            xin = H.nchw_to_nhwc_pad(H._req(x.detach(), "network input (NCHW)"), 32)
+            y, stat = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd", H.F16X3), bias.detach() if bias is not None else None,
+                                    K, ups=False, epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3)
+        elif first:
             xin = H._req(x.detach(), "network input (NCHW)")
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training)
         else:
@@ -63,13 +76,13 @@ class ConvBNReLUPool(torch.autograd.Function):
             coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(y, coef, pool)
         ctx.save_for_backward(xin, y, coef, weight)
-        ctx.cfg = (training, pool, first, C, K)
+        ctx.cfg = (training, pool, first, C, K, padded)
         return from_nhwc(out)
 
     @staticmethod
     def backward(ctx, dout):
         xin, y, coef, weight = ctx.saved_tensors
-        training, pool, first, C, K = ctx.cfg
+        training, pool, first, C, K, padded = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path "
                                       "(SP.py:119 trains in model.train(); eval runs under torch.no_grad())")
@@ -80,7 +93,10 @@ class ConvBNReLUPool(torch.autograd.Function):
             db = _zero_bias_grad(dy, K)
         with fork("wgrad") as f:                # weight gradient || data gradient (both only read dy)
             if ng[1]:
-                dw = H.conv_first_wgrad(xin, dy) if first else H.conv3x3_wgrad(xin, dy)
+                if padded:
+                    dw = H.conv3x3_wgrad(xin, dy)[:, :C].contiguous()      # gradient of the zero-padded channels dropped
+                else:
+                    dw = H.conv_first_wgrad(xin, dy) if first else H.conv3x3_wgrad(xin, dy)
         if ng[0]:
             if first:
                 raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")

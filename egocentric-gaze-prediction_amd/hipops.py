@@ -508,6 +508,15 @@ def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def nchw_to_nhwc_pad(x: torch.Tensor, Cp: int) -> torch.Tensor:
+    """(B, C, H, W) -> (B, H, W, Cp) with zero channels C .. Cp-1."""
+    _req(x, "x")
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, Cp), dtype=torch.float32, device=x.device)
+    check(LIB.egz_nchw_to_nhwc_pad(x.data_ptr(), out.data_ptr(), B, C, H, W, Cp, _stream()), "egz_nchw_to_nhwc_pad")
+    return out
+
+
 def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     _req(x, "x")
     B, H, W, C = x.shape

@@ -126,6 +126,9 @@ int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, float* db,
 int egz_upsample2x_bwd(const float* dxu, float* dx, int B, int H, int W, int C, hipStream_t stream);
 int egz_colsum(const float* x, long rows, int K, float* out, void* workspace, size_t ws_bytes, hipStream_t stream);
 int egz_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
+/* the same transpose with the channel dimension zero-padded to Cp (the 20-channel flow stack -> 32 channels so that the
+ * temporal encoder's first conv, SP.py:53, runs on the split-half kernels) */
+int egz_nchw_to_nhwc_pad(const float* in, float* out, int B, int C, int H, int W, int Cp, hipStream_t stream);
 int egz_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
 
 /* ---- nn.Conv2d(C, 1, 1) + nn.Sigmoid head (models/model_SP.py:30,32,49; models/late_fusion.py:13,15,22) */

@@ -453,3 +453,29 @@ def test_gradient_absmax_scaling(mag):
         h.GRAD_SPLIT = keep
     want = (dy2.abs().max()).reshape(1).cpu()
     assert torch.equal(dy2._egz_absmax[:1].view(torch.float32).cpu(), want)
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C", [(2, 16, 32, 20), (1, 24, 28, 20), (2, 9, 7, 17)])
+def test_first_conv_padded_split_path(B, Hh, Ww, C):
+    """The flow-stack first conv (Cin = 20, SP.py:53) on the split-half kernels after zero-padding Cin to 32:
+    padded transpose, forward with BN statistics, and the C = 32 half-tile weight gradient."""
+    h = H()
+    K = 64
+    x = rnd(B, C, Hh, Ww, seed=91)
+    w = rnd(K, C, 3, 3, seed=92, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=93, scale=0.1)
+    dy = rnd(B, K, Hh, Ww, seed=94)
+    xp = h.nchw_to_nhwc_pad(x.to(DEV), 32)
+    assert tuple(xp.shape) == (B, Hh, Ww, 32)
+    assert torch.equal(xp[..., :C].cpu(), x.permute(0, 2, 3, 1)) and float(xp[..., C:].abs().max()) == 0.0
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    wd = torch.nn.Parameter(w.to(DEV))
+    y, stat = h.conv3x3_fwd(xp, h.packed_weight(wd, "fwd", 1), b.to(DEV), K, epi=2, dtype=1)
+    assert rel(nchw(y), ref) < 2e-6
+    assert rel(stat.sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
+    wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
+    for prec, tol in (("split_bf16", 2e-5), ("split_f16", 2e-6), ("f32", 1e-5)):
+        dw = h.conv3x3_wgrad(xp, nhwc(dy), precision=prec)
+        assert tuple(dw.shape) == (K, 32, 3, 3)
+        assert rel(dw[:, :C].cpu(), wref) < tol, prec
+        assert float(dw[:, C:].abs().max()) == 0.0, prec
