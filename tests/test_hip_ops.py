@@ -446,11 +446,12 @@ def test_gradient_absmax_scaling(mag):
     assert rel(h.conv3x3_wgrad(nhwc(x), dyd, precision="split_bf16").cpu(), wref) < 2e-5
     # a producer attaches the same scalar in its own pass
     out = torch.rand(B, Hh, Ww, K, device=DEV) - 0.3
-    h.GRAD_SPLIT, keep = "f16", h.GRAD_SPLIT
+    keep = (h.PRECISION, h.GRAD_SPLIT)
+    h.PRECISION, h.GRAD_SPLIT = "split", "f16"
     try:
         dy2, _ = h.relu_bwd_bias(out, dyd)
     finally:
-        h.GRAD_SPLIT = keep
+        h.PRECISION, h.GRAD_SPLIT = keep
     want = (dy2.abs().max()).reshape(1).cpu()
     assert torch.equal(dy2._egz_absmax[:1].view(torch.float32).cpu(), want)
 
