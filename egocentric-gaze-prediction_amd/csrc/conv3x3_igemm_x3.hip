@@ -1,18 +1,21 @@
-// Error-compensated split-half variant of the 3x3 implicit GEMM (conv3x3_igemm.hip) for the wide layers
-// (GEMM output channels a multiple of 128): every fp32 operand is represented as hi + lo in a 16-bit type and the
-// product is accumulated in fp32 as  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  -- three v_mfma_f32_32x32x16_{f16,bf16}
+// Error-compensated split-half variant of the 3x3 implicit GEMM (conv3x3_igemm.hip) for layers whose GEMM output
+// channel count is a multiple of 64: every fp32 operand is represented as hi + lo in a 16-bit type and the product is
+// accumulated in fp32 as  a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  -- three v_mfma_f32_32x32x16_{f16,bf16}
 // (2.5 PFLOP/s class, 16x the rate of the exact-f32 MFMA) per 16 k instead of eight v_mfma_f32_32x32x2_f32:
 // 5.3x less matrix-pipe time at fp32-class accuracy ("error-compensated split-half").
-//   * f16 x3 (forward): 22 significant bits per operand; measured |err| 3e-7 of max|ref| on K = 4608 dot products,
-//     the same as an fp32 matmul (4.8e-7).  Weights are pre-scaled by 2^10 at pack time (keeps the lo half normal),
-//     undone exactly in the epilogue; activations are clamped to +-65504 before the split (no inf).
-//   * bf16 x3 (data gradient): fp32 exponent range for tiny gradients, 16 significant bits, |err| 5.5e-6.
+//   * f16 x3 (forward; gradients with EGAZE_GRAD_SPLIT=f16): 22 significant bits per operand; measured |err| 2e-7 of
+//     max|ref| on K = 4608 dot products (the exact-f32 MFMA kernel: 8.6e-7).  Weights are pre-scaled by 2^10 at pack time
+//     (keeps the lo half normal), undone exactly in the epilogue; hi = round-toward-zero (saturating), lo = RNE residual;
+//     a gradient operand is first multiplied by absmax_scale(max |x|) (egz_common.h).
+//   * bf16 x3 (data gradient, default): fp32 exponent range for tiny gradients, 16 significant bits, |err| 5e-6.
 // The activation operand is split on the fly while it is staged into LDS (it stays fp32 in HBM); the weight operand is
-// split once at pack time (egz_pack_w3x3_split).  Same gather modes and epilogues as the fp32 kernel.
-//   block tile 128 x 128, K-slice = one tap x 32 channels, 4 waves as 2 x 2, each wave 2 x 2 MFMA 32x32 tiles;
-//   LDS (single buffer, 40 KB): hi / lo planes of A [128][32] and B [128][32] 16-bit, 80-byte row stride (conflict-free
-//   ds_read_b128 fragments: lane l reads 8 consecutive k of row l&31 at k = 8*(l>>5)); the next slice is prefetched
-//   into registers during the MFMAs and converted / stored between two barriers; 2 blocks per CU overlap each other.
+// split once per optimizer step (egz_pack_w3x3_split).  Same gather modes and epilogues as the fp32 kernel.
+// Two kernels:
+//   conv3x3_igemm_x3_kernel   per-tap gather (all modes: plain, upsample fold / phase, upsampled dgrad): block tile
+//       128 x {128, 64}, K-slice = one tap x 32 channels, 4 waves as 2 x 2; software-pipelined (double-buffered LDS, two
+//       register sets, conversion in the MFMA shadow), buffer-load gathers with per-row tap masks, swizzled 64-byte rows.
+//   conv3x3_igemm_x3h_kernel  halo tile (plain convs): the input halo of a compact 128-pixel tile is staged ONCE per
+//       32-channel block and the nine taps read it at shifted addresses; weights by LDS-DMA; fragments one k-step ahead.
 #include "egz_common.h"
 #include <type_traits>
 

@@ -230,9 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Split-half (bf16 x3) form of the 9-tap fused kernel: x and dY stay fp32 in HBM and are split into bf16 hi + lo
+// Split-half form of the 9-tap fused kernel (operand type T = bf16, the default, or f16 with abs-max scaled dY -- see
+// W16 below): x and dY stay fp32 in HBM and are split into 16-bit hi + lo
 // halves while they are staged into LDS; every product is  x*dy ~= xh*dh + xh*dl + xl*dh  on
-// v_mfma_f32_32x32x16_bf16 (16x the rate of the exact-f32 MFMA, 3 per 16 pixels instead of 8), fp32 accumulate.
+// v_mfma_f32_32x32x16_{bf16,f16} (16x the rate of the exact-f32 MFMA, 3 per 16 pixels instead of 8), fp32 accumulate.
 // The reduction dimension of this GEMM is the PIXEL, but both operands are channel-contiguous in HBM and in LDS
 // ([pixel][channel]); the 16-bit MFMA wants 8 consecutive reduction elements per lane, i.e. the transposed image.
 // gfx950's ds_read_b64_tr_b16 does that transpose inside the LDS read: each 16-lane group hands in sixteen 8-byte
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_kernel(
 // the pixel -> halo mapping free, so the stage is a 2-D patch of R x WD pixels (R * WD = 32) with an (R+2) x (WD+2)
 // halo, the nine taps are immediate offsets off ONE per-lane base address, and row widths that are not a
 // multiple of 16 (28, 14) run as masked WD = 32 / 16 patches (zero dY beyond the row end).
-//   LDS image: [plane hi/lo][channel half][halo pixel][32 ch] bf16 -- a wave only touches the 64-byte rows of its own
+//   LDS image: [plane hi/lo][channel half][halo pixel][32 ch] 16-bit -- a wave only touches the 64-byte rows of its own
 //   channel half, and the four pixel rows a 16-lane group reads tile one 256-byte bank row exactly.
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 //   dWeff[py][px][a][b][c][k] = sum_{b,y,x} X[y+a+py-1][x+b+px-1][c] * dY[2y+py][2x+px][k]      (LOW-res y, x)
 // One block = one 64(c) x 64(k) tile of BOTH column phases of one row phase py (blockIdx.z): 8 accumulators per wave
 // (px, a, b).  A stage is an R x WD patch of low-res pixels: its (R+1) x (WD+2) input halo and the two stride-2 dY
-// sub-grids (px = 0, 1) are split into bf16 hi / lo and staged once; the A fragment at halo column offset px + b is
+// sub-grids (px = 0, 1) are split into 16-bit hi / lo halves and staged once; the A fragment at halo column offset px + b is
 // shared by the two (px, b) pairs that reach it.  Same LDS image / ds_read_b64_tr_b16 addressing as
 // conv3x3_wgrad9_x3_kernel; partial tiles in the [split][16 phase-taps][C][K] layout of wgrad_reduce_ups_kernel.
 template <typename T, int R, int WD>
@@ -1104,7 +1105,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
             return 0;
         }
     }
-    if (const int WD = pick_patch_x3(W, C, K, flags)) {   // split-half bf16 x3 on the 16-bit MFMA path
+    if (const int WD = pick_patch_x3(W, C, K, flags)) {   // split-half (bf16 x3 / f16 x3) on the 16-bit MFMA path
         const long np = npatch_x3(B, H, W, WD);
         const int S = pick_splits9(np, C, K, X3_BLOCKS);
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
