@@ -172,10 +172,12 @@ class AT():
                 del features_blobs[:]
                 output = self.model(input_s, input_t)                 # (1,1,224,224)
                 feature_s = features_blobs[0]                          # (1,512,14,14)
-                outim = np.uint8(255 * output.cpu().numpy().squeeze())
+                quant = (255 * output).to(torch.uint8)                  # np.uint8(255 * x): truncation, on the device
+                outim = quant.cpu().numpy().squeeze()
                 imwrite(os.path.join(pred_folder, currname), outim)
                 # computeAAEAUC's third value is the GROUND-TRUTH arg-max, used as the "predicted" gaze point
-                _, _, pred_gp = computeAAEAUC(outim, target.cpu().numpy().squeeze())
+                # (AT.py:221-224); evaluated on the quantised map like the reference, by the device kernel
+                _, _, pred_gp = computeAAEAUC(quant.float(), target)
                 if self.align:
                     cfeature = crop_align_feature(feature_s, pred_gp, self.crop_size).contiguous()
                     chn_weight = cfeature.view(cfeature.size(0), cfeature.size(1), -1).mean(2)  # (1,512)
