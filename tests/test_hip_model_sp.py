@@ -269,3 +269,22 @@ def test_no_cpu_fallback():
     model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20))
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 32, 32), torch.zeros(1, 20, 32, 32))
+
+
+def test_train_step_is_bitwise_deterministic():
+    """No atomics anywhere on the path (split-K partials, BN statistics, abs-max and bias sums all reduce in a fixed
+    order) and stream concurrency only reorders independent kernels: two runs of the same step agree bit for bit."""
+    from egaze_amd.floss import floss
+    runs = []
+    for _ in range(2):
+        model, _ = build_model()
+        x_s, x_t, gt, _ = synth.synth_sp_batch(2, 64, seed=9)
+        model.train()
+        out = model(x_s.to(DEV), x_t.to(DEV))
+        loss = floss()(out, gt.to(DEV).view(out.size()))
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((out.detach().cpu(), loss.item(), {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}))
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
