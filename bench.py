@@ -210,7 +210,9 @@ def main():
                                    "algorithmic MAC costs 3 MFMA MACs, priced against the dense 16-bit MFMA peak)" if split else
                                    "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
                                    "launches, exact-f32 MFMA)") +
-                                  "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it",
+                                  "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
+                                  "timed with HIP events on the launch stream with stream concurrency off, as in "
+                                  "profiles/r01_bench_b32_kernel_stats_split_streams0.txt",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": traffic,
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
