@@ -65,14 +65,36 @@ def main():
     ap.add_argument("--no-at", action="store_true", help="leave the AT (lstmnet T=16, B=32) training step out")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the untimed exact-f32-mode step timing")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU.
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus}: launching {args.gpus} ranks under torch.distributed.run", file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    backend = os.environ.get("EGAZE_DIST_BACKEND", "nccl")       # "gloo": functional DP test on a 1-GPU box
-    if os.environ.get("EGAZE_SINGLE_DEVICE") == "1":
-        local = 0
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    backend = os.environ.get("EGAZE_DIST_BACKEND", "nccl")       # "gloo": functional DP run, e.g. N ranks on a 1-GPU box
+    ndev = torch.cuda.device_count()
+    shared_device = os.environ.get("EGAZE_SINGLE_DEVICE") == "1"
+    if shared_device:
+        local = 0                 # all ranks on GPU 0: a FUNCTIONAL data-parallel run (needs EGAZE_DIST_BACKEND=gloo)
+        if backend == "nccl":
+            raise SystemExit("EGAZE_SINGLE_DEVICE=1 needs EGAZE_DIST_BACKEND=gloo (RCCL wants one device per rank)")
+    elif world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks but {ndev} visible GPU(s); set EGAZE_SINGLE_DEVICE=1 "
+                         f"EGAZE_DIST_BACKEND=gloo for a functional run of the data-parallel path on one GPU")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -83,6 +105,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+        if rank == 0:
+            print(f"[bench] {'RCCL' if backend == 'nccl' else backend} ranks: {dist.get_world_size()}"
+                  f"{' (all on one GPU: functional run)' if shared_device else ''}", file=sys.stderr, flush=True)
 
     import egaze_amd  # noqa: F401
     import egaze_amd.hipops as H
@@ -174,6 +200,7 @@ def main():
 
     roofline = None
     breakdown = None
+    f32_ms = None
     if not args.no_roofline:
         # Every rank runs these two extra (untimed) steps -- the gradient all-reduce inside step() is a collective --
         # but only rank 0 reports.  Per-kernel HIP-event timing needs the kernels serialised: the multi-stream
@@ -218,6 +245,20 @@ def main():
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
                         "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
                         "algorithmic_flop_per_step": ig["flops"]}
+        if split and not args.no_f32_leg:
+            # the same step on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), untimed leg, reported beside the headline
+            H.PRECISION = "f32"
+            for _ in range(2):
+                step()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            f32_ms = (time.perf_counter() - t1) / 3 * 1e3
+            H.PRECISION = "split"
         tot = sum(v["ms"] for v in prof.values())
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         breakdown["_sum_kernel_ms"] = round(tot, 3)
@@ -235,8 +276,9 @@ def main():
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("f32 (conv fwd: f16x3 split-half MFMA; dgrad and wgrad: bf16x3 split-half MFMA; fp32 accumulate; "
-                      "everything else exact f32)" if H.PRECISION == "split" else "f32"),
+            "dtype": (f"f32 (conv fwd: f16x3 split-half MFMA, 22 significant bits per operand; dgrad and wgrad: "
+                      f"{'f16x3 (22 bits, abs-max scaled)' if H.GRAD_SPLIT == 'f16' else 'bf16x3 (16 bits)'} split-half MFMA; "
+                      f"fp32 accumulate; everything else exact f32)" if H.PRECISION == "split" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"SP two-stream (RGB + 10-pair flow stack) forward + floss + backward + Adam, "
                                    f"batch {args.batch}/GPU, {args.size}x{args.size}, train-mode BN, all "
@@ -244,13 +286,19 @@ def main():
                                    + (f"; + AT lstmnet forward + MSE + backward + Adam over T=16, B={args.batch} "
                                       f"512-vectors per step" if use_at else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "precision": ("split-half f16x3 / bf16x3 MFMA for conv fwd / dgrad / wgrad (fp32-class accuracy, "
-                                     "gaze map within 1e-5 of the reference)"
+                       "collective": (None if world == 1 else
+                                      f"gradient all-reduce, backend {'rccl' if backend == 'nccl' else backend}, "
+                                      f"{'ALL RANKS ON ONE GPU (functional run, not a scaling number)' if shared_device else 'one GPU per rank'}"),
+                       "precision": (f"split-half f16x3 MFMA for conv fwd, {'f16x3' if H.GRAD_SPLIT == 'f16' else 'bf16x3'} "
+                                     "for dgrad / wgrad (fp32-class accuracy, gaze map within 1e-5 of the reference; "
+                                     "8-step training trajectory within 1e-3 of the CPU reference path, tests/test_hip_model_sp.py)"
                                      if H.PRECISION == "split" else "exact f32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "roofline": roofline, "cpu_baseline": cpu,
             "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
             "step_hbm_frac": BYTES_PER_FRAME * args.batch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "loss": last_loss, "kernel_ms_breakdown": breakdown,
+            "extra": {"f32_ms_per_step": f32_ms,
+                      "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps"},
         }
         print(json.dumps(out))
     if dist is not None and os.environ.get("EGAZE_DP_CHECK") == "1":

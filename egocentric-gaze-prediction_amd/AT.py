@@ -19,7 +19,8 @@ from .models.LSTMnet import lstmnet
 from .models.model_SP import model_SP
 from .optim import FusedAdam
 from .SP import _progress
-from .utils import (AverageMeter, cfg, computeAAEAUC, generalException, make_layers, plot_loss, repackage_hidden)
+from .utils import (AverageMeter, cfg, computeAAEAUC, generalException, make_layers, owned_state_dict, plot_loss,
+                    repackage_hidden)
 
 hook_name = 'features_s'
 features_blobs = []
@@ -146,12 +147,12 @@ class AT():
             l = self.trainLSTM()
             loss_train.append(l)
             if l < prevt:
-                torch.save(self.lstm.state_dict(), os.path.join(self.save_path, self.save_name))
+                torch.save(owned_state_dict(self.lstm), os.path.join(self.save_path, self.save_name))
             l = self.testLSTM()
             loss_val.append(l)
             if l < prev:
                 prev = l
-                torch.save(self.lstm.state_dict(), os.path.join(self.save_path, 'val' + self.save_name))
+                torch.save(owned_state_dict(self.lstm), os.path.join(self.save_path, 'val' + self.save_name))
             plot_loss(loss_train, loss_val, os.path.join(self.save_path, self.lstm_save_img))
         print('lstm training finished!')
 

@@ -11,7 +11,7 @@ from .data.lateDataset import lateDataset
 from .floss import BCELoss, floss
 from .models.late_fusion import late_fusion
 from .optim import FusedAdam
-from .utils import AverageMeter, computeAAEAUC, plot_loss
+from .utils import AverageMeter, computeAAEAUC, owned_state_dict, plot_loss
 from .SP import _progress
 
 
@@ -48,12 +48,15 @@ class LF():
         listTrainFeats, listValFeats = _split(late_feat_path, val_name, task)
         assert(len(listTrainFeats) == len(listTrainFiles) and len(listGtFiles) > 0)
         assert(len(listValGtFiles) == len(listValFiles))
-        self.train_loader = DataLoader(dataset=lateDataset(late_pred_path, gt_path, late_feat_path, listTrainFiles,
-                                                           listGtFiles, listTrainFeats),
-                                       batch_size=batch_size, shuffle=True, num_workers=0, pin_memory=True)
-        self.val_loader = DataLoader(dataset=lateDataset(late_pred_path, gt_path, late_feat_path, listValFiles,
-                                                         listValGtFiles, listValFeats),
-                                     batch_size=batch_size, shuffle=False, num_workers=0, pin_memory=True)
+        train_set = lateDataset(late_pred_path, gt_path, late_feat_path, listTrainFiles, listGtFiles, listTrainFeats)
+        val_set = lateDataset(late_pred_path, gt_path, late_feat_path, listValFiles, listValGtFiles, listValFeats)
+        # rank-sharded under torch.distributed (dp.RankShardSampler); the reference's loaders (LF.py:69-72) at world 1
+        self.train_sampler = dp.RankShardSampler(train_set, True, batch_size) if dp.world_size() > 1 else None
+        val_sampler = dp.RankShardSampler(val_set, False, batch_size, pad=False) if dp.world_size() > 1 else None
+        self.train_loader = DataLoader(dataset=train_set, batch_size=batch_size, shuffle=self.train_sampler is None,
+                                       sampler=self.train_sampler, num_workers=0, pin_memory=True)
+        self.val_loader = DataLoader(dataset=val_set, batch_size=batch_size, shuffle=False, sampler=val_sampler,
+                                     num_workers=0, pin_memory=True)
         self.criterion = (floss() if loss_function == 'f' else BCELoss()).to(self.device)
         self.optimizer = FusedAdam(self.model.parameters(), lr=lr)
         self.reducer = dp.attach(self.optimizer) if torch.distributed.is_initialized() else None
@@ -78,6 +81,8 @@ class LF():
                 print('Epoch: [{0}][{1}/{2}]\t''AUCAAE_late {auc.avg:.3f} ({aae.avg:.3f})\t'
                       'Loss {loss.val:.4f} ({loss.avg:.4f})\t'.format(self.epochnow, i + 1, len(loader) + 1, auc=auc,
                                                                       loss=losses, aae=aae))
+        if dp.world_size() > 1:                      # global averages so that every rank agrees on the best epoch
+            return tuple(dp.reduce_meters((losses.sum, losses.count), (auc.sum, auc.count), (aae.sum, aae.count)))
         return losses.avg, auc.avg, aae.avg
 
     def trainLate(self):
@@ -85,6 +90,7 @@ class LF():
         return self._run(self.train_loader, True, 3000)
 
     def testLate(self):
+        dp.sync_buffers(self.model)                  # train-mode BN here too (never eval()), but checkpoints are rank 0's
         with torch.no_grad():
             return self._run(self.val_loader, False, 1000)
 
@@ -93,20 +99,26 @@ class LF():
         trainprev, valprev, loss_train, loss_val = 999, 999, [], []
         for epoch in range(self.num_epoch):
             self.epochnow = epoch
+            if self.train_sampler is not None:
+                self.train_sampler.set_epoch(epoch)
             loss, auc, aae = self.trainLate()
             loss_train.append(loss)
             print('training, auc is %5f, aae is %5f' % (auc, aae))
             if loss < trainprev:
-                torch.save({'state_dict': self.model.state_dict(), 'loss': loss, 'auc': auc, 'aae': aae},
-                           os.path.join(self.save_path, self.save_name))
+                if dp.is_main():                      # rank 0 owns the files (LF.py:144-153)
+                    torch.save({'state_dict': owned_state_dict(self.model), 'loss': loss, 'auc': auc, 'aae': aae},
+                               os.path.join(self.save_path, self.save_name))
                 trainprev = loss
             loss, auc, aae = self.testLate()
             loss_val.append(loss)
-            plot_loss(loss_train, loss_val, os.path.join(self.save_path, self.late_save_img))
+            if dp.is_main():
+                plot_loss(loss_train, loss_val, os.path.join(self.save_path, self.late_save_img))
             if loss < valprev:
-                torch.save({'state_dict': self.model.state_dict(), 'loss': loss, 'auc': auc, 'aae': aae},
-                           os.path.join(self.save_path, 'val' + self.save_name))
+                if dp.is_main():
+                    torch.save({'state_dict': owned_state_dict(self.model), 'loss': loss, 'auc': auc, 'aae': aae},
+                               os.path.join(self.save_path, 'val' + self.save_name))
                 valprev = loss
+            dp.barrier()
             print('testing, auc is %5f, aae is %5f' % (auc, aae))
         print('LF module training finished!')
 

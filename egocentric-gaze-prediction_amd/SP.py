@@ -15,7 +15,8 @@ from .floss import BCELoss, floss
 from .models.model_SP import model_SP
 from .optim import FusedAdam
 from .data.STdatas import stage_batch
-from .utils import (AverageMeter, cfg, change_key_names, computeAAEAUC, make_layers, plot_loss, save_checkpoint)
+from .utils import (AverageMeter, cfg, change_key_names, computeAAEAUC, make_layers, owned_state_dict, plot_loss,
+                    save_checkpoint)
 
 VGG16_BN_URL = 'https://download.pytorch.org/models/vgg16_bn-6c64b313.pth'
 
@@ -52,10 +53,14 @@ class SP():
         self.loss_function, self.num_epoch, self.batch_size = loss_function, num_epoch, batch_size
         self.device = torch.device('cuda:' + device)
         self.pretrained_spatial, self.pretrained_temporal = pretrained_spatial, pretrained_temporal
-        self.STTrainLoader = DataLoader(dataset=traindata, batch_size=batch_size, shuffle=True, num_workers=1,
-                                        pin_memory=True)
-        self.STValLoader = DataLoader(dataset=valdata, batch_size=batch_size, shuffle=False, num_workers=1,
-                                      pin_memory=True)
+        # one process per GPU: every rank draws a disjoint 1/world share of each epoch (dp.RankShardSampler); at world 1
+        # these are exactly the reference's loaders (SP.py:34-35)
+        self.train_sampler = dp.RankShardSampler(traindata, True, batch_size) if dp.world_size() > 1 else None
+        val_sampler = dp.RankShardSampler(valdata, False, batch_size, pad=False) if dp.world_size() > 1 else None
+        self.STTrainLoader = DataLoader(dataset=traindata, batch_size=batch_size, shuffle=self.train_sampler is None,
+                                        sampler=self.train_sampler, num_workers=1, pin_memory=True)
+        self.STValLoader = DataLoader(dataset=valdata, batch_size=batch_size, shuffle=False, sampler=val_sampler,
+                                      num_workers=1, pin_memory=True)
         in_channels = 20
         self.model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], in_channels))
         self.epochnow = 0
@@ -130,6 +135,7 @@ class SP():
         return losses.avg
 
     def testSP(self):
+        dp.sync_buffers(self.model)                 # all ranks validate rank 0's BN running statistics
         self.model.eval()
         batch_time, losses, auc, aae = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
         end = time.time()
@@ -149,19 +155,30 @@ class SP():
                     print('Test: [{0}/{1}]\t''Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
                           'Loss {loss.val:.4f} ({loss.avg:.4f})\t'.format(i, len(self.STValLoader),
                                                                           batch_time=batch_time, loss=losses))
-        print('AUC: {0}\t AAE: {1}'.format(auc.avg, aae.avg))
-        return losses.avg, auc.avg, aae.avg
+        if dp.world_size() > 1:                      # global averages: every rank takes the same 'best epoch' decision
+            loss_avg, auc_avg, aae_avg = dp.reduce_meters((losses.sum, losses.count), (auc.sum, auc.count),
+                                                          (aae.sum, aae.count))
+        else:
+            loss_avg, auc_avg, aae_avg = losses.avg, auc.avg, aae.avg
+        if dp.is_main():
+            print('AUC: {0}\t AAE: {1}'.format(auc_avg, aae_avg))
+        return loss_avg, auc_avg, aae_avg
 
     def train(self):
         train_loss, val_loss, best_loss = [], [], 100
         for epoch in range(self.epochnow, self.num_epoch):
             self.epochnow = epoch
+            if self.train_sampler is not None:
+                self.train_sampler.set_epoch(epoch)
             train_loss.append(self.trainSP())
             loss1, auc1, aae1 = self.testSP()
             val_loss.append(loss1)
-            plot_loss(train_loss, val_loss, os.path.join(self.save_path, self.loss_save))
+            if dp.is_main():                         # rank 0 owns the files (SP.py:203-208)
+                plot_loss(train_loss, val_loss, os.path.join(self.save_path, self.loss_save))
             if loss1 < best_loss:
                 best_loss = loss1
-                save_checkpoint({'epoch': epoch, 'arch': 'SP', 'state_dict': self.model.state_dict(),
-                                 'optimizer': self.optimizer.state_dict(), 'auc': auc1, 'aae': aae1},
-                                self.save_name, self.save_path)
+                if dp.is_main():
+                    save_checkpoint({'epoch': epoch, 'arch': 'SP', 'state_dict': owned_state_dict(self.model),
+                                     'optimizer': self.optimizer.state_dict(), 'auc': auc1, 'aae': aae1},
+                                    self.save_name, self.save_path)
+            dp.barrier()

@@ -105,3 +105,84 @@ def attach(optimizer, bucket_bytes: int = 25 * 1024 * 1024, group=None) -> GradR
         from . import hipops
         hipops.bump_weight_epoch()          # parameters were overwritten by the broadcast
     return red
+
+
+# ----------------------------------------------------------------------------- rank helpers for the drivers
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_main() -> bool:
+    """Rank 0 writes checkpoints / plots / extracted files (reference sites SP.py:205-208, LF.py:144-153, AT.py:189-195)."""
+    return rank() == 0
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
+class RankShardSampler(torch.utils.data.Sampler):
+    """Shards a dataset over the ranks: rank r takes indices r, r+world, ... of a (per-epoch seeded) permutation.
+
+    The reference's loaders are ``DataLoader(shuffle=True)`` (SP.py:34, LF.py:69) on one GPU; with one process per GPU
+    every rank must see a disjoint 1/world share and -- because the gradient all-reduce is a collective -- the SAME
+    number of minibatches, so the permutation is padded by wrapping around to a multiple of world * batch_size
+    (``drop_last=False`` semantics; at world == 1 nothing is padded and the order is a plain shuffle).  Validation
+    loops hold no collective, so they shard with ``pad=False``: no sample is counted twice."""
+
+    def __init__(self, dataset, shuffle: bool, batch_size: int = 1, seed: int = 0, pad: bool = True,
+                 world: Optional[int] = None, rank_: Optional[int] = None):
+        self.n = len(dataset)
+        self.shuffle, self.seed, self.epoch = shuffle, seed, 0
+        self.world = world_size() if world is None else world
+        self.rank = rank() if rank_ is None else rank_
+        # pad=False (validation: no collective inside the loop): plain stride, ranks may differ by one sample
+        unit = self.world * max(1, batch_size) if (self.world > 1 and pad) else 1
+        self.total = (self.n + unit - 1) // unit * unit
+        self.num_samples = len(range(self.rank, self.total, self.world))
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.num_samples
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            order = torch.randperm(self.n, generator=g).tolist()
+        else:
+            order = list(range(self.n))
+        if self.n and self.total > self.n:
+            order = (order * (self.total // self.n + 1))[:self.total]
+        return iter(order[self.rank:self.total:self.world])
+
+
+def reduce_meters(*pairs):
+    """[(sum, count), ...] summed over the ranks -> list of global averages: every rank then takes the same
+    'is this the best epoch' decision (reference: SP.py:203-208, LF.py:141-153)."""
+    vals = [float(v) for pr in pairs for v in pr]
+    if world_size() > 1:
+        t = torch.tensor(vals, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        vals = t.tolist()
+    return [vals[2 * i] / max(vals[2 * i + 1], 1e-30) for i in range(len(pairs))]
+
+
+def sync_buffers(module: torch.nn.Module):
+    """Rank 0's BatchNorm running statistics to every rank (training keeps them per rank like the single-GPU reference
+    would; validation and checkpoints use rank 0's, so all ranks evaluate the same model)."""
+    if world_size() > 1:
+        for b in module.buffers():
+            if b.is_cuda and dist.get_backend() != "nccl":
+                h = b.detach().cpu()
+                dist.broadcast(h, src=0)
+                b.copy_(h)
+            else:
+                dist.broadcast(b, src=0)

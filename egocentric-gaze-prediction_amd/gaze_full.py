@@ -63,10 +63,14 @@ def main(argv=None):
     from .LF import LF
     from .SP import SP
     from .data.STdatas import STDataset
+    from . import dp
     if 'LOCAL_RANK' in os.environ and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import datetime
         args.device = os.environ['LOCAL_RANK']
         torch.cuda.set_device(int(args.device))
-        torch.distributed.init_process_group('nccl')
+        # the AT stage below is sequential (rank 0 only) and takes hours: the other ranks wait at a barrier
+        torch.distributed.init_process_group(os.environ.get('EGAZE_DIST_BACKEND', 'nccl'),
+                                             timeout=datetime.timedelta(days=7))
     listFolders = sorted(os.listdir(args.flowPath))
     listGtFiles, listValGtFiles = _split(args.gtPath, args.val_name)
     print('num of training samples: ', len(listGtFiles))
@@ -85,19 +89,24 @@ def main(argv=None):
                 pretrained_temporal=args.pretrained_temporal, traindata=STTrainData, valdata=STValData)
         sp.train()
         args.pretrained_model = os.path.join(args.save_path, args.save_sp)
-    att = AT(pretrained_model=args.pretrained_model, pretrained_lstm=args.pretrained_lstm,
-             extract_lstm=args.extract_lstm, crop_size=args.crop_size, num_epoch_lstm=args.num_epoch_lstm,
-             lstm_save_img=args.lstm_save_img, save_path=args.save_path, save_name=args.save_lstm, device=args.device,
-             lstm_data_path=args.extract_lstm_path, traindata=STTrainData, valdata=STValData, task=args.task,
-             align=args.align)
-    if args.train_lstm:
-        att.train()
-    if args.extract_late:
-        if not args.train_lstm:
-            att.reload_LSTM(os.path.join(args.save_path, args.save_lstm))
-        for data in (STValData, STTrainData):
-            att.extract_late(DataLoader(dataset=data, batch_size=1, shuffle=False, num_workers=1, pin_memory=True),
-                             args.extract_late_pred_folder, args.extract_late_feat_folder)
+    # AT is a batch-1, sequence-1 recurrence whose hidden state is carried from sample to sample across the whole
+    # dataset (AT.py:127-145, 199-253): it does not shard without changing its results, so under torch.distributed it
+    # runs on rank 0 only (which also owns every file it writes) while the other ranks wait.
+    if dp.is_main():
+        att = AT(pretrained_model=args.pretrained_model, pretrained_lstm=args.pretrained_lstm,
+                 extract_lstm=args.extract_lstm, crop_size=args.crop_size, num_epoch_lstm=args.num_epoch_lstm,
+                 lstm_save_img=args.lstm_save_img, save_path=args.save_path, save_name=args.save_lstm,
+                 device=args.device, lstm_data_path=args.extract_lstm_path, traindata=STTrainData, valdata=STValData,
+                 task=args.task, align=args.align)
+        if args.train_lstm:
+            att.train()
+        if args.extract_late:
+            if not args.train_lstm:
+                att.reload_LSTM(os.path.join(args.save_path, args.save_lstm))
+            for data in (STValData, STTrainData):
+                att.extract_late(DataLoader(dataset=data, batch_size=1, shuffle=False, num_workers=1, pin_memory=True),
+                                 args.extract_late_pred_folder, args.extract_late_feat_folder)
+    dp.barrier()
     lf = LF(pretrained_model=args.pretrained_late, save_path=args.save_path, late_save_img=args.late_save_img,
             save_name=args.save_late, device=args.device, late_pred_path=args.extract_late_pred_folder,
             num_epoch=args.num_epoch, late_feat_path=args.extract_late_feat_folder, gt_path=args.gtPath,

@@ -147,17 +147,17 @@ _PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad",
             "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1, 2), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1, 3)}
 
 # Arithmetic of the wide convolutions (GEMM output channels % 128 == 0):
-#   "split" (default) error-compensated split-half operands on the 16-bit MFMA path: f16 x3 forward (measured err
-#           5e-7 of max|ref| per layer vs 8.6e-7 for the exact-f32 MFMA kernel), bf16 x3 data gradient (err ~5e-6,
-#           fp32 exponent range for tiny gradients)  -- conv3x3_igemm_x3.hip.  Weight gradients stay exact-f32.
+#   "split" (default) error-compensated split-half operands on the 16-bit MFMA path: f16 x3 (22 significant bits;
+#           measured err 5e-7 of max|ref| per layer vs 8.6e-7 for the exact-f32 MFMA kernel) in the forward pass, the
+#           data gradient and the weight gradient (GRAD_SPLIT below) -- conv3x3_igemm_x3.hip, conv3x3_wgrad.hip.
 #   "f32"   exact-f32 MFMA everywhere (v_mfma_f32_32x32x2_f32); EGAZE_PRECISION=f32 selects it.
 PRECISION = _os.environ.get("EGAZE_PRECISION", "split")
 # Operand type of the split-half GRADIENT kernels (data and weight gradients):
-#   "bf16" (default) bf16 x3, 16 significant bits (5e-6 per layer), fp32 exponent range, no scaling;
-#   "f16"  f16 x3, 22 bits (3e-7 per layer, the exact-f32 kernels' own level): the gradient producers (BN / ReLU / fusion
-#          backward) also emit max |dy| and the conv backward scales dy by the matching power of two.  Measured ~2.5 %
-#          slower per step and no different at whole-model level (subgradient flips dominate), hence opt-in.
-GRAD_SPLIT = _os.environ.get("EGAZE_GRAD_SPLIT", "bf16")
+#   "f16" (default) f16 x3, 22 significant bits (3e-7 per layer, the exact-f32 kernels' own level -- the reference's
+#          arithmetic class): the gradient producers (BN / ReLU / fusion backward) also emit max |dy| and the conv backward
+#          scales dy by the matching power of two so that gradients of 1e-3 ... 1e-13 stay representable;
+#   "bf16" bf16 x3, 16 significant bits (5e-6 per layer), fp32 exponent range, no scaling: ~3 % faster per step, opt-in.
+GRAD_SPLIT = _os.environ.get("EGAZE_GRAD_SPLIT", "f16")
 F32, F16X3, BF16X3 = 0, 1, 2
 
 

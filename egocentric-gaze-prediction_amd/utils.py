@@ -131,6 +131,13 @@ def init_like_reference(root: nn.Module):
             m.bias.data.zero_()
 
 
+def owned_state_dict(module):
+    """``module.state_dict()`` with every tensor cloned: the optimizer re-homes all parameters into ONE flat buffer
+    (optim.FusedAdam), and torch.save of views would write that shared storage and make every parameter of a re-loaded
+    checkpoint alias one buffer.  Checkpoints written by the drivers are storage-independent like the reference's."""
+    return collections.OrderedDict((k, v.detach().clone()) for k, v in module.state_dict().items())
+
+
 def save_checkpoint(state, filename, save_path):
     torch.save(state, os.path.join(save_path, filename))
 

@@ -90,3 +90,25 @@ def test_grad_reducer_two_ranks():
     for rank in range(world):
         for step in range(2):
             assert torch.allclose(res[rank][2][step], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_rank_shard_sampler_partitions_and_pads():
+    """Every rank sees a disjoint share, the same number of minibatches (the all-reduce is a collective), a new
+    order per epoch; pad=False (validation) never repeats a sample."""
+    sys.path.insert(0, ROOT)
+    import egaze_amd  # noqa: F401
+    from egaze_amd.dp import RankShardSampler
+    data = list(range(103))
+    for world, bs in ((2, 8), (8, 4), (3, 5)):
+        sam = [RankShardSampler(data, True, bs, seed=7, world=world, rank_=r) for r in range(world)]
+        shares = [list(s) for s in sam]
+        assert len({len(s) for s in shares}) == 1 and len(shares[0]) % bs == 0 and len(sam[0]) == len(shares[0])
+        flat = [i for s in shares for i in s]
+        assert set(flat) == set(data) and len(flat) - len(data) < world * bs          # only the wrap-around padding repeats
+        for s in sam:
+            s.set_epoch(1)
+        assert [list(s) for s in sam] != shares
+        val = [list(RankShardSampler(data, False, bs, pad=False, world=world, rank_=r)) for r in range(world)]
+        assert sorted(i for s in val for i in s) == data
+    one = RankShardSampler(data, False, 8, world=1, rank_=0)
+    assert list(one) == data

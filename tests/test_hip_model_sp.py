@@ -143,7 +143,8 @@ def test_model_sp_train_step(tag, size):
 # seeded inputs with two criteria:
 #   * every seed, every tensor: direction and size agree (cosine >= 0.995, norm within 3 %) -- a formula, layout or
 #     indexing bug breaks this on every input, a subgradient flip does not;
-#   * at least one seed is flip-free and then matches tightly (98 % of the entries within 2e-3 / the fp32-class bound).
+#   * at least two of the three seeds are flip-free and then match tightly (98 % of the entries within 2e-3 / the
+#     fp32-class bound); the test prints which.
 GRAD_SEEDS = (5, 6, 7)
 
 
@@ -184,8 +185,8 @@ def _full_grads_small(seed):
 def test_model_sp_vs_oracle_full_grads_small():
     """Every gradient tensor element-wise against the CPU oracle at 32x32 (seconds on CPU)."""
     results = [_full_grads_small(seed) for seed in GRAD_SEEDS]
-    print("full-grads:", results)
-    assert any(ok for ok, _ in results), results
+    print("full-grads (tight on seeds %s):" % [r[1][0] for r in results if r[0]], results)
+    assert sum(ok for ok, _ in results) >= 2, results
 
 
 def _grads_vs_fp64(seed):
@@ -230,8 +231,8 @@ def test_model_sp_grads_vs_fp64():
     """Accuracy, not just agreement: the same train step in fp64 on the CPU oracle is the truth; the HIP
     path's gradient error must be of the same size as the fp32 CPU reference path's own error."""
     results = [_grads_vs_fp64(seed) for seed in GRAD_SEEDS]
-    print("grads-vs-fp64:", results)
-    assert any(ok for ok, _ in results), results
+    print("grads-vs-fp64 (tight on seeds %s):" % [r[1][0] for r in results if r[0]], results)
+    assert sum(ok for ok, _ in results) >= 2, results
 
 
 def test_floss_golden_bit_exact_weights():
@@ -288,3 +289,69 @@ def test_train_step_is_bitwise_deterministic():
     assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
     for k in runs[0][2]:
         assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+
+
+# ----------------------------------------------------------------------------- multi-step training trajectory
+TRAJ_STEPS, TRAJ_SIZE, TRAJ_B, TRAJ_LR = 8, 64, 4, 1e-4
+_TRAJ_ORACLE = {}
+
+
+def _oracle_trajectory():
+    """TRAJ_STEPS literal SP.trainSP iterations (SP.py:126-138) on the CPU oracle, fresh batch per step."""
+    if not _TRAJ_ORACLE:
+        sd = {k: v.clone() for k, v in synth.synth_state_dict(O.sp_shapes(), seed=1, head_gain=0.25).items()}
+        opt, losses = {}, []
+        for i in range(TRAJ_STEPS):
+            x_s, x_t, gt, _ = synth.synth_sp_batch(TRAJ_B, TRAJ_SIZE, seed=40 + i)
+            loss, _, _ = O.sp_train_step(sd, opt, i + 1, x_s, x_t, gt, TRAJ_LR)
+            losses.append(loss.item())
+        x_s, x_t, _, _ = synth.synth_sp_batch(TRAJ_B, TRAJ_SIZE, seed=99)
+        with torch.no_grad():
+            ev, _ = O.sp_forward(sd, x_s, x_t, training=False)
+        _TRAJ_ORACLE.update(losses=losses, sd=sd, eval_out=ev.numpy())
+    return _TRAJ_ORACLE
+
+
+@pytest.mark.parametrize("precision,grad_split", [("split", "f16"), ("split", "bf16"), ("f32", "f16")])
+def test_training_trajectory_vs_oracle(precision, grad_split, monkeypatch):
+    """Does the arithmetic of the backward pass DRIFT over a run of Adam steps?  Eight training steps at lr 1e-4 (weights
+    move by up to 8e-4 against a typical |w| of 2e-2) against the same steps on the CPU oracle: loss sequence within
+    1e-3 relative, final eval-mode gaze map within the north_star's 1e-3, BN running statistics within 1e-3 -- in the
+    default mode (f16 x3 forward and gradients), with bf16 x3 gradients, and with exact-f32 MFMA."""
+    import egaze_amd.hipops as H
+    from egaze_amd.floss import floss
+    from egaze_amd.optim import FusedAdam
+    monkeypatch.setattr(H, "PRECISION", precision)
+    monkeypatch.setattr(H, "GRAD_SPLIT", grad_split)
+    want = _oracle_trajectory()
+    model, _ = build_model()
+    model.train()
+    crit = floss().to(DEV)
+    opt = FusedAdam(model.parameters(), lr=TRAJ_LR)
+    opt.zero_grad()
+    losses = []
+    for i in range(TRAJ_STEPS):
+        x_s, x_t, gt, _ = synth.synth_sp_batch(TRAJ_B, TRAJ_SIZE, seed=40 + i)
+        out = model(x_s.to(DEV), x_t.to(DEV))
+        loss = crit(out, gt.to(DEV).view(out.size()))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    lrel = [abs(a - b) / abs(b) for a, b in zip(losses, want["losses"])]
+    print(f"[{precision}/{grad_split}] loss rel dev per step:", ["%.1e" % v for v in lrel])
+    assert max(lrel) < 1e-3, (losses, want["losses"])
+    assert abs(want["losses"][-1] - want["losses"][0]) > 1e-2 * abs(want["losses"][0])     # the run did train
+    model.eval()
+    x_s, x_t, _, _ = synth.synth_sp_batch(TRAJ_B, TRAJ_SIZE, seed=99)
+    with torch.no_grad():
+        ev = model(x_s.to(DEV), x_t.to(DEV))
+    r = rel(ev.cpu().numpy(), want["eval_out"])
+    print(f"[{precision}/{grad_split}] final eval gaze map rel dev {r:.2e}")
+    assert r < TOL_MAP, r
+    sd, worst = model.state_dict(), 0.0
+    for k, v in want["sd"].items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            worst = max(worst, rel(sd[k].cpu().numpy(), v.numpy()))
+    print(f"[{precision}/{grad_split}] BN running stats worst rel dev {worst:.2e}")
+    assert worst < 1e-3, worst
