@@ -64,6 +64,8 @@ SIGNATURES = {
     "egz_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "egz_nchw_to_nhwc_pad": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, S]),
     "egz_nhwc_to_nchw": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_copy": (c_int, [P, P, c_long, S]),
+    "egz_fill_zero": (c_int, [P, c_size_t, S]),
     # --- head + losses
     "egz_conv1x1_sigmoid_fwd": (c_int, [P, P, P, P, P, c_long, c_int, S]),
     "egz_conv1x1_sigmoid_bwd_ws_bytes": (c_size_t, [c_int]),

@@ -744,3 +744,21 @@ EGZ_API int egz_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, i
     EGZ_CHECK_LAUNCH("egz_nhwc_to_nchw");
     return 0;
 }
+
+// Stream-ordered device copy / zero fill (hipMemcpyAsync / hipMemsetAsync on the caller's stream): plumbing for the
+// host side where the reference writes torch.cat((x_s, x_t), 2) (models/model_SP.py:39) and optimizer.zero_grad()
+// (SP.py:138) -- no kernels of the tensor library in the step.
+EGZ_API int egz_copy(const float* src, float* dst, long n, hipStream_t st) {
+    EGZ_CHECK_ARG(src && dst && n >= 0, "egz_copy: bad arguments");
+    if (n == 0) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    EGZ_CHECK_ARG(e == hipSuccess, "egz_copy: %s", hipGetErrorString(e));
+    return 0;
+}
+EGZ_API int egz_fill_zero(void* dst, size_t bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(dst || bytes == 0, "egz_fill_zero: null pointer");
+    if (bytes == 0) return 0;
+    hipError_t e = hipMemsetAsync(dst, 0, bytes, st);
+    EGZ_CHECK_ARG(e == hipSuccess, "egz_fill_zero: %s", hipGetErrorString(e));
+    return 0;
+}

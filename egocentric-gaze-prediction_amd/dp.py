@@ -53,7 +53,11 @@ class GradReducer:
             if flat_param is not None:
                 dist.broadcast(flat_param, src=0, group=group)       # identical replicas to start from
             for i, p in enumerate(params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                hook = self._make_hook(i)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))      # gradient came through autograd
+                sink = getattr(p, "_egz_sink", None)
+                if sink is not None:
+                    sink.hooks.append(hook)                                         # ... or was written in place
 
     def _reset(self):
         self._pending = [b[2] for b in self.buckets]

@@ -34,6 +34,15 @@ def from_nhwc(y: torch.Tensor) -> torch.Tensor:
     return y.permute(0, 3, 1, 2)
 
 
+def _finish(param, sink, grad):
+    """End of a parameter-gradient computation: with a sink the gradient already sits in the optimizer's flat buffer --
+    run the sink hooks and hand ``None`` to autograd; without one, return the tensor for autograd to accumulate."""
+    if sink is None:
+        return grad
+    H.grad_done(param)
+    return None
+
+
 def _zero_bias_grad(dy: torch.Tensor, K: int) -> torch.Tensor:
     """Gradient of a conv bias that feeds a train-mode BatchNorm.  BN subtracts the batch mean, so the loss
     does not depend on that bias: sum(dy) = scale * (sum dz - N*mean(dz) - mean(dz*xhat) * sum(xhat)) = 0
@@ -51,7 +60,9 @@ def _first_conv_on_split(C: int, K: int) -> bool:
 class ConvBNReLUPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, pool,
-                first):
+                first, out_buf=None):
+        """``out_buf``: optional (B, H', W', K) NHWC destination of the block output (model_SP hands the two encoders the
+        halves of ONE buffer so that the fusion conv reads the depth-2 stack without a concatenation copy)."""
         K, C = weight.shape[0], weight.shape[1]
         padded = first and _first_conv_on_split(C, K)
         if padded:
@@ -74,37 +85,40 @@ class ConvBNReLUPool(torch.autograd.Function):
                                  running_var, momentum, eps)
         else:
             coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
-        out = H.bn_relu_pool_fwd(y, coef, pool)
-        ctx.save_for_backward(xin, y, coef, weight)
+        out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
+        ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta)
         ctx.cfg = (training, pool, first, C, K, padded)
         return from_nhwc(out)
 
     @staticmethod
     def backward(ctx, dout):
-        xin, y, coef, weight = ctx.saved_tensors
+        xin, y, coef, weight, bias, gamma, beta = ctx.saved_tensors
         training, pool, first, C, K, padded = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path "
                                       "(SP.py:119 trains in model.train(); eval runs under torch.no_grad())")
-        dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, to_nhwc(dout), coef, pool)
         ng = ctx.needs_input_grad
+        sg, sb = H.grad_sink(gamma, ng[3]), H.grad_sink(beta, ng[4])
+        dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, to_nhwc(dout), coef, pool, out_dgamma=sg, out_dbeta=sb)
         dx = dw = db = None
-        if ng[2]:
+        sbias = H.grad_sink(bias, ng[2])           # analytically zero: the sink keeps zero_grad()'s zeros
+        if ng[2] and sbias is None:
             db = _zero_bias_grad(dy, K)
+        sw = H.grad_sink(weight, ng[1] and not padded)
         with fork("wgrad") as f:                # weight gradient || data gradient (both only read dy)
             if ng[1]:
                 if padded:
                     dw = H.conv3x3_wgrad(xin, dy)[:, :C].contiguous()      # gradient of the zero-padded channels dropped
                 else:
-                    dw = H.conv_first_wgrad(xin, dy) if first else H.conv3x3_wgrad(xin, dy)
+                    dw = H.conv_first_wgrad(xin, dy, out=sw) if first else H.conv3x3_wgrad(xin, dy, out=sw)
         if ng[0]:
             if first:
                 raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
             dt = H.conv_dtype("dgrad", C, K, dy)
             dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
         f.join(dw)
-        return (dx, dw, db, dgamma if ng[3] else None, dbeta if ng[4] else None, None, None, None, None, None,
-                None, None)
+        return (dx, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
+                _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None)
 
 
 class ConvReLU(torch.autograd.Function):
@@ -116,23 +130,25 @@ class ConvReLU(torch.autograd.Function):
         y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "ups_fwd" if ups else "fwd", dt),
                              bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
                              epi=H.EPI_BIAS_RELU, dtype=dt)
-        ctx.save_for_backward(xin, y, weight)
+        ctx.save_for_backward(xin, y, weight, bias)
         ctx.cfg = (ups, C, K)
         return from_nhwc(y)
 
     @staticmethod
     def backward(ctx, dout):
-        xin, y, weight = ctx.saved_tensors
+        xin, y, weight, bias = ctx.saved_tensors
         ups, C, K = ctx.cfg
         ng = ctx.needs_input_grad
         dx = dw = db = None
+        sbias = H.grad_sink(bias, ng[2])
         if ng[2]:
-            dy, db = H.relu_bwd_bias(y, to_nhwc(dout))
+            dy, db = H.relu_bwd_bias(y, to_nhwc(dout), out_db=sbias)
         else:
             dy = H.relu_bwd(y, to_nhwc(dout))
+        sw = H.grad_sink(weight, ng[1])
         with fork("wgrad") as f:
             if ng[1]:
-                dw = H.conv3x3_wgrad(xin, dy, ups=ups)
+                dw = H.conv3x3_wgrad(xin, dy, ups=ups, out=sw)
         if ng[0]:
             dt = H.conv_dtype("dgrad", C, K, dy)
             if ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
@@ -140,14 +156,22 @@ class ConvReLU(torch.autograd.Function):
             else:
                 dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
         f.join(dw)
-        return dx, dw, db, None
+        return dx, _finish(weight, sw, dw), _finish(bias, sbias, db), None
 
 
 class FusionBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fs, ft, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps):
         K, C = weight.shape[0], weight.shape[1]
-        x2 = torch.cat((to_nhwc(fs), to_nhwc(ft)), 0)            # depth-2 stack folded into the batch dim
+        a, b = to_nhwc(fs), to_nhwc(ft)
+        if (a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+                and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                and b.data_ptr() == a.data_ptr() + 4 * a.numel()):
+            # the encoders wrote the two halves of one buffer (model_SP.forward): the depth-2 stack, folded into the
+            # batch dim, already exists -- no concatenation copy
+            x2 = a.as_strided((2 * a.shape[0],) + tuple(a.shape[1:]), a.stride())
+        else:
+            x2 = H.stack2(a, b)
         dt = H.conv_dtype("fwd", K, C, x2)
         y2, _ = H.conv3x3_fwd(x2, H.packed_weight(weight, "fwd", dt), bias.detach() if bias is not None else None, K,
                               ups=False, epi=H.EPI_BIAS, dtype=dt)
@@ -159,33 +183,37 @@ class FusionBlock(torch.autograd.Function):
         else:
             coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(z, coef, False)
-        ctx.save_for_backward(x2, y2, z, coef, weight)
+        ctx.save_for_backward(x2, y2, z, coef, weight, bias, gamma, beta)
         ctx.cfg = (training, C, K)
         return from_nhwc(out)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, y2, z, coef, weight = ctx.saved_tensors
+        x2, y2, z, coef, weight, bias, gamma, beta = ctx.saved_tensors
         training, C, K = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path")
-        dz, dgamma, dbeta = H.bn_relu_pool_bwd(z, to_nhwc(dout), coef, False)
-        dy2 = H.pairmax_bwd(y2, dz)
         ng = ctx.needs_input_grad
+        sg, sb = H.grad_sink(gamma, ng[4]), H.grad_sink(beta, ng[5])
+        dz, dgamma, dbeta = H.bn_relu_pool_bwd(z, to_nhwc(dout), coef, False, out_dgamma=sg, out_dbeta=sb)
+        dy2 = H.pairmax_bwd(y2, dz)
         dfs = dft = dw = db = None
-        if ng[3]:
+        sbias = H.grad_sink(bias, ng[3])
+        if ng[3] and sbias is None:
             db = _zero_bias_grad(dy2, K)
+        sw = H.grad_sink(weight, ng[2])
         with fork("wgrad") as f:
             if ng[2]:
-                dw = H.conv3x3_wgrad(x2, dy2).view(weight.shape)
+                dw = H.conv3x3_wgrad(x2, dy2, out=sw).view(weight.shape)
         if ng[0] or ng[1]:
             dt = H.conv_dtype("dgrad", C, K, dy2)
             dx2 = H.conv3x3_dgrad(dy2, H.packed_weight(weight, "dgrad", dt), C, dtype=dt)
             B = dx2.shape[0] // 2
             dfs, dft = from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
         f.join(dw)
-        return (dfs, dft, dw, db, dgamma if ng[4] else None, dbeta if ng[5] else None, None, None, None, None,
-                None)
+        return (dfs, dft, _finish(weight, sw, dw), _finish(bias, sbias, db),
+                _finish(gamma, sg, dgamma if ng[4] else None), _finish(beta, sb, dbeta if ng[5] else None),
+                None, None, None, None, None)
 
 
 class HeadSigmoid(torch.autograd.Function):
@@ -193,16 +221,19 @@ class HeadSigmoid(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         xin = to_nhwc(x)
         out, _ = H.conv1x1_sigmoid_fwd(xin, H._req(weight.detach(), "weight"), bias.detach() if bias is not None else None)
-        ctx.save_for_backward(xin, out, weight)
+        ctx.save_for_backward(xin, out, weight, bias)
         B, Hh, Ww = out.shape
         return out.view(B, 1, Hh, Ww)
 
     @staticmethod
     def backward(ctx, dout):
-        xin, out, weight = ctx.saved_tensors
-        dx, dw, db = H.conv1x1_sigmoid_bwd(xin, weight.detach(), out, dout.contiguous(), need_dx=ctx.needs_input_grad[0])
-        return (from_nhwc(dx) if dx is not None else None, dw if ctx.needs_input_grad[1] else None,
-                db if ctx.needs_input_grad[2] else None)
+        xin, out, weight, bias = ctx.saved_tensors
+        ng = ctx.needs_input_grad
+        sw, sb = H.grad_sink(weight, ng[1]), H.grad_sink(bias, ng[2] and bias is not None)
+        dx, dw, db = H.conv1x1_sigmoid_bwd(xin, weight.detach(), out, dout.contiguous(), need_dx=ng[0], out_dw=sw,
+                                           out_db=sb)
+        return (from_nhwc(dx) if dx is not None else None, _finish(weight, sw, dw if ng[1] else None),
+                _finish(bias, sb, db if ng[2] else None))
 
 
 class FlossLoss(torch.autograd.Function):

@@ -92,6 +92,18 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def _out(out: Optional[torch.Tensor], shape, device) -> torch.Tensor:
+    """A kernel output: a fresh tensor, or the caller's destination (e.g. a gradient sink) viewed with that shape."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    n = 1
+    for d in shape:
+        n *= d
+    if out.numel() != n or out.dtype != torch.float32 or not out.is_contiguous() or not out.is_cuda:
+        raise RuntimeError(f"output buffer {tuple(out.shape)} / {out.dtype} does not fit {tuple(shape)} fp32 contiguous")
+    return out.view(shape)
+
+
 # ----------------------------------------------------------------------------- workspace
 _WS = {}
 
@@ -245,6 +257,47 @@ def repack_params(params) -> int:
     return len(rows)
 
 
+# ----------------------------------------------------------------------------- gradient sinks
+class GradSink:
+    """Where a parameter's gradient lands when the parameter lives in a fused optimizer's flat buffers (optim.FusedAdam):
+    the backward kernels write ``p.grad`` (a view of the flat gradient buffer) DIRECTLY and the autograd node returns
+    ``None`` for that input, so no stock ``AccumulateGrad`` add (one launch + 3 HBM passes per parameter, reference
+    SP.py:136-138) runs in the step.  torch's accumulation semantics are kept: only the FIRST gradient of a
+    ``zero_grad()`` generation is written in place; a second backward without ``zero_grad`` (or a weight used twice in one
+    graph) finds the sink taken and goes through autograd's ordinary accumulation.  ``hooks`` fire after the in-place
+    write (dp.GradReducer counts its buckets down there, as its post-accumulate-grad hook does on the autograd route)."""
+    __slots__ = ("buf", "owner", "gen_written", "hooks")
+
+    def __init__(self, buf, owner):
+        self.buf, self.owner, self.gen_written, self.hooks = buf, owner, -1, []
+
+
+def grad_sink(param, wanted: bool = True) -> Optional[torch.Tensor]:
+    """The in-place gradient destination of ``param`` for this backward pass, or None (-> return the gradient to autograd).
+    Taking the sink marks it used for the current zero_grad generation."""
+    if not wanted:
+        return None
+    sk = getattr(param, "_egz_sink", None)
+    if sk is None or not DIRECT_GRADS:
+        return None
+    gen = sk.owner.zero_gen
+    if sk.gen_written == gen:
+        return None
+    sk.gen_written = gen
+    return sk.buf
+
+
+def grad_done(param):
+    """Run the sink hooks of ``param`` (its gradient is final on the current stream)."""
+    sk = getattr(param, "_egz_sink", None)
+    if sk is not None:
+        for h in sk.hooks:
+            h(param)
+
+
+DIRECT_GRADS = _os.environ.get("EGAZE_DIRECT_GRADS", "1") != "0"      # A/B knob
+
+
 # ----------------------------------------------------------------------------- abs-max of gradient tensors
 _ABSMAX_ELEMS = [0]
 
@@ -334,11 +387,12 @@ WGRAD_SPLIT = 0x2000       # egz_conv3x3_wgrad flag: split-half arithmetic (bf16
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0,
-                  precision: Optional[str] = None) -> torch.Tensor:
+                  precision: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dw (K, C, 3, 3); ``out`` = a contiguous K*C*9 destination (a gradient sink) written instead of a fresh tensor."""
     _req(x, "x"); _req(dy, "dy")
     B, H, W, K = dy.shape
     C = x.shape[3]
-    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=x.device)
+    dw = _out(out, (K, C, 3, 3), x.device)
     flags = (1 if ups else 0) | variant_flag
     am = None
     prec = precision or PRECISION
@@ -368,11 +422,11 @@ def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
     return y, stat
 
 
-def conv_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+def conv_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(x_nchw, "x"); _req(dy, "dy")
     B, C, H, W = x_nchw.shape
     K = dy.shape[3]
-    dw = torch.empty((K, C, 3, 3), dtype=torch.float32, device=dy.device)
+    dw = _out(out, (K, C, 3, 3), dy.device)
     ws = workspace(LIB.egz_conv_first_wgrad_ws_bytes(B, H, W, C), dy.device)
     PROF.note_flops("egz_conv_first_wgrad", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv_first_wgrad(x_nchw.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, C, K, ws.data_ptr(),
@@ -402,30 +456,31 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps: float):
     return coef
 
 
-def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool) -> torch.Tensor:
+def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(y, "y")
     B, H, W, K = y.shape
-    out = torch.empty((B, H // 2, W // 2, K) if pool else (B, H, W, K), dtype=torch.float32, device=y.device)
+    out = _out(out, (B, H // 2, W // 2, K) if pool else (B, H, W, K), y.device)
     check(LIB.egz_bn_relu_pool_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), out.data_ptr(), B, H, W, K,
                                    int(pool), _stream()), "egz_bn_relu_pool_fwd")
     return out
 
 
-def bn_relu_pool_bwd(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, pool: bool):
-    """Returns (dy, dgamma, dbeta)."""
+def bn_relu_pool_bwd(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, pool: bool,
+                     out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
+    """Returns (dy, dgamma, dbeta); ``out_dgamma`` / ``out_dbeta``: K-float destinations (gradient sinks)."""
     _req(y, "y"); _req(dout, "dout")
     B, H, W, K = y.shape
     dy = torch.empty_like(y)
-    dgb = torch.empty((2, K), dtype=torch.float32, device=y.device)
+    dg, db = _out(out_dgamma, (K,), y.device), _out(out_dbeta, (K,), y.device)
     ws = workspace(LIB.egz_bn_relu_pool_bwd_ws_bytes(K), y.device)
     am = _new_absmax(y.device) if _want_absmax() else None
     check(LIB.egz_bn_relu_pool_bwd(y.data_ptr(), dout.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
-                                   coef[0].data_ptr(), coef[1].data_ptr(), dy.data_ptr(), dgb[0].data_ptr(),
-                                   dgb[1].data_ptr(), B, H, W, K, int(pool), ws.data_ptr(), ws.numel(), _p(am),
+                                   coef[0].data_ptr(), coef[1].data_ptr(), dy.data_ptr(), dg.data_ptr(),
+                                   db.data_ptr(), B, H, W, K, int(pool), ws.data_ptr(), ws.numel(), _p(am),
                                    _stream()), "egz_bn_relu_pool_bwd")
     if am is not None:
         dy._egz_absmax = am      # max |dy|, folded into the same pass: scales the f16 split of the conv backward
-    return dy, dgb[0], dgb[1]
+    return dy, dg, db
 
 
 def pairmax_fwd(y2: torch.Tensor) -> torch.Tensor:
@@ -448,6 +503,22 @@ def pairmax_bwd(y2: torch.Tensor, dz: torch.Tensor) -> torch.Tensor:
     return dy2
 
 
+def stack2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """(B, ...) + (B, ...) -> (2B, ...): the depth-2 stack of the fusion block folded into the batch dim, for callers
+    whose two maps do not already share one buffer (two stream-ordered device copies, no torch.cat kernel)."""
+    _req(a, "a"); _req(b, "b")
+    out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
+    n = a.numel()
+    check(LIB.egz_copy(a.data_ptr(), out.data_ptr(), n, _stream()), "egz_copy")
+    check(LIB.egz_copy(b.data_ptr(), out.data_ptr() + 4 * n, n, _stream()), "egz_copy")
+    return out
+
+
+def fill_zero(t: torch.Tensor):
+    """hipMemsetAsync on the current stream (zero_grad of the flat gradient buffer)."""
+    check(LIB.egz_fill_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()), "egz_fill_zero")
+
+
 def channel_stats(x: torch.Tensor) -> torch.Tensor:
     _req(x, "x")
     K = x.shape[-1]
@@ -464,13 +535,13 @@ def relu_bwd(out: torch.Tensor, dout: torch.Tensor) -> torch.Tensor:
     return dy
 
 
-def relu_bwd_bias(out: torch.Tensor, dout: torch.Tensor):
+def relu_bwd_bias(out: torch.Tensor, dout: torch.Tensor, out_db: Optional[torch.Tensor] = None):
     """ReLU backward fused with the producing conv's bias gradient: (dy, db)."""
     _req(out, "out"); _req(dout, "dout")
     K = out.shape[-1]
     rows = out.numel() // K
     dy = torch.empty_like(dout)
-    db = torch.empty((K,), dtype=torch.float32, device=out.device)
+    db = _out(out_db, (K,), out.device)
     ws = workspace(LIB.egz_relu_bwd_bias_ws_bytes(K), out.device)
     am = _new_absmax(out.device) if _want_absmax() else None
     check(LIB.egz_relu_bwd_bias(out.data_ptr(), dout.data_ptr(), dy.data_ptr(), db.data_ptr(), rows, K,
@@ -537,13 +608,13 @@ def conv1x1_sigmoid_fwd(x: torch.Tensor, w: torch.Tensor, bias, want_logits: boo
     return out, logits
 
 
-def conv1x1_sigmoid_bwd(x, w, out, dout, need_dx: bool = True):
+def conv1x1_sigmoid_bwd(x, w, out, dout, need_dx: bool = True, out_dw=None, out_db=None):
     _req(x, "x"); _req(out, "out"); _req(dout, "dout")
     C = x.shape[-1]
     M = x.numel() // C
     dx = torch.empty_like(x) if need_dx else None
-    dw = torch.empty((1, C, 1, 1), dtype=torch.float32, device=x.device)
-    db = torch.empty((1,), dtype=torch.float32, device=x.device)
+    dw = _out(out_dw, (1, C, 1, 1), x.device)
+    db = _out(out_db, (1,), x.device)
     ws = workspace(LIB.egz_conv1x1_sigmoid_bwd_ws_bytes(C), x.device)
     check(LIB.egz_conv1x1_sigmoid_bwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), dout.data_ptr(), _p(dx),
                                       dw.data_ptr(), db.data_ptr(), M, C, ws.data_ptr(), ws.numel(), _stream()),

@@ -38,12 +38,36 @@ class model_SP(nn.Module):
         self.final = nn.Sigmoid()
         self._initialize_weights()
 
+    def _stack_buffer(self, x_s, x_t):
+        """One (2B, h, w, 512) NHWC buffer whose halves the two encoders write directly: the reference's
+        ``torch.cat((x_s, x_t), 2)`` (models/model_SP.py:38-39) then costs nothing.  None when the encoders are not the
+        stock cfg['D'] stacks (their output geometry is then unknown here) -- FusionBlock copies in that case."""
+        try:
+            n_pool = sum(isinstance(m, nn.MaxPool2d) for m in self.features_s.children())
+            last = [m for m in self.features_s.children() if isinstance(m, nn.Conv2d)][-1]
+            last_t = [m for m in self.features_t.children() if isinstance(m, nn.Conv2d)][-1]
+            ok = (isinstance(self.features_s, FusedSequential) and isinstance(self.features_t, FusedSequential)
+                  and x_s.is_cuda and x_s.shape[0] == x_t.shape[0] and x_s.shape[2:] == x_t.shape[2:]
+                  and last.out_channels == last_t.out_channels and isinstance(list(self.features_s.children())[-1], nn.ReLU)
+                  and isinstance(list(self.features_t.children())[-1], nn.ReLU)
+                  and sum(isinstance(m, nn.MaxPool2d) for m in self.features_t.children()) == n_pool)
+        except Exception:
+            ok = False
+        if not ok:
+            return None
+        B, _, Hh, Ww = x_s.shape
+        return torch.empty((2 * B, Hh >> n_pool, Ww >> n_pool, last.out_channels), dtype=torch.float32, device=x_s.device)
+
     def forward(self, x_s, x_t):
+        stack = self._stack_buffer(x_s, x_t)
+        B = x_s.shape[0]
         with fork("encoder_t") as f:                     # the two encoders are independent: two HIP streams
             if f.enabled:
                 x_t.record_stream(torch.cuda.current_stream())
-            x_t = self.features_t(x_t)
-        x_s = self.features_s(x_s)                       # (B,512,h,w) channels_last; hooks fire here
+                if stack is not None:
+                    stack.record_stream(torch.cuda.current_stream())
+            x_t = self.features_t(x_t, out_buf=stack[B:] if stack is not None else None)
+        x_s = self.features_s(x_s, out_buf=stack[:B] if stack is not None else None)   # (B,512,h,w) channels_last; hooks fire here
         f.join(x_t)
         bn = self.bn
         if bn.training and bn.track_running_stats:

@@ -19,6 +19,7 @@ import os
 import torch
 
 from . import hipops as H
+from . import streams
 
 
 # One-launch refresh of all split packings after the step (hipops.repack_params).  Measured SLOWER than the lazy
@@ -56,18 +57,22 @@ class FusedAdam:
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.zero_gen = 0                 # zero_grad() generation: hipops.GradSink lets ONE in-place write through per generation
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 n = p.numel()
                 self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
                 p.grad = self.flat_g[o:o + n].view(p.shape)
+                # backward kernels write this view directly instead of returning a tensor for AccumulateGrad to add
+                p._egz_sink = H.GradSink(self.flat_g[o:o + n], self)
         H.bump_weight_epoch()
         self.pre_step_hooks = []          # dp.GradReducer registers its wait() here
 
     # -- torch.optim.Optimizer surface used by the drivers
     def zero_grad(self, set_to_none: bool = False):
-        self.flat_g.zero_()
+        H.fill_zero(self.flat_g)
+        self.zero_gen += 1
         for p, o in zip(self.params, self.offsets):         # re-attach if something dropped the views
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
@@ -76,6 +81,9 @@ class FusedAdam:
     def step(self):
         for hook in self.pre_step_hooks:
             hook()
+        # gradients are written in place by kernels on several HIP streams (encoder / wgrad helper streams, streams.py);
+        # autograd only orders the streams its own AccumulateGrad nodes ran on, so order all of them here
+        streams.join_all_into_current()
         self.step_count += 1
         H.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
                     self.eps, self.step_count, self.grad_scale)

@@ -37,14 +37,14 @@ def _bn_args(bn: nn.BatchNorm2d):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps)
 
 
-def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first: bool):
+def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first: bool, out_buf=None):
     """One fused encoder block on the HIP path; keeps BatchNorm's num_batches_tracked bookkeeping."""
     if conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.stride != (1, 1):
         raise NotImplementedError("only 3x3 / pad 1 / stride 1 convolutions are on the reference path")
     if bn.training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     g, b, rm, rv, training, mom, eps = _bn_args(bn)
-    return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first)
+    return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first, out_buf)
 
 
 class FusedSequential(nn.Sequential):
@@ -59,7 +59,9 @@ class FusedSequential(nn.Sequential):
     late-fusion stack (models/late_fusion.py:10-13).  A first conv with < 32 input channels reads the NCHW
     network input directly; every later tensor is channels_last."""
 
-    def forward(self, x, fuse_sigmoid=False):
+    def forward(self, x, fuse_sigmoid=False, out_buf=None):
+        """``out_buf``: optional NHWC destination for the output of the LAST block when that block is a conv-BN-ReLU
+        block (model_SP passes the two encoders the halves of one buffer, see functions.FusionBlock)."""
         mods = list(self.children())
         i, n = 0, len(mods)
         first, ups = True, False
@@ -77,8 +79,10 @@ class FusedSequential(nn.Sequential):
                 if ups:
                     raise NotImplementedError("upsample in front of a BatchNorm block is not on the reference path")
                 pool = i + 3 < n and isinstance(mods[i + 3], nn.MaxPool2d)
-                x = conv_bn_relu_pool(x, m, nxt, pool, first and m.in_channels < 32)
-                i += 4 if pool else 3
+                step = 4 if pool else 3
+                x = conv_bn_relu_pool(x, m, nxt, pool, first and m.in_channels < 32,
+                                      out_buf if i + step >= n else None)
+                i += step
             elif isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and isinstance(nxt, nn.ReLU):
                 x = ConvReLU.apply(x, m.weight, m.bias, ups)
                 ups = False

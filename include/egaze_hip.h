@@ -130,6 +130,10 @@ int egz_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hi
  * temporal encoder's first conv, SP.py:53, runs on the split-half kernels) */
 int egz_nchw_to_nhwc_pad(const float* in, float* out, int B, int C, int H, int W, int Cp, hipStream_t stream);
 int egz_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
+/* stream-ordered device copy of n floats / zero fill of `bytes` bytes: torch.cat of the two encoder maps
+ * (models/model_SP.py:39) when they do not already share a buffer; optimizer.zero_grad() (SP.py:138) */
+int egz_copy(const float* src, float* dst, long n, hipStream_t stream);
+int egz_fill_zero(void* dst, size_t bytes, hipStream_t stream);
 
 /* ---- nn.Conv2d(C, 1, 1) + nn.Sigmoid head (models/model_SP.py:30,32,49; models/late_fusion.py:13,15,22) */
 int egz_conv1x1_sigmoid_fwd(const float* x, const float* w, const float* bias, float* out, float* logits, long M,
