@@ -60,6 +60,7 @@ class GradReducer:
                     sink.hooks.append(hook)                                         # ... or was written in place
 
     def _reset(self):
+        self._fired = [False] * len(self.bucket_of)
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
@@ -79,6 +80,12 @@ class GradReducer:
         b = self.bucket_of[i]
 
         def hook(_param):
+            # a parameter can report twice per backward: from its gradient sink (in-place write, hipops.GradSink) and
+            # again from autograd, which runs the post-accumulate hook even when the node returned None for it
+            # (observed on torch 2.10) -- the first report is the one that follows the gradient kernels
+            if self._fired[i]:
+                return
+            self._fired[i] = True
             self._pending[b] -= 1
             if self._pending[b] == 0 and not self._launched[b]:
                 self._launch(b)

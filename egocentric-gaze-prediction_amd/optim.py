@@ -71,7 +71,10 @@ class FusedAdam:
 
     # -- torch.optim.Optimizer surface used by the drivers
     def zero_grad(self, set_to_none: bool = False):
-        H.fill_zero(self.flat_g)
+        if os.environ.get('EGAZE_TORCH_ZERO') == '1':
+            self.flat_g.zero_()
+        else:
+            H.fill_zero(self.flat_g)
         self.zero_gen += 1
         for p, o in zip(self.params, self.offsets):         # re-attach if something dropped the views
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:

@@ -69,7 +69,9 @@ def main():
         losses.append(loss.item())
     torch.cuda.synchronize()
     torch.save({"rank": rank, "g_local": gathered, "g_sum": g_sum, "flat_p": opt.flat_p.detach().cpu(),
-                "losses": losses, "n_buckets": len(red.buckets), "grad_scale": opt.grad_scale},
+                "losses": losses, "n_buckets": len(red.buckets), "grad_scale": opt.grad_scale,
+                "layout": [(n, o, p.numel()) for (n, p), o in zip(model.named_parameters(), opt.offsets)],
+                "buckets": [tuple(b) for b in red.buckets]},
                f"{out_prefix}.{rank}")
     dist.barrier()
     dist.destroy_process_group()

@@ -112,3 +112,103 @@ def test_rank_shard_sampler_partitions_and_pads():
         assert sorted(i for s in val for i in s) == data
     one = RankShardSampler(data, False, 8, world=1, rank_=0)
     assert list(one) == data
+
+
+def _sink_worker(rank, world, port, q):
+    """Gradient sinks (hipops.GradSink: the backward writes p.grad in place and returns None to autograd) under the
+    reducer: a bucket's all-reduce must start only after EVERY parameter of the bucket has its final gradient, although
+    torch also runs the post-accumulate hook for the None gradients (each parameter then reports twice)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import egaze_amd  # noqa: F401
+    import egaze_amd.hipops as H
+    from egaze_amd.dp import GradReducer
+
+    class Lin(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w, b)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w, b = ctx.saved_tensors
+            dw, db = g.t() @ x, g.sum(0)
+            sw, sb = H.grad_sink(w), H.grad_sink(b)
+            if sw is not None:
+                sw.view(w.shape).copy_(dw)
+                H.grad_done(w)
+                dw = None
+            if sb is not None:
+                sb.copy_(db)
+                H.grad_done(b)
+                db = None
+            return g @ w, dw, db
+
+    torch.manual_seed(0)
+    dims = [37, 50, 21, 16, 9, 3]
+    ps = []
+    for a, b_ in zip(dims[:-1], dims[1:]):
+        ps += [torch.nn.Parameter(torch.randn(b_, a) * 0.3), torch.nn.Parameter(torch.randn(b_) * 0.1)]
+    offsets, off = [], 0
+    for p in ps:
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    flat_p, flat_g = torch.zeros(off), torch.zeros(off)
+
+    class Owner:
+        zero_gen = 0
+    owner = Owner()
+    with torch.no_grad():
+        for p, o in zip(ps, offsets):
+            flat_p[o:o + p.numel()].copy_(p.reshape(-1))
+            p.data = flat_p[o:o + p.numel()].view(p.shape)
+            p.grad = flat_g[o:o + p.numel()].view(p.shape)
+            p._egz_sink = H.GradSink(flat_g[o:o + p.numel()], owner)
+    x = torch.randn(4, 37, generator=torch.Generator().manual_seed(10 + rank))
+
+    def fwd_bwd():
+        flat_g.zero_()
+        owner.zero_gen += 1
+        h = x
+        for i in range(0, len(ps), 2):
+            h = Lin.apply(h, ps[i], ps[i + 1]).relu()
+        h.sum().backward()
+
+    fwd_bwd()
+    g_local = flat_g.clone()
+    gathered = [torch.empty_like(g_local) for _ in range(world)]
+    dist.all_gather(gathered, g_local)
+    red = GradReducer(flat_g, ps, offsets, bucket_bytes=2048, flat_param=flat_p)
+    early = []
+    launch = red._launch
+
+    def checked_launch(b):
+        s_, e_, _ = red.buckets[b]
+        early.append(not torch.equal(flat_g[s_:e_], g_local[s_:e_]))      # launched before the bucket was complete?
+        launch(b)
+    red._launch = checked_launch
+    fwd_bwd()
+    red.wait()
+    q.put((rank, len(red.buckets), any(early), torch.equal(flat_g, gathered[0] + gathered[1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_sinks_report_once_per_bucket():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sink_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n_buckets, early, summed in res:
+        assert n_buckets >= 3
+        assert not early, "a bucket was all-reduced before all of its gradients had landed"
+        assert summed
