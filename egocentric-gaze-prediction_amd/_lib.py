@@ -43,7 +43,7 @@ SIGNATURES = {
     "egz_conv_first_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
     # --- BatchNorm / ReLU / pool / fusion max / misc streaming passes
     "egz_bn_ws_bytes": (c_size_t, [c_int]),
-    "egz_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P,
+    "egz_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P, P,
                                 c_size_t, S]),
     "egz_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P, S]),
     "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
@@ -79,6 +79,8 @@ SIGNATURES = {
     "egz_gemm": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, S]),
     "egz_lstm_cell_fwd": (c_int, [P, P, P, P, P, c_int, c_int, S]),
     "egz_lstm_cell_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, S]),
+    "egz_lstm_seq_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, S]),
+    "egz_lstm_seq_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, S]),
     "egz_tanh_fwd": (c_int, [P, P, c_long, S]),
     "egz_tanh_bwd": (c_int, [P, P, P, c_long, S]),
     "egz_add": (c_int, [P, P, P, c_long, S]),

@@ -49,10 +49,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part2, int nparts,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
+                                   float* __restrict__ shift, long long* __restrict__ num_batches_tracked) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
+    if (k == 0 && num_batches_tracked) *num_batches_tracked += 1;      // BatchNorm2d bookkeeping, same launch
     double s1 = 0.0, s2 = 0.0;
+#pragma unroll 16                                   // independent loads in flight; the sum keeps its fixed order
     for (int p = 0; p < nparts; ++p) {
         s1 += part2[((long)p * 2 + 0) * K + k];
         s2 += part2[((long)p * 2 + 1) * K + k];
@@ -216,6 +218,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int npar
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     double s1 = 0.0, s2 = 0.0;
+#pragma unroll 16
     for (int p = 0; p < nparts; ++p) {
         s1 += part[((long)p * 2 + 0) * K + k];
         s2 += part[((long)p * 2 + 1) * K + k];
@@ -505,11 +508,12 @@ EGZ_API size_t egz_bn_ws_bytes(int K) {
 }
 
 // stat_partial: [rows][2][K] fp64 as written by the conv epilogues.  Produces batch mean / invstd and the fused
-// affine (scale, shift); updates running_mean / running_var in place when they are non-null.
+// affine (scale, shift); updates running_mean / running_var in place when they are non-null and increments the int64
+// num_batches_tracked counter when that is non-null.
 EGZ_API int egz_bn_finalize(const double* stat_partial, int rows, int K, double count, const float* gamma,
                             const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                            float* mean_out, float* invstd_out, float* scale, float* shift, void* workspace,
-                            size_t ws_bytes, hipStream_t st) {
+                            float* mean_out, float* invstd_out, float* scale, float* shift,
+                            long long* num_batches_tracked, void* workspace, size_t ws_bytes, hipStream_t st) {
     EGZ_CHECK_ARG(stat_partial && mean_out && invstd_out && scale && shift && workspace, "egz_bn_finalize: null pointer");
     EGZ_CHECK_ARG(ws_bytes >= (size_t)RED_ROWS * 2 * K * sizeof(double), "egz_bn_finalize: workspace too small");
     EGZ_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "egz_bn_finalize: running stats must come in pairs");
@@ -523,7 +527,7 @@ EGZ_API int egz_bn_finalize(const double* stat_partial, int rows, int K, double 
         nparts = RED_ROWS;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, src, nparts, K, count, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift);
+                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift, num_batches_tracked);
     EGZ_CHECK_LAUNCH("egz_bn_finalize");
     return 0;
 }

@@ -60,7 +60,7 @@ def _first_conv_on_split(C: int, K: int) -> bool:
 class ConvBNReLUPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, pool,
-                first, out_buf=None):
+                first, out_buf=None, nbt=None):
         """``out_buf``: optional (B, H', W', K) NHWC destination of the block output (model_SP hands the two encoders the
         halves of ONE buffer so that the fusion conv reads the depth-2 stack without a concatenation copy)."""
         K, C = weight.shape[0], weight.shape[1]
@@ -82,7 +82,7 @@ class ConvBNReLUPool(torch.autograd.Function):
         B, Hh, Ww, _ = y.shape
         if training:
             coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
-                                 running_var, momentum, eps)
+                                 running_var, momentum, eps, nbt)
         else:
             coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
@@ -118,7 +118,7 @@ class ConvBNReLUPool(torch.autograd.Function):
             dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
         f.join(dw)
         return (dx, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
-                _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None)
+                _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None)
 
 
 class ConvReLU(torch.autograd.Function):
@@ -161,7 +161,7 @@ class ConvReLU(torch.autograd.Function):
 
 class FusionBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fs, ft, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, fs, ft, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, nbt=None):
         K, C = weight.shape[0], weight.shape[1]
         a, b = to_nhwc(fs), to_nhwc(ft)
         if (a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
@@ -179,7 +179,7 @@ class FusionBlock(torch.autograd.Function):
         B, Hh, Ww, _ = z.shape
         if training:
             coef = H.bn_finalize(H.channel_stats(z), float(B * Hh * Ww), gamma.detach(), beta.detach(),
-                                 running_mean, running_var, momentum, eps)
+                                 running_mean, running_var, momentum, eps, nbt)
         else:
             coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(z, coef, False)
@@ -213,7 +213,7 @@ class FusionBlock(torch.autograd.Function):
         f.join(dw)
         return (dfs, dft, _finish(weight, sw, dw), _finish(bias, sbias, db),
                 _finish(gamma, sg, dgamma if ng[4] else None), _finish(beta, sb, dbeta if ng[5] else None),
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class HeadSigmoid(torch.autograd.Function):

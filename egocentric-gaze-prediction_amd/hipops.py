@@ -436,15 +436,18 @@ def conv_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, out: Optional[torch
 
 # ----------------------------------------------------------------------------- BN / ReLU / pool
 def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, running_var, momentum: float,
-                eps: float):
+                eps: float, num_batches_tracked: Optional[torch.Tensor] = None):
+    """``num_batches_tracked``: the BatchNorm's int64 counter on the device, incremented by the same launch."""
     rows, _, K = stat.shape
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise RuntimeError("num_batches_tracked: expected an int64 HIP tensor")
     dev = stat.device
     coef = torch.empty((4, K), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
     ws = workspace(LIB.egz_bn_ws_bytes(K), dev)
     check(LIB.egz_bn_finalize(stat.data_ptr(), rows, K, float(count), _p(gamma), _p(beta), _p(running_mean),
                               _p(running_var), momentum, eps, coef[0].data_ptr(), coef[1].data_ptr(),
-                              coef[2].data_ptr(), coef[3].data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
-          "egz_bn_finalize")
+                              coef[2].data_ptr(), coef[3].data_ptr(), _p(num_batches_tracked), ws.data_ptr(), ws.numel(),
+                              _stream()), "egz_bn_finalize")
     return coef
 
 
@@ -560,12 +563,12 @@ def upsample2x_bwd(dxu: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def colsum(x: torch.Tensor) -> torch.Tensor:
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Sum over all leading dims of an NHWC tensor -> (K,) (conv bias gradient)."""
     _req(x, "x")
     K = x.shape[-1]
     rows = x.numel() // K
-    out = torch.empty((K,), dtype=torch.float32, device=x.device)
+    out = _out(out, (K,), x.device)
     ws = workspace(64 * K * 8, x.device)
     check(LIB.egz_colsum(x.data_ptr(), rows, K, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "egz_colsum")
     return out
@@ -691,11 +694,59 @@ def matmul_nn(a2d: torch.Tensor, w: torch.Tensor):
     return gemm(a2d, w, M, K, N, (N, 1), (K, 1))
 
 
-def matmul_tn(a2d: torch.Tensor, b2d: torch.Tensor):
-    """a2d[R][M]^T @ b2d[R][N] -> [M][N]  (weight gradient: dY^T X)."""
+def matmul_tn(a2d: torch.Tensor, b2d: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """a2d[R][M]^T @ b2d[R][N] -> [M][N]  (weight gradient: dY^T X); ``out`` = an M*N destination (gradient sink)."""
     R, M = a2d.shape
     N = b2d.shape[1]
-    return gemm(a2d, b2d, M, N, R, (1, M), (N, 1))
+    return gemm(a2d, b2d, M, N, R, (1, M), (N, 1), out=None if out is None else _out(out, (M, N), a2d.device),
+                accumulate=accumulate)
+
+
+def transpose2d(x: torch.Tensor) -> torch.Tensor:
+    """[R][C] -> [C][R] (LDS-tiled; W_hh -> W_hh^T for the LSTM backward)."""
+    _req(x, "x")
+    R, C = x.shape
+    out = torch.empty((C, R), dtype=torch.float32, device=x.device)
+    check(LIB.egz_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), 1, C, R, 1, _stream()), "egz_nhwc_to_nchw")
+    return out
+
+
+def copy_into(dst: torch.Tensor, src: torch.Tensor):
+    """Stream-ordered device copy between contiguous fp32 buffers of the same size."""
+    _req(dst, "dst"); _req(src, "src")
+    if dst.numel() != src.numel():
+        raise RuntimeError("copy_into: size mismatch")
+    check(LIB.egz_copy(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "egz_copy")
+
+
+def lstm_seq_fwd(gx, w_hh, h0, c0, want_acts: bool = True):
+    """One nn.LSTM layer over all T steps: gx (T,B,4H) = x W_ih^T + b_ih + b_hh -> hs, cs (T,B,H), acts (T,B,4H) | None."""
+    _req(gx, "gx"); _req(w_hh, "w_hh"); _req(h0, "h0"); _req(c0, "c0")
+    T, B, H4 = gx.shape
+    Hd = H4 // 4
+    hs = torch.empty((T, B, Hd), dtype=torch.float32, device=gx.device)
+    cs = torch.empty_like(hs)
+    acts = torch.empty((T, B, H4), dtype=torch.float32, device=gx.device) if want_acts else None
+    PROF.note_flops("egz_lstm_seq_fwd", 2.0 * T * B * H4 * Hd)
+    check(LIB.egz_lstm_seq_fwd(gx.data_ptr(), w_hh.data_ptr(), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(),
+                               _p(acts), T, B, Hd, _stream()), "egz_lstm_seq_fwd")
+    return hs, cs, acts
+
+
+def lstm_seq_bwd(dh_out, dhn, dcn, acts, cs, c0, w_hh_t):
+    """Backward through time of one layer -> (dgates (T,B,4H), dh0 (B,H), dc0 (B,H))."""
+    T, B, Hd = cs.shape
+    dgates = torch.empty((T, B, 4 * Hd), dtype=torch.float32, device=cs.device)
+    dh0 = torch.empty((B, Hd), dtype=torch.float32, device=cs.device)
+    dc0 = torch.empty_like(dh0)
+    for name, t in (("dh_out", dh_out), ("dhn", dhn), ("dcn", dcn)):
+        if t is not None:
+            _req(t, name)
+    PROF.note_flops("egz_lstm_seq_bwd", 2.0 * (T + 1) * B * 4 * Hd * Hd)
+    check(LIB.egz_lstm_seq_bwd(_p(dh_out), _p(dhn), _p(dcn), acts.data_ptr(), cs.data_ptr(), c0.data_ptr(),
+                               w_hh_t.data_ptr(), dgates.data_ptr(), dh0.data_ptr(), dc0.data_ptr(), T, B, Hd, _stream()),
+          "egz_lstm_seq_bwd")
+    return dgates, dh0, dc0
 
 
 def lstm_cell_fwd(gates, c_prev, h_out, c_out, act):

@@ -16,7 +16,12 @@ batch_size = 1
 
 
 class _LSTMNetFn(torch.autograd.Function):
-    """input (T,B,C), h0/c0 (L,B,H), then per layer (w_ih, w_hh, b_ih, b_hh), then lin.weight, lin.bias."""
+    """input (T,B,C), h0/c0 (L,B,H), then per layer (w_ih, w_hh, b_ih, b_hh), then lin.weight, lin.bias.
+
+    Per layer: ONE batched GEMM for the input projections of all T steps, then the recurrence as T fused
+    [h W_hh^T + cell] launches issued by one C-ABI call (csrc/lstm_seq.hip); backward: T + 1 fused
+    [dgates W_hh + cell backward] launches, then batched GEMMs for dW_ih, dW_hh, db and the gradient into the layer
+    below.  Parameter gradients go straight into the optimizer's flat buffer when it offers a sink (hipops.GradSink)."""
 
     @staticmethod
     def forward(ctx, inp, h0, c0, *params):
@@ -25,77 +30,81 @@ class _LSTMNetFn(torch.autograd.Function):
         Hd = params[1].shape[1]
         inp_c = H._req(inp.detach().contiguous(), "input")
         h0c, c0c = H._req(h0.detach().contiguous(), "h0"), H._req(c0.detach().contiguous(), "c0")
+        train = any(ctx.needs_input_grad)          # no-grad runs (AT.testLSTM, extract_late) skip the saved gate activations
         x = H.tanh_fwd(inp_c)
         saved_layers = []
         layer_in = x.view(T * B, C)
-        hn, cn = [], []
+        hn = torch.empty((L, B, Hd), dtype=torch.float32, device=inp.device)
+        cn = torch.empty_like(hn)
         for l in range(L):
             w_ih, w_hh, b_ih, b_hh = (p.detach() for p in params[4 * l:4 * l + 4])
             bsum = H.add(b_ih, b_hh)
             gx = H.linear_fwd(layer_in, w_ih, bias=bsum).view(T, B, 4 * Hd)      # all time steps at once
-            hs = torch.empty((T, B, Hd), dtype=torch.float32, device=inp.device)
-            cs = torch.empty_like(hs)
-            acts = torch.empty((T, B, 4 * Hd), dtype=torch.float32, device=inp.device)
-            h, c = h0c[l], c0c[l]
-            for t in range(T):
-                H.linear_fwd(h, w_hh, out=gx[t], accumulate=True)                 # gates += h W_hh^T
-                H.lstm_cell_fwd(gx[t], c, hs[t], cs[t], acts[t])
-                h, c = hs[t], cs[t]
+            hs, cs, acts = H.lstm_seq_fwd(gx, H._req(w_hh, "w_hh"), h0c[l], c0c[l], want_acts=train)
             saved_layers.append((layer_in, hs, cs, acts))
             layer_in = hs.view(T * B, Hd)
-            hn.append(h)
-            cn.append(c)
+            H.copy_into(hn[l], hs[T - 1])
+            H.copy_into(cn[l], cs[T - 1])
         lin_w, lin_b = params[-2].detach(), params[-1].detach()
         out = H.linear_fwd(layer_in, lin_w, bias=lin_b, relu=True).view(T, B, lin_w.shape[0])
         ctx.saved = (x, h0c, c0c, saved_layers, out)
-        ctx.params = [p.detach() for p in params]
+        ctx.params = list(params)
         ctx.dims = (T, B, C, Hd, L)
         ctx.set_materialize_grads(False)
-        return out, torch.stack(hn, 0), torch.stack(cn, 0)
+        return out, hn, cn
 
     @staticmethod
     def backward(ctx, dout, dhn, dcn):
         x, h0c, c0c, saved_layers, out = ctx.saved
         params = ctx.params
         T, B, C, Hd, L = ctx.dims
-        dev = out.device
-        lin_w = params[-2]
+        ng = ctx.needs_input_grad
+        lin_w = params[-2].detach()
         if dout is None:
-            dout = torch.zeros_like(out)
-        dpre = H.relu_bwd(out.view(T * B, -1), H._req(dout.contiguous().view(T * B, -1), "grad"))
+            dpre = torch.empty((T * B, out.shape[-1]), dtype=torch.float32, device=out.device)
+            H.fill_zero(dpre)
+        else:
+            dpre = H.relu_bwd(out.view(T * B, -1), H._req(dout.contiguous().view(T * B, -1), "grad"))
         grads = [None] * len(params)
+        sinks = [H.grad_sink(p, ng[3 + i]) for i, p in enumerate(params)]
         h_top = saved_layers[-1][1].view(T * B, Hd)
-        grads[-2] = H.matmul_tn(dpre, h_top)                      # d lin.weight = dpre^T h
-        grads[-1] = H.colsum(dpre)
+        if ng[3 + len(params) - 2]:
+            grads[-2] = H.matmul_tn(dpre, h_top, out=sinks[-2])                  # d lin.weight = dpre^T h
+        if ng[3 + len(params) - 1]:
+            grads[-1] = H.colsum(dpre, out=sinks[-1])
         dh_all = H.matmul_nn(dpre, lin_w).view(T, B, Hd)          # gradient into the top layer's outputs
-        dh0 = torch.zeros((L, B, Hd), dtype=torch.float32, device=dev)
-        dc0 = torch.zeros((L, B, Hd), dtype=torch.float32, device=dev)
+        dh0 = torch.empty((L, B, Hd), dtype=torch.float32, device=out.device)
+        dc0 = torch.empty_like(dh0)
         for l in reversed(range(L)):
             layer_in, hs, cs, acts = saved_layers[l]
-            w_ih, w_hh = params[4 * l], params[4 * l + 1]
-            dgates = torch.empty((T, B, 4 * Hd), dtype=torch.float32, device=dev)
-            dh_next = dhn[l].contiguous() if dhn is not None else None
-            dc_next = dcn[l].contiguous() if dcn is not None else None
-            for t in reversed(range(T)):
-                dh = dh_all[t] if dh_next is None else H.add(dh_all[t], dh_next)
-                c_prev = cs[t - 1] if t > 0 else c0c[l]
-                dc_prev = torch.empty((B, Hd), dtype=torch.float32, device=dev)
-                H.lstm_cell_bwd(acts[t], cs[t], c_prev, dh, dc_next, dgates[t], dc_prev)
-                dh_next = H.matmul_nn(dgates[t], w_hh)           # [B,4H] @ [4H,H]
-                dc_next = dc_prev
-            dh0[l], dc0[l] = dh_next, dc_next
+            if acts is None:
+                raise RuntimeError("lstmnet: backward through a forward pass that ran without gradient tracking")
+            w_ih, w_hh = params[4 * l].detach(), params[4 * l + 1].detach()
+            dgates, dh0_l, dc0_l = H.lstm_seq_bwd(dh_all, dhn[l].contiguous() if dhn is not None else None,
+                                                  dcn[l].contiguous() if dcn is not None else None, acts, cs, c0c[l],
+                                                  H.transpose2d(H._req(w_hh, "w_hh")))
+            H.copy_into(dh0[l], dh0_l)
+            H.copy_into(dc0[l], dc0_l)
             dg2 = dgates.view(T * B, 4 * Hd)
-            h_prev_all = torch.cat((h0c[l:l + 1], hs[:-1]), 0).view(T * B, Hd)
-            grads[4 * l] = H.matmul_tn(dg2, layer_in)             # d W_ih
-            grads[4 * l + 1] = H.matmul_tn(dg2, h_prev_all)       # d W_hh
-            db = H.colsum(dg2)
-            grads[4 * l + 2] = db
-            grads[4 * l + 3] = db.clone()
-            dh_all = H.matmul_nn(dg2, w_ih).view(T, B, -1)        # into the layer below / the tanh'd input
-        dinp = H.tanh_bwd(x, dh_all.contiguous()).view(T, B, C)
-        ng = ctx.needs_input_grad
-        return (dinp if ng[0] else None, dh0 if ng[1] else None, dc0 if ng[2] else None,
-                *[g if ng[3 + i] else None for i, g in enumerate(grads)])
+            if ng[3 + 4 * l]:
+                grads[4 * l] = H.matmul_tn(dg2, layer_in, out=sinks[4 * l])                     # d W_ih
+            if ng[3 + 4 * l + 1]:       # d W_hh = sum_t dgates_t^T h_{t-1}: the t = 0 term sees h0, the rest hs[:-1]
+                g = H.matmul_tn(dgates[0], h0c[l], out=sinks[4 * l + 1])
+                if T > 1:
+                    H.matmul_tn(dgates[1:].view((T - 1) * B, 4 * Hd), hs[:-1].view((T - 1) * B, Hd), out=g, accumulate=True)
+                grads[4 * l + 1] = g
+            if ng[3 + 4 * l + 2]:
+                grads[4 * l + 2] = H.colsum(dg2, out=sinks[4 * l + 2])
+            if ng[3 + 4 * l + 3]:
+                grads[4 * l + 3] = H.colsum(dg2, out=sinks[4 * l + 3])
+            if l > 0 or ng[0]:
+                dh_all = H.matmul_nn(dg2, w_ih).view(T, B, -1)        # into the layer below / the tanh'd input
+        dinp = H.tanh_bwd(x, dh_all.contiguous()).view(T, B, C) if ng[0] else None
+        for i, p in enumerate(params):
+            if sinks[i] is not None:
+                H.grad_done(p)
+                grads[i] = None
+        return (dinp, dh0 if ng[1] else None, dc0 if ng[2] else None, *grads)
 
 
 class lstmnet(nn.Module):

@@ -70,10 +70,9 @@ class model_SP(nn.Module):
         x_s = self.features_s(x_s, out_buf=stack[:B] if stack is not None else None)   # (B,512,h,w) channels_last; hooks fire here
         f.join(x_t)
         bn = self.bn
-        if bn.training and bn.track_running_stats:
-            bn.num_batches_tracked += 1
+        nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None     # bumped by the stats kernel
         x_fused = FusionBlock.apply(x_s, x_t, self.fusion.weight, self.fusion.bias, bn.weight, bn.bias,
-                                    bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps))
+                                    bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), nbt)
         return self.decoder(x_fused, fuse_sigmoid=True)  # decoder + self.final fused
 
     def _initialize_weights(self):

@@ -41,10 +41,10 @@ def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first:
     """One fused encoder block on the HIP path; keeps BatchNorm's num_batches_tracked bookkeeping."""
     if conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.stride != (1, 1):
         raise NotImplementedError("only 3x3 / pad 1 / stride 1 convolutions are on the reference path")
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked += 1
     g, b, rm, rv, training, mom, eps = _bn_args(bn)
-    return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first, out_buf)
+    # num_batches_tracked += 1 happens inside the statistics kernel (egz_bn_finalize), not as a separate launch
+    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+    return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first, out_buf, nbt)
 
 
 class FusedSequential(nn.Sequential):

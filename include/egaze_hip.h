@@ -91,8 +91,8 @@ int egz_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw, i
 size_t egz_bn_ws_bytes(int K);
 int egz_bn_finalize(const double* stat_partial, int rows, int K, double count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
-                    float* invstd_out, float* scale, float* shift, void* workspace, size_t ws_bytes,
-                    hipStream_t stream);
+                    float* invstd_out, float* scale, float* shift, long long* num_batches_tracked, void* workspace,
+                    size_t ws_bytes, hipStream_t stream);
 int egz_bn_eval_coeffs(int K, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
 int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W,
@@ -164,6 +164,14 @@ int egz_lstm_cell_fwd(const float* gates, const float* c_prev, float* h_out, flo
                       hipStream_t stream);
 int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, const float* dh, const float* dc_in,
                       float* dgates, float* dc_prev, int B, int Hd, hipStream_t stream);
+/* nn.LSTM recurrence, one launch per time step, product and cell fused (models/LSTMnet.py:18,32-35 = torch's
+ * nn.LSTM(512, 512, 2) forward / backward through time; AT.py:133-145).  gx [T][B][4H] = x W_ih^T + b_ih + b_hh;
+ * w_hh [4H][H]; w_hh_t [H][4H]; hs, cs [T][B][H]; acts, dgates [T][B][4H]; H % 256 == 0. */
+int egz_lstm_seq_fwd(const float* gx, const float* w_hh, const float* h0, const float* c0, float* hs, float* cs,
+                     float* acts, int T, int B, int H, hipStream_t stream);
+int egz_lstm_seq_bwd(const float* dh_out, const float* dhn, const float* dcn, const float* acts, const float* cs,
+                     const float* c0, const float* w_hh_t, float* dgates, float* dh0, float* dc0, int T, int B, int H,
+                     hipStream_t stream);
 int egz_tanh_fwd(const float* x, float* y, long n, hipStream_t stream);
 int egz_tanh_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream);
 int egz_add(const float* a, const float* b, float* out, long n, hipStream_t stream);
