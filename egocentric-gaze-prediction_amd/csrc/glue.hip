@@ -41,6 +41,19 @@ __global__ void crop_mean_kernel(const float* __restrict__ feat, const int* __re
     out[idx] = s / (float)(size * size);
 }
 
+// one thread per (b, c): mean of the explicit window rows [y0, y1) x columns [x0, x1) of sample b (win: (B, 4) int32)
+__global__ void window_mean_kernel(const float* __restrict__ feat, const int* __restrict__ win, float* __restrict__ out,
+                                   int B, int H, int W, int C) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)B * C) return;
+    const int b = (int)(idx / C), c = (int)(idx % C);
+    const int y0 = win[4 * b], y1 = win[4 * b + 1], x0 = win[4 * b + 2], x1 = win[4 * b + 3];
+    float s = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) s += feat[(((long)b * H + y) * W + x) * C + c];
+    out[idx] = s / (float)((y1 - y0) * (x1 - x0));
+}
+
 // one block per image: out[p] = sum_c feat[p][c] * w[c]; then (out - min) / max(out - min)
 __global__ __launch_bounds__(256) void weighted_minmax_kernel(const float* __restrict__ feat, const float* __restrict__ w,
                                                                float* __restrict__ out, int HW, int C) {
@@ -91,6 +104,16 @@ EGZ_API int egz_crop_mean(const float* feat, const int* gp, float* out, int B, i
     EGZ_CHECK_ARG(size > 0 && size <= H && size <= W && cell > 0, "egz_crop_mean: window %d does not fit a %d x %d map", size, H, W);
     hipLaunchKernelGGL(crop_mean_kernel, dim3(egz_cdiv((long)B * C, 256)), dim3(256), 0, st, feat, gp, out, B, H, W, C, size, cell);
     EGZ_CHECK_LAUNCH("egz_crop_mean");
+    return 0;
+}
+
+// feat: (B, H, W, C) channels-last fp32; win: (B, 4) int32 {y0, y1, x0, x1} (host-validated: 0 <= y0 < y1 <= H, same for
+// x); out: (B, C) = mean over the window.  Serves extractLSTMw.crop_feature_var (extractLSTMw.py:46-58), whose window
+// comes from a float clip and int() truncation and is therefore not always size x size.
+EGZ_API int egz_window_mean(const float* feat, const int* win, float* out, int B, int H, int W, int C, hipStream_t st) {
+    EGZ_CHECK_ARG(feat && win && out && B > 0 && C > 0 && H > 0 && W > 0, "egz_window_mean: bad arguments");
+    hipLaunchKernelGGL(window_mean_kernel, dim3(egz_cdiv((long)B * C, 256)), dim3(256), 0, st, feat, win, out, B, H, W, C);
+    EGZ_CHECK_LAUNCH("egz_window_mean");
     return 0;
 }
 

@@ -846,6 +846,20 @@ def crop_mean(feat_nhwc: torch.Tensor, gp, size: int, cell: int = 16) -> torch.T
     return out
 
 
+def window_mean(feat_nhwc: torch.Tensor, windows) -> torch.Tensor:
+    """feat_nhwc: (B,H,W,C) fp32; windows: B x (y0, y1, x0, x1) half-open cell ranges -> (B, C) window means."""
+    _req(feat_nhwc, "feature")
+    B, Hh, Ww, C = feat_nhwc.shape
+    win = [tuple(int(v) for v in w) for w in windows]
+    if len(win) != B or any(not (0 <= y0 < y1 <= Hh and 0 <= x0 < x1 <= Ww) for y0, y1, x0, x1 in win):
+        raise ValueError(f"window_mean: windows {win} do not fit a {Hh} x {Ww} map of batch {B}")
+    g = torch.tensor(win, dtype=torch.int32).to(feat_nhwc.device)
+    out = torch.empty((B, C), dtype=torch.float32, device=feat_nhwc.device)
+    check(LIB.egz_window_mean(feat_nhwc.data_ptr(), g.data_ptr(), out.data_ptr(), B, Hh, Ww, C, _stream()),
+          "egz_window_mean")
+    return out
+
+
 def weighted_minmax(feat_nhwc: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """feat_nhwc: (B,H,W,C), w: (B,C) -> (B,H,W): channel-weighted sum, min-max normalised per image."""
     _req(feat_nhwc, "feature"); _req(w, "chn_weight")

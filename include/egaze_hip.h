@@ -196,6 +196,8 @@ int egz_u8_normalize(const unsigned char* src, float* dst, long n, long plane, i
  * channels-last (B,H,W,C) feature map around gaze_point / cell; weighted map = min-max normalised sum_c feat * w. */
 int egz_crop_mean(const float* feat, const int* gp, float* out, int B, int H, int W, int C, int size, int cell,
                   hipStream_t stream);
+/* extractLSTMw.crop_feature_var (extractLSTMw.py:46-58) + mean: explicit window {y0, y1, x0, x1} per sample */
+int egz_window_mean(const float* feat, const int* win, float* out, int B, int H, int W, int C, hipStream_t stream);
 int egz_weighted_minmax(const float* feat, const float* w, float* out, int B, int HW, int C, hipStream_t stream);
 
 #ifdef __cplusplus
