@@ -11,7 +11,8 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libegaze_hip.so")
+# EGAZE_HIP_LIB: load another build of the same C-ABI (kernel A/B runs: csrc/build.sh -D... -o variant); default in-tree .so
+LIB_PATH = os.environ.get("EGAZE_HIP_LIB") or os.path.join(_HERE, "csrc", "libegaze_hip.so")
 
 P = c_void_p          # device pointer
 S = c_void_p          # hipStream_t
@@ -34,6 +35,9 @@ SIGNATURES = {
     "egz_pack_w3x3_split_multi": (c_int, [P, c_int, c_int, S]),
     "egz_conv3x3_fwd_split_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
+    "egz_conv3x3_streamed_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "egz_pack_w3x3_split_frag": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)

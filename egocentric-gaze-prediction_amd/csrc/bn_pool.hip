@@ -446,6 +446,7 @@ __global__ void colsum_final_kernel(const double* __restrict__ part, int nparts,
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= cols) return;
     double s = 0.0;
+#pragma unroll 16
     for (int p = 0; p < nparts; ++p) s += part[(long)p * cols + k];
     out[k] = (float)s;
 }

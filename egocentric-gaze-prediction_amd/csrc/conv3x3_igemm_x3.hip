@@ -17,6 +17,7 @@
 //   conv3x3_igemm_x3h_kernel  halo tile (plain convs): the input halo of a compact 128-pixel tile is staged ONCE per
 //       32-channel block and the nine taps read it at shifted addresses; weights by LDS-DMA; fragments one k-step ahead.
 #include "egz_common.h"
+#include "x3_split.h"
 #include <type_traits>
 
 namespace {
@@ -25,71 +26,21 @@ constexpr int XBM = 128, XBK = 32;
 constexpr int XLD = 32;                 // row stride in 16-bit elements: 64 B, no padding -- the four 16-byte chunks
                                         // of a row are XOR-swizzled with (row >> 2) & 3, which makes the ds_read_b128
                                         // fragment reads conflict-free in every 16-lane service group
-constexpr float F16_WSCALE = 1024.f;    // 2^10
 #ifndef EGZ_X3_SCHED
 #define EGZ_X3_SCHED 1
+#endif
+#ifndef EGZ_X3H_SPREAD       // halo kernel: issue one weight LDS-DMA piece behind every SPREAD-th MFMA of a slice (0 = all up front)
+#define EGZ_X3H_SPREAD 0
+#endif
+#ifndef EGZ_X3H_DIAG         // timing diagnostics (WRONG RESULTS): 1 no weight DMA, 2 no per-slice wait + barrier, 4 no halo restaging
+#define EGZ_X3H_DIAG 0
 #endif
 constexpr int NSET = 2;                 // staging register sets (slice s+1 being converted, slice s+2 in flight)
 
 enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
 enum { PLAIN = 0, UPS_FOLD = 1, UPS_PHASE = 2, UPS_DGRAD = 3 };
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <typename T> struct Half;
-template <> struct Half<_Float16> {
-    static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
-        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-        const _Float16 hi = (_Float16)x;
-        const _Float16 lo = (_Float16)(x - (float)hi);
-        h = __builtin_bit_cast(unsigned short, hi);
-        l = __builtin_bit_cast(unsigned short, lo);
-    }
-    // 4 floats -> packed hi / lo halves in 3 VALU per float: hi = v_cvt_pkrtz (round toward zero: the residual is then
-    // exact in fp32 and an out-of-range input saturates hi instead of producing inf), lo = RNE of the residual, so the
-    // pair carries 22 significant bits with an unbiased error.  |x| > 65504 is outside the f16 x3 domain (lo overflows).
-    static __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * e], v[2 * e + 1]));
-            const f16x2 l = __builtin_convertvector(f32x2{v[2 * e] - (float)h[0], v[2 * e + 1] - (float)h[1]}, f16x2);
-            hi[e] = __builtin_bit_cast(unsigned, h);
-            lo[e] = __builtin_bit_cast(unsigned, l);
-        }
-    }
-    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Half<__bf16> {
-    static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
-        const __bf16 hi = (__bf16)x;
-        const __bf16 lo = (__bf16)(x - (float)hi);
-        h = __builtin_bit_cast(unsigned short, hi);
-        l = __builtin_bit_cast(unsigned short, lo);
-    }
-    // v_cvt_pk_bf16_f32 (RNE), two bit ops to widen the halves back, one packed subtract, v_cvt_pk_bf16_f32: 2.5 VALU / float
-    static __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const f32x2 x = {v[2 * e], v[2 * e + 1]};
-            const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
-            const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
-            hi[e] = hu;
-            lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, bf16x2));
-        }
-    }
-    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
+using namespace x3;
 
 // wp: [2 planes (hi, lo)][taps][Kp][Cp] 16-bit.  H, W: hi-res (conv output) dims for the UPS_* modes.
 template <typename T, int XBN, int MODE, int EPI>   // XBN = 128 (Cout % 128 == 0) or 64 (Cout = 64 layers)
@@ -552,17 +503,22 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
             *reinterpret_cast<u32x2*>(Ah + APL + a_lds[j]) = lo;
         }
     };
-    auto dma_b = [&](int s, const int buf) {             // slice s = cblk * 9 + tap -> B buffer buf
+    auto dma_so = [&](int s) {                           // scalar offset of slice s = cblk * 9 + tap in a weight plane
         const int cblk = s / 9, tap = s - cblk * 9;
-        const unsigned so = (unsigned)((((long)tap * Kp) * Cp + cblk * XBK) * 2);
+        return (unsigned)((((long)tap * Kp) * Cp + cblk * XBK) * 2);
+    };
+    auto dma_piece = [&](const unsigned so, const int buf, const int k) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the host pass of hipcc rejects the LDS-DMA builtin (and then drops the kernel stub)
-#pragma unroll
-        for (int k = 0; k < NPIECE; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                b_rs, (__attribute__((address_space(3))) void*)(Bs + buf * BBUF + b_lds[k]), 16, b_vo[k], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            b_rs, (__attribute__((address_space(3))) void*)(Bs + buf * BBUF + b_lds[k]), 16, b_vo[k], so, 0, 0);
 #else
-        (void)so;
+        (void)so; (void)buf; (void)k;
 #endif
+    };
+    auto dma_b = [&](int s, const int buf) {             // slice s -> B buffer buf
+        const unsigned so = dma_so(s);
+#pragma unroll
+        for (int k = 0; k < NPIECE; ++k) dma_piece(so, buf, k);
     };
 
     f32x16 acc[2][NR];
@@ -597,7 +553,7 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
         }
     };
     // one K-slice (tap t of the staged channel block) on B buffer `buf`
-    auto slice = [&](const int t, const int buf, const bool next_a) {
+    auto slice = [&](const int t, const int buf, const bool next_a, const unsigned dso) {
         u32x4 ah1[2], al1[2], bh1[NR], bl1[NR];
 #pragma unroll
         for (int mr = 0; mr < 2; ++mr) {
@@ -617,8 +573,22 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-                for (int mr = 0; mr < 2; ++mr)
+                for (int mr = 0; mr < 2; ++mr) {
                     acc[mr][nr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bl0[nr] : bh0[nr], acc[mr][nr]);
+#if EGZ_X3H_SPREAD
+                    // the LDS-DMA pieces of the NEXT slice's weights, one behind each of the first MFMAs: an LDS-DMA issue
+                    // costs ~60 cycles of the wave's issue slot (MI355X_MICROARCH.md), which an MFMA already in the pipe covers
+                    {
+                        constexpr int SP = EGZ_X3H_SPREAD;
+                        const int idx = (term * NR + nr) * 2 + mr;
+                        if (idx % SP == SP - 1 && idx / SP < NPIECE) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            dma_piece(dso, buf ^ 1, idx / SP);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#endif
+                }
         __builtin_amdgcn_sched_barrier(0);
         if (next_a) read_a0(t + 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -650,17 +620,30 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int s = c * 9 + t, par = (h + t) & 1;          // s & 1 == par (cb is even)
+#if EGZ_X3H_SPREAD
+                    const unsigned dso = dma_so(s + 1 < S ? s + 1 : S - 1);
+#else
+                    const unsigned dso = 0;
+#if !(EGZ_X3H_DIAG & 1)
                     dma_b(s + 1 < S ? s + 1 : S - 1, par ^ 1);
+#endif
+#endif
+#if !(EGZ_X3H_DIAG & 4)
                     if (t == 6 && c + 1 < ncb) gload_a(c + 1);            // lands during slices 6..8
-                    slice(t, par, t < 8);
+#endif
+                    slice(t, par, t < 8, dso);
+#if !(EGZ_X3H_DIAG & 2)
                     __builtin_amdgcn_s_waitcnt(0);            // vmcnt(0) (+ lgkmcnt(0)): B pieces of slice s + 1 in LDS
                     __syncthreads();
+#endif
                     read_b0(par ^ 1);                         // next slice's B, k-step 0
                 }
+#if !(EGZ_X3H_DIAG & 4)
                 if (c + 1 < ncb) {                            // restage the halo image for the next channel block
                     lstore_a();
                     __syncthreads();
                 }
+#endif
                 read_a0(0);
             }
         }

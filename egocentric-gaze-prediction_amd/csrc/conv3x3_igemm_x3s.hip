@@ -1,0 +1,410 @@
+// Streamed-weight halo-tile 3x3 implicit GEMM in split-half arithmetic (f16 x3 / bf16 x3, see conv3x3_igemm_x3.hip):
+// the default kernel of every plain (stride 1, pad 1) convolution forward and data gradient of the SP path
+// (utils.py:64-76 encoders, models/model_SP.py:13-31 decoder; Conv2d + its autograd backward in the reference).
+//
+// What differs from conv3x3_igemm_x3h_kernel: the weight operand never touches LDS.
+//   * Activations: as there -- the input halo of a compact pixel tile is fetched, split into hi / lo 16-bit halves and
+//     written to LDS once per 32-channel block; the nine taps read their MFMA fragments from that image at shifted
+//     addresses (patch geometry: 8 x 16 or 16 x 16 pixels; raster-run geometry for narrow images).
+//   * Weights: packed ONCE per optimizer step in MFMA *fragment order* (egz_pack_w3x3_split kinds 4 / 5):
+//     [slice = channel block x tap][32-column tile][k-step][hi | lo][lane][8 halves], so that the B fragment of a wave is
+//     one fully coalesced 1 KB buffer_load_b128 per (k-step, plane) straight from L2 into the registers the MFMA reads.
+//     No LDS-DMA, no LDS write bandwidth, no LDS read for B, and -- because nothing about B is shared through LDS -- no
+//     barrier per K-slice: the only barriers left guard the activation image (one per channel block).
+//     Measured motivation (profiles/r02_x3h_diag.txt): removing the weight LDS-DMA from the x3h kernel was worth 12 %,
+//     DMA + barriers + halo restaging 20 %; re-placing the DMA issue between the MFMAs changed nothing.
+//   * Wave layout WM x (4 / WM): every wave owns 128 pixel rows x 32 output columns (4 accumulator tiles), so the four
+//     waves of a block load DISJOINT weight columns (no duplicate L2 traffic) and share the activation fragments.
+//     WM = 1: tile 128 x 128 (GEMM N % 128 == 0), activation image double buffered (64 KB, 2 blocks / CU);
+//     WM = 2: tile 256 x 64 (the 64-channel layers), single image of 384 slots (48 KB).
+//   * B fragments are prefetched two slices ahead into a ring of three register sets (9 taps per channel block keep the
+//     ring index compile-time); the activation fragments one k-step ahead, as in the x3h kernel.
+//   * blockIdx -> tile map: the column tiles of one pixel tile run on the same XCD (b % 8 is the XCD), adjacent in time,
+//     so the activation halo is fetched into ONE L2 instead of up to four.
+#include "egz_common.h"
+#include "x3_split.h"
+
+namespace {
+using namespace x3;
+
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
+constexpr int XLD = 32;                 // 16-bit elements per LDS row: 64 B = 32 channels of one plane of one pixel
+constexpr int XBK = 32;                 // channels per block of the reduction
+constexpr int HPITCH = 20;              // patch geometry: halo columns per LDS grid row (18 used)
+
+template <int WM> struct Geo {
+    static constexpr int BM = 128 * WM, NWN = 4 / WM, BN = 32 * NWN;
+    static constexpr int HSLOTS = (WM == 1) ? 256 : 384, HZERO = HSLOTS - 1;
+    static constexpr int NABUF = (WM == 1) ? 2 : 1;
+    static constexpr int PROWS = 8 * WM;                       // patch: PROWS x 16 pixels
+    static constexpr int NJ = HSLOTS / 32;                     // halo slots per thread (8 threads x 4 channels per slot)
+};
+
+// workgroup barrier that leaves this wave's global loads (the weight prefetch ring) in flight: __syncthreads() would
+// wait for vmcnt(0).  lgkmcnt(0) = this wave's LDS reads / writes are done; the "memory" clobber pins the compiler.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// wq: fragment-ordered split weights (see the header); x: [B][H][W][C] fp32; y: [B][H][W][K] fp32 (GEMM N = K columns).
+template <typename T, int WM, int EPI, bool PATCH>
+__global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
+    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
+    int mt, int total, const unsigned int* __restrict__ a_absmax) {
+    using G = Geo<WM>;
+    constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
+    constexpr int APL = HSLOTS * XLD;                          // elements per plane of an activation image
+    constexpr int ABUF = 2 * APL;                              // elements per image (hi + lo)
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
+    __shared__ long Ro[BM];
+
+    const float a_scale = absmax_scale(a_absmax);
+    out_scale /= a_scale;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / NWN, wn = wave % NWN, hl = lane >> 5, l31 = lane & 31;
+    const int ntn = Kp / BN;
+    // XCD-aware tile id: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
+    const int per = (total + 7) >> 3;
+    const int gt = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (gt >= total) return;
+    const int tile_n = gt % ntn, tile_m = gt / ntn;
+    const int n0 = tile_n * BN;
+    const long HW = (long)H * W, M = (long)B * HW;
+    const long m0 = (long)tile_m * BM;
+    const int pw = W >> 4, ppi = (H / G::PROWS) * pw;           // patches per row / per image
+    const int b0 = PATCH ? tile_m / ppi : 0;
+    const int y0 = PATCH ? ((tile_m - b0 * ppi) / pw) * G::PROWS : 0, x0 = PATCH ? ((tile_m - b0 * ppi) % pw) * 16 : 0;
+
+    for (int i = tid; i < BM; i += 256) {
+        long off = -1;
+        if (PATCH) off = (((long)b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15)) * K;
+        else if (m0 + i < M) off = (m0 + i) * K;
+        Ro[i] = off;
+    }
+
+    // ---- activation halo staging map: slot q = (tid >> 3) + 32 j holds 4 channels (tid & 7) of one input pixel
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
+    const int a_c4 = tid & 7;
+    unsigned a_vo[NJ];
+    int a_lds[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = (tid >> 3) + 32 * j;
+        long pix = -1;
+        int col = q;
+        if (PATCH) {
+            const int hy = q / HPITCH, hx = q - hy * HPITCH;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            col = hx;
+            if (hy < G::PROWS + 2 && hx < 18 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                pix = ((long)b0 * H + iy) * W + ix;
+        } else {
+            const long g = m0 - W - 1 + q;
+            if (q < BM + 2 * W + 2 && g >= 0 && g < M) pix = g;
+        }
+        a_vo[j] = (pix >= 0) ? (unsigned)((pix * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
+        a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
+    }
+
+    // ---- weight fragments: lane-linear 1 KB pieces, [slice][ntile32][ks][plane][lane][8 halves]
+    const int nt32 = Kp >> 5, ncb = Cp / XBK, S = ncb * 9;
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(wq), 0, (int)((unsigned)S * nt32 * 4096u), 0x00020000);
+    const unsigned b_vo = (unsigned)lane * 16u;
+    const unsigned b_tile = (unsigned)(tile_n * NWN + wn) * 4096u;
+    u32x4 bq[3][4];                                             // [ring][ks * 2 + plane]
+    auto gload_b = [&](int s, const int ring) {
+        const unsigned so = (unsigned)s * (unsigned)nt32 * 4096u + b_tile;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[ring][c] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo + c * 1024, so, 0);
+    };
+
+    // ---- activation fragment addresses (bytes, plane 0, k-step 0, image 0) of the wave's four 32-row groups for one tap.
+    // patch: one table entry per tap, the row groups are 2 grid rows = 2560 B apart (immediate offsets);
+    // run: slot = row + W + 1 + tap shift; the 32-slot row groups share the swizzle key, so one address + 2048 B steps,
+    // and a row whose tap falls outside the image (per-group validity mask) reads the all-zero slot instead.
+    // The per-tap value is recomputed from an opaque base every slice: hoisting all 36 of them costs more registers than
+    // the kernel has.
+    int fa9[9];
+    int sl0 = wm * 128 + l31 + W + 1;
+    unsigned vmask[4] = {0, 0, 0, 0};
+    if (PATCH) {
+        const int i = wm * 128 + l31;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const int slot = ((i >> 4) + 1 + dy) * HPITCH + (i & 15) + 1 + dx, col = (i & 15) + 1 + dx;
+            fa9[t] = (slot * XLD + ((hl ^ ((col >> 2) & 3)) << 3)) * 2;
+        }
+    } else {
+#pragma unroll
+        for (int mr = 0; mr < 4; ++mr) {
+            const long m = m0 + wm * 128 + mr * 32 + l31;
+            const int rem = (int)(m % HW), py = rem / W, px = rem - py * W;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                mk |= (m < M && (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W) ? (1u << t) : 0u;
+            }
+            vmask[mr] = mk;
+        }
+    }
+    constexpr int MRSTEP = PATCH ? 2 * HPITCH * XLD * 2 : 32 * XLD * 2;      // bytes between the wave's row groups
+    // addresses of the four row groups for tap t in image `abuf` -> fa[0..3]
+    auto tap_addr = [&](const int t, const int abuf, int* fa) {
+        if (PATCH) {
+            int f = fa9[t] + abuf * (ABUF * 2);
+            asm volatile("" : "+v"(f));
+#pragma unroll
+            for (int mr = 0; mr < 4; ++mr) fa[mr] = f + mr * MRSTEP;
+        } else {
+            int base = sl0;
+            asm volatile("" : "+v"(base));
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const int slot = base + dy * W + dx;
+            const int a = slot * (XLD * 2) + ((hl ^ ((slot >> 2) & 3)) << 4) + abuf * (ABUF * 2);
+            const int z = HZERO * (XLD * 2) + (hl << 4) + abuf * (ABUF * 2);          // the all-zero slot
+#pragma unroll
+            for (int mr = 0; mr < 4; ++mr) fa[mr] = ((vmask[mr] >> t) & 1u) ? a + mr * MRSTEP : z;
+        }
+    };
+
+    f32x4 ra[NJ / 2];
+    auto gload_a = [&](int cblk, const int half) {
+        const unsigned so = (unsigned)(cblk * XBK * 4);
+#pragma unroll
+        for (int j = 0; j < NJ / 2; ++j)
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[half * (NJ / 2) + j], so, 0));
+    };
+    auto lstore_a = [&](const int abuf, const int half) {
+#pragma unroll
+        for (int j = 0; j < NJ / 2; ++j) {
+            u32x2 hi, lo;
+            Half<T>::split4(ra[j] * a_scale, hi, lo);
+            unsigned short* d = Ah + abuf * ABUF + a_lds[half * (NJ / 2) + j];
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + APL) = lo;
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const char* Ab = reinterpret_cast<const char*>(Ah);
+    u32x4 ah0[4], al0[4];                                     // k-step 0 fragments of the tap about to run
+    int cur[4];                                               // their addresses (k-step 1 = address ^ 32)
+    auto read_a0 = [&](const int t, const int abuf) {
+        tap_addr(t, abuf, cur);
+#pragma unroll
+        for (int mr = 0; mr < 4; ++mr) {
+            ah0[mr] = *reinterpret_cast<const u32x4*>(Ab + cur[mr]);
+            al0[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[mr]);
+        }
+    };
+    auto mfma12 = [&](const u32x4* ah, const u32x4* al, const u32x4 bh, const u32x4 bl) {
+        // small terms first; the three products of one accumulator are four MFMAs apart (no dependent back-to-back issue)
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int mr = 0; mr < 4; ++mr)
+                acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl : bh, acc[mr]);
+    };
+
+    // ---- prologue
+    gload_b(0, 0);
+    gload_b(S > 1 ? 1 : 0, 1);
+    gload_a(0, 0);
+    lstore_a(0, 0);
+    gload_a(0, 1);
+    lstore_a(0, 1);
+    lds_barrier();
+    read_a0(0, 0);
+
+    for (int c = 0; c < ncb; ++c) {
+        const int abuf = (G::NABUF == 2) ? (c & 1) : 0;
+        const bool more = c + 1 < ncb;                         // block-uniform
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int s = c * 9 + t, ring = t % 3;
+            gload_b(s + 2 < S ? s + 2 : S - 1, (t + 2) % 3);   // set (t + 2) % 3 was last read by slice s - 1
+            u32x4 ah1[4], al1[4];
+#pragma unroll
+            for (int mr = 0; mr < 4; ++mr) {
+                ah1[mr] = *reinterpret_cast<const u32x4*>(Ab + (cur[mr] ^ 32));
+                al1[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[mr] ^ 32));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma12(ah0, al0, bq[ring][0], bq[ring][1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (G::NABUF == 2) {
+                // next channel block's halo goes into the OTHER image while this one is being multiplied
+                if (more) {
+                    if (t == 1) gload_a(c + 1, 0);
+                    if (t == 3) lstore_a(abuf ^ 1, 0);
+                    if (t == 4) gload_a(c + 1, 1);
+                    if (t == 6) lstore_a(abuf ^ 1, 1);
+                }
+                if (t < 8) {
+                    read_a0(t + 1, abuf);
+                } else if (more) {
+                    lds_barrier();                             // every wave has staged its share and is done reading
+                    read_a0(0, abuf ^ 1);
+                }
+            } else {
+                if (more && t == 6) gload_a(c + 1, 0);
+                if (t < 8) read_a0(t + 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma12(ah1, al1, bq[ring][2], bq[ring][3]);
+            if (G::NABUF == 1 && t == 8 && more) {
+                // single image: everyone finishes reading, then the two halves are restaged in place
+                lds_barrier();
+                lstore_a(0, 0);
+                gload_a(c + 1, 1);
+                lstore_a(0, 1);
+                lds_barrier();
+                read_a0(0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: every wave owns 128 rows x 32 columns; out_scale undoes the f16 weight pre-scaling exactly
+    const int col = n0 + wn * 32 + l31;
+    const bool nok = col < K;
+    const float bz = (bias && nok) ? bias[col] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int mr = 0; mr < 4; ++mr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long off = Ro[wm * 128 + mr * 32 + egz_acc_row(r, lane)];
+            if (off >= 0 && nok) {
+                float v = acc[mr][r] * out_scale + bz;
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                y[off + col] = v;
+                if (EPI == EPI_BIAS_STATS) {
+                    s1 += (double)v;
+                    s2 += (double)v * (double)v;
+                }
+            }
+        }
+    }
+    if (EPI == EPI_BIAS_STATS) {
+        // one partial row per 128 pixel rows (the granularity egz_conv3x3_stat_rows promises): this wave's own
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const long srow = (long)tile_m * WM + wm;
+        if (hl == 0 && nok && srow * 128 < M) {
+            stat[(srow * 2 + 0) * K + col] = s1;
+            stat[(srow * 2 + 1) * K + col] = s2;
+        }
+    }
+}
+
+// value of GEMM-view weight element (tap, n, k): kind 4 = forward (n = output channel, k = input channel),
+// kind 5 = data gradient (n = input channel, k = output channel, taps flipped)
+__device__ __forceinline__ float frag_value(const float* __restrict__ w, int C, int K, int kind, int tap, int n, int k) {
+    if (kind == 4) return (n < K && k < C) ? w[((long)n * C + k) * 9 + tap] : 0.f;
+    return (n < C && k < K) ? w[((long)k * C + n) * 9 + (8 - tap)] : 0.f;
+}
+
+// one thread per (slice, ntile32, ks, lane, e): both planes of one value
+template <typename T>
+__global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wq,
+                                                             int C, int K, int kind, int Np, int Rp, float scale) {
+    const int nt32 = Np >> 5;
+    const long n = (long)(Rp / XBK) * 9 * nt32 * 1024;       // values (each has a hi and a lo half)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
+        const long r = i >> 10;
+        const int ntile = (int)(r % nt32);
+        const int s = (int)(r / nt32);
+        const int cblk = s / 9, tap = s - cblk * 9;
+        const int col = ntile * 32 + (lane & 31), k = cblk * XBK + ks * 16 + (lane >> 5) * 8 + e;
+        unsigned short h, l;
+        Half<T>::split(frag_value(w, C, K, kind, tap, col, k) * scale, h, l);
+        const long base = ((r * 2 + ks) * 2) * 512 + lane * 8 + e;     // plane 0; plane 1 is 512 elements on
+        wq[base] = h;
+        wq[base + 512] = l;
+    }
+}
+
+template <typename T, int WM>
+int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
+               int W, int C, int K, float out_scale, const unsigned int* a_absmax, hipStream_t st) {
+    using G = Geo<WM>;
+    const long M = (long)B * H * W;
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const bool patch = (W % 16 == 0) && (H % G::PROWS == 0);
+    const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
+    const int total = mt * (Kp / G::BN);
+    const dim3 grid(((total + 7) / 8) * 8);
+#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P>), grid, dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax)
+    if (patch) {
+        if (epi == EPI_BIAS) EGZ_X3S(EPI_BIAS, true);
+        else if (epi == EPI_BIAS_RELU) EGZ_X3S(EPI_BIAS_RELU, true);
+        else EGZ_X3S(EPI_BIAS_STATS, true);
+    } else {
+        if (epi == EPI_BIAS) EGZ_X3S(EPI_BIAS, false);
+        else if (epi == EPI_BIAS_RELU) EGZ_X3S(EPI_BIAS_RELU, false);
+        else EGZ_X3S(EPI_BIAS_STATS, false);
+    }
+#undef EGZ_X3S
+    EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed");
+    return 0;
+}
+
+}  // namespace
+
+// 1 when the streamed-weight kernel covers this plain-conv geometry (C = reduction channels, K = GEMM columns):
+// split-half channel constraints, and either the patch geometry or a raster run whose halo fits the LDS image.
+EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0 || K % 64 != 0) return 0;
+    if (4ull * B * H * W * C >= (1ull << 32)) return 0;
+    const int prow = (K % 128 == 0) ? 8 : 16, bm = (K % 128 == 0) ? 128 : 256, hzero = (K % 128 == 0) ? 255 : 383;
+    if (W % 16 == 0 && H % prow == 0) return 1;
+    return (bm + 2 * W + 2 <= hzero) ? 1 : 0;
+}
+
+// Fragment-ordered split packing for the streamed kernel.  kind 4: forward of a (K, C, 3, 3) weight (GEMM columns = K,
+// reduction = C); kind 5: its data gradient (columns = C, reduction = K, taps flipped).  dtype 1 = f16 (values pre-scaled
+// by 2^10), 2 = bf16.  wq needs egz_pack_w3x3_elems(C, K, 0) * 4 bytes, like the plane-ordered packings.
+EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t st) {
+    EGZ_CHECK_ARG(w && wq && C > 0 && K > 0 && (kind == 4 || kind == 5) && (dtype == 1 || dtype == 2),
+                  "egz_pack_w3x3_split_frag: bad arguments");
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const int Np = (kind == 4) ? Kp : Cp, Rp = (kind == 4) ? Cp : Kp;
+    const long n = (long)9 * Np * Rp;
+    const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
+    unsigned short* o = static_cast<unsigned short*>(wq);
+    if (dtype == 1) hipLaunchKernelGGL(pack_split_frag_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, F16_WSCALE);
+    else            hipLaunchKernelGGL(pack_split_frag_kernel<__bf16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, 1.f);
+    EGZ_CHECK_LAUNCH("egz_pack_w3x3_split_frag");
+    return 0;
+}
+
+// Plain 3x3 conv, split-half arithmetic, streamed fragment-ordered weights.  GEMM view as egz_conv3x3_fwd_split:
+// x [B][H][W][C] (the gathered operand), y [B][H][W][K]; for a data gradient the caller passes dy as x, C = Cout,
+// K = Cin and the kind-5 packing.  epi: 0 bias, 1 bias + ReLU, 2 bias + per-channel (sum, sumsq) partials, one row per
+// 128 pixels as egz_conv3x3_stat_rows(B, H, W, K, 0x200) promises.  Only for geometries egz_conv3x3_streamed_ok accepts.
+EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
+                                     int B, int H, int W, int C, int K, int epi, int dtype,
+                                     const unsigned int* x_absmax, hipStream_t st) {
+    EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
+    EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d is "
+                  "not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K);
+    EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && epi >= 0 && epi <= 2, "egz_conv3x3_fwd_streamed: bad dtype / epilogue");
+    EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_streamed: stats epilogue needs stat_partial");
+    const unsigned short* w16 = static_cast<const unsigned short*>(wq);
+    const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
+    if (K % 128 == 0) {
+        if (dtype == 1) return launch_x3s<_Float16, 1>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        return launch_x3s<__bf16, 1>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    }
+    if (dtype == 1) return launch_x3s<_Float16, 2>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    return launch_x3s<__bf16, 2>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+}

@@ -206,14 +206,26 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
     }
 }
 
-// dw[k][c][tap] (= [k][kk], kk < 9C) = sum_s part[s][k][kk]
-__global__ void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int K, int KK, int KP, int S) {
-    const int n = K * KK;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+// dw[k][c][tap] (= [k][kk], kk < 9C) = sum_s part[s][k][kk].  32 outputs x 8 split groups per block: group g sums the
+// splits g, g + 8, ... with independent loads in flight, the groups are combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 int K, int KK, int KP, int S) {
+    __shared__ float red[8][33];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n = K * KK, i = blockIdx.x * 32 + o;
+    float s = 0.f;
+    if (i < n) {
         const int k = i / KK, kk = i - k * KK;
-        float s = 0.f;
-        for (int sp = 0; sp < S; ++sp) s += part[((long)sp * K + k) * KP + kk];
-        dw[i] = s;
+#pragma unroll 8
+        for (int sp = g; sp < S; sp += 8) s += part[((long)sp * K + k) * KP + kk];
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][o];
+        dw[i] = t;
     }
 }
 
@@ -271,7 +283,7 @@ EGZ_API int egz_conv_first_wgrad(const float* x, const float* dy, float* dw, int
         else          hipLaunchKernelGGL((conv_first_wgrad_kernel<6, 1>), dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
     }
     EGZ_CHECK_LAUNCH("egz_conv_first_wgrad");
-    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(egz_cdiv(K * 9 * C, 256)), dim3(256), 0, st, part, dw, K, 9 * C, KP, S);
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(egz_cdiv(K * 9 * C, 32)), dim3(256), 0, st, part, dw, K, 9 * C, KP, S);
     EGZ_CHECK_LAUNCH("egz_conv_first_wgrad(reduce)");
     return 0;
 }

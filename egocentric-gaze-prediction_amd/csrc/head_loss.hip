@@ -69,14 +69,28 @@ __global__ __launch_bounds__(256) void conv1x1_sigmoid_bwd_kernel(const float* _
     }
 }
 
-__global__ void head_bwd_final_kernel(const double* __restrict__ part, int nparts, int C, float* __restrict__ dw,
-                                      float* __restrict__ db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > C) return;
+// dw[i] = sum_p part[p][i] (i < C), db = column C.  8 columns x 32 row groups per block: group g sums the partials
+// p = g, g + 32, ... (independent loads in flight), the groups are combined in a fixed order -- deterministic and
+// ~20 x faster than one thread walking all partials of a column.
+__global__ __launch_bounds__(256) void head_bwd_final_kernel(const double* __restrict__ part, int nparts, int C,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ double red[32][9];
+    const int o = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + o;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += part[(long)p * (C + 1) + i];
-    if (i < C) dw[i] = (float)s;
-    else if (db) db[0] = (float)s;
+    if (i <= C) {
+#pragma unroll 8
+        for (int p = g; p < nparts; p += 32) s += part[(long)p * (C + 1) + i];
+    }
+    red[g][o] = s;
+    __syncthreads();
+    if (g == 0 && i <= C) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) t += red[q][o];
+        if (i < C) dw[i] = (float)t;
+        else if (db) db[0] = (float)t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- floss
@@ -254,7 +268,7 @@ EGZ_API int egz_conv1x1_sigmoid_bwd(const float* x, const float* w, const float*
     }
 #undef EGZ_HEAD_BWD
     EGZ_CHECK_LAUNCH("egz_conv1x1_sigmoid_bwd");
-    hipLaunchKernelGGL(head_bwd_final_kernel, dim3(egz_cdiv(C + 1, 128)), dim3(128), 0, st, part, grid, C, dw, db);
+    hipLaunchKernelGGL(head_bwd_final_kernel, dim3(egz_cdiv(C + 1, 8)), dim3(256), 0, st, part, grid, C, dw, db);
     EGZ_CHECK_LAUNCH("egz_conv1x1_sigmoid_bwd(final)");
     return 0;
 }

@@ -1,0 +1,68 @@
+// Split-half (hi + lo 16-bit) operand helpers shared by the split-half conv kernels (conv3x3_igemm_x3.hip,
+// conv3x3_igemm_x3s.hip): packed conversions of 4 floats and the three-product MFMA wrapper.
+#pragma once
+#include "egz_common.h"
+
+namespace x3 {
+
+constexpr float F16_WSCALE = 1024.f;    // 2^10: f16 weights are pre-scaled so that the lo half stays normal
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct Half;
+template <> struct Half<_Float16> {
+    static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
+        x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        h = __builtin_bit_cast(unsigned short, hi);
+        l = __builtin_bit_cast(unsigned short, lo);
+    }
+    // 4 floats -> packed hi / lo halves in 3 VALU per float: hi = v_cvt_pkrtz (round toward zero: the residual is then
+    // exact in fp32 and an out-of-range input saturates hi instead of producing inf), lo = RNE of the residual, so the
+    // pair carries 22 significant bits with an unbiased error.  |x| > 65504 is outside the f16 x3 domain (lo overflows).
+    static __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2 * e], v[2 * e + 1]));
+            const f16x2 l = __builtin_convertvector(f32x2{v[2 * e] - (float)h[0], v[2 * e + 1] - (float)h[1]}, f16x2);
+            hi[e] = __builtin_bit_cast(unsigned, h);
+            lo[e] = __builtin_bit_cast(unsigned, l);
+        }
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Half<__bf16> {
+    static __device__ __forceinline__ void split(float x, unsigned short& h, unsigned short& l) {
+        const __bf16 hi = (__bf16)x;
+        const __bf16 lo = (__bf16)(x - (float)hi);
+        h = __builtin_bit_cast(unsigned short, hi);
+        l = __builtin_bit_cast(unsigned short, lo);
+    }
+    // v_cvt_pk_bf16_f32 (RNE), two bit ops to widen the halves back, one packed subtract, v_cvt_pk_bf16_f32: 2.5 VALU / float
+    static __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const f32x2 x = {v[2 * e], v[2 * e + 1]};
+            const unsigned hu = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2));
+            const f32x2 hf = {__builtin_bit_cast(float, hu << 16), __builtin_bit_cast(float, hu & 0xffff0000u)};
+            hi[e] = hu;
+            lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, bf16x2));
+        }
+    }
+    static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+
+}  // namespace x3

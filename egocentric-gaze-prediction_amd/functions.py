@@ -34,6 +34,20 @@ def from_nhwc(y: torch.Tensor) -> torch.Tensor:
     return y.permute(0, 3, 1, 2)
 
 
+DETACH_WGRAD = __import__("os").environ.get("EGAZE_DETACH_WGRAD", "1") != "0"      # A/B knob
+
+
+def _close_fork(f, sink, dw, *inputs):
+    """End of a forked weight-gradient computation.  With a gradient sink the result is not consumed by autograd, so the
+    helper stream is left running (streams.fork.detach): the weight gradient of layer L then overlaps the HBM-bound
+    BN / ReLU backward pass and the data gradient of layer L-1 instead of holding the chain up.  Without a sink the
+    gradient tensor goes back to autograd and the streams are joined."""
+    if sink is not None and DETACH_WGRAD:
+        f.detach(*inputs)
+    else:
+        f.join(dw)
+
+
 def _finish(param, sink, grad):
     """End of a parameter-gradient computation: with a sink the gradient already sits in the optimizer's flat buffer --
     run the sink hooks and hand ``None`` to autograd; without one, return the tensor for autograd to accumulate."""
@@ -69,16 +83,18 @@ class ConvBNReLUPool(torch.autograd.Function):
             # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
             # for this one layer); the packed weight is padded the same way by the pack kernel
             xin = H.nchw_to_nhwc_pad(H._req(x.detach(), "network input (NCHW)"), 32)
-            y, stat = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd", H.F16X3), bias.detach() if bias is not None else None,
-                                    K, ups=False, epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3)
+            wp, st = H.conv_weight(weight, "fwd", H.F16X3, xin, K)
+            y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
+                                    epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3, streamed=st)
         elif first:
             xin = H._req(x.detach(), "network input (NCHW)")
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training)
         else:
             xin = to_nhwc(x)
             dt = H.conv_dtype("fwd", K, C, xin)
-            y, stat = H.conv3x3_fwd(xin, H.packed_weight(weight, "fwd", dt), bias.detach() if bias is not None else None,
-                                    K, ups=False, epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt)
+            wp, st = H.conv_weight(weight, "fwd", dt, xin, K)
+            y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
+                                    epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt, streamed=st)
         B, Hh, Ww, _ = y.shape
         if training:
             coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
@@ -115,8 +131,9 @@ class ConvBNReLUPool(torch.autograd.Function):
             if first:
                 raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
             dt = H.conv_dtype("dgrad", C, K, dy)
-            dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
-        f.join(dw)
+            wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
+            dx = from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
+        _close_fork(f, sw, dw, xin, dy)
         return (dx, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
                 _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None)
 
@@ -127,9 +144,9 @@ class ConvReLU(torch.autograd.Function):
         K, C = weight.shape[0], weight.shape[1]
         xin = to_nhwc(x)
         dt = H.conv_dtype("fwd", K, C, xin)
-        y, _ = H.conv3x3_fwd(xin, H.packed_weight(weight, "ups_fwd" if ups else "fwd", dt),
-                             bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
-                             epi=H.EPI_BIAS_RELU, dtype=dt)
+        wp, st = (H.packed_weight(weight, "ups_fwd", dt), False) if ups else H.conv_weight(weight, "fwd", dt, xin, K)
+        y, _ = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
+                             epi=H.EPI_BIAS_RELU, dtype=dt, streamed=st)
         ctx.save_for_backward(xin, y, weight, bias)
         ctx.cfg = (ups, C, K)
         return from_nhwc(y)
@@ -154,8 +171,9 @@ class ConvReLU(torch.autograd.Function):
             if ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
                 dx = from_nhwc(H.conv3x3_ups_dgrad(dy, H.packed_weight(weight, "ups_dgrad", dt), C, dtype=dt))
             else:
-                dx = from_nhwc(H.conv3x3_dgrad(dy, H.packed_weight(weight, "dgrad", dt), C, dtype=dt))
-        f.join(dw)
+                wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
+                dx = from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
+        _close_fork(f, sw, dw, xin, dy)
         return dx, _finish(weight, sw, dw), _finish(bias, sbias, db), None
 
 
@@ -173,8 +191,9 @@ class FusionBlock(torch.autograd.Function):
         else:
             x2 = H.stack2(a, b)
         dt = H.conv_dtype("fwd", K, C, x2)
-        y2, _ = H.conv3x3_fwd(x2, H.packed_weight(weight, "fwd", dt), bias.detach() if bias is not None else None, K,
-                              ups=False, epi=H.EPI_BIAS, dtype=dt)
+        wp, st = H.conv_weight(weight, "fwd", dt, x2, K)
+        y2, _ = H.conv3x3_fwd(x2, wp, bias.detach() if bias is not None else None, K, ups=False, epi=H.EPI_BIAS, dtype=dt,
+                              streamed=st)
         z = H.pairmax_fwd(y2)
         B, Hh, Ww, _ = z.shape
         if training:
@@ -207,10 +226,11 @@ class FusionBlock(torch.autograd.Function):
                 dw = H.conv3x3_wgrad(x2, dy2, out=sw).view(weight.shape)
         if ng[0] or ng[1]:
             dt = H.conv_dtype("dgrad", C, K, dy2)
-            dx2 = H.conv3x3_dgrad(dy2, H.packed_weight(weight, "dgrad", dt), C, dtype=dt)
+            wp, st = H.conv_weight(weight, "dgrad", dt, dy2, C)
+            dx2 = H.conv3x3_dgrad(dy2, wp, C, dtype=dt, streamed=st)
             B = dx2.shape[0] // 2
             dfs, dft = from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
-        f.join(dw)
+        _close_fork(f, sw, dw, x2, dy2)
         return (dfs, dft, _finish(weight, sw, dw), _finish(bias, sbias, db),
                 _finish(gamma, sg, dgamma if ng[4] else None), _finish(beta, sb, dbeta if ng[5] else None),
                 None, None, None, None, None, None)

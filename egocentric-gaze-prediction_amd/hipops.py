@@ -156,7 +156,9 @@ def _uid(w: torch.Tensor) -> int:
 
 
 _PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad", 0, 1),
-            "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1, 2), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1, 3)}
+            "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1, 2), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1, 3),
+            # MFMA-fragment-ordered split packings of the streamed-weight kernel (split dtypes only)
+            "fwd_frag": (None, 0, 4), "dgrad_frag": (None, 0, 5)}
 
 # Arithmetic of the wide convolutions (GEMM output channels % 128 == 0):
 #   "split" (default) error-compensated split-half operands on the 16-bit MFMA path: f16 x3 (22 significant bits;
@@ -186,6 +188,20 @@ def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.T
     return F16X3 if (role == "fwd" or GRAD_SPLIT == "f16") else BF16X3
 
 
+STREAMED = _os.environ.get("EGAZE_STREAMED", "1") != "0"      # A/B knob: 0 = halo kernel with LDS-DMA weights for plain convs
+
+
+def conv_weight(w: torch.Tensor, role: str, dtype: int, x: torch.Tensor, gemm_out: int):
+    """The packed weight a plain 3x3 conv launch over the NHWC operand ``x`` needs -> (packed buffer, streamed flag).
+    Split-half launches whose geometry the streamed-weight kernel covers (egz_conv3x3_streamed_ok) use the MFMA-fragment-
+    ordered packing; everything else the plane-ordered one.  role: 'fwd' | 'dgrad'."""
+    if dtype and STREAMED:
+        B, H, W, C = x.shape
+        if LIB.egz_conv3x3_streamed_ok(B, H, W, C, gemm_out):
+            return packed_weight(w, role + "_frag", dtype), True
+    return packed_weight(w, role, dtype), False
+
+
 def _drop_packed(uid: int):
     for kind in _PACK_FN:
         for dt in (0, 1, 2):
@@ -206,7 +222,12 @@ def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
     fname, ekind, kidx = _PACK_FN[kind]
     buf = hit[1] if hit is not None else torch.empty(LIB.egz_pack_w3x3_elems(C, K, ekind), dtype=torch.float32,
                                                      device=w.device)
-    if dtype:      # hi / lo 16-bit planes (same byte count as the fp32 packing)
+    if kidx >= 4:
+        if not dtype:
+            raise RuntimeError("fragment-ordered packings exist for the split-half dtypes only")
+        check(LIB.egz_pack_w3x3_split_frag(w.data_ptr(), buf.data_ptr(), C, K, kidx, dtype, _stream()),
+              "egz_pack_w3x3_split_frag")
+    elif dtype:      # hi / lo 16-bit planes (same byte count as the fp32 packing)
         check(LIB.egz_pack_w3x3_split(w.data_ptr(), buf.data_ptr(), C, K, kidx, dtype, _stream()), "egz_pack_w3x3_split")
     else:
         check(getattr(LIB, fname)(w.data_ptr(), buf.data_ptr(), C, K, _stream()), fname)
@@ -227,7 +248,7 @@ def repack_params(params) -> int:
     uids.discard(None)
     for key, ent in _PACKED.items():
         uid, kind, dtype = key
-        if uid not in uids or not dtype:
+        if uid not in uids or not dtype or _PACK_FN[kind][2] >= 4:
             continue
         w = ent[2]()
         if w is None or not w.is_cuda:
@@ -328,7 +349,8 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- convolutions
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
-                epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None):
+                epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None,
+                streamed: bool = False):
     """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups.
     ups: False | 'fold' (3x3 taps on the virtual upsampled image, wp = 'fwd' packing) | 'phase' or True (four 2x2
     phase convolutions on the low-res input, 4/9 of the MACs, wp = 'ups_fwd' packing)."""
@@ -342,6 +364,13 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     if epi == EPI_BIAS_STATS:
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
+    if dtype and streamed:       # wp = fragment-ordered packing (conv_weight): weights L2 -> registers, halo through LDS
+        if ups:
+            raise RuntimeError("the streamed-weight kernel covers plain convolutions only")
+        PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
+                                           epi, dtype, _p(absmax), _stream()), "egz_conv3x3_fwd_split")
+        return y, stat
     if dtype:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         sflags = (flags & 0x33) | (tile_flag & 0x6000)      # 0x4000: split-K tail schedule, 0x2000: no halo-tile kernel
@@ -356,11 +385,11 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     return y, stat
 
 
-def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int, dtype: int = 0) -> torch.Tensor:
+def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int, dtype: int = 0, streamed: bool = False) -> torch.Tensor:
     """dy: (B,H,W,K) -> dx (B,H,W,C) (for an upsampled conv this is the gradient of the upsampled input).
     dtype F16X3: dy is scaled by a power of two derived from its abs-max so that the f16 halves carry it."""
     y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS, dtype=dtype,
-                       absmax=absmax_of(dy) if dtype == F16X3 else None)
+                       absmax=absmax_of(dy) if dtype == F16X3 else None, streamed=streamed)
     return y
 
 

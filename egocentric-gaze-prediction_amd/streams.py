@@ -55,6 +55,19 @@ class fork:
                 if t is not None:
                     t.record_stream(self.cur)
 
+    def detach(self, *inputs):
+        """Leave the side stream running instead of joining it: its kernels only produce results nobody on the current
+        stream reads (a weight gradient written straight into the optimizer's buffer -- the optimizer step and the
+        gradient all-reduce order themselves after every helper stream).  ``inputs`` are the tensors the side-stream
+        kernels read: the caching allocator must not hand their memory out again before those kernels have run."""
+        if self.enabled:
+            for t in inputs:
+                if t is not None:
+                    t.record_stream(self.side)
+                    am = getattr(t, "_egz_absmax", None)         # the abs-max scalar a gradient tensor carries (hipops)
+                    if am is not None:
+                        am.record_stream(self.side)
+
 
 def join_all_into_current():
     """Make the current stream wait for every helper stream created so far (used before a gradient bucket that may

@@ -480,3 +480,69 @@ def test_first_conv_padded_split_path(B, Hh, Ww, C):
         assert tuple(dw.shape) == (K, 32, 3, 3)
         assert rel(dw[:, :C].cpu(), wref) < tol, prec
         assert float(dw[:, C:].abs().max()) == 0.0, prec
+
+
+# ----------------------------------------------------------------------------- streamed-weight kernel (conv3x3_igemm_x3s)
+@pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
+@pytest.mark.parametrize("B,Hh,Ww,C,K", [
+    # patch geometry, 128-column tiles (8 x 16 patches) / 64-column tiles (16 x 16 patches)
+    (2, 16, 32, 64, 128), (1, 8, 16, 32, 256), (3, 24, 48, 96, 128), (2, 16, 16, 64, 64), (1, 32, 48, 32, 64),
+    # raster runs: row ends, image borders, ragged last tile, several channel blocks (double-buffered image switches)
+    (3, 28, 28, 64, 128), (2, 14, 14, 256, 256), (1, 56, 56, 64, 128), (5, 5, 3, 64, 64), (1, 20, 56, 96, 64),
+    (2, 12, 12, 128, 64), (3, 9, 7, 32, 128), (1, 8, 24, 64, 192)])
+def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
+    """Streamed-weight halo kernel (fragment-ordered weights L2 -> registers, activation halo through LDS) against an fp64
+    reference: forward with all three epilogues (BN partial sums included) and the data gradient, f16 x3 and bf16 x3."""
+    h = H()
+    x = rnd(B, C, Hh, Ww, seed=61)
+    w = rnd(K, C, 3, 3, seed=62, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=63, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    wd, xd = w.to(DEV), nhwc(x)
+    wp, st = h.conv_weight(wd, "fwd", dtype, xd, K)
+    assert st, "geometry expected on the streamed kernel"
+    for epi in (0, 1, 2):
+        want = F.relu(ref) if epi == 1 else ref
+        y, stat = h.conv3x3_fwd(xd, wp, b.to(DEV), K, epi=epi, dtype=dtype, streamed=True)
+        assert rel(nchw(y), want) < tol, epi
+        if epi == 2:
+            assert stat.shape[0] == (B * Hh * Ww + 127) // 128
+            assert rel(stat.sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
+            assert rel(stat.sum(0)[1].cpu(), (ref * ref).sum(dim=(0, 2, 3))) < 1e-5
+    # same values as the LDS-DMA halo kernel up to fp32 summation order
+    yh, sh = h.conv3x3_fwd(xd, h.packed_weight(wd, "fwd", dtype), b.to(DEV), K, epi=2, dtype=dtype)
+    assert rel(y, yh) < 2e-6 and rel(stat.sum(0), sh.sum(0)) < 1e-6
+    if C % 64 == 0:
+        dy = rnd(B, K, Hh, Ww, seed=64)
+        dref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1)
+        dyd = nhwc(dy)
+        wq, st = h.conv_weight(wd, "dgrad", dtype, dyd, C)
+        assert st
+        dx = h.conv3x3_dgrad(dyd, wq, C, dtype=dtype, streamed=True)
+        assert rel(nchw(dx), dref) < tol
+
+
+def test_conv3x3_streamed_shape_fuzz():
+    """Random geometries through the streamed kernel wherever egz_conv3x3_streamed_ok accepts them, against the exact-f32
+    kernels: patch / run selection, ragged tiles, XCD tile map with tile counts that are not multiples of 8."""
+    h = H()
+    rs = np.random.RandomState(77)
+    n_streamed = 0
+    for it in range(40):
+        B = int(rs.randint(1, 5))
+        Hh = int(rs.choice([2, 3, 5, 7, 8, 14, 16, 24, 28, 30, 32, 48, 56, 57]))
+        Ww = int(rs.choice([2, 3, 4, 7, 8, 14, 16, 28, 32, 48, 56, 60, 62, 64, 80]))
+        C, K = int(rs.choice([32, 64, 96, 128, 256])), int(rs.choice([64, 128, 192, 256]))
+        x = torch.from_numpy(rs.standard_normal((B, Hh, Ww, C)).astype(np.float32)).to(DEV)
+        w = torch.from_numpy((rs.standard_normal((K, C, 3, 3)) * (2.0 / (9 * C)) ** 0.5).astype(np.float32)).to(DEV)
+        b = torch.from_numpy(rs.standard_normal(K).astype(np.float32) * 0.1).to(DEV)
+        wp, st = h.conv_weight(w, "fwd", 1, x, K)
+        if not st:
+            assert Ww > 62 and (Ww % 16 != 0 or Hh % (8 if K % 128 == 0 else 16) != 0), (it, B, Hh, Ww, C, K)
+            continue
+        n_streamed += 1
+        y0, s0 = h.conv3x3_fwd(x, h.packed_weight(w, "fwd", 0), b, K, epi=2, dtype=0)
+        y1, s1 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
+        assert rel(y1, y0) < 5e-6, (it, B, Hh, Ww, C, K)
+        assert rel(s1.sum(0), s0.sum(0)) < 1e-5, (it, B, Hh, Ww, C, K)
+    assert n_streamed >= 25

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--shape", action="append", default=[], help="extra shape C,K,H,B (plain conv)")
     ap.add_argument("--dtype", type=int, default=0, help="1 = f16 x3 forward / 2 = bf16 x3 (split-half kernels)")
+    ap.add_argument("--zero", action="store_true", help="all-zero operands (DVFS probe: same instruction stream, no data toggling)")
     ap.add_argument("--wflag", type=lambda v: int(v, 0), default=0, help="0x800 = per-tap wgrad kernel")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -68,20 +69,23 @@ def main():
         w = torch.randn(K, C, 3, 3, device=dev) * 0.05
         bias = torch.randn(K, device=dev)
         dy = torch.randn(B, Hh, Hh, K, device=dev)
+        if a.zero:
+            x.zero_(); w.zero_(); dy.zero_()
         flops = 2.0 * B * Hh * Hh * K * 9 * C
         fdt = a.dtype if (a.dtype and K % 64 == 0) else 0
         ddt = a.dtype if (a.dtype and C % 64 == 0) else 0
-        wp = H.packed_weight(w, "ups_fwd" if ups else "fwd", fdt)
-        wd = H.packed_weight(w, "dgrad", ddt)
+        # plain convs: the packing / kernel hipops picks for this geometry (streamed-weight kernel unless EGAZE_STREAMED=0)
+        wp, fst = (H.packed_weight(w, "ups_fwd", fdt), False) if ups else H.conv_weight(w, "fwd", fdt, x, K)
+        wd, dst = H.conv_weight(w, "dgrad", ddt, dy, C)
         res = []
         if "fwd" in a.what:
             t = timeit(lambda: H.conv3x3_fwd(x, wp, bias, K, ups="phase" if ups else False,
                                              epi=H.EPI_BIAS_RELU if ups else H.EPI_BIAS_STATS,
-                                             tile_flag=a.tile, dtype=fdt), a.iters)
+                                             tile_flag=a.tile, dtype=fdt, streamed=fst), a.iters)
             res.append(("fwd", t))
         if "dgrad" in a.what:
-            t = timeit(lambda: H.conv3x3_fwd(dy, wd, None, C, ups=False, epi=H.EPI_BIAS, tile_flag=a.tile, dtype=ddt),
-                       a.iters)
+            t = timeit(lambda: H.conv3x3_fwd(dy, wd, None, C, ups=False, epi=H.EPI_BIAS, tile_flag=a.tile, dtype=ddt,
+                                             streamed=dst), a.iters)
             res.append(("dgrad", t))
         if "wgrad" in a.what:
             t = timeit(lambda: H.conv3x3_wgrad(x, dy, ups=ups, variant_flag=a.wflag), a.iters)
