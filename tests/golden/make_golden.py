@@ -319,9 +319,131 @@ def gen_config1():
     print("config1 out range", out.min().item(), out.max().item(), "fin range", fin.min().item(), fin.max().item())
 
 
+def bilinear_u8(arr, size):
+    """Stand-in for cv2.resize(arr, size) (INTER_LINEAR) on a uint8 map -- cv2 is absent in the build container, so the
+    reference's ONE call to it (AT.py:251, the 14x14 -> 224x224 AT map) is emulated in float with half-pixel centres and
+    edge clamping, rounded to nearest.  cv2 itself works in 11-bit fixed point and can differ by 1 LSB; consumers compare
+    the exact 14x14 map and treat the 224x224 one as data."""
+    h, w = arr.shape
+    W2, H2 = size
+    ys = np.clip((np.arange(H2) + 0.5) * h / H2 - 0.5, 0, h - 1)
+    xs = np.clip((np.arange(W2) + 0.5) * w / W2 - 0.5, 0, w - 1)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+    fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+    a = arr.astype(np.float64)
+    out = (a[y0][:, x0] * (1 - fy) * (1 - fx) + a[y0][:, x1] * (1 - fy) * fx
+           + a[y1][:, x0] * fy * (1 - fx) + a[y1][:, x1] * fy * fx)
+    return np.uint8(np.floor(out + 0.5))
+
+
+def gen_extract_lstm():
+    """extractLSTMw.py: crop_feature_var for every gaze cell of a 14x14 map (float clip + int() slicing, :46-58) and the
+    fixation state machine of extractw (:60-112) driven through the reference's own function with a fake loader/model."""
+    import tempfile
+    import extractLSTMw as rex
+    arrs = {}
+    rs = np.random.RandomState(51)
+    feat = torch.from_numpy(np.abs(rs.standard_normal((1, 6, 14, 14))).astype(np.float32))
+    for size in (2, 3, 4):
+        means, shapes = [], []
+        for ind in range(196):
+            c = rex.crop_feature_var(feat, torch.tensor([[ind]]), size).contiguous()
+            shapes.append(c.shape[2:])
+            means.append(c.view(1, 6, -1).mean(2).numpy()[0])
+        arrs[f"var_mean_s{size}"] = np.array(means)
+        arrs[f"var_shape_s{size}"] = np.array(shapes)
+    # state machine: which frames get extracted, and what is stored for them (AvgPool2d(16) arg-max cell)
+    fix = [0, 1, 1, 1, 0, 0, 1, 1, 0, 1, 1, 1, 1, 0]
+    gts = synth.synth_gt(len(fix), 224, np.random.RandomState(52))
+    ims = rs.standard_normal((len(fix), 3, 224, 224)).astype(np.float32)
+    loader = [{"fixsac": torch.tensor([[float(f)]]), "imname": ["vid_%05d.jpg" % i],
+               "image": torch.from_numpy(ims[i:i + 1]), "gt": torch.from_numpy(gts[i:i + 1])} for i, f in enumerate(fix)]
+
+    class Fake(torch.nn.Module):            # a cheap deterministic stand-in for features_s: (1,3,224,224) -> (1,512,14,14)
+        def forward(self, x):
+            p = torch.nn.functional.avg_pool2d(x, 16)                                  # (1,3,14,14)
+            k = torch.arange(512, dtype=torch.float32).view(1, 512, 1, 1)
+            return torch.relu(p[:, 0:1] * torch.sin(k * 0.37) + p[:, 1:2] * torch.cos(k * 0.11) + p[:, 2:3] * 0.5)
+
+    with tempfile.TemporaryDirectory() as d:
+        rex.extractw(loader, Fake(), d, crop_size=3, device="cpu", align=False)
+        names = sorted(os.listdir(d))
+        arrs["extractw_names"] = np.array(names)
+        arrs["extractw_vecs"] = np.stack([torch.load(os.path.join(d, n)).numpy() for n in names])
+    arrs["extractw_fix"] = np.array(fix)
+    save("extract_lstm.npz", **arrs)
+
+
+def gen_config5():
+    """BASELINE config 5, the hand-over between the stages: AT.extract_late (AT.py:199-253) on three seeded frames --
+    SP gaze map -> uint8; hooked features_s; GT gaze point; 3x3 crop mean; LSTM branch on saccade frames with the hidden
+    state carried over; channel-weighted map -> uint8 -> resize -- followed by ONE LF.trainLate step (LF.py:83-100) on what
+    was extracted.  AT.__init__ / LF.__init__ need CUDA and dataset folders, so the objects are assembled with __new__ and
+    the reference METHODS run unmodified.  cv2 is stubbed: imwrite captures the arrays, resize = bilinear_u8 above."""
+    import tempfile
+    import AT as rat
+    import utils as rutils
+    from models.model_SP import model_SP
+    from models.LSTMnet import lstmnet
+    from models.late_fusion import late_fusion
+    from floss import floss
+    written = {}
+    resized_in = []
+    cv2 = sys.modules["cv2"]
+    cv2.imwrite = lambda path, arr: written.__setitem__(path, np.array(arr, copy=True))
+    def _resize(arr, size):
+        resized_in.append(np.array(arr, copy=True))
+        return bilinear_u8(arr, size)
+    cv2.resize = _resize
+    rat.cv2 = cv2
+    at = rat.AT.__new__(rat.AT)
+    at.device = torch.device("cpu")
+    at.align, at.crop_size = False, 3
+    at.model = model_SP(rutils.make_layers(rutils.cfg["D"], 3), rutils.make_layers(rutils.cfg["D"], 20))
+    load_synth(at.model, seed=1, head_gain=0.25)
+    at.model._modules.get(rat.hook_name).register_forward_hook(rat.hook_feature)
+    at.lstm = lstmnet()
+    load_synth(at.lstm, seed=2)
+    n = 3
+    x_s, x_t, gt, _ = synth.synth_sp_batch(n, 224, seed=31)
+    fixsac = [1.0, 0.0, 0.0]              # a fixation frame, then two saccade frames (LSTM branch, hidden carried over)
+    loader = [{"imname": ["f%d.png" % i], "fixsac": torch.tensor([[fixsac[i]]]), "image": x_s[i:i + 1],
+               "flow": x_t[i:i + 1], "gt": gt[i:i + 1]} for i in range(n)]
+    with tempfile.TemporaryDirectory() as d:
+        pred_dir, feat_dir = os.path.join(d, "pred") + "/", os.path.join(d, "feat") + "/"
+        at.extract_late(loader, pred_dir, feat_dir)
+        pred = np.stack([written[os.path.join(pred_dir, "f%d.png" % i)] for i in range(n)])
+        feat = np.stack([written[os.path.join(feat_dir, "f%d.png" % i)] for i in range(n)])
+    feat14 = np.stack(resized_in)
+    assert pred.dtype == np.uint8 and feat.dtype == np.uint8 and feat14.shape == (n, 14, 14)
+    # one LF.trainLate step on the extracted maps (tensors as data/lateDataset.py:22-33 builds them)
+    lf = late_fusion()
+    load_synth(lf, seed=3, head_gain=0.5)
+    crit = floss()
+    opt = torch.optim.Adam(lf.parameters(), lr=1e-4)
+    im = torch.from_numpy(pred).float().div(255).unsqueeze(1)
+    ft = torch.from_numpy(feat).float().div(255).unsqueeze(1)
+    gtq = torch.from_numpy(np.uint8(np.round(gt.numpy() * 255))).float().div(255)       # the gt as an 8-bit image
+    out = lf(ft, im)                                                                     # LF.py:90 argument order
+    loss = crit(out, gtq)
+    aae, auc, _ = rutils.computeAAEAUC(out.detach().numpy().squeeze(), gtq.numpy().squeeze())
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    arrs = dict(pred_u8=pred, feat14_u8=feat14, feat_u8=feat, fixsac=np.array(fixsac), lf_out=out.detach().numpy(),
+                lf_loss=np.array(loss.item()), lf_aae_auc=np.array([aae, auc]))
+    for k, p in lf.named_parameters():
+        arrs["lf_after_sum/" + k] = np.array([p.detach().double().sum().item(), p.detach().double().norm().item()])
+    print("config5: pred range", pred.min(), pred.max(), "feat14 range", feat14.min(), feat14.max(), "loss", loss.item())
+    save("config5.npz", **arrs)
+
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "config1":
-        gen_config1()
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            {"config1": gen_config1, "config5": gen_config5, "extract_lstm": gen_extract_lstm}[name]()
         sys.exit(0)
     gen_floss()
     gen_lstm()
@@ -330,3 +452,5 @@ if __name__ == "__main__":
     gen_model_sp(32, 2, "s32", head_gain=0.25)
     gen_model_sp(224, 2, "s224", head_gain=0.25)
     gen_config1()
+    gen_extract_lstm()
+    gen_config5()

@@ -120,3 +120,45 @@ def test_stdataset_raw_u8_contract(tmp_path):
         assert torch.equal((b['flow'].float().div(255) - 0.5) / 0.5, a['flow'])
         assert torch.equal(b['gt'].float().div(255), a['gt'])
         assert float(a['fixsac']) == 1.0                       # [0, 1] dilated by [1, 1, 1] -> [1, 1]
+
+
+def test_extract_lstm_mirror_matches_reference_golden(tmp_path):
+    """extractLSTMw mirror against fixtures produced by the reference's own crop_feature_var / extractw
+    (tests/golden/make_golden.py gen_extract_lstm): float-clip window for every gaze cell and crop size, the
+    AvgPool2d(16) arg-max cell, the fixation state machine and the stored vectors."""
+    import numpy as np
+    import torch
+    import egaze_amd  # noqa: F401
+    from egaze_amd import extractLSTMw as ex
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "extract_lstm.npz"))
+    rs = np.random.RandomState(51)
+    feat = torch.from_numpy(np.abs(rs.standard_normal((1, 6, 14, 14))).astype(np.float32))
+    for size in (2, 3, 4):
+        for ind in range(196):
+            c = ex.crop_feature_var(feat, torch.tensor([[ind]]), size).contiguous()
+            assert tuple(c.shape[2:]) == tuple(gold[f"var_shape_s{size}"][ind]), (size, ind)
+            assert np.allclose(c.view(1, 6, -1).mean(2).numpy()[0], gold[f"var_mean_s{size}"][ind], rtol=1e-6, atol=1e-7)
+    assert ex.var_window(0, 3, 14, 14) == (0, 3, 0, 3) and ex.var_window(5 * 14 + 5, 3, 14, 14) == (3, 7, 3, 7)
+    # state machine + stored vectors, driven exactly like the generator drove the reference
+    from oracle import synth
+    fix = [int(v) for v in gold["extractw_fix"]]
+    gts = synth.synth_gt(len(fix), 224, np.random.RandomState(52))
+    ims = rs.standard_normal((len(fix), 3, 224, 224)).astype(np.float32)
+    loader = [{"fixsac": torch.tensor([[float(f)]]), "imname": ["vid_%05d.jpg" % i],
+               "image": torch.from_numpy(ims[i:i + 1]), "gt": torch.from_numpy(gts[i:i + 1])} for i, f in enumerate(fix)]
+
+    class Fake(torch.nn.Module):
+        def forward(self, x):
+            p = torch.nn.functional.avg_pool2d(x, 16)
+            k = torch.arange(512, dtype=torch.float32).view(1, 512, 1, 1)
+            return torch.relu(p[:, 0:1] * torch.sin(k * 0.37) + p[:, 1:2] * torch.cos(k * 0.11) + p[:, 2:3] * 0.5)
+
+    ex.extractw(loader, Fake(), str(tmp_path), crop_size=3, device="cpu", align=False)
+    names = sorted(os.listdir(str(tmp_path)))
+    assert names == [str(n) for n in gold["extractw_names"]]
+    vecs = np.stack([torch.load(os.path.join(str(tmp_path), n)).numpy() for n in names])
+    assert np.allclose(vecs, gold["extractw_vecs"], rtol=1e-5, atol=1e-7)
+    # a fixation that ends after one frame is an error in the reference (extractLSTMw.py:110-111)
+    bad = [dict(loader[0], fixsac=torch.tensor([[1.0]])), dict(loader[1], fixsac=torch.tensor([[0.0]]))]
+    with pytest.raises(RuntimeError):
+        ex.extractw(bad, Fake(), str(tmp_path / "bad"), crop_size=3, device="cpu")
