@@ -35,9 +35,9 @@ SIGNATURES = {
     "egz_pack_w3x3_split_multi": (c_int, [P, c_int, c_int, S]),
     "egz_conv3x3_fwd_split_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
-    "egz_conv3x3_streamed_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "egz_conv3x3_streamed_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_pack_w3x3_split_frag": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
-    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, S]),
+    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)

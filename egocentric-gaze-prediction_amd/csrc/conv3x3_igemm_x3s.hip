@@ -44,8 +44,12 @@ template <int WM> struct Geo {
 // wait for vmcnt(0).  lgkmcnt(0) = this wave's LDS reads / writes are done; the "memory" clobber pins the compiler.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// wq: fragment-ordered split weights (see the header); x: [B][H][W][C] fp32; y: [B][H][W][K] fp32 (GEMM N = K columns).
-template <typename T, int WM, int EPI, bool PATCH>
+enum { PLAIN = 0, UPSD = 1 };
+
+// wq: fragment-ordered split weights (see the header); x: [B][H][W][C] fp32 (the gathered operand);
+// MODE PLAIN: y [B][H][W][K] = conv3x3(x);  MODE UPSD: y [B][H/2][W/2][K] = the data gradient of [nearest x2 upsample ->
+// conv3x3] w.r.t. the LOW-res input, x = the hi-res dy (see the UPSD notes in front of the image loop).
+template <typename T, int WM, int EPI, bool PATCH, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
@@ -54,6 +58,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
     constexpr int APL = HSLOTS * XLD;                          // elements per plane of an activation image
     constexpr int ABUF = 2 * APL;                              // elements per image (hi + lo)
+    constexpr int NIMG = (MODE == UPSD) ? 4 : 1;               // staged images per channel block
+    constexpr int NT = (MODE == UPSD) ? 4 : 9;                 // taps per staged image
+    constexpr int NRING = (MODE == UPSD) ? 2 : 3;              // weight-fragment register sets (NIMG * NT % NRING == 0)
+    static_assert(MODE == PLAIN || WM == 1, "the upsample data gradient is built for the 128-column tile only");
     __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
     __shared__ long Ro[BM];
 
@@ -68,20 +76,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     if (gt >= total) return;
     const int tile_n = gt % ntn, tile_m = gt / ntn;
     const int n0 = tile_n * BN;
-    const long HW = (long)H * W, M = (long)B * HW;
+    const int Ho = (MODE == UPSD) ? (H >> 1) : H, Wo = (MODE == UPSD) ? (W >> 1) : W;     // output image
+    const long HW = (long)Ho * Wo, M = (long)B * HW;
     const long m0 = (long)tile_m * BM;
-    const int pw = W >> 4, ppi = (H / G::PROWS) * pw;           // patches per row / per image
+    const int pw = Wo >> 4, ppi = (Ho / G::PROWS) * pw;         // patches per row / per image
     const int b0 = PATCH ? tile_m / ppi : 0;
     const int y0 = PATCH ? ((tile_m - b0 * ppi) / pw) * G::PROWS : 0, x0 = PATCH ? ((tile_m - b0 * ppi) % pw) * 16 : 0;
 
     for (int i = tid; i < BM; i += 256) {
         long off = -1;
-        if (PATCH) off = (((long)b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15)) * K;
+        if (PATCH) off = (((long)b0 * Ho + y0 + (i >> 4)) * Wo + x0 + (i & 15)) * K;
         else if (m0 + i < M) off = (m0 + i) * K;
         Ro[i] = off;
     }
 
-    // ---- activation halo staging map: slot q = (tid >> 3) + 32 j holds 4 channels (tid & 7) of one input pixel
+    // ---- activation halo staging map: slot q = (tid >> 3) + 32 j holds 4 channels (tid & 7) of one pixel of the staged
+    // image.  PLAIN: the image is x itself.  UPSD: the image is one of the four polyphase components of the hi-res dy,
+    // D_pq[yy][xx] = dy[2 yy + p][2 xx + q] -- an Ho x Wo image whose pixel (yy, xx) sits at a byte offset that is affine
+    // in (p, q): the map below is built for (p, q) = (0, 0) and a component is selected by ONE scalar offset.
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
     const int a_c4 = tid & 7;
@@ -90,43 +102,53 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = (tid >> 3) + 32 * j;
-        long pix = -1;
+        long pix = -1;                                         // source pixel index in x (class (0, 0) for UPSD)
         int col = q;
+        int iy = -1, ix = -1, ib = 0;
         if (PATCH) {
             const int hy = q / HPITCH, hx = q - hy * HPITCH;
-            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            iy = y0 - 1 + hy;
+            ix = x0 - 1 + hx;
+            ib = b0;
             col = hx;
-            if (hy < G::PROWS + 2 && hx < 18 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                pix = ((long)b0 * H + iy) * W + ix;
+            if (!(hy < G::PROWS + 2 && hx < 18)) iy = -1;
         } else {
-            const long g = m0 - W - 1 + q;
-            if (q < BM + 2 * W + 2 && g >= 0 && g < M) pix = g;
+            const long g = m0 - Wo - 1 + q;
+            if (q < BM + 2 * Wo + 2 && g >= 0 && g < M) {
+                ib = (int)(g / HW);
+                const int rem = (int)(g - (long)ib * HW);
+                iy = rem / Wo;
+                ix = rem - iy * Wo;
+            }
         }
+        if ((unsigned)iy < (unsigned)Ho && (unsigned)ix < (unsigned)Wo)
+            pix = (MODE == UPSD) ? ((long)ib * H + 2 * iy) * W + 2 * ix : ((long)ib * H + iy) * W + ix;
         a_vo[j] = (pix >= 0) ? (unsigned)((pix * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
         a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
     }
 
     // ---- weight fragments: lane-linear 1 KB pieces, [slice][ntile32][ks][plane][lane][8 halves]
-    const int nt32 = Kp >> 5, ncb = Cp / XBK, S = ncb * 9;
+    const int nt32 = Kp >> 5, ncb = Cp / XBK, S = ncb * NIMG * NT;
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(wq), 0, (int)((unsigned)S * nt32 * 4096u), 0x00020000);
     const unsigned b_vo = (unsigned)lane * 16u;
     const unsigned b_tile = (unsigned)(tile_n * NWN + wn) * 4096u;
-    u32x4 bq[3][4];                                             // [ring][ks * 2 + plane]
+    u32x4 bq[NRING][4];                                         // [ring][ks * 2 + plane]
     auto gload_b = [&](int s, const int ring) {
         const unsigned so = (unsigned)s * (unsigned)nt32 * 4096u + b_tile;
 #pragma unroll
         for (int c = 0; c < 4; ++c) bq[ring][c] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo + c * 1024, so, 0);
     };
 
-    // ---- activation fragment addresses (bytes, plane 0, k-step 0, image 0) of the wave's four 32-row groups for one tap.
-    // patch: one table entry per tap, the row groups are 2 grid rows = 2560 B apart (immediate offsets);
-    // run: slot = row + W + 1 + tap shift; the 32-slot row groups share the swizzle key, so one address + 2048 B steps,
-    // and a row whose tap falls outside the image (per-group validity mask) reads the all-zero slot instead.
+    // ---- activation fragment addresses (bytes, plane 0, k-step 0, image 0) of the wave's four 32-row groups for one tap
+    // shift t9 = (dy + 1) * 3 + (dx + 1).
+    // patch: one table entry per shift, the row groups are 2 grid rows = 2560 B apart (immediate offsets);
+    // run: slot = row + Wo + 1 + shift; the 32-slot row groups share the swizzle key, so one address + 2048 B steps,
+    // and a row whose shifted pixel falls outside the image (per-group validity mask) reads the all-zero slot instead.
     // The per-tap value is recomputed from an opaque base every slice: hoisting all 36 of them costs more registers than
     // the kernel has.
     int fa9[9];
-    int sl0 = wm * 128 + l31 + W + 1;
+    int sl0 = wm * 128 + l31 + Wo + 1;
     unsigned vmask[4] = {0, 0, 0, 0};
     if (PATCH) {
         const int i = wm * 128 + l31;
@@ -140,39 +162,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
 #pragma unroll
         for (int mr = 0; mr < 4; ++mr) {
             const long m = m0 + wm * 128 + mr * 32 + l31;
-            const int rem = (int)(m % HW), py = rem / W, px = rem - py * W;
+            const int rem = (int)(m % HW), py = rem / Wo, px = rem - py * Wo;
             unsigned mk = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int dy = t / 3 - 1, dx = t % 3 - 1;
-                mk |= (m < M && (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W) ? (1u << t) : 0u;
+                mk |= (m < M && (unsigned)(py + dy) < (unsigned)Ho && (unsigned)(px + dx) < (unsigned)Wo) ? (1u << t) : 0u;
             }
             vmask[mr] = mk;
         }
     }
     constexpr int MRSTEP = PATCH ? 2 * HPITCH * XLD * 2 : 32 * XLD * 2;      // bytes between the wave's row groups
-    // addresses of the four row groups for tap t in image `abuf` -> fa[0..3]
-    auto tap_addr = [&](const int t, const int abuf, int* fa) {
+    // addresses of the four row groups for shift t9 in image `abuf` -> fa[0..3]
+    auto tap_addr = [&](const int t9, const int abuf, int* fa) {
         if (PATCH) {
-            int f = fa9[t] + abuf * (ABUF * 2);
+            int f = fa9[t9] + abuf * (ABUF * 2);
             asm volatile("" : "+v"(f));
 #pragma unroll
             for (int mr = 0; mr < 4; ++mr) fa[mr] = f + mr * MRSTEP;
         } else {
             int base = sl0;
             asm volatile("" : "+v"(base));
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const int slot = base + dy * W + dx;
+            const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+            const int slot = base + dy * Wo + dx;
             const int a = slot * (XLD * 2) + ((hl ^ ((slot >> 2) & 3)) << 4) + abuf * (ABUF * 2);
             const int z = HZERO * (XLD * 2) + (hl << 4) + abuf * (ABUF * 2);          // the all-zero slot
 #pragma unroll
-            for (int mr = 0; mr < 4; ++mr) fa[mr] = ((vmask[mr] >> t) & 1u) ? a + mr * MRSTEP : z;
+            for (int mr = 0; mr < 4; ++mr) fa[mr] = ((vmask[mr] >> t9) & 1u) ? a + mr * MRSTEP : z;
         }
+    };
+    // UPSD: image `img` = polyphase component (p, q) = (img >> 1, img & 1); its tap (a, b) = (tap >> 1, tap & 1) is dy row
+    // 2 (yy + a - p) + p: the shift in the component image is (a - p, b - q) -- the same nine shifts as a plain conv.
+    auto shift_of = [&](const int img, const int tap) -> int {
+        if (MODE == UPSD) return ((tap >> 1) - (img >> 1) + 1) * 3 + ((tap & 1) - (img & 1) + 1);
+        return tap;
     };
 
     f32x4 ra[NJ / 2];
-    auto gload_a = [&](int cblk, const int half) {
-        const unsigned so = (unsigned)(cblk * XBK * 4);
+    auto gload_a = [&](int cblk, const int img, const int half) {
+        const unsigned so = (unsigned)(cblk * XBK * 4) +
+                            ((MODE == UPSD) ? (unsigned)(((img >> 1) * W + (img & 1)) * C * 4) : 0u);
 #pragma unroll
         for (int j = 0; j < NJ / 2; ++j)
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[half * (NJ / 2) + j], so, 0));
@@ -197,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     const char* Ab = reinterpret_cast<const char*>(Ah);
     u32x4 ah0[4], al0[4];                                     // k-step 0 fragments of the tap about to run
     int cur[4];                                               // their addresses (k-step 1 = address ^ 32)
-    auto read_a0 = [&](const int t, const int abuf) {
-        tap_addr(t, abuf, cur);
+    auto read_a0 = [&](const int t9, const int abuf) {
+        tap_addr(t9, abuf, cur);
 #pragma unroll
         for (int mr = 0; mr < 4; ++mr) {
             ah0[mr] = *reinterpret_cast<const u32x4*>(Ab + cur[mr]);
@@ -216,58 +245,66 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
 
     // ---- prologue
     gload_b(0, 0);
-    gload_b(S > 1 ? 1 : 0, 1);
-    gload_a(0, 0);
+    if (NRING > 2) gload_b(S > 1 ? 1 : 0, 1);
+    gload_a(0, 0, 0);
     lstore_a(0, 0);
-    gload_a(0, 1);
+    gload_a(0, 0, 1);
     lstore_a(0, 1);
     lds_barrier();
-    read_a0(0, 0);
+    read_a0(shift_of(0, 0), 0);
 
+    // staging schedule of the NEXT image inside the NT taps of the current one (double-buffered images)
+    constexpr int G0 = (NT == 9) ? 1 : 0, L0 = (NT == 9) ? 3 : 1, G1 = (NT == 9) ? 4 : 1, L1 = (NT == 9) ? 6 : 2;
     for (int c = 0; c < ncb; ++c) {
-        const int abuf = (G::NABUF == 2) ? (c & 1) : 0;
-        const bool more = c + 1 < ncb;                         // block-uniform
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int s = c * 9 + t, ring = t % 3;
-            gload_b(s + 2 < S ? s + 2 : S - 1, (t + 2) % 3);   // set (t + 2) % 3 was last read by slice s - 1
-            u32x4 ah1[4], al1[4];
+        for (int img = 0; img < NIMG; ++img) {
+            const int abuf = (G::NABUF == 2) ? ((NIMG == 1) ? (c & 1) : (img & 1)) : 0;
+            const bool more = (img + 1 < NIMG) || (c + 1 < ncb);        // block-uniform
+            const int nimg = (img + 1 < NIMG) ? img + 1 : 0;
+            const int ncblk = (img + 1 < NIMG) ? c : c + 1;
 #pragma unroll
-            for (int mr = 0; mr < 4; ++mr) {
-                ah1[mr] = *reinterpret_cast<const u32x4*>(Ab + (cur[mr] ^ 32));
-                al1[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[mr] ^ 32));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma12(ah0, al0, bq[ring][0], bq[ring][1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (G::NABUF == 2) {
-                // next channel block's halo goes into the OTHER image while this one is being multiplied
-                if (more) {
-                    if (t == 1) gload_a(c + 1, 0);
-                    if (t == 3) lstore_a(abuf ^ 1, 0);
-                    if (t == 4) gload_a(c + 1, 1);
-                    if (t == 6) lstore_a(abuf ^ 1, 1);
+            for (int t = 0; t < NT; ++t) {
+                const int s = (c * NIMG + img) * NT + t, ring = (img * NT + t) % NRING;
+                // the set being refilled was last read by slice s - 1
+                gload_b(s + NRING - 1 < S ? s + NRING - 1 : S - 1, (img * NT + t + NRING - 1) % NRING);
+                u32x4 ah1[4], al1[4];
+#pragma unroll
+                for (int mr = 0; mr < 4; ++mr) {
+                    ah1[mr] = *reinterpret_cast<const u32x4*>(Ab + (cur[mr] ^ 32));
+                    al1[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[mr] ^ 32));
                 }
-                if (t < 8) {
-                    read_a0(t + 1, abuf);
-                } else if (more) {
-                    lds_barrier();                             // every wave has staged its share and is done reading
-                    read_a0(0, abuf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma12(ah0, al0, bq[ring][0], bq[ring][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (G::NABUF == 2) {
+                    // the next image goes into the OTHER buffer while this one is being multiplied
+                    if (more) {
+                        if (t == L0) lstore_a(abuf ^ 1, 0);
+                        if (t == G0) gload_a(ncblk, nimg, 0);
+                        if (t == L1) lstore_a(abuf ^ 1, 1);
+                        if (t == G1) gload_a(ncblk, nimg, 1);
+                    }
+                    if (t < NT - 1) {
+                        read_a0(shift_of(img, t + 1), abuf);
+                    } else if (more) {
+                        lds_barrier();                         // every wave has staged its share and is done reading
+                        read_a0(shift_of(nimg, 0), abuf ^ 1);
+                    }
+                } else {
+                    if (more && t == 6) gload_a(ncblk, nimg, 0);
+                    if (t < NT - 1) read_a0(shift_of(img, t + 1), 0);
                 }
-            } else {
-                if (more && t == 6) gload_a(c + 1, 0);
-                if (t < 8) read_a0(t + 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma12(ah1, al1, bq[ring][2], bq[ring][3]);
-            if (G::NABUF == 1 && t == 8 && more) {
-                // single image: everyone finishes reading, then the two halves are restaged in place
-                lds_barrier();
-                lstore_a(0, 0);
-                gload_a(c + 1, 1);
-                lstore_a(0, 1);
-                lds_barrier();
-                read_a0(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma12(ah1, al1, bq[ring][2], bq[ring][3]);
+                if (G::NABUF == 1 && t == NT - 1 && more) {
+                    // single image: everyone finishes reading, then the two halves are restaged in place
+                    lds_barrier();
+                    lstore_a(0, 0);
+                    gload_a(ncblk, nimg, 1);
+                    lstore_a(0, 1);
+                    lds_barrier();
+                    read_a0(shift_of(nimg, 0), 0);
+                }
             }
         }
     }
@@ -305,25 +342,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     }
 }
 
-// value of GEMM-view weight element (tap, n, k): kind 4 = forward (n = output channel, k = input channel),
-// kind 5 = data gradient (n = input channel, k = output channel, taps flipped)
-__device__ __forceinline__ float frag_value(const float* __restrict__ w, int C, int K, int kind, int tap, int n, int k) {
-    if (kind == 4) return (n < K && k < C) ? w[((long)n * C + k) * 9 + tap] : 0.f;
-    return (n < C && k < K) ? w[((long)k * C + n) * 9 + (8 - tap)] : 0.f;
+// pre-summed 3x3 weights of the upsample-fused forms (same definition as weff9 in conv3x3_igemm_x3.hip)
+__device__ __forceinline__ float weff9s(const float* __restrict__ w9, int py, int a, int px, int b) {
+    const int rlo = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), rhi = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int slo = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), shi = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float s = 0.f;
+    for (int r = rlo; r <= rhi; ++r)
+        for (int q = slo; q <= shi; ++q) s += w9[r * 3 + q];
+    return s;
+}
+
+// value of GEMM-view weight element (slice-in-block si, n, k): kind 4 = forward (n = output channel, k = input channel,
+// si = tap), kind 5 = data gradient (n = input channel, k = output channel, taps flipped), kind 6 = data gradient of
+// [upsample x2 -> conv] w.r.t. the low-res input: si = component (p, q) * 4 + tap (a, b)  <->  the 4x4 / stride-2 gather
+// tap (ty, tx) = (2a + 1 - p, 2b + 1 - q) of the 'ups_dgrad' packing (egz_pack_w3x3_split kind 3).
+__device__ __forceinline__ float frag_value(const float* __restrict__ w, int C, int K, int kind, int si, int n, int k) {
+    if (kind == 4) return (n < K && k < C) ? w[((long)n * C + k) * 9 + si] : 0.f;
+    if (kind == 5) return (n < C && k < K) ? w[((long)k * C + n) * 9 + (8 - si)] : 0.f;
+    if (!(n < C && k < K)) return 0.f;
+    const int img = si >> 2, tap = si & 3;
+    const int oy = 2 * (tap >> 1) - (img >> 1), ox = 2 * (tap & 1) - (img & 1);        // ty - 1, tx - 1
+    return weff9s(w + ((long)k * C + n) * 9, (oy == -1 || oy == 1) ? 1 : 0, (oy <= 0) ? 1 : 0, (ox == -1 || ox == 1) ? 1 : 0,
+                  (ox <= 0) ? 1 : 0);
 }
 
 // one thread per (slice, ntile32, ks, lane, e): both planes of one value
 template <typename T>
 __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wq,
                                                              int C, int K, int kind, int Np, int Rp, float scale) {
-    const int nt32 = Np >> 5;
-    const long n = (long)(Rp / XBK) * 9 * nt32 * 1024;       // values (each has a hi and a lo half)
+    const int nt32 = Np >> 5, spb = (kind == 6) ? 16 : 9;      // slices per channel block
+    const long n = (long)(Rp / XBK) * spb * nt32 * 1024;      // values (each has a hi and a lo half)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
         const long r = i >> 10;
         const int ntile = (int)(r % nt32);
         const int s = (int)(r / nt32);
-        const int cblk = s / 9, tap = s - cblk * 9;
+        const int cblk = s / spb, tap = s - cblk * spb;
         const int col = ntile * 32 + (lane & 31), k = cblk * XBK + ks * 16 + (lane >> 5) * 8 + e;
         unsigned short h, l;
         Half<T>::split(frag_value(w, C, K, kind, tap, col, k) * scale, h, l);
@@ -333,17 +387,18 @@ __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __res
     }
 }
 
-template <typename T, int WM>
+template <typename T, int WM, int MODE>
 int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
                int W, int C, int K, float out_scale, const unsigned int* a_absmax, hipStream_t st) {
     using G = Geo<WM>;
-    const long M = (long)B * H * W;
+    const int Ho = (MODE == UPSD) ? H / 2 : H, Wo = (MODE == UPSD) ? W / 2 : W;
+    const long M = (long)B * Ho * Wo;
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
-    const bool patch = (W % 16 == 0) && (H % G::PROWS == 0);
+    const bool patch = (Wo % 16 == 0) && (Ho % G::PROWS == 0);
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
     const int total = mt * (Kp / G::BN);
     const dim3 grid(((total + 7) / 8) * 8);
-#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P>), grid, dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax)
+#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax)
     if (patch) {
         if (epi == EPI_BIAS) EGZ_X3S(EPI_BIAS, true);
         else if (epi == EPI_BIAS_RELU) EGZ_X3S(EPI_BIAS_RELU, true);
@@ -360,25 +415,33 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 
 }  // namespace
 
-// 1 when the streamed-weight kernel covers this plain-conv geometry (C = reduction channels, K = GEMM columns):
-// split-half channel constraints, and either the patch geometry or a raster run whose halo fits the LDS image.
-EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0 || K % 64 != 0) return 0;
+// 1 when the streamed-weight kernel covers this geometry (C = reduction channels, K = GEMM columns).
+// mode 0: plain conv over an H x W image; mode 1: data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res
+// input, H x W = the hi-res gradient image (both even), 128-column tiles only.  Needs the split-half channel constraints
+// and either the patch geometry or a raster run whose halo fits the LDS image (on the OUTPUT image: H/2 x W/2 in mode 1).
+EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0 || K % 64 != 0 || mode < 0 || mode > 1) return 0;
     if (4ull * B * H * W * C >= (1ull << 32)) return 0;
+    if (mode == 1) {
+        if (K % 128 != 0 || (H & 1) || (W & 1)) return 0;
+        H >>= 1;
+        W >>= 1;
+    }
     const int prow = (K % 128 == 0) ? 8 : 16, bm = (K % 128 == 0) ? 128 : 256, hzero = (K % 128 == 0) ? 255 : 383;
     if (W % 16 == 0 && H % prow == 0) return 1;
     return (bm + 2 * W + 2 <= hzero) ? 1 : 0;
 }
 
 // Fragment-ordered split packing for the streamed kernel.  kind 4: forward of a (K, C, 3, 3) weight (GEMM columns = K,
-// reduction = C); kind 5: its data gradient (columns = C, reduction = K, taps flipped).  dtype 1 = f16 (values pre-scaled
-// by 2^10), 2 = bf16.  wq needs egz_pack_w3x3_elems(C, K, 0) * 4 bytes, like the plane-ordered packings.
+// reduction = C); kind 5: its data gradient (columns = C, reduction = K, taps flipped); kind 6: the data gradient of
+// [upsample x2 -> conv] w.r.t. the low-res input (columns = C, reduction = K, 16 polyphase taps).  dtype 1 = f16 (values
+// pre-scaled by 2^10), 2 = bf16.  wq needs egz_pack_w3x3_elems(C, K, kind == 6) * 4 bytes, like the plane-ordered packings.
 EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t st) {
-    EGZ_CHECK_ARG(w && wq && C > 0 && K > 0 && (kind == 4 || kind == 5) && (dtype == 1 || dtype == 2),
+    EGZ_CHECK_ARG(w && wq && C > 0 && K > 0 && kind >= 4 && kind <= 6 && (dtype == 1 || dtype == 2),
                   "egz_pack_w3x3_split_frag: bad arguments");
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
     const int Np = (kind == 4) ? Kp : Cp, Rp = (kind == 4) ? Cp : Kp;
-    const long n = (long)9 * Np * Rp;
+    const long n = (long)(kind == 6 ? 16 : 9) * Np * Rp;
     const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
     unsigned short* o = static_cast<unsigned short*>(wq);
     if (dtype == 1) hipLaunchKernelGGL(pack_split_frag_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, F16_WSCALE);
@@ -387,24 +450,30 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
     return 0;
 }
 
-// Plain 3x3 conv, split-half arithmetic, streamed fragment-ordered weights.  GEMM view as egz_conv3x3_fwd_split:
-// x [B][H][W][C] (the gathered operand), y [B][H][W][K]; for a data gradient the caller passes dy as x, C = Cout,
-// K = Cin and the kind-5 packing.  epi: 0 bias, 1 bias + ReLU, 2 bias + per-channel (sum, sumsq) partials, one row per
-// 128 pixels as egz_conv3x3_stat_rows(B, H, W, K, 0x200) promises.  Only for geometries egz_conv3x3_streamed_ok accepts.
+// 3x3 conv in split-half arithmetic with streamed fragment-ordered weights.  GEMM view as egz_conv3x3_fwd_split:
+// x [B][H][W][C] (the gathered operand), y [B][H'][W'][K].  mode 0: plain conv (forward: kind-4 packing; data gradient: the
+// caller passes dy as x, C = Cout, K = Cin and the kind-5 packing), H' x W' = H x W.  mode 1: data gradient of an
+// upsample-fused conv w.r.t. its low-res input (x = hi-res dy, kind-6 packing, H' x W' = H/2 x W/2).
+// epi: 0 bias, 1 bias + ReLU, 2 bias + per-channel (sum, sumsq) partials, one row per 128 output pixels as
+// egz_conv3x3_stat_rows(B, H', W', K, 0x200) promises.  Only for geometries egz_conv3x3_streamed_ok accepts.
 EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
-                                     int B, int H, int W, int C, int K, int epi, int dtype,
+                                     int B, int H, int W, int C, int K, int epi, int dtype, int mode,
                                      const unsigned int* x_absmax, hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
-    EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d is "
-                  "not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K);
+    EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, mode), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d "
+                  "mode=%d is not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K, mode);
     EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && epi >= 0 && epi <= 2, "egz_conv3x3_fwd_streamed: bad dtype / epilogue");
     EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_streamed: stats epilogue needs stat_partial");
     const unsigned short* w16 = static_cast<const unsigned short*>(wq);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
-    if (K % 128 == 0) {
-        if (dtype == 1) return launch_x3s<_Float16, 1>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-        return launch_x3s<__bf16, 1>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    if (mode == 1) {
+        if (dtype == 1) return launch_x3s<_Float16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        return launch_x3s<__bf16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
     }
-    if (dtype == 1) return launch_x3s<_Float16, 2>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-    return launch_x3s<__bf16, 2>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    if (K % 128 == 0) {
+        if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    }
+    if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
 }

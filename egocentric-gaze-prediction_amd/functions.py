@@ -169,7 +169,8 @@ class ConvReLU(torch.autograd.Function):
         if ng[0]:
             dt = H.conv_dtype("dgrad", C, K, dy)
             if ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
-                dx = from_nhwc(H.conv3x3_ups_dgrad(dy, H.packed_weight(weight, "ups_dgrad", dt), C, dtype=dt))
+                wp, st = H.conv_weight(weight, "ups_dgrad", dt, dy, C)
+                dx = from_nhwc(H.conv3x3_ups_dgrad(dy, wp, C, dtype=dt, streamed=st))
             else:
                 wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
                 dx = from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))

@@ -158,7 +158,7 @@ def _uid(w: torch.Tensor) -> int:
 _PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad", 0, 1),
             "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1, 2), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1, 3),
             # MFMA-fragment-ordered split packings of the streamed-weight kernel (split dtypes only)
-            "fwd_frag": (None, 0, 4), "dgrad_frag": (None, 0, 5)}
+            "fwd_frag": (None, 0, 4), "dgrad_frag": (None, 0, 5), "ups_dgrad_frag": (None, 1, 6)}
 
 # Arithmetic of the wide convolutions (GEMM output channels % 128 == 0):
 #   "split" (default) error-compensated split-half operands on the 16-bit MFMA path: f16 x3 (22 significant bits;
@@ -194,10 +194,10 @@ STREAMED = _os.environ.get("EGAZE_STREAMED", "1") != "0"      # A/B knob: 0 = ha
 def conv_weight(w: torch.Tensor, role: str, dtype: int, x: torch.Tensor, gemm_out: int):
     """The packed weight a plain 3x3 conv launch over the NHWC operand ``x`` needs -> (packed buffer, streamed flag).
     Split-half launches whose geometry the streamed-weight kernel covers (egz_conv3x3_streamed_ok) use the MFMA-fragment-
-    ordered packing; everything else the plane-ordered one.  role: 'fwd' | 'dgrad'."""
+    ordered packing; everything else the plane-ordered one.  role: 'fwd' | 'dgrad' | 'ups_dgrad' (x = the hi-res dy)."""
     if dtype and STREAMED:
         B, H, W, C = x.shape
-        if LIB.egz_conv3x3_streamed_ok(B, H, W, C, gemm_out):
+        if LIB.egz_conv3x3_streamed_ok(B, H, W, C, gemm_out, 1 if role == "ups_dgrad" else 0):
             return packed_weight(w, role + "_frag", dtype), True
     return packed_weight(w, role, dtype), False
 
@@ -369,7 +369,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
             raise RuntimeError("the streamed-weight kernel covers plain convolutions only")
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, _p(absmax), _stream()), "egz_conv3x3_fwd_split")
+                                           epi, dtype, 0, _p(absmax), _stream()), "egz_conv3x3_fwd_split")
         return y, stat
     if dtype:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
@@ -393,11 +393,18 @@ def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int, dtype: int =
     return y
 
 
-def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtype: int = 0) -> torch.Tensor:
-    """Data gradient of [upsample x2 -> conv3x3] w.r.t. the LOW-res input: dy (B,H,W,K) -> dx (B,H/2,W/2,C)."""
+def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtype: int = 0, streamed: bool = False) -> torch.Tensor:
+    """Data gradient of [upsample x2 -> conv3x3] w.r.t. the LOW-res input: dy (B,H,W,K) -> dx (B,H/2,W/2,C).
+    streamed: wp = the 'ups_dgrad_frag' packing (conv_weight(..., 'ups_dgrad', ...)), polyphase streamed-weight kernel."""
     _req(dy, "dy")
     B, H, W, K = dy.shape
     dx = torch.empty((B, H // 2, W // 2, C), dtype=torch.float32, device=dy.device)
+    if dtype and streamed:
+        PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        am = absmax_of(dy) if dtype == F16X3 else None
+        check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
+                                           0, dtype, 1, _p(am), _stream()), "egz_conv3x3_fwd_streamed(ups_dgrad)")
+        return dx
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         nb = LIB.egz_conv3x3_fwd_split_ws_bytes(B, H, W, K, C, 4)

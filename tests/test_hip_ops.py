@@ -546,3 +546,26 @@ def test_conv3x3_streamed_shape_fuzz():
         assert rel(y1, y0) < 5e-6, (it, B, Hh, Ww, C, K)
         assert rel(s1.sum(0), s0.sum(0)) < 1e-5, (it, B, Hh, Ww, C, K)
     assert n_streamed >= 25
+
+
+@pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
+@pytest.mark.parametrize("B,Hl,Wl,C,K", [
+    (2, 16, 32, 128, 64),      # low-res patch geometry (hi-res 32 x 64)
+    (1, 8, 16, 256, 32),
+    (3, 28, 28, 128, 64),      # raster runs on the polyphase components, several channel blocks
+    (2, 14, 14, 128, 96), (1, 5, 3, 128, 64), (2, 9, 7, 256, 128)])
+def test_conv3x3_streamed_ups_dgrad(B, Hl, Wl, C, K, dtype, tol):
+    """Streamed polyphase form of the data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res input
+    (models/model_SP.py:17-18 etc.) against autograd in fp64 and against the per-tap gather kernel."""
+    h = H()
+    x = rnd(B, C, Hl, Wl, seed=71).double().requires_grad_(True)
+    w = rnd(K, C, 3, 3, seed=72, scale=(2.0 / (9 * C)) ** 0.5)
+    dy = rnd(B, K, 2 * Hl, 2 * Wl, seed=73)
+    F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w.double(), None, padding=1).backward(dy.double())
+    wd, dyd = w.to(DEV), nhwc(dy)
+    wq, st = h.conv_weight(wd, "ups_dgrad", dtype, dyd, C)
+    assert st, "geometry expected on the streamed kernel"
+    dx = h.conv3x3_ups_dgrad(dyd, wq, C, dtype=dtype, streamed=True)
+    assert rel(nchw(dx), x.grad) < tol
+    dg = h.conv3x3_ups_dgrad(dyd, h.packed_weight(wd, "ups_dgrad", dtype), C, dtype=dtype)
+    assert rel(dx, dg) < (2e-6 if dtype == 1 else 3e-5)
