@@ -308,6 +308,28 @@ template <> struct W16<_Float16> {
     static __device__ __forceinline__ float scale(const unsigned int* am) { return absmax_scale(am); }
 };
 
+// XCD-aware (tile, split) of a block of a (tiles, splits[, z]) grid.  Hardware places consecutive flat block ids on
+// consecutive XCDs (id % 8) and every XCD has its own L2.  The natural map puts the 64 (c, k) tiles of ONE pixel range on all
+// eight XCDs, so each XCD's L2 fetches that range of x and dy from HBM separately (measured 2.5 x the algorithmic bytes);
+// here XCD j runs whole splits j, j + 8, ... -- all tiles of a pixel range share one L2 and stream through it together.
+// Needs gridDim.y % 8 == 0 (otherwise the natural map is kept); the result is independent of the map.
+#ifndef EGZ_WGRAD_XCD
+#define EGZ_WGRAD_XCD 1
+#endif
+__device__ __forceinline__ void wgrad_block(int& tile, int& split) {
+    tile = blockIdx.x;
+    split = blockIdx.y;
+#if EGZ_WGRAD_XCD
+    const int nt = gridDim.x, ns = gridDim.y;
+    if ((ns & 7) == 0) {
+        const int flat = blockIdx.y * nt + blockIdx.x;
+        const int r = flat >> 3;
+        tile = r % nt;
+        split = (flat & 7) + 8 * (r / nt);
+    }
+#endif
+}
+
 template <typename T, bool UPS, int R, int WD>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
@@ -327,10 +349,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wk = wave & 1, l31 = lane & 31;
     const int tk = K / 64;
-    const int c0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
+    int tile, split;
+    wgrad_block(tile, split);
+    const int c0 = (tile / tk) * 64, k0 = (tile % tk) * 64;
     const int cpr = (W + WD - 1) / WD, rpi = (H + R - 1) / R;  // patches per row / patch rows per image
     const long npatch = (long)B * rpi * cpr;
-    const long g0 = (long)blockIdx.y * patches_per_split;
+    const long g0 = (long)split * patches_per_split;
     const long g1 = (g0 + patches_per_split < npatch) ? (g0 + patches_per_split) : npatch;
     const int Hs = UPS ? (H >> 1) : H, Ws = UPS ? (W >> 1) : W;
 
@@ -488,7 +512,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        float* out = part + ((long)blockIdx.y * 9 + tap) * C * K;
+        float* out = part + ((long)split * 9 + tap) * C * K;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);
@@ -525,12 +549,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wk = wave & 1, l31 = lane & 31;
     const int tk = K / 64;
-    const int c0 = (blockIdx.x / tk) * 64, k0 = (blockIdx.x % tk) * 64;
+    int tile, split;
+    wgrad_block(tile, split);
+    const int c0 = (tile / tk) * 64, k0 = (tile % tk) * 64;
     const int py = blockIdx.z;
     const int Hl = H >> 1, Wl = W >> 1;                        // low-res dims (H, W: the conv's hi-res output dims)
     const int cpr = (Wl + WD - 1) / WD, rpi = (Hl + R - 1) / R;
     const long npatch = (long)B * rpi * cpr;
-    const long g0 = (long)blockIdx.y * patches_per_split;
+    const long g0 = (long)split * patches_per_split;
     const long g1 = (g0 + patches_per_split < npatch) ? (g0 + patches_per_split) : npatch;
 
     const unsigned x_bias = (unsigned)(Wl + 1) * (unsigned)C * 4u;
@@ -660,7 +686,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int px = t >> 2, ab = t & 3;
-        float* out = part + ((long)blockIdx.y * 16 + (py * 2 + px) * 4 + ab) * C * K;
+        float* out = part + ((long)split * 16 + (py * 2 + px) * 4 + ab) * C * K;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);

@@ -13,6 +13,8 @@ from ..functions import FusionBlock
 from ..streams import fork
 from ..utils import FusedSequential, init_like_reference
 
+_STAGGER = __import__("os").environ.get("EGAZE_STAGGER", "1") != "0"      # A/B knob
+
 # models/model_SP.py:13-31 as (Cin, Cout) 3x3+ReLU blocks and 'U' = nearest x2 upsample; a 1x1 head follows
 _DECODER_PLAN = [(512, 512), (512, 512), 'U', (512, 512), (512, 512), (512, 512), 'U', (512, 256), (256, 256),
                  (256, 256), 'U', (256, 128), (128, 128), 'U', (128, 64), (64, 64)]
@@ -61,12 +63,21 @@ class model_SP(nn.Module):
     def forward(self, x_s, x_t):
         stack = self._stack_buffer(x_s, x_t)
         B = x_s.shape[0]
+        stagger = None
         with fork("encoder_t") as f:                     # the two encoders are independent: two HIP streams
             if f.enabled:
                 x_t.record_stream(torch.cuda.current_stream())
                 if stack is not None:
                     stack.record_stream(torch.cuda.current_stream())
-            x_t = self.features_t(x_t, out_buf=stack[B:] if stack is not None else None)
+                if _STAGGER:
+                    stagger = torch.cuda.Event()
+            x_t = self.features_t(x_t, out_buf=stack[B:] if stack is not None else None,
+                                  after_first_block=(lambda: stagger.record()) if stagger is not None else None)
+        if stagger is not None:
+            # The encoders have the same layer sequence; started together they stay in lock-step (both in a conv, then both in
+            # a BN pass) and the matrix cores idle during every BN pass.  Holding the RGB encoder back by the flow encoder's
+            # first block puts them half a layer apart: one stream's HBM-bound pass runs under the other's MFMA-bound conv.
+            torch.cuda.current_stream().wait_event(stagger)
         x_s = self.features_s(x_s, out_buf=stack[:B] if stack is not None else None)   # (B,512,h,w) channels_last; hooks fire here
         f.join(x_t)
         bn = self.bn

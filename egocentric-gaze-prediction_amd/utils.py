@@ -59,9 +59,11 @@ class FusedSequential(nn.Sequential):
     late-fusion stack (models/late_fusion.py:10-13).  A first conv with < 32 input channels reads the NCHW
     network input directly; every later tensor is channels_last."""
 
-    def forward(self, x, fuse_sigmoid=False, out_buf=None):
+    def forward(self, x, fuse_sigmoid=False, out_buf=None, after_first_block=None):
         """``out_buf``: optional NHWC destination for the output of the LAST block when that block is a conv-BN-ReLU
-        block (model_SP passes the two encoders the halves of one buffer, see functions.FusionBlock)."""
+        block (model_SP passes the two encoders the halves of one buffer, see functions.FusionBlock).
+        ``after_first_block``: optional callable run once the first block's kernels have been issued (model_SP records a
+        stream event there to run its two encoders half a layer apart)."""
         mods = list(self.children())
         i, n = 0, len(mods)
         first, ups = True, False
@@ -94,6 +96,8 @@ class FusedSequential(nn.Sequential):
                 i += 1
             else:
                 raise NotImplementedError(f"layer pattern at index {i} ({type(m).__name__}) is not on the HIP path")
+            if first and after_first_block is not None:
+                after_first_block()
             first = False
         return x
 

@@ -19,9 +19,14 @@ def main():
         for r in csv.DictReader(open(f)):
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     ev.sort()
-    t0, t1 = ev[0][0], max(e[1] for e in ev)
-    lo = t0 + (t1 - t0) * skip                       # second half of the trace = warmed-up steps
-    ev = [e for e in ev if e[0] >= lo]
+    marks = [e[0] for e in ev if "floss_centroid" in e[2]]          # one per SP step
+    if len(marks) >= 7:
+        lo, hi = marks[-6], marks[-1]                # five whole steady-state steps
+        nsteps = 5
+    else:
+        t0, t1 = ev[0][0], max(e[1] for e in ev)
+        lo, hi, nsteps = t0 + (t1 - t0) * skip, t1, 0
+    ev = [(max(s, lo), min(e, hi), n) for s, e, n in ev if e > lo and s < hi]
     pts = []
     for s, e, n in ev:
         m = any(k in n for k in MFMA)
@@ -45,7 +50,8 @@ def main():
                 for k in active:
                     exposed[k] += share
         last = t
-        short = n.split("(")[0][-60:]
+        short = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("_ZN12_GLOBAL__N_1", "")
+        short = short.split("(")[0][:60]
         if dlt > 0:
             active[short] += 1
             nm += m
@@ -54,6 +60,8 @@ def main():
             if active[short] == 0:
                 del active[short]
             nm -= m
+    if nsteps:
+        print(f"{nsteps} steps, {tot/1e6/nsteps:.2f} ms per step")
     print(f"window {tot/1e6:.2f} ms: MFMA-bound kernel active {100*mfma_t/tot:.1f} %, GPU idle {100*idle/tot:.1f} %, "
           f"only other kernels {100*(tot-mfma_t-idle)/tot:.1f} %")
     for k, v in sorted(exposed.items(), key=lambda kv: -kv[1])[:25]:
