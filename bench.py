@@ -29,6 +29,15 @@ FLOP_PER_FRAME_FWD_BWD = 341.2e9    # BASELINE.md section 3 (all parameters trai
 BYTES_PER_FRAME = 1.046e9
 
 
+def kernel_src_sha():
+    """Short hash of the split-half conv kernel sources (what the committed PMC traffic profile is valid for)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("conv3x3_igemm_x3s.hip", "conv3x3_igemm_x3.hip", "x3_split.h", "conv3x3_wgrad.hip"):
+        h.update(open(os.path.join(ROOT, "egocentric-gaze-prediction_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(batch=8, size=224, threads=16, timed_steps=3):
     """The reference's CPU algorithm (oracle/, pinned to the reference by golden vectors) on the host cores:
     one warm-up + one timed SP train step (fwd + floss + bwd + Adam) at a bounded batch."""
@@ -201,6 +210,7 @@ def main():
     roofline = None
     breakdown = None
     f32_ms = None
+    at_ms = None
     if not args.no_roofline:
         # Every rank runs these two extra (untimed) steps -- the gradient all-reduce inside step() is a collective --
         # but only rank 0 reports.  Per-kernel HIP-event timing needs the kernels serialised: the multi-stream
@@ -222,13 +232,20 @@ def main():
         for entry in entries:
             for k2 in ig:
                 ig[k2] += prof.get(entry, {}).get(k2, 0)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_igemm_x3.json" if split else "r01_pmc_traffic_igemm.json")
+        # HBM bytes per launch of this kernel family: PMC counters cannot be sampled from inside the process, so the value
+        # comes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_profiles.sh
+        # -> tools/pmc_traffic.py; gfx950 FETCH half-count corrected).  The profile is stamped with a hash of the kernel
+        # sources it was taken from: if the kernels changed since, the number is NOT quoted (traffic = null).
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
         if os.path.exists(tpath):
-            # HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
-            # this same command (tools/pmc_traffic.py; gfx950 FETCH half-count corrected) -- PMC cannot be sampled
-            # from inside the process, so the committed profile is quoted
-            traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+            tj = json.load(open(tpath))
+            if not split or tj.get("kernel_src_sha") == kernel_src_sha():
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_note = f"profiles/{os.path.basename(tpath)}"
+            else:
+                traffic_note = (f"profiles/{os.path.basename(tpath)} was taken from other kernel sources "
+                                f"({tj.get('kernel_src_sha')} vs {kernel_src_sha()}): re-run tools/collect_profiles.sh")
         if ig["ms"] > 0:
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
@@ -243,10 +260,18 @@ def main():
                                   "timed with HIP events on the launch stream with stream concurrency off, as in "
                                   "profiles/r01_bench_b32_kernel_stats_split_streams0.txt",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": traffic,
+                        "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
                         "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
                         "algorithmic_flop_per_step": ig["flops"]}
+        if use_at:
+            # config 4 standalone: the AT step alone (lstmnet T=16, B=32 forward + MSE + backward + Adam), untimed leg
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                at_step()
+            torch.cuda.synchronize()
+            at_ms = (time.perf_counter() - t1) / 20 * 1e3
         if split and not args.no_f32_leg:
             # the same step on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), untimed leg, reported beside the headline
             H.PRECISION = "f32"
@@ -299,7 +324,10 @@ def main():
             "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
             "step_hbm_frac": BYTES_PER_FRAME * args.batch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "loss": last_loss, "kernel_ms_breakdown": breakdown,
-            "extra": {"f32_ms_per_step": f32_ms,
+            "extra": {"at_ms_per_step": at_ms,
+                      "at_note": ("AT alone (BASELINE config 4 shape): lstmnet T=16, B=%d forward + MSE + backward + Adam, "
+                                  "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),
+                      "f32_ms_per_step": f32_ms,
                       "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps"},
         }
         print(json.dumps(out))
