@@ -32,11 +32,15 @@ constexpr int XLD = 32;                 // 16-bit elements per LDS row: 64 B = 3
 constexpr int XBK = 32;                 // channels per block of the reduction
 constexpr int HPITCH = 20;              // patch geometry: halo columns per LDS grid row (18 used)
 
+// WM = waves along the pixel dimension, 4 / WM along the columns.  WM 1: tile 128 x 128; WM 2: 256 x 64; WM 4: 256 x 32
+// (every wave 64 rows = two 32-row groups; the narrow-channel layers of the late-fusion stack, models/late_fusion.py:10-12).
 template <int WM> struct Geo {
-    static constexpr int BM = 128 * WM, NWN = 4 / WM, BN = 32 * NWN;
+    static constexpr int MR = (WM == 4) ? 2 : 4;               // 32-row groups (accumulator tiles) per wave
+    static constexpr int RPW = 32 * MR;                        // pixel rows per wave
+    static constexpr int BM = RPW * WM, NWN = 4 / WM, BN = 32 * NWN;
     static constexpr int HSLOTS = (WM == 1) ? 256 : 384, HZERO = HSLOTS - 1;
     static constexpr int NABUF = (WM == 1) ? 2 : 1;
-    static constexpr int PROWS = 8 * WM;                       // patch: PROWS x 16 pixels
+    static constexpr int PROWS = BM / 16;                      // patch: PROWS x 16 pixels
     static constexpr int NJ = HSLOTS / 32;                     // halo slots per thread (8 threads x 4 channels per slot)
 };
 
@@ -56,6 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     int mt, int total, const unsigned int* __restrict__ a_absmax) {
     using G = Geo<WM>;
     constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
+    constexpr int MR = G::MR, RPW = G::RPW;
     constexpr int APL = HSLOTS * XLD;                          // elements per plane of an activation image
     constexpr int ABUF = 2 * APL;                              // elements per image (hi + lo)
     constexpr int NIMG = (MODE == UPSD) ? 4 : 1;               // staged images per channel block
@@ -64,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     static_assert(MODE == PLAIN || WM == 1, "the upsample data gradient is built for the 128-column tile only");
     __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
     __shared__ long Ro[BM];
+    __shared__ double sred[(RPW < 128) ? 4 * 2 * 32 : 1];       // BN partial sums of the waves that share a 128-row stat row
 
     const float a_scale = absmax_scale(a_absmax);
     out_scale /= a_scale;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
         }
         if ((unsigned)iy < (unsigned)Ho && (unsigned)ix < (unsigned)Wo)
             pix = (MODE == UPSD) ? ((long)ib * H + 2 * iy) * W + 2 * ix : ((long)ib * H + iy) * W + ix;
+        if (a_c4 * 4 >= C) pix = -1;                           // C < 32 (one zero-padded channel block): channels past C read zeros
         a_vo[j] = (pix >= 0) ? (unsigned)((pix * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
         a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
     }
@@ -148,10 +155,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     // The per-tap value is recomputed from an opaque base every slice: hoisting all 36 of them costs more registers than
     // the kernel has.
     int fa9[9];
-    int sl0 = wm * 128 + l31 + Wo + 1;
-    unsigned vmask[4] = {0, 0, 0, 0};
+    int sl0 = wm * RPW + l31 + Wo + 1;
+    unsigned vmask[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) vmask[mr] = 0;
     if (PATCH) {
-        const int i = wm * 128 + l31;
+        const int i = wm * RPW + l31;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int dy = t / 3 - 1, dx = t % 3 - 1;
@@ -160,8 +169,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
         }
     } else {
 #pragma unroll
-        for (int mr = 0; mr < 4; ++mr) {
-            const long m = m0 + wm * 128 + mr * 32 + l31;
+        for (int mr = 0; mr < MR; ++mr) {
+            const long m = m0 + wm * RPW + mr * 32 + l31;
             const int rem = (int)(m % HW), py = rem / Wo, px = rem - py * Wo;
             unsigned mk = 0;
 #pragma unroll
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
             int f = fa9[t9] + abuf * (ABUF * 2);
             asm volatile("" : "+v"(f));
 #pragma unroll
-            for (int mr = 0; mr < 4; ++mr) fa[mr] = f + mr * MRSTEP;
+            for (int mr = 0; mr < MR; ++mr) fa[mr] = f + mr * MRSTEP;
         } else {
             int base = sl0;
             asm volatile("" : "+v"(base));
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
             const int a = slot * (XLD * 2) + ((hl ^ ((slot >> 2) & 3)) << 4) + abuf * (ABUF * 2);
             const int z = HZERO * (XLD * 2) + (hl << 4) + abuf * (ABUF * 2);          // the all-zero slot
 #pragma unroll
-            for (int mr = 0; mr < 4; ++mr) fa[mr] = ((vmask[mr] >> t9) & 1u) ? a + mr * MRSTEP : z;
+            for (int mr = 0; mr < MR; ++mr) fa[mr] = ((vmask[mr] >> t9) & 1u) ? a + mr * MRSTEP : z;
         }
     };
     // UPSD: image `img` = polyphase component (p, q) = (img >> 1, img & 1); its tap (a, b) = (tap >> 1, tap & 1) is dy row
@@ -217,19 +226,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
         }
     };
 
-    f32x16 acc[4];
+    f32x16 acc[MR];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
     const char* Ab = reinterpret_cast<const char*>(Ah);
-    u32x4 ah0[4], al0[4];                                     // k-step 0 fragments of the tap about to run
-    int cur[4];                                               // their addresses (k-step 1 = address ^ 32)
+    u32x4 ah0[MR], al0[MR];                                   // k-step 0 fragments of the tap about to run
+    int cur[MR];                                              // their addresses (k-step 1 = address ^ 32)
     auto read_a0 = [&](const int t9, const int abuf) {
         tap_addr(t9, abuf, cur);
 #pragma unroll
-        for (int mr = 0; mr < 4; ++mr) {
+        for (int mr = 0; mr < MR; ++mr) {
             ah0[mr] = *reinterpret_cast<const u32x4*>(Ab + cur[mr]);
             al0[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[mr]);
         }
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
-            for (int mr = 0; mr < 4; ++mr)
+            for (int mr = 0; mr < MR; ++mr)
                 acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl : bh, acc[mr]);
     };
 
@@ -267,9 +276,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
                 const int s = (c * NIMG + img) * NT + t, ring = (img * NT + t) % NRING;
                 // the set being refilled was last read by slice s - 1
                 gload_b(s + NRING - 1 < S ? s + NRING - 1 : S - 1, (img * NT + t + NRING - 1) % NRING);
-                u32x4 ah1[4], al1[4];
+                u32x4 ah1[MR], al1[MR];
 #pragma unroll
-                for (int mr = 0; mr < 4; ++mr) {
+                for (int mr = 0; mr < MR; ++mr) {
                     ah1[mr] = *reinterpret_cast<const u32x4*>(Ab + (cur[mr] ^ 32));
                     al1[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[mr] ^ 32));
                 }
@@ -309,16 +318,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
         }
     }
 
-    // ---- epilogue: every wave owns 128 rows x 32 columns; out_scale undoes the f16 weight pre-scaling exactly
+    // ---- epilogue: every wave owns RPW rows x 32 columns; out_scale undoes the f16 weight pre-scaling exactly
     const int col = n0 + wn * 32 + l31;
     const bool nok = col < K;
     const float bz = (bias && nok) ? bias[col] : 0.f;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int mr = 0; mr < 4; ++mr) {
+    for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long off = Ro[wm * 128 + mr * 32 + egz_acc_row(r, lane)];
+            const long off = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)];
             if (off >= 0 && nok) {
                 float v = acc[mr][r] * out_scale + bz;
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
@@ -331,13 +340,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
         }
     }
     if (EPI == EPI_BIAS_STATS) {
-        // one partial row per 128 pixel rows (the granularity egz_conv3x3_stat_rows promises): this wave's own
+        // one partial row per 128 pixel rows (the granularity egz_conv3x3_stat_rows promises)
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
-        const long srow = (long)tile_m * WM + wm;
-        if (hl == 0 && nok && srow * 128 < M) {
-            stat[(srow * 2 + 0) * K + col] = s1;
-            stat[(srow * 2 + 1) * K + col] = s2;
+        if (RPW == 128) {                                      // the wave's own row
+            const long srow = (long)tile_m * WM + wm;
+            if (hl == 0 && nok && srow * 128 < M) {
+                stat[(srow * 2 + 0) * K + col] = s1;
+                stat[(srow * 2 + 1) * K + col] = s2;
+            }
+        } else {                                               // two 64-row waves per stat row: combine through LDS
+            if (hl == 0) {
+                sred[(wave * 2 + 0) * 32 + l31] = s1;
+                sred[(wave * 2 + 1) * 32 + l31] = s2;
+            }
+            lds_barrier();
+            const long srow = (long)tile_m * (BM / 128) + (wm >> 1);
+            if ((wm & 1) == 0 && hl == 0 && nok && srow * 128 < M) {
+                stat[(srow * 2 + 0) * K + col] = s1 + sred[((wave + NWN) * 2 + 0) * 32 + l31];
+                stat[(srow * 2 + 1) * K + col] = s2 + sred[((wave + NWN) * 2 + 1) * 32 + l31];
+            }
         }
     }
 }
@@ -415,18 +437,21 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 
 }  // namespace
 
-// 1 when the streamed-weight kernel covers this geometry (C = reduction channels, K = GEMM columns).
+// 1 when the streamed-weight kernel covers this geometry (C = reduction channels: a multiple of 32, or a multiple of 4
+// below 32; K = GEMM columns: any).
 // mode 0: plain conv over an H x W image; mode 1: data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res
 // input, H x W = the hi-res gradient image (both even), 128-column tiles only.  Needs the split-half channel constraints
 // and either the patch geometry or a raster run whose halo fits the LDS image (on the OUTPUT image: H/2 x W/2 in mode 1).
 EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0 || K % 64 != 0 || mode < 0 || mode > 1) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || mode < 0 || mode > 1) return 0;
+    if (!(C % 32 == 0 || (C < 32 && C % 4 == 0))) return 0;            // whole channel blocks, or one zero-padded block
     if (4ull * B * H * W * C >= (1ull << 32)) return 0;
     if (mode == 1) {
-        if (K % 128 != 0 || (H & 1) || (W & 1)) return 0;
+        if (K % 128 != 0 || C % 32 != 0 || (H & 1) || (W & 1)) return 0;
         H >>= 1;
         W >>= 1;
     }
+    // column tile: 128 (K % 128 == 0), 64 (K % 64 == 0), else 32-column tiles padded up to K (narrow layers)
     const int prow = (K % 128 == 0) ? 8 : 16, bm = (K % 128 == 0) ? 128 : 256, hzero = (K % 128 == 0) ? 255 : 383;
     if (W % 16 == 0 && H % prow == 0) return 1;
     return (bm + 2 * W + 2 <= hzero) ? 1 : 0;
@@ -474,6 +499,10 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
         return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
     }
-    if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-    return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    if (K % 64 == 0) {
+        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    }
+    if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
 }

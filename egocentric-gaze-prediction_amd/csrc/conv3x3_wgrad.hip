@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wc = wave >> 1, wk = wave & 1, l31 = lane & 31;
-    const int tk = K / 64;
+    const int tk = (K + 63) / 64;
     int tile, split;
     wgrad_block(tile, split);
     const int c0 = (tile / tk) * 64, k0 = (tile % tk) * 64;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
         const int i = tid + 256 * j, pp = i >> 4, k4 = i & 15;
-        d_vo[j] = (unsigned)(((pp / WD) * W + pp % WD) * K * 4 + k4 * 16);
+        d_vo[j] = (k0 + k4 * 4 < K) ? (unsigned)(((pp / WD) * W + pp % WD) * K * 4 + k4 * 16) : 0xFFFFFFFFu;   // K < 64: masked k-tile
         d_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
     }
 
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);
             const int k = k0 + wk * 32 + l31;
-            if (c < C) out[(long)c * K + k] = acc[tap][r] * d_inv;
+            if (c < C && k < K) out[(long)c * K + k] = acc[tap][r] * d_inv;
         }
     }
 }
@@ -1027,7 +1027,7 @@ int pick_seg(int W, int C, int K, int flags) {
     return 0;
 }
 int pick_splits9(long nseg, int C, int K, int target = 1024) {
-    const long tiles = (long)((C + 63) / 64) * (K / 64);
+    const long tiles = (long)((C + 63) / 64) * ((K + 63) / 64);
     long s = (target + tiles - 1) / tiles;            // 1024: ~4 blocks per CU (two rounds of 2 resident)
     const long smax = (nseg + 7) / 8;                 // at least 8 segments per split
     if (s > smax) s = smax;
@@ -1037,7 +1037,8 @@ int pick_splits9(long nseg, int C, int K, int target = 1024) {
 
 // split-half 9-tap kernel (flags 0x2000): patch width (0 = not applicable); rows narrower than the patch are masked
 int pick_patch_x3(int W, int C, int K, int flags) {
-    if (!(flags & 0x2000) || (flags & 0x800) || C % 32 != 0 || K % 64 != 0) return 0;
+    if (!(flags & 0x2000) || (flags & 0x800) || C % 32 != 0) return 0;
+    if (K % 64 != 0 && ((flags & 1) || K > 64 || K % 4 != 0)) return 0;   // K < 64 (late-fusion widths): plain form, masked k-tile
     if (C % 64 != 0 && ((flags & 1) || C != 32)) return 0;       // C = 32 (padded first conv): plain 9-tap form, half c-tile
     if (W % 32 == 0 || (W > 16 && W < 32)) return 32;
     if (W % 16 == 0 || (W > 8 && W < 16)) return 16;
@@ -1136,7 +1137,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         const int S = pick_splits9(np, C, K, X3_BLOCKS);
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int pps = (int)((np + S - 1) / S);
-        dim3 grid(((C + 63) / 64) * (K / 64), S);
+        dim3 grid(((C + 63) / 64) * ((K + 63) / 64), S);
 #define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
 #define EGZ_W9T(TT)                                                                                                    \
         if (ups) { if (WD == 32) EGZ_W9X(TT, true, 1, 32); else if (WD == 16) EGZ_W9X(TT, true, 2, 16); else EGZ_W9X(TT, true, 4, 8); } \

@@ -181,10 +181,16 @@ _SPLIT_MAX_BYTES = (1 << 32) - (1 << 24)      # the split kernels fetch through 
 def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.Tensor] = None) -> int:
     """dtype code for a conv launch under the current PRECISION policy (role: 'fwd' | 'dgrad').  ``operand`` = the gathered
     activation / gradient tensor: one of 4 GiB or more (B >= 320 at 224 x 224 x 64) stays on the 64-bit-addressed f32 kernels."""
-    if PRECISION != "split" or gemm_out % 64 != 0 or gemm_in % 32 != 0:
+    if PRECISION != "split":
         return F32
     if operand is not None and operand.numel() * 4 >= _SPLIT_MAX_BYTES:
         return F32
+    if gemm_out % 64 != 0 or gemm_in % 32 != 0:
+        # narrow layers (the late-fusion stack: 32 -> 32 -> 8 channels): only the streamed-weight kernel's 32-column tile
+        # takes them, and only for plain convs over an operand whose geometry it covers
+        if not (STREAMED and operand is not None and operand.dim() == 4
+                and LIB.egz_conv3x3_streamed_ok(operand.shape[0], operand.shape[1], operand.shape[2], gemm_in, gemm_out, 0)):
+            return F32
     return F16X3 if (role == "fwd" or GRAD_SPLIT == "f16") else BF16X3
 
 
