@@ -52,6 +52,39 @@ def crop_align_feature(feature, maxind, size):
     return torch.cat(out, 0)
 
 
+def align_window_weights(gp, size, cells=14, scale=16):
+    """Per-cell weights W (cells x cells, float64) with  mean(crop of the bilinear x``scale`` upsampling around gp)
+    = sum_cells W * map:  the upsampling (align_corners=True, as nn.functional.upsample_bilinear) and the window mean are
+    both linear and separable, so W = outer(wy, wx) with 1-D sums of the interpolation weights over the window rows /
+    columns.  Window as AT.crop_align_feature (AT.py:41-56): ``size * scale`` pixels around gp, clipped to the image."""
+    full, win = cells * scale, size * scale
+    out = []
+    for f in gp:
+        f = min(max(int(f), win // 2), full - win // 2)
+        w = np.zeros(cells)
+        for y in range(f - win // 2, f + win // 2):
+            sy = y * (cells - 1) / (full - 1)
+            i0 = min(int(math.floor(sy)), cells - 1)
+            i1 = min(i0 + 1, cells - 1)
+            fr = sy - i0
+            w[i0] += 1 - fr
+            w[i1] += fr
+        out.append(w / win)
+    return np.outer(out[0], out[1])
+
+
+def crop_align_mean(feature, maxind, size):
+    """chn_weight of the ``--align`` path: spatial mean of crop_align_feature(feature, maxind, size) (AT.py:41-56 + :229).
+    On the GPU it is one small kernel on the 14 x 14 map (no x16 upsampled tensor, no tensor-library interpolation)."""
+    if feature.is_cuda and feature.size(2) == feature.size(3):
+        from . import hipops as H
+        from .functions import to_nhwc
+        wm = np.stack([align_window_weights(list(map(int, m)), size, feature.size(2)) for m in maxind])
+        return H.pixel_weighted_sum(to_nhwc(feature), wm)
+    c = crop_align_feature(feature, maxind, size).contiguous()
+    return c.view(c.size(0), c.size(1), -1).mean(2)
+
+
 def crop_mean_weight(feature, maxind, size):
     """chn_weight = spatial mean of crop_feature(feature, maxind, size) (AT.py:25-39 + :229) in one kernel
     (egz_crop_mean) when the map lives on the GPU."""
@@ -180,8 +213,7 @@ class AT():
                 # (AT.py:221-224); evaluated on the quantised map like the reference, by the device kernel
                 _, _, pred_gp = computeAAEAUC(quant.float(), target)
                 if self.align:
-                    cfeature = crop_align_feature(feature_s, pred_gp, self.crop_size).contiguous()
-                    chn_weight = cfeature.view(cfeature.size(0), cfeature.size(1), -1).mean(2)  # (1,512)
+                    chn_weight = crop_align_mean(feature_s, pred_gp, self.crop_size)            # (1,512)
                 else:
                     chn_weight = crop_mean_weight(feature_s, pred_gp, self.crop_size)           # (1,512)
                 if int(fixsac) != 1:

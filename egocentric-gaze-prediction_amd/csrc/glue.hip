@@ -54,6 +54,18 @@ __global__ void window_mean_kernel(const float* __restrict__ feat, const int* __
     out[idx] = s / (float)((y1 - y0) * (x1 - x0));
 }
 
+// one thread per (b, c): out[b][c] = sum_p wmap[b][p] * feat[b][p][c]  (a linear functional of the map, e.g. the mean of a
+// window of its bilinear x16 upsampling: AT.crop_align_feature + mean, AT.py:41-56,229)
+__global__ void pixel_weighted_sum_kernel(const float* __restrict__ feat, const float* __restrict__ wmap,
+                                          float* __restrict__ out, int B, int HW, int C) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)B * C) return;
+    const int b = (int)(idx / C), c = (int)(idx % C);
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += wmap[(long)b * HW + p] * feat[((long)b * HW + p) * C + c];
+    out[idx] = s;
+}
+
 // one block per image: out[p] = sum_c feat[p][c] * w[c]; then (out - min) / max(out - min)
 __global__ __launch_bounds__(256) void weighted_minmax_kernel(const float* __restrict__ feat, const float* __restrict__ w,
                                                                float* __restrict__ out, int HW, int C) {
@@ -114,6 +126,14 @@ EGZ_API int egz_window_mean(const float* feat, const int* win, float* out, int B
     EGZ_CHECK_ARG(feat && win && out && B > 0 && C > 0 && H > 0 && W > 0, "egz_window_mean: bad arguments");
     hipLaunchKernelGGL(window_mean_kernel, dim3(egz_cdiv((long)B * C, 256)), dim3(256), 0, st, feat, win, out, B, H, W, C);
     EGZ_CHECK_LAUNCH("egz_window_mean");
+    return 0;
+}
+
+// feat: (B, H*W, C) channels-last, wmap: (B, H*W) per-pixel weights, out: (B, C) = sum_p wmap[b][p] * feat[b][p][:].
+EGZ_API int egz_pixel_weighted_sum(const float* feat, const float* wmap, float* out, int B, int HW, int C, hipStream_t st) {
+    EGZ_CHECK_ARG(feat && wmap && out && B > 0 && HW > 0 && C > 0, "egz_pixel_weighted_sum: bad arguments");
+    hipLaunchKernelGGL(pixel_weighted_sum_kernel, dim3(egz_cdiv((long)B * C, 256)), dim3(256), 0, st, feat, wmap, out, B, HW, C);
+    EGZ_CHECK_LAUNCH("egz_pixel_weighted_sum");
     return 0;
 }
 

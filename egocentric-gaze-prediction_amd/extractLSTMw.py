@@ -62,6 +62,11 @@ def channel_weight(feat, gt, crop_size, align):
     if align:
         flat = gt.float().view(gt.size(0), gt.size(1), -1)
         _, maxind = torch.max(flat, 2)
+        if feat.is_cuda:             # the window mean of the x16 bilinear upsampling as one kernel on the 14 x 14 map
+            from .AT import crop_align_mean
+            full = feat.size(3) * 16
+            gp = [[int(maxind[b].item()) // full, int(maxind[b].item()) % full] for b in range(feat.size(0))]
+            return crop_align_mean(feat, gp, crop_size).squeeze(0)
         up = nn.functional.interpolate(feat.contiguous(), scale_factor=16, mode='bilinear', align_corners=True)
         crop = crop_feature_align(up, maxind, crop_size).contiguous()
         return crop.view(crop.size(0), crop.size(1), -1).mean(2).squeeze(0)

@@ -902,6 +902,17 @@ def window_mean(feat_nhwc: torch.Tensor, windows) -> torch.Tensor:
     return out
 
 
+def pixel_weighted_sum(feat_nhwc: torch.Tensor, wmap) -> torch.Tensor:
+    """feat_nhwc: (B,H,W,C); wmap: (B,H,W) per-pixel weights (host array / tensor) -> (B, C) = sum_p wmap[p] * feat[p]."""
+    _req(feat_nhwc, "feature")
+    B, Hh, Ww, C = feat_nhwc.shape
+    wm = torch.as_tensor(wmap, dtype=torch.float32).reshape(B, Hh * Ww).contiguous().to(feat_nhwc.device)
+    out = torch.empty((B, C), dtype=torch.float32, device=feat_nhwc.device)
+    check(LIB.egz_pixel_weighted_sum(feat_nhwc.data_ptr(), wm.data_ptr(), out.data_ptr(), B, Hh * Ww, C, _stream()),
+          "egz_pixel_weighted_sum")
+    return out
+
+
 def weighted_minmax(feat_nhwc: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """feat_nhwc: (B,H,W,C), w: (B,C) -> (B,H,W): channel-weighted sum, min-max normalised per image."""
     _req(feat_nhwc, "feature"); _req(w, "chn_weight")

@@ -209,6 +209,9 @@ int egz_crop_mean(const float* feat, const int* gp, float* out, int B, int H, in
                   hipStream_t stream);
 /* extractLSTMw.crop_feature_var (extractLSTMw.py:46-58) + mean: explicit window {y0, y1, x0, x1} per sample */
 int egz_window_mean(const float* feat, const int* win, float* out, int B, int H, int W, int C, hipStream_t stream);
+/* AT.crop_align_feature + mean (AT.py:41-56,229; extractLSTMw.py:32-44, `--align`): the mean of a window of the bilinearly
+ * x16-upsampled map is a linear functional of the map -- out[b][c] = sum_p wmap[b][p] * feat[b][p][c] */
+int egz_pixel_weighted_sum(const float* feat, const float* wmap, float* out, int B, int HW, int C, hipStream_t stream);
 int egz_weighted_minmax(const float* feat, const float* w, float* out, int B, int HW, int C, hipStream_t stream);
 
 #ifdef __cplusplus

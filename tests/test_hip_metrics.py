@@ -111,3 +111,28 @@ def test_at_glue_kernels_vs_oracle():
     ref = gold["get_weighted"]
     assert np.abs(got.cpu().numpy() - ref).max() < 2e-6
     assert float(got.min()) == 0.0 and float(got.max()) == 1.0
+
+
+def test_window_and_align_means_on_device():
+    """egz_window_mean (extractLSTMw.crop_feature_var + mean) and egz_pixel_weighted_sum (the --align crop mean) against the
+    host formulations on a (B, 512, 14, 14) map."""
+    import egaze_amd  # noqa: F401
+    from egaze_amd import extractLSTMw as ex
+    from egaze_amd.AT import crop_align_feature, crop_align_mean
+    rs = np.random.RandomState(3)
+    feat = torch.from_numpy(np.abs(rs.standard_normal((3, 512, 14, 14))).astype(np.float32))
+    fd = feat.to("cuda:0").contiguous(memory_format=torch.channels_last)
+    gps = [[5, 220], [117, 60], [223, 0]]
+    ref = crop_align_feature(feat, gps, 3).contiguous().view(3, 512, -1).mean(2)
+    got = crop_align_mean(fd, gps, 3).cpu()
+    assert np.abs(got.numpy() - ref.numpy()).max() < 1e-5 * np.abs(ref.numpy()).max()
+    # extractLSTMw window (float clip + int slicing) through channel_weight: device vs host path, one sample at a time
+    for ind in (0, 13, 5 * 14 + 5, 195):
+        gt = torch.zeros(1, 1, 224, 224)
+        gt[0, 0, (ind // 14) * 16 + 8, (ind % 14) * 16 + 8] = 1.0
+        w_dev = ex.channel_weight(fd[:1], gt, 3, False).cpu()
+        w_cpu = ex.channel_weight(feat[:1], gt, 3, False)
+        assert np.allclose(w_dev.numpy(), w_cpu.numpy(), rtol=1e-5, atol=1e-7), ind
+        a_dev = ex.channel_weight(fd[:1], gt, 3, True).cpu()
+        a_cpu = ex.channel_weight(feat[:1], gt, 3, True)
+        assert np.allclose(a_dev.numpy(), a_cpu.numpy(), rtol=1e-4, atol=1e-6), ind

@@ -162,3 +162,21 @@ def test_extract_lstm_mirror_matches_reference_golden(tmp_path):
     bad = [dict(loader[0], fixsac=torch.tensor([[1.0]])), dict(loader[1], fixsac=torch.tensor([[0.0]]))]
     with pytest.raises(RuntimeError):
         ex.extractw(bad, Fake(), str(tmp_path / "bad"), crop_size=3, device="cpu")
+
+
+def test_align_window_weights_equal_interpolate_crop_mean():
+    """`--align` chn_weight (AT.py:41-56 + :229): the mean of a window of the x16 bilinear upsampling written as per-cell
+    weights on the 14 x 14 map, against torch's interpolate + crop + mean (the reference's own sequence of ops)."""
+    import numpy as np
+    import torch
+    import egaze_amd  # noqa: F401
+    from egaze_amd.AT import align_window_weights, crop_align_feature
+    rs = np.random.RandomState(0)
+    feat = torch.from_numpy(rs.standard_normal((1, 7, 14, 14)).astype(np.float32))
+    for size in (1, 3, 5):
+        for gp in ([5, 220], [117, 60], [0, 0], [223, 223], [100, 30], [111, 112]):
+            ref = crop_align_feature(feat, [gp], size).contiguous().view(1, 7, -1).mean(2)[0].numpy()
+            W = align_window_weights(gp, size)
+            assert abs(W.sum() - 1.0) < 1e-12
+            got = (feat[0].double().numpy() * W[None]).sum((1, 2))
+            assert np.abs(got - ref).max() < 1e-6, (size, gp)
