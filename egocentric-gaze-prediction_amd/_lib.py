@@ -37,7 +37,9 @@ SIGNATURES = {
     "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
     "egz_conv3x3_streamed_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_pack_w3x3_split_frag": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
-    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, S]),
+    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
+    "egz_absmax_fold": (c_int, [P, c_int, S]),
+    "egz_colsum_f64": (c_int, [P, c_int, c_int, c_int, P, P, c_size_t, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)

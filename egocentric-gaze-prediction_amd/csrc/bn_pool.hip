@@ -767,3 +767,41 @@ EGZ_API int egz_fill_zero(void* dst, size_t bytes, hipStream_t st) {
     EGZ_CHECK_ARG(e == hipSuccess, "egz_fill_zero: %s", hipGetErrorString(e));
     return 0;
 }
+
+namespace {
+// out[k] = sum_p part[p][k] for k < nout (row stride `cols`)
+__global__ void colsum_final_n_kernel(const double* __restrict__ part, int nparts, int cols, int nout, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nout) return;
+    double s = 0.0;
+#pragma unroll 16
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * cols + k];
+    out[k] = (float)s;
+}
+}  // namespace
+
+// absmax[0] = max over the partial slots absmax[1 .. nparts] a producer kernel filled (bit patterns of non-negative floats)
+EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st) {
+    EGZ_CHECK_ARG(absmax && nparts > 0 && nparts <= ABSMAX_PARTIALS, "egz_absmax_fold: bad arguments");
+    return absmax_finish(absmax, nparts, st, "egz_absmax_fold");
+}
+
+// out[c] = sum over rows of part[row][c] for c < ncols_out; part: [rows][cols] fp64 (e.g. the stat rows of a conv epilogue,
+// cols = 2 K, ncols_out = K = the sum plane).  workspace: RED_ROWS * cols doubles.  Fixed summation order.
+EGZ_API int egz_colsum_f64(const double* part, int rows, int cols, int ncols_out, float* out, void* workspace,
+                           size_t ws_bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(part && out && workspace && rows > 0 && cols > 0 && ncols_out > 0 && ncols_out <= cols, "egz_colsum_f64: bad arguments");
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)RED_ROWS * cols * sizeof(double), "egz_colsum_f64: workspace too small");
+    const double* src = part;
+    int n = rows;
+    if (rows > RED_ROWS) {
+        double* part2 = static_cast<double*>(workspace);
+        int rc = colsum_partial<double>(part, part2, rows, cols, st);
+        if (rc) return rc;
+        src = part2;
+        n = RED_ROWS;
+    }
+    hipLaunchKernelGGL(colsum_final_n_kernel, dim3(egz_cdiv(ncols_out, 128)), dim3(128), 0, st, src, n, cols, ncols_out, out);
+    EGZ_CHECK_LAUNCH("egz_colsum_f64");
+    return 0;
+}

@@ -27,7 +27,11 @@
 namespace {
 using namespace x3;
 
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2 };
+// EPI_MASK_SUMS: the launch is a data gradient whose result is the gradient w.r.t. a post-ReLU activation `mask_src` (same
+// layout as y): the epilogue applies the ReLU mask (mask_src > 0), accumulates the per-channel sums of the masked gradient
+// (= the bias gradient of the layer below, plane 0 of the stat rows; plane 1 = 0) and the per-tile max |value| (for the
+// f16 scaling of the next backward kernels) -- the separate ReLU-backward pass of that layer disappears.
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2, EPI_MASK_SUMS = 3 };
 constexpr int XLD = 32;                 // 16-bit elements per LDS row: 64 B = 32 channels of one plane of one pixel
 constexpr int XBK = 32;                 // channels per block of the reduction
 constexpr int HPITCH = 20;              // patch geometry: halo columns per LDS grid row (18 used)
@@ -57,7 +61,8 @@ template <typename T, int WM, int EPI, bool PATCH, int MODE>
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
-    int mt, int total, const unsigned int* __restrict__ a_absmax) {
+    int mt, int total, const unsigned int* __restrict__ a_absmax, const float* __restrict__ mask_src,
+    unsigned int* __restrict__ absmax_out) {
     using G = Geo<WM>;
     constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
     constexpr int MR = G::MR, RPW = G::RPW;
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
     __shared__ long Ro[BM];
     __shared__ double sred[(RPW < 128) ? 4 * 2 * 32 : 1];       // BN partial sums of the waves that share a 128-row stat row
+    __shared__ float samax[4];
 
     const float a_scale = absmax_scale(a_absmax);
     out_scale /= a_scale;
@@ -323,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     const bool nok = col < K;
     const float bz = (bias && nok) ? bias[col] : 0.f;
     double s1 = 0.0, s2 = 0.0;
+    float amx = 0.f;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -331,15 +338,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
             if (off >= 0 && nok) {
                 float v = acc[mr][r] * out_scale + bz;
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                y[off + col] = v;
-                if (EPI == EPI_BIAS_STATS) {
-                    s1 += (double)v;
-                    s2 += (double)v * (double)v;
+                if (EPI == EPI_MASK_SUMS) {
+                    v = (mask_src[off + col] > 0.f) ? v : 0.f;
+                    amx = fmaxf(amx, fabsf(v));
                 }
+                y[off + col] = v;
+                if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS) s1 += (double)v;
+                if (EPI == EPI_BIAS_STATS) s2 += (double)v * (double)v;
             }
         }
     }
-    if (EPI == EPI_BIAS_STATS) {
+    if (EPI == EPI_MASK_SUMS) {
+        // per-tile max |value| -> absmax_out[1 + tile] (bit pattern; folded by egz_absmax_fold, no atomics)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+        if (lane == 0) samax[wave] = amx;
+        lds_barrier();
+        if (tid == 0) absmax_out[1 + gt] = __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
+    }
+    if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS) {
         // one partial row per 128 pixel rows (the granularity egz_conv3x3_stat_rows promises)
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
@@ -411,7 +428,8 @@ __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __res
 
 template <typename T, int WM, int MODE>
 int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
-               int W, int C, int K, float out_scale, const unsigned int* a_absmax, hipStream_t st) {
+               int W, int C, int K, float out_scale, const unsigned int* a_absmax, const float* mask_src,
+               unsigned int* absmax_out, hipStream_t st) {
     using G = Geo<WM>;
     const int Ho = (MODE == UPSD) ? H / 2 : H, Wo = (MODE == UPSD) ? W / 2 : W;
     const long M = (long)B * Ho * Wo;
@@ -420,8 +438,16 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
     const int total = mt * (Kp / G::BN);
     const dim3 grid(((total + 7) / 8) * 8);
-#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax)
-    if (patch) {
+#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out)
+    if (epi == EPI_MASK_SUMS) {
+        EGZ_CHECK_ARG(total <= 8192, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
+        if constexpr (WM != 4) {                 // data gradients of the SP decoder: 128- and 64-column tiles
+            if (patch) EGZ_X3S(EPI_MASK_SUMS, true); else EGZ_X3S(EPI_MASK_SUMS, false);
+        } else {
+            egz_set_error("egz_conv3x3_fwd_streamed: the mask epilogue is not built for 32-column tiles");
+            return (int)hipErrorInvalidValue;
+        }
+    } else if (patch) {
         if (epi == EPI_BIAS) EGZ_X3S(EPI_BIAS, true);
         else if (epi == EPI_BIAS_RELU) EGZ_X3S(EPI_BIAS_RELU, true);
         else EGZ_X3S(EPI_BIAS_STATS, true);
@@ -480,29 +506,35 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
 // caller passes dy as x, C = Cout, K = Cin and the kind-5 packing), H' x W' = H x W.  mode 1: data gradient of an
 // upsample-fused conv w.r.t. its low-res input (x = hi-res dy, kind-6 packing, H' x W' = H/2 x W/2).
 // epi: 0 bias, 1 bias + ReLU, 2 bias + per-channel (sum, sumsq) partials, one row per 128 output pixels as
-// egz_conv3x3_stat_rows(B, H', W', K, 0x200) promises.  Only for geometries egz_conv3x3_streamed_ok accepts.
+// egz_conv3x3_stat_rows(B, H', W', K, 0x200) promises; 3 (data gradients, 128- / 64-column tiles): y = result where
+// mask_src > 0 else 0 (mask_src: [B][H'][W'][K], the post-ReLU activation whose gradient this is), stat rows = per-channel
+// sums of the masked result (plane 0; the bias gradient of the layer below), absmax_out[1 + tile] = per-tile max |y| (fold
+// with egz_absmax_fold(absmax_out, tiles)).  Only for geometries egz_conv3x3_streamed_ok accepts.
 EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
                                      int B, int H, int W, int C, int K, int epi, int dtype, int mode,
-                                     const unsigned int* x_absmax, hipStream_t st) {
+                                     const unsigned int* x_absmax, const float* mask_src, unsigned int* absmax_out,
+                                     hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, mode), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d "
                   "mode=%d is not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K, mode);
-    EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && epi >= 0 && epi <= 2, "egz_conv3x3_fwd_streamed: bad dtype / epilogue");
-    EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_streamed: stats epilogue needs stat_partial");
+    EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && epi >= 0 && epi <= 3, "egz_conv3x3_fwd_streamed: bad dtype / epilogue");
+    EGZ_CHECK_ARG(epi < EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_streamed: stats / mask epilogue needs stat_partial");
+    EGZ_CHECK_ARG(epi != EPI_MASK_SUMS || (mask_src && absmax_out && !bias), "egz_conv3x3_fwd_streamed: mask epilogue needs "
+                  "mask_src and absmax_out and takes no bias");
     const unsigned short* w16 = static_cast<const unsigned short*>(wq);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
     if (mode == 1) {
-        if (dtype == 1) return launch_x3s<_Float16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-        return launch_x3s<__bf16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        if (dtype == 1) return launch_x3s<_Float16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        return launch_x3s<__bf16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
     if (K % 128 == 0) {
-        if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-        return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
     if (K % 64 == 0) {
-        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
-    if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-    return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+    return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
 }

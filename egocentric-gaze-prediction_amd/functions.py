@@ -139,8 +139,14 @@ class ConvBNReLUPool(torch.autograd.Function):
 
 
 class ConvReLU(torch.autograd.Function):
+    """[Upsample x2 ->] Conv2d 3x3 -> ReLU.  ``relu_below``: the input is the output of another ConvReLU block (decoder
+    chains, models/model_SP.py:13-29).  Then this node's data gradient IS the gradient w.r.t. that block's post-ReLU output,
+    and the ReLU mask of the block below (input > 0), its bias gradient (column sums of the masked gradient) and the abs-max
+    of the result are produced in the epilogue of this node's dgrad kernel (hipops.conv3x3_dgrad_masked); the gradient
+    tensor handed down carries them (``_egz_premasked``), and the block below skips its own ReLU-backward pass."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, ups):
+    def forward(ctx, x, weight, bias, ups, relu_below=False):
         K, C = weight.shape[0], weight.shape[1]
         xin = to_nhwc(x)
         dt = H.conv_dtype("fwd", K, C, xin)
@@ -148,17 +154,27 @@ class ConvReLU(torch.autograd.Function):
         y, _ = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
                              epi=H.EPI_BIAS_RELU, dtype=dt, streamed=st)
         ctx.save_for_backward(xin, y, weight, bias)
-        ctx.cfg = (ups, C, K)
+        ctx.cfg = (ups, C, K, bool(relu_below))
         return from_nhwc(y)
 
     @staticmethod
     def backward(ctx, dout):
         xin, y, weight, bias = ctx.saved_tensors
-        ups, C, K = ctx.cfg
+        ups, C, K, relu_below = ctx.cfg
         ng = ctx.needs_input_grad
         dx = dw = db = None
         sbias = H.grad_sink(bias, ng[2])
-        if ng[2]:
+        pre = getattr(dout, "_egz_premasked", None)
+        if pre is not None and tuple(dout.shape) == (y.shape[0], K, y.shape[1], y.shape[2]):
+            # the block above already applied this block's ReLU mask in its dgrad epilogue
+            dy = to_nhwc(dout)
+            stat, am = pre
+            H.MASK_FUSE_STATS["consumed"] += 1
+            if am is not None:
+                dy._egz_absmax = am
+            if ng[2]:
+                db = H.colsum_f64(stat, K, out=sbias)
+        elif ng[2]:
             dy, db = H.relu_bwd_bias(y, to_nhwc(dout), out_db=sbias)
         else:
             dy = H.relu_bwd(y, to_nhwc(dout))
@@ -168,14 +184,18 @@ class ConvReLU(torch.autograd.Function):
                 dw = H.conv3x3_wgrad(xin, dy, ups=ups, out=sw)
         if ng[0]:
             dt = H.conv_dtype("dgrad", C, K, dy)
-            if ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
-                wp, st = H.conv_weight(weight, "ups_dgrad", dt, dy, C)
+            role = "ups_dgrad" if ups else "dgrad"
+            wp, st = H.conv_weight(weight, role, dt, dy, C)
+            if relu_below and st and H.MASK_FUSE and C % 64 == 0:
+                dxn, stat, am = H.conv3x3_dgrad_masked(dy, wp, C, dt, xin, ups)
+                dx = from_nhwc(dxn)
+                dx._egz_premasked = (stat, am if H._want_absmax() else None)
+            elif ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
                 dx = from_nhwc(H.conv3x3_ups_dgrad(dy, wp, C, dtype=dt, streamed=st))
             else:
-                wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
                 dx = from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
         _close_fork(f, sw, dw, xin, dy)
-        return dx, _finish(weight, sw, dw), _finish(bias, sbias, db), None
+        return dx, _finish(weight, sw, dw), _finish(bias, sbias, db), None, None
 
 
 class FusionBlock(torch.autograd.Function):

@@ -375,7 +375,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
             raise RuntimeError("the streamed-weight kernel covers plain convolutions only")
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, 0, _p(absmax), _stream()), "egz_conv3x3_fwd_split")
+                                           epi, dtype, 0, _p(absmax), None, None, _stream()), "egz_conv3x3_fwd_split")
         return y, stat
     if dtype:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
@@ -409,7 +409,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                           0, dtype, 1, _p(am), _stream()), "egz_conv3x3_fwd_streamed(ups_dgrad)")
+                                           0, dtype, 1, _p(am), None, None, _stream()), "egz_conv3x3_fwd_streamed(ups_dgrad)")
         return dx
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
@@ -423,6 +423,53 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
     check(LIB.egz_conv3x3_ups_dgrad(dy.data_ptr(), wp_ups_dgrad.data_ptr(), dx.data_ptr(), B, H, W, C, K,
                                     _TILE_FLAG, _stream()), "egz_conv3x3_ups_dgrad")
     return dx
+
+
+EPI_MASK_SUMS = 3
+# ReLU backward of a decoder block folded into the epilogue of the dgrad kernel above it (functions.ConvReLU).  Opt-in:
+# it removes 11 passes over the decoder gradients (relu_bwd_bias 1.06 -> 0.1 ms per step) but lengthens the MFMA-bound dgrad
+# launches by the same amount -- measured 35.56 vs 35.39 ms per step (profiles/r02_bench_ab_knobs.txt), so the default keeps
+# the separate HBM-bound pass, which overlaps with the weight-gradient stream.
+MASK_FUSE = _os.environ.get("EGAZE_MASK_FUSE", "0") != "0"
+MASK_FUSE_STATS = {"produced": 0, "consumed": 0}                 # how often the fused form ran / was picked up (tests)
+
+
+def conv3x3_dgrad_masked(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int, mask_src: torch.Tensor, ups: bool):
+    """Data gradient of a plain (``ups`` False) or upsample-fused (True) 3x3 conv on the streamed-weight kernel, with the
+    ReLU backward of the layer BELOW folded into the epilogue: ``mask_src`` (B, H', W', C) is that layer's post-ReLU output
+    (= this conv's input).  Returns (dx masked, stat rows (rows, 2, C) fp64 whose plane 0 sums to the bias gradient of the
+    layer below, abs-max buffer of dx)."""
+    _req(dy, "dy"); _req(mask_src, "mask_src")
+    B, H, W, K = dy.shape
+    Ho, Wo = (H // 2, W // 2) if ups else (H, W)
+    if tuple(mask_src.shape) != (B, Ho, Wo, C):
+        raise RuntimeError(f"mask_src {tuple(mask_src.shape)} does not match the gradient {(B, Ho, Wo, C)}")
+    dx = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=dy.device)
+    rows = (B * Ho * Wo + 127) // 128
+    stat = torch.empty((rows, 2, C), dtype=torch.float64, device=dy.device)
+    MASK_FUSE_STATS["produced"] += 1
+    amo = _new_absmax(dy.device)
+    PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+    am = absmax_of(dy) if dtype == F16X3 else None
+    check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
+                                       EPI_MASK_SUMS, dtype, 1 if ups else 0, _p(am), mask_src.data_ptr(), amo.data_ptr(),
+                                       _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
+    tile_rows = 128 if C % 128 == 0 else 256
+    tile_cols = 128 if C % 128 == 0 else 64
+    ntiles = ((B * Ho * Wo + tile_rows - 1) // tile_rows) * (C // tile_cols)
+    check(LIB.egz_absmax_fold(amo.data_ptr(), ntiles, _stream()), "egz_absmax_fold")
+    return dx, stat, amo
+
+
+def colsum_f64(stat: torch.Tensor, ncols_out: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """stat: (rows, cols...) fp64 partial rows -> fp32 sums of the first ``ncols_out`` columns (fixed order)."""
+    rows = stat.shape[0]
+    cols = stat.numel() // rows
+    res = _out(out, (ncols_out,), stat.device)
+    ws = workspace(64 * cols * 8, stat.device)
+    check(LIB.egz_colsum_f64(stat.data_ptr(), rows, cols, ncols_out, res.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "egz_colsum_f64")
+    return res
 
 
 WGRAD_SPLIT = 0x2000       # egz_conv3x3_wgrad flag: split-half arithmetic (bf16 x3, or f16 x3 when dy_absmax is passed)

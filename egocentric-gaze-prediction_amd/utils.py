@@ -67,6 +67,7 @@ class FusedSequential(nn.Sequential):
         mods = list(self.children())
         i, n = 0, len(mods)
         first, ups = True, False
+        relu_below = False           # the current tensor is the output of a ConvReLU block of THIS stack
         while i < n:
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
@@ -84,10 +85,12 @@ class FusedSequential(nn.Sequential):
                 step = 4 if pool else 3
                 x = conv_bn_relu_pool(x, m, nxt, pool, first and m.in_channels < 32,
                                       out_buf if i + step >= n else None)
+                relu_below = False
                 i += step
             elif isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and isinstance(nxt, nn.ReLU):
-                x = ConvReLU.apply(x, m.weight, m.bias, ups)
+                x = ConvReLU.apply(x, m.weight, m.bias, ups, relu_below)
                 ups = False
+                relu_below = True
                 i += 2
             elif isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.out_channels == 1 and i == n - 1:
                 if not fuse_sigmoid:

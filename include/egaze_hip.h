@@ -76,12 +76,18 @@ int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, flo
  * L2 -> registers, the activation halo goes through LDS.  egz_conv3x3_streamed_ok: 1 when a geometry is covered
  * (C = reduction channels % 32 == 0, K = GEMM columns % 64 == 0).  mode 0 = plain conv; mode 1 = data gradient of
  * [nn.Upsample(x2) -> nn.Conv2d] (models/model_SP.py:17-18,22-23,25-26,28-29) w.r.t. the low-res input, x = hi-res dy,
- * kind-6 packing.  epi: 0 bias, 1 bias + ReLU, 2 bias + BN partials (one row per 128 output pixels). */
+ * kind-6 packing.  epi: 0 bias, 1 bias + ReLU, 2 bias + BN partials (one row per 128 output pixels), 3 = data gradient
+ * masked by mask_src > 0 with per-channel sums and per-tile abs-max (see below). */
 int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode);
 int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t stream);
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
-                             hipStream_t stream);
+                             const float* mask_src, unsigned int* absmax_out, hipStream_t stream);
+/* helpers of the epi = 3 (ReLU mask + bias-gradient sums + abs-max) form of egz_conv3x3_fwd_streamed, which folds the
+ * nn.ReLU backward of a decoder layer (models/model_SP.py:13-29) into the data gradient of the layer above it */
+int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t stream);
+int egz_colsum_f64(const double* part, int rows, int cols, int ncols_out, float* out, void* workspace, size_t ws_bytes,
+                   hipStream_t stream);
 /* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
 size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,

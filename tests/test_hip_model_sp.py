@@ -387,3 +387,33 @@ def test_training_trajectory_vs_oracle(precision, grad_split, factor, monkeypatc
     b_hip, b_cpu = _bn_stats_dev(model.state_dict(), truth["sd"]), _bn_stats_dev(ref32["sd"], truth["sd"])
     print(f"{tag} BN running stats vs fp64: HIP {b_hip:.2e}, CPU fp32 {b_cpu:.2e}")
     assert b_hip <= factor * b_cpu + 1e-4, (b_hip, b_cpu)
+
+
+def test_relu_backward_folded_into_dgrad_above(monkeypatch):
+    """Decoder chains: the ReLU backward (mask, bias gradient, abs-max) of a conv block is produced by the epilogue of the
+    data-gradient kernel of the block above it.  The folded form must actually run (11 of the 12 decoder convs sit on top of
+    another ConvReLU block), be picked up by the block below, and give the same gradients as the separate pass: identical
+    for everything but the bias sums (different summation order)."""
+    import egaze_amd.hipops as H
+    from egaze_amd.floss import floss
+    grads = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(H, "MASK_FUSE", fuse)
+        H.MASK_FUSE_STATS.update(produced=0, consumed=0)
+        model, _ = build_model()
+        x_s, x_t, gt, _ = synth.synth_sp_batch(2, 64, seed=9)
+        model.train()
+        out = model(x_s.to(DEV), x_t.to(DEV))
+        floss()(out, gt.to(DEV).view(out.size())).backward()
+        torch.cuda.synchronize()
+        grads[fuse] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+        if fuse:
+            assert H.MASK_FUSE_STATS == {"produced": 11, "consumed": 11}, H.MASK_FUSE_STATS
+        else:
+            assert H.MASK_FUSE_STATS == {"produced": 0, "consumed": 0}
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        if k.startswith("decoder.") and k.endswith(".bias"):
+            assert rel(a.numpy(), b.numpy()) < 2e-6, k
+        else:
+            assert torch.equal(a, b), k
