@@ -189,8 +189,13 @@ class AT():
             plot_loss(loss_train, loss_val, os.path.join(self.save_path, self.lstm_save_img))
         print('lstm training finished!')
 
-    def extract_late(self, st_loader, pred_folder='../new_pred/', feat_folder='../new_feat/'):
-        """pred = SP gaze map, feat = AT-weighted conv5_3 map, both written as uint8 PNGs (AT.py:199-253)."""
+    def extract_late(self, st_loader, pred_folder='../new_pred/', feat_folder='../new_feat/', chunk=32):
+        """pred = SP gaze map, feat = AT-weighted conv5_3 map, both written as uint8 PNGs (AT.py:199-253).
+
+        Same per-frame results and the same sequential LSTM state as the reference's batch-1 loop, but the frames of the
+        (batch-1) loader are gathered ``chunk`` at a time: the SP forward (eval mode, every sample independent), the uint8
+        quantisation, the gaze-point metric and the crop means run once per chunk on the device; only the recurrent step,
+        the weighted map and the image hand-over stay per frame.  ``chunk=1`` is the reference's schedule."""
         print('begin to extract files for training LF module ...')
         os.makedirs(pred_folder, exist_ok=True)
         os.makedirs(feat_folder, exist_ok=True)
@@ -198,29 +203,47 @@ class AT():
         self.model.eval()
         self.lstm.eval()
         hidden = None
-        with torch.no_grad():
-            for i, sample in _progress(enumerate(st_loader)):
-                currname = sample['imname'][0]
-                fixsac = sample['fixsac']
-                input_s, input_t, target = stage_batch(sample, self.device)
-                del features_blobs[:]
-                output = self.model(input_s, input_t)                 # (1,1,224,224)
-                feature_s = features_blobs[0]                          # (1,512,14,14)
-                quant = (255 * output).to(torch.uint8)                  # np.uint8(255 * x): truncation, on the device
-                outim = quant.cpu().numpy().squeeze()
-                imwrite(os.path.join(pred_folder, currname), outim)
-                # computeAAEAUC's third value is the GROUND-TRUTH arg-max, used as the "predicted" gaze point
-                # (AT.py:221-224); evaluated on the quantised map like the reference, by the device kernel
-                _, _, pred_gp = computeAAEAUC(quant.float(), target)
-                if self.align:
-                    chn_weight = crop_align_mean(feature_s, pred_gp, self.crop_size)            # (1,512)
-                else:
-                    chn_weight = crop_mean_weight(feature_s, pred_gp, self.crop_size)           # (1,512)
-                if int(fixsac) != 1:
+
+        def flush(samples):
+            nonlocal hidden
+            if not samples:
+                return
+            n = len(samples)
+            # stage the frames one by one (each crosses PCIe as it is: bytes for raw_u8 datasets) and stack them on the device
+            staged = [stage_batch(sm, self.device) for sm in samples]
+            input_s, input_t, target = (staged[0][k] if n == 1 else torch.cat([st[k] for st in staged], 0) for k in range(3))
+            del features_blobs[:]
+            output = self.model(input_s, input_t)                     # (n,1,224,224)
+            feature_s = features_blobs[0]                             # (n,512,14,14)
+            quant = (255 * output).to(torch.uint8)                    # np.uint8(255 * x): truncation, on the device
+            # computeAAEAUC's third value is the GROUND-TRUTH arg-max, used as the "predicted" gaze point
+            # (AT.py:221-224); evaluated on the quantised map like the reference, by the device kernel
+            _, _, pred_gp = computeAAEAUC(quant.float().squeeze(1), target.squeeze(1))
+            if self.align:
+                chn_weights = crop_align_mean(feature_s, pred_gp, self.crop_size)            # (n,512)
+            else:
+                chn_weights = crop_mean_weight(feature_s, pred_gp, self.crop_size)           # (n,512)
+            feats = []
+            for i, sm in enumerate(samples):                          # the recurrent part: frame by frame, state carried
+                chn_weight = chn_weights[i:i + 1]
+                if int(sm['fixsac']) != 1:
                     hidden = repackage_hidden(hidden)
                     chn_weight, hidden = self.lstm(chn_weight.unsqueeze(0), hidden)
                     chn_weight = chn_weight.squeeze(0)
-                feat = get_weighted(chn_weight, feature_s)
-                feat = np.uint8(255 * feat.cpu().numpy().squeeze())
-                imwrite(os.path.join(feat_folder, currname), resize(feat, (224, 224)))
+                feats.append(get_weighted(chn_weight, feature_s[i:i + 1]).reshape(1, feature_s.size(2), feature_s.size(3)))
+            outims = quant.cpu().numpy()                              # one read-back per chunk, after everything was queued
+            featims = np.uint8(255 * torch.cat(feats, 0).cpu().numpy())
+            for i, sm in enumerate(samples):
+                currname = sm['imname'][0]
+                imwrite(os.path.join(pred_folder, currname), outims[i].squeeze())
+                imwrite(os.path.join(feat_folder, currname), resize(featims[i], (224, 224)))
+
+        pending = []
+        with torch.no_grad():
+            for i, sample in _progress(enumerate(st_loader)):
+                pending.append(sample)
+                if len(pending) >= max(1, int(chunk)):
+                    flush(pending)
+                    pending = []
+            flush(pending)
         print('Finished extracting files for LF module!')
