@@ -69,10 +69,18 @@ class GradReducer:
         start, end, _ = self.buckets[b]
         self._launched[b] = True
         if self.flat_grad.is_cuda:
-            # a bucket may hold gradients accumulated on different HIP streams (the two encoders and the
-            # wgrad helper streams run concurrently, streams.py): order all of them before the collective
+            # A bucket holds gradients written on several HIP streams (the two encoders, the detached weight-gradient
+            # streams: streams.py).  The collective is issued from a dedicated comm stream that waits for ALL of them; the
+            # compute streams themselves are not held up (joining them here would serialise the weight-gradient streams
+            # with the data-gradient chain once per bucket).  The library orders the collective after the stream it is
+            # issued from; wait() orders the optimizer step after the collective.
             from . import streams
-            streams.join_all_into_current()
+            comm = streams.comm_stream(self.flat_grad.device)
+            streams.join_all_into(comm)
+            with torch.cuda.stream(comm):
+                self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
+            return
         self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True))
 

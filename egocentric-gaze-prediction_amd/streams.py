@@ -69,15 +69,33 @@ class fork:
                         am.record_stream(self.side)
 
 
-def join_all_into_current():
-    """Make the current stream wait for every helper stream created so far (used before a gradient bucket that may
-    hold gradients produced on several streams is handed to RCCL)."""
-    if not torch.cuda.is_available():
-        return
+def join_all_into(target: torch.cuda.Stream):
+    """Make ``target`` wait for every helper stream created so far, the current stream and the default stream."""
     cur = torch.cuda.current_stream()
-    for st in _SIDE.values():
-        if st.device == cur.device and st.cuda_stream != cur.cuda_stream:
-            cur.wait_stream(st)
-    default = torch.cuda.default_stream(cur.device)
-    if default.cuda_stream != cur.cuda_stream:
-        cur.wait_stream(default)
+    seen = {target.cuda_stream}
+    for st in list(_SIDE.values()) + [cur, torch.cuda.default_stream(target.device)]:
+        if st.device == target.device and st.cuda_stream not in seen:
+            target.wait_stream(st)
+            seen.add(st.cuda_stream)
+
+
+def join_all_into_current():
+    """Make the current stream wait for every helper stream created so far (the optimizer step: gradients are written in
+    place by kernels on several streams)."""
+    if torch.cuda.is_available():
+        join_all_into(torch.cuda.current_stream())
+
+
+_COMM = {}
+
+
+def comm_stream(device=None) -> torch.cuda.Stream:
+    """One stream per device on which gradient buckets are handed to the collective library: it waits for the producers of
+    a bucket, the compute streams do NOT wait for it (dp.GradReducer)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    st = _COMM.get(dev.index)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _COMM[dev.index] = st
+        _SIDE[(dev.index, 0, "comm")] = st            # joined by join_all_* like any helper stream
+    return st
