@@ -24,6 +24,10 @@
 #include "egz_common.h"
 #include "x3_split.h"
 
+#ifndef EGZ_X3S_DIAG          // timing diagnostics (WRONG RESULTS): 1 no weight loads in the loop, 2 half the activation
+#define EGZ_X3S_DIAG 0        // fragment reads, 4 no halo restaging
+#endif
+
 namespace {
 using namespace x3;
 
@@ -36,16 +40,25 @@ constexpr int XLD = 32;                 // 16-bit elements per LDS row: 64 B = 3
 constexpr int XBK = 32;                 // channels per block of the reduction
 constexpr int HPITCH = 20;              // patch geometry: halo columns per LDS grid row (18 used)
 
-// WM = waves along the pixel dimension, 4 / WM along the columns.  WM 1: tile 128 x 128; WM 2: 256 x 64; WM 4: 256 x 32
-// (every wave 64 rows = two 32-row groups; the narrow-channel layers of the late-fusion stack, models/late_fusion.py:10-12).
+// Tile configurations (template parameter WM):
+//   1: 4 waves 1 x 4, tile 128 x 128, activation image double buffered (2 blocks / CU)
+//   2: 4 waves 2 x 2, tile 256 x 64 (the 64-channel layers)
+//   4: 4 waves 4 x 1, tile 256 x 32, every wave 64 rows (the narrow layers of the late-fusion stack, late_fusion.py:10-12)
+//   8: 8 waves 2 x 4, tile 256 x 128, one 512-thread block per CU.  The two waves of a column share their weight fragments:
+//      they issue the same 1 KB loads at the same time and the second is served by the CU's vector L1 instead of L2 -- the
+//      weight-fragment stream is the largest non-MFMA cost of this kernel (profiles/r02_x3s_diag.txt: -21 % without it).
 template <int WM> struct Geo {
+    static constexpr int WMM = (WM == 8) ? 2 : WM;             // waves along the pixel dimension
+    static constexpr int NWN = (WM == 8) ? 4 : 4 / WM;         // waves along the columns
+    static constexpr int NTHR = 64 * WMM * NWN;
     static constexpr int MR = (WM == 4) ? 2 : 4;               // 32-row groups (accumulator tiles) per wave
     static constexpr int RPW = 32 * MR;                        // pixel rows per wave
-    static constexpr int BM = RPW * WM, NWN = 4 / WM, BN = 32 * NWN;
+    static constexpr int BM = RPW * WMM, BN = 32 * NWN;
     static constexpr int HSLOTS = (WM == 1) ? 256 : 384, HZERO = HSLOTS - 1;
-    static constexpr int NABUF = (WM == 1) ? 2 : 1;
+    static constexpr int NABUF = (WM == 1 || WM == 8) ? 2 : 1;
     static constexpr int PROWS = BM / 16;                      // patch: PROWS x 16 pixels
-    static constexpr int NJ = HSLOTS / 32;                     // halo slots per thread (8 threads x 4 channels per slot)
+    static constexpr int SPP = NTHR / 8;                       // halo slots staged per pass (8 threads x 4 channels per slot)
+    static constexpr int NJ = HSLOTS / SPP;                    // halo slots per thread
 };
 
 // workgroup barrier that leaves this wave's global loads (the weight prefetch ring) in flight: __syncthreads() would
@@ -58,24 +71,24 @@ enum { PLAIN = 0, UPSD = 1 };
 // MODE PLAIN: y [B][H][W][K] = conv3x3(x);  MODE UPSD: y [B][H/2][W/2][K] = the data gradient of [nearest x2 upsample ->
 // conv3x3] w.r.t. the LOW-res input, x = the hi-res dy (see the UPSD notes in front of the image loop).
 template <typename T, int WM, int EPI, bool PATCH, int MODE>
-__global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
+__global__ __launch_bounds__(Geo<WM>::NTHR, 2) void conv3x3_igemm_x3s_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
     int mt, int total, const unsigned int* __restrict__ a_absmax, const float* __restrict__ mask_src,
     unsigned int* __restrict__ absmax_out) {
     using G = Geo<WM>;
     constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
-    constexpr int MR = G::MR, RPW = G::RPW;
+    constexpr int MR = G::MR, RPW = G::RPW, NTHR = G::NTHR, SPP = G::SPP;
     constexpr int APL = HSLOTS * XLD;                          // elements per plane of an activation image
     constexpr int ABUF = 2 * APL;                              // elements per image (hi + lo)
     constexpr int NIMG = (MODE == UPSD) ? 4 : 1;               // staged images per channel block
     constexpr int NT = (MODE == UPSD) ? 4 : 9;                 // taps per staged image
     constexpr int NRING = (MODE == UPSD) ? 2 : 3;              // weight-fragment register sets (NIMG * NT % NRING == 0)
-    static_assert(MODE == PLAIN || WM == 1, "the upsample data gradient is built for the 128-column tile only");
+    static_assert(MODE == PLAIN || WM == 1 || WM == 8, "the upsample data gradient is built for the 128-column tiles only");
     __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
     __shared__ long Ro[BM];
     __shared__ double sred[(RPW < 128) ? 4 * 2 * 32 : 1];       // BN partial sums of the waves that share a 128-row stat row
-    __shared__ float samax[4];
+    __shared__ float samax[NTHR / 64];
 
     const float a_scale = absmax_scale(a_absmax);
     out_scale /= a_scale;
@@ -95,14 +108,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     const int b0 = PATCH ? tile_m / ppi : 0;
     const int y0 = PATCH ? ((tile_m - b0 * ppi) / pw) * G::PROWS : 0, x0 = PATCH ? ((tile_m - b0 * ppi) % pw) * 16 : 0;
 
-    for (int i = tid; i < BM; i += 256) {
+    for (int i = tid; i < BM; i += NTHR) {
         long off = -1;
         if (PATCH) off = (((long)b0 * Ho + y0 + (i >> 4)) * Wo + x0 + (i & 15)) * K;
         else if (m0 + i < M) off = (m0 + i) * K;
         Ro[i] = off;
     }
 
-    // ---- activation halo staging map: slot q = (tid >> 3) + 32 j holds 4 channels (tid & 7) of one pixel of the staged
+    // ---- activation halo staging map: slot q = (tid >> 3) + SPP j holds 4 channels (tid & 7) of one pixel of the staged
     // image.  PLAIN: the image is x itself.  UPSD: the image is one of the four polyphase components of the hi-res dy,
     // D_pq[yy][xx] = dy[2 yy + p][2 xx + q] -- an Ho x Wo image whose pixel (yy, xx) sits at a byte offset that is affine
     // in (p, q): the map below is built for (p, q) = (0, 0) and a component is selected by ONE scalar offset.
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
     int a_lds[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int q = (tid >> 3) + 32 * j;
+        const int q = (tid >> 3) + SPP * j;
         long pix = -1;                                         // source pixel index in x (class (0, 0) for UPSD)
         int col = q;
         int iy = -1, ix = -1, ib = 0;
@@ -245,6 +258,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
         tap_addr(t9, abuf, cur);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
+#if EGZ_X3S_DIAG & 2
+            if (mr >= MR / 2) { ah0[mr] = ah0[mr - MR / 2]; al0[mr] = al0[mr - MR / 2]; continue; }
+#endif
             ah0[mr] = *reinterpret_cast<const u32x4*>(Ab + cur[mr]);
             al0[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[mr]);
         }
@@ -281,10 +297,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
             for (int t = 0; t < NT; ++t) {
                 const int s = (c * NIMG + img) * NT + t, ring = (img * NT + t) % NRING;
                 // the set being refilled was last read by slice s - 1
+#if !(EGZ_X3S_DIAG & 1)
                 gload_b(s + NRING - 1 < S ? s + NRING - 1 : S - 1, (img * NT + t + NRING - 1) % NRING);
+#endif
                 u32x4 ah1[MR], al1[MR];
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
+#if EGZ_X3S_DIAG & 2
+                    if (mr >= MR / 2) { ah1[mr] = ah1[mr - MR / 2]; al1[mr] = al1[mr - MR / 2]; continue; }
+#endif
                     ah1[mr] = *reinterpret_cast<const u32x4*>(Ab + (cur[mr] ^ 32));
                     al1[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[mr] ^ 32));
                 }
@@ -293,12 +314,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 if (G::NABUF == 2) {
                     // the next image goes into the OTHER buffer while this one is being multiplied
+#if !(EGZ_X3S_DIAG & 4)
                     if (more) {
                         if (t == L0) lstore_a(abuf ^ 1, 0);
                         if (t == G0) gload_a(ncblk, nimg, 0);
                         if (t == L1) lstore_a(abuf ^ 1, 1);
                         if (t == G1) gload_a(ncblk, nimg, 1);
                     }
+#endif
                     if (t < NT - 1) {
                         read_a0(shift_of(img, t + 1), abuf);
                     } else if (more) {
@@ -354,14 +377,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3s_kernel(
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
         if (lane == 0) samax[wave] = amx;
         lds_barrier();
-        if (tid == 0) absmax_out[1 + gt] = __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
+        if (tid == 0) {
+            float m = samax[0];
+#pragma unroll
+            for (int w = 1; w < NTHR / 64; ++w) m = fmaxf(m, samax[w]);
+            absmax_out[1 + gt] = __float_as_uint(m);
+        }
     }
     if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS) {
         // one partial row per 128 pixel rows (the granularity egz_conv3x3_stat_rows promises)
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (RPW == 128) {                                      // the wave's own row
-            const long srow = (long)tile_m * WM + wm;
+            const long srow = (long)tile_m * G::WMM + wm;
             if (hl == 0 && nok && srow * 128 < M) {
                 stat[(srow * 2 + 0) * K + col] = s1;
                 stat[(srow * 2 + 1) * K + col] = s2;
@@ -438,10 +466,10 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
     const int total = mt * (Kp / G::BN);
     const dim3 grid(((total + 7) / 8) * 8);
-#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out)
+#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out)
     if (epi == EPI_MASK_SUMS) {
         EGZ_CHECK_ARG(total <= 8192, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
-        if constexpr (WM != 4) {                 // data gradients of the SP decoder: 128- and 64-column tiles
+        if constexpr (WM == 1 || WM == 2) {      // data gradients of the SP decoder: 128- and 64-column 4-wave tiles
             if (patch) EGZ_X3S(EPI_MASK_SUMS, true); else EGZ_X3S(EPI_MASK_SUMS, false);
         } else {
             egz_set_error("egz_conv3x3_fwd_streamed: the mask epilogue is not built for 32-column tiles");
@@ -466,10 +494,13 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 // 1 when the streamed-weight kernel covers this geometry (C = reduction channels: a multiple of 32, or a multiple of 4
 // below 32; K = GEMM columns: any).
 // mode 0: plain conv over an H x W image; mode 1: data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res
-// input, H x W = the hi-res gradient image (both even), 128-column tiles only.  Needs the split-half channel constraints
+// input, H x W = the hi-res gradient image (both even), 128-column tiles only; mode | 0x10: on the 8-wave 256 x 128 tile.  Needs the split-half channel constraints
 // and either the patch geometry or a raster run whose halo fits the LDS image (on the OUTPUT image: H/2 x W/2 in mode 1).
 EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode) {
+    const bool tile8 = (mode & 0x10) != 0;                              // the 8-wave 256 x 128 tile (K % 128 == 0 only)
+    mode &= 0xF;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || mode < 0 || mode > 1) return 0;
+    if (tile8 && K % 128 != 0) return 0;
     if (!(C % 32 == 0 || (C < 32 && C % 4 == 0))) return 0;            // whole channel blocks, or one zero-padded block
     if (4ull * B * H * W * C >= (1ull << 32)) return 0;
     if (mode == 1) {
@@ -478,7 +509,8 @@ EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode)
         W >>= 1;
     }
     // column tile: 128 (K % 128 == 0), 64 (K % 64 == 0), else 32-column tiles padded up to K (narrow layers)
-    const int prow = (K % 128 == 0) ? 8 : 16, bm = (K % 128 == 0) ? 128 : 256, hzero = (K % 128 == 0) ? 255 : 383;
+    const bool small = (K % 128 == 0) && !tile8;                        // 128 x 128 tile: 8 x 16 patches, 256 slots
+    const int prow = small ? 8 : 16, bm = small ? 128 : 256, hzero = small ? 255 : 383;
     if (W % 16 == 0 && H % prow == 0) return 1;
     return (bm + 2 * W + 2 <= hzero) ? 1 : 0;
 }
@@ -523,6 +555,15 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                   "mask_src and absmax_out and takes no bias");
     const unsigned short* w16 = static_cast<const unsigned short*>(wq);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
+    if (mode & 0x10) {                                                  // 8-wave 256 x 128 tile
+        EGZ_CHECK_ARG(epi != EPI_MASK_SUMS, "egz_conv3x3_fwd_streamed: the mask epilogue runs on the 4-wave tiles");
+        if ((mode & 0xF) == 1) {
+            if (dtype == 1) return launch_x3s<_Float16, 8, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+            return launch_x3s<__bf16, 8, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        }
+        if (dtype == 1) return launch_x3s<_Float16, 8, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        return launch_x3s<__bf16, 8, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+    }
     if (mode == 1) {
         if (dtype == 1) return launch_x3s<_Float16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
         return launch_x3s<__bf16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);

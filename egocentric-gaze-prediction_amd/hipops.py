@@ -195,6 +195,23 @@ def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.T
 
 
 STREAMED = _os.environ.get("EGAZE_STREAMED", "1") != "0"      # A/B knob: 0 = halo kernel with LDS-DMA weights for plain convs
+# 8-wave 256 x 128 tile of the streamed kernel (the two waves of a column share their weight fragments through the vector
+# L1).  Measured per layer shape (profiles/r02_x3s_tile8.txt): -5 ... -7 % where the weight matrix is largest (512 GEMM
+# columns at 28 x 28), +5 ... +10 % on the 128- / 256-column layers (one 512-thread block per CU interleaves worse than two
+# independent 256-thread blocks); restricted to >= 512 columns and at least one tile per CU it changes the SP step by less
+# than the run-to-run noise (35.63 vs 35.60 ms) -- so it is opt-in: EGAZE_TILE8=1 (>= 512 columns), EGAZE_TILE8=all (wherever
+# the geometry allows; tests).
+TILE8 = _os.environ.get("EGAZE_TILE8", "0")
+
+
+def _tile8(B, Ho, Wo, C, gemm_out, mode) -> int:
+    """0x10 when the launch should run on the 8-wave tile."""
+    if TILE8 == "0" or gemm_out % 128 != 0:
+        return 0
+    if TILE8 != "all" and (gemm_out < 512 or ((B * Ho * Wo + 255) // 256) * (gemm_out // 128) < 256):
+        return 0
+    H_, W_ = (2 * Ho, 2 * Wo) if mode else (Ho, Wo)
+    return 0x10 if LIB.egz_conv3x3_streamed_ok(B, H_, W_, C, gemm_out, mode | 0x10) else 0
 
 
 def conv_weight(w: torch.Tensor, role: str, dtype: int, x: torch.Tensor, gemm_out: int):
@@ -375,7 +392,8 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
             raise RuntimeError("the streamed-weight kernel covers plain convolutions only")
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, 0, _p(absmax), None, None, _stream()), "egz_conv3x3_fwd_split")
+                                           epi, dtype, _tile8(B, H, W, C, K, 0), _p(absmax), None, None, _stream()),
+              "egz_conv3x3_fwd_split")
         return y, stat
     if dtype:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
@@ -409,7 +427,8 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                           0, dtype, 1, _p(am), None, None, _stream()), "egz_conv3x3_fwd_streamed(ups_dgrad)")
+                                           0, dtype, 1 | _tile8(B, H // 2, W // 2, K, C, 1), _p(am), None, None, _stream()),
+              "egz_conv3x3_fwd_streamed(ups_dgrad)")
         return dx
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)

@@ -526,6 +526,34 @@ def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
         assert rel(nchw(dx), dref) < tol
 
 
+def test_conv3x3_streamed_tile8(monkeypatch):
+    """The 8-wave 256 x 128 tile configuration of the streamed kernel (opt-in, EGAZE_TILE8): plain and upsample-gradient
+    launches against the 4-wave tiles -- same values up to fp32 summation order, same BN partial sums."""
+    h = H()
+    for (B, Hh, Ww, C, K) in [(2, 16, 32, 64, 128), (3, 28, 28, 64, 256), (1, 56, 56, 32, 128), (2, 14, 14, 128, 512)]:
+        x = nhwc(rnd(B, C, Hh, Ww, seed=81))
+        w = rnd(K, C, 3, 3, seed=82, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
+        b = rnd(K, seed=83, scale=0.1).to(DEV)
+        wp, st = h.conv_weight(w, "fwd", 1, x, K)
+        assert st
+        monkeypatch.setattr(h, "TILE8", "0")
+        y0, s0 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
+        monkeypatch.setattr(h, "TILE8", "all")
+        assert h._tile8(B, Hh, Ww, C, K, 0) == 0x10
+        y1, s1 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
+        assert rel(y1, y0) < 2e-6 and rel(s1.sum(0), s0.sum(0)) < 1e-6, (B, Hh, Ww, C, K)
+    for (B, Hl, Wl, C, K) in [(2, 16, 32, 128, 64), (3, 28, 28, 128, 64)]:
+        w = rnd(K, C, 3, 3, seed=84, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
+        dy = nhwc(rnd(B, K, 2 * Hl, 2 * Wl, seed=85))
+        wq, st = h.conv_weight(w, "ups_dgrad", 1, dy, C)
+        assert st
+        monkeypatch.setattr(h, "TILE8", "0")
+        d0 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
+        monkeypatch.setattr(h, "TILE8", "all")
+        d1 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
+        assert rel(d1, d0) < 2e-6, (B, Hl, Wl, C, K)
+
+
 def test_conv3x3_streamed_shape_fuzz():
     """Random geometries through the streamed kernel wherever egz_conv3x3_streamed_ok accepts them, against the exact-f32
     kernels: patch / run selection, ragged tiles, XCD tile map with tile counts that are not multiples of 8."""
