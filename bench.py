@@ -61,7 +61,9 @@ def cpu_baseline(batch=8, size=224, threads=16, timed_steps=3):
     return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle SP train step (fwd+floss+bwd+Adam; the reference's PyTorch-CPU algorithm), batch "
                       f"{batch}, {size}x{size}, 1 warm-up + {timed_steps} timed steps, {dt:.2f} s/step, torch-CPU "
-                      f"fp32 on {cores} threads (best of a 16/32/64/256 sweep; host has {avail})"}
+                      f"fp32 on {cores} threads (best of an 8/16/32/64 sweep, profiles/r02_cpu_baseline_thread_sweep.txt; host has "
+                      f"{avail}); frames/s is batch-independent here (a batch-32 step takes 4x as long), so it is also the "
+                      f"batch-32 figure"}
 
 
 def main():

@@ -60,6 +60,8 @@ class LF():
         self.criterion = (floss() if loss_function == 'f' else BCELoss()).to(self.device)
         self.optimizer = FusedAdam(self.model.parameters(), lr=lr)
         self.reducer = dp.attach(self.optimizer) if torch.distributed.is_initialized() else None
+        from . import hipops
+        print(hipops.precision_banner())
 
     def _run(self, loader, train, every):
         losses, auc, aae = AverageMeter(), AverageMeter(), AverageMeter()

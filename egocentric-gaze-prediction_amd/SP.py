@@ -107,6 +107,8 @@ class SP():
         if pretrained_optimizer is not None:
             self.optimizer.load_state_dict(pretrained_optimizer)
         self.reducer = dp.attach(self.optimizer) if torch.distributed.is_initialized() else None
+        from . import hipops
+        print(hipops.precision_banner())
         print('SP module init done!')
 
     def _batch(self, sample):

@@ -166,6 +166,15 @@ _PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad",
 #           data gradient and the weight gradient (GRAD_SPLIT below) -- conv3x3_igemm_x3.hip, conv3x3_wgrad.hip.
 #   "f32"   exact-f32 MFMA everywhere (v_mfma_f32_32x32x2_f32); EGAZE_PRECISION=f32 selects it.
 PRECISION = _os.environ.get("EGAZE_PRECISION", "split")
+
+
+def precision_banner() -> str:
+    """One line for the drivers' logs: which arithmetic the convolutions run in (an environment default, so say it)."""
+    if PRECISION != "split":
+        return "egaze-hip arithmetic: exact-f32 MFMA (EGAZE_PRECISION=f32)"
+    g = "f16x3, 22 bits, abs-max scaled" if GRAD_SPLIT == "f16" else "bf16x3, 16 bits"
+    return (f"egaze-hip arithmetic: split-half MFMA -- forward f16x3 (22 significant bits per operand), gradients {g}; fp32 "
+            f"accumulate; EGAZE_PRECISION=f32 selects exact-f32 MFMA")
 # Operand type of the split-half GRADIENT kernels (data and weight gradients):
 #   "f16" (default) f16 x3, 22 significant bits (3e-7 per layer, the exact-f32 kernels' own level -- the reference's
 #          arithmetic class): the gradient producers (BN / ReLU / fusion backward) also emit max |dy| and the conv backward

@@ -96,7 +96,9 @@ class FusedAdam:
 
     @property
     def param_groups(self):
-        return [dict(self.defaults, lr=self.lr, params=list(range(len(self.params))))]
+        # the keys torch.optim.Adam groups carry (so that the state dict loads into the reference's optimizer unchanged)
+        return [dict(self.defaults, lr=self.lr, maximize=False, foreach=None, capturable=False, differentiable=False,
+                     fused=None, decoupled_weight_decay=False, params=list(range(len(self.params))))]
 
     def state_dict(self):
         state = {}

@@ -105,8 +105,6 @@ class FusedSequential(nn.Sequential):
         return x
 
 
-EncoderSequential = FusedSequential
-
 
 def make_layers(cfg, in_channels, batch_norm=True):
     """utils.make_layers (utils.py:64-76): same children, same indices, fused execution."""
