@@ -35,6 +35,14 @@ def from_nhwc(y: torch.Tensor) -> torch.Tensor:
 
 
 DETACH_WGRAD = __import__("os").environ.get("EGAZE_DETACH_WGRAD", "1") != "0"      # A/B knob
+# Issue order inside a conv backward.  The weight gradient W_L and the data gradient D_L of a layer both need dy_L; issued
+# together they share the matrix cores (whose throughput is fixed by the power budget), finish together, and the HBM-bound
+# BN / ReLU backward pass R_(L-1) of the next layer then runs with the matrix cores idle.  Issued D_L first and W_L behind it
+# (the helper stream waits for the stream position AFTER the dgrad launch), the chain becomes D_L, [W_L || R_(L-1)], D_(L-1),
+# ... -- the HBM-bound pass hides under the weight gradient.  Measured: no difference (35.58 vs 35.57 ms per step,
+# profiles/r02_bench_ab_knobs.txt) -- with detached weight-gradient streams the helper queue is never empty anyway -- so the
+# original order stays the default.
+WGRAD_AFTER_DGRAD = __import__("os").environ.get("EGAZE_WGRAD_AFTER_DGRAD", "0") != "0"
 
 
 def _close_fork(f, sink, dw, *inputs):
@@ -121,18 +129,26 @@ class ConvBNReLUPool(torch.autograd.Function):
         if ng[2] and sbias is None:
             db = _zero_bias_grad(dy, K)
         sw = H.grad_sink(weight, ng[1] and not padded)
-        with fork("wgrad") as f:                # weight gradient || data gradient (both only read dy)
+
+        def data_grad():
+            if not ng[0]:
+                return None
+            if first:
+                raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
+            dt = H.conv_dtype("dgrad", C, K, dy)
+            wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
+            return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
+
+        if WGRAD_AFTER_DGRAD:
+            dx = data_grad()
+        with fork("wgrad") as f:                # the weight gradient runs on a helper stream (both only read dy)
             if ng[1]:
                 if padded:
                     dw = H.conv3x3_wgrad(xin, dy)[:, :C].contiguous()      # gradient of the zero-padded channels dropped
                 else:
                     dw = H.conv_first_wgrad(xin, dy, out=sw) if first else H.conv3x3_wgrad(xin, dy, out=sw)
-        if ng[0]:
-            if first:
-                raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
-            dt = H.conv_dtype("dgrad", C, K, dy)
-            wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
-            dx = from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
+        if not WGRAD_AFTER_DGRAD:
+            dx = data_grad()
         _close_fork(f, sw, dw, xin, dy)
         return (dx, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
                 _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None)
@@ -179,21 +195,29 @@ class ConvReLU(torch.autograd.Function):
         else:
             dy = H.relu_bwd(y, to_nhwc(dout))
         sw = H.grad_sink(weight, ng[1])
-        with fork("wgrad") as f:
-            if ng[1]:
-                dw = H.conv3x3_wgrad(xin, dy, ups=ups, out=sw)
-        if ng[0]:
+
+        def data_grad():
+            if not ng[0]:
+                return None
             dt = H.conv_dtype("dgrad", C, K, dy)
             role = "ups_dgrad" if ups else "dgrad"
             wp, st = H.conv_weight(weight, role, dt, dy, C)
             if relu_below and st and H.MASK_FUSE and C % 64 == 0:
                 dxn, stat, am = H.conv3x3_dgrad_masked(dy, wp, C, dt, xin, ups)
-                dx = from_nhwc(dxn)
-                dx._egz_premasked = (stat, am if H._want_absmax() else None)
-            elif ups:     # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
-                dx = from_nhwc(H.conv3x3_ups_dgrad(dy, wp, C, dtype=dt, streamed=st))
-            else:
-                dx = from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
+                d = from_nhwc(dxn)
+                d._egz_premasked = (stat, am if H._want_absmax() else None)
+                return d
+            if ups:       # gradient w.r.t. the low-res input directly (4x4 / stride-2 gather over dy)
+                return from_nhwc(H.conv3x3_ups_dgrad(dy, wp, C, dtype=dt, streamed=st))
+            return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
+
+        if WGRAD_AFTER_DGRAD:
+            dx = data_grad()
+        with fork("wgrad") as f:
+            if ng[1]:
+                dw = H.conv3x3_wgrad(xin, dy, ups=ups, out=sw)
+        if not WGRAD_AFTER_DGRAD:
+            dx = data_grad()
         _close_fork(f, sw, dw, xin, dy)
         return dx, _finish(weight, sw, dw), _finish(bias, sbias, db), None, None
 
@@ -242,15 +266,23 @@ class FusionBlock(torch.autograd.Function):
         if ng[3] and sbias is None:
             db = _zero_bias_grad(dy2, K)
         sw = H.grad_sink(weight, ng[2])
-        with fork("wgrad") as f:
-            if ng[2]:
-                dw = H.conv3x3_wgrad(x2, dy2, out=sw).view(weight.shape)
-        if ng[0] or ng[1]:
+
+        def data_grad():
+            if not (ng[0] or ng[1]):
+                return None, None
             dt = H.conv_dtype("dgrad", C, K, dy2)
             wp, st = H.conv_weight(weight, "dgrad", dt, dy2, C)
             dx2 = H.conv3x3_dgrad(dy2, wp, C, dtype=dt, streamed=st)
             B = dx2.shape[0] // 2
-            dfs, dft = from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
+            return from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
+
+        if WGRAD_AFTER_DGRAD:
+            dfs, dft = data_grad()
+        with fork("wgrad") as f:
+            if ng[2]:
+                dw = H.conv3x3_wgrad(x2, dy2, out=sw).view(weight.shape)
+        if not WGRAD_AFTER_DGRAD:
+            dfs, dft = data_grad()
         _close_fork(f, sw, dw, x2, dy2)
         return (dfs, dft, _finish(weight, sw, dw), _finish(bias, sbias, db),
                 _finish(gamma, sg, dgamma if ng[4] else None), _finish(beta, sb, dbeta if ng[5] else None),
