@@ -252,15 +252,17 @@ def main():
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
             roofline = {"bound": "mfma",
-                        "kernel": ("conv3x3_igemm_x3h_kernel + conv3x3_igemm_x3_kernel (egz_conv3x3_fwd_split: all conv fwd + dgrad "
-                                   "launches -- halo-tile kernel for plain convs, per-tap gather kernel for the upsample "
-                                   "forms; split-half f16x3 / bf16x3 operands on v_mfma_f32_32x32x16_{f16,bf16}; each "
-                                   "algorithmic MAC costs 3 MFMA MACs, priced against the dense 16-bit MFMA peak)" if split else
+                        "kernel": ("conv3x3_igemm_x3s_kernel + conv3x3_igemm_x3h_kernel (egz_conv3x3_fwd_streamed + "
+                                   "egz_conv3x3_fwd_split: all conv fwd + dgrad launches -- the streamed-weight halo kernel "
+                                   "for plain convs and the polyphase upsample dgrad, the LDS-DMA halo kernel for the "
+                                   "upsample forward; split-half f16x3 / bf16x3 operands on "
+                                   "v_mfma_f32_32x32x16_{f16,bf16}; each algorithmic MAC costs 3 MFMA MACs, priced against "
+                                   "the dense 16-bit MFMA peak)" if split else
                                    "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
                                    "launches, exact-f32 MFMA)") +
                                   "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
                                   "timed with HIP events on the launch stream with stream concurrency off, as in "
-                                  "profiles/r01_bench_b32_kernel_stats_split_streams0.txt",
+                                  "profiles/r02_bench_b32_kernel_stats_streams0.txt",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,

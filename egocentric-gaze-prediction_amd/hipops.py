@@ -59,7 +59,7 @@ class _LibProxy:
         fn = getattr(self._raw, name)
 
         def call(*a):
-            if not PROF.enabled or name.endswith(("_bytes", "_rows", "_elems")):      # size queries launch nothing
+            if not PROF.enabled or name.endswith(("_bytes", "_rows", "_elems", "_ok")):   # host-side queries launch nothing
                 return fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
