@@ -523,6 +523,165 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Narrow form of the split-half 9-tap kernel for C <= 32 and K <= 32 (the late-fusion widths, late_fusion.py:10-13): the
+// whole (c, k) range is ONE 32 x 32 MFMA tile, so the 2 x 2 wave grid of the kernel above would leave three waves multiplying
+// zeros.  Here the four waves split the REDUCTION instead: a stage is a patch of R x WD = 64 pixels, wave w owns its w-th
+// 16-pixel run (one MFMA k-step, 27 MFMAs for the nine taps) and keeps its own nine accumulators; the four partial sums are
+// added through LDS in a fixed order at the end.  Only 32 channels are staged (8 float4 per pixel), half of the wide
+// kernel's fetch / split work per pixel.  Same LDS image per plane and the same ds_read_b64_tr_b16 addressing.
+template <typename T, int R, int WD>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax) {
+    static_assert(R * WD == 64 && (WD == 32 || WD == 16), "patch = 64 pixels in rows of 16-pixel runs");
+    const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
+    constexpr int NP = R * WD;
+    constexpr int HPW = WD + 2, NH = (R + 2) * HPW;            // halo row width / halo pixels
+    constexpr int XH = NH * 32 + 32, DH = NP * 32 + 32;        // plane strides (elements)
+    constexpr int XB = 2 * XH, DB = 2 * DH;                    // per-buffer strides ([plane hi / lo])
+    constexpr int NX = (NH * 8 + 255) / 256;                   // float4 halo loads per thread
+    constexpr int ND = (NP * 8) / 256;                         // float4 dY loads per thread (2)
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[2 * XB];
+    __shared__ __attribute__((aligned(16))) unsigned short Ds[2 * DB];
+    static_assert(sizeof(unsigned short) * 2 * XB >= 4 * 1024 * sizeof(float), "final reduction reuses the halo buffers");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
+    const int split = blockIdx.y;
+    const int cpr = (W + WD - 1) / WD, rpi = (H + R - 1) / R;  // patches per row / patch rows per image
+    const long npatch = (long)B * rpi * cpr;
+    const long g0 = (long)split * patches_per_split;
+    const long g1 = (g0 + patches_per_split < npatch) ? (g0 + patches_per_split) : npatch;
+
+    // operand fetch as in conv3x3_wgrad9_x3_kernel: buffer loads, fixed per-thread slot offsets, out-of-image -> zeros
+    const unsigned x_bias = (unsigned)(W + 1) * (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(x)) - x_bias, 0, (int)((unsigned)B * H * W * C * 4u + x_bias), 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dy), 0, (int)((unsigned)B * H * W * K * 4u), 0x00020000);
+    unsigned x_vo[NX], x_rc[NX], d_vo[ND], d_rc[ND];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int i = tid + 256 * j, pos = i >> 3, c4 = i & 7;
+        const int hr = pos / HPW, hx = pos - hr * HPW;
+        x_vo[j] = (pos < NH && c4 * 4 < C) ? (unsigned)((hr * W + hx) * C * 4 + c4 * 16) : 0xFFFFFFFFu;
+        x_rc[j] = (unsigned)(hr << 8 | hx);
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int i = tid + 256 * j, pp = i >> 3, k4 = i & 7;
+        d_vo[j] = (k4 * 4 < K) ? (unsigned)(((pp / WD) * W + pp % WD) * K * 4 + k4 * 16) : 0xFFFFFFFFu;
+        d_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
+    }
+    f32x4 rx[NX], rd[ND];
+    auto gload = [&](long g) {
+        const int x0 = (int)(g % cpr) * WD;
+        const long t = g / cpr;
+        const int y0 = (int)(t % rpi) * R;
+        const long b = t / rpi;
+        const unsigned rlo = (y0 == 0) ? 1u : 0u, rn = (unsigned)((H - y0 < R + 1) ? (H - y0) : (R + 1)) - rlo;
+        const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((W - x0 < WD + 1) ? (W - x0) : (WD + 1)) - clo;
+        const unsigned so_x = (unsigned)((((b * H + y0) * W + x0) * C) * 4);
+        const unsigned so_d = (unsigned)((((b * H + y0) * W + x0) * K) * 4);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const bool ok = ((x_rc[j] >> 8) - rlo <= rn) && ((x_rc[j] & 255u) - clo <= cn);
+            rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? x_vo[j] : 0xFFFFFFFFu, so_x, 0));
+        }
+        const unsigned rmax = (unsigned)(H - y0), cmax = (unsigned)(W - x0);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const bool ok = ((d_rc[j] >> 8) < rmax) && ((d_rc[j] & 255u) < cmax);
+            rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, ok ? d_vo[j] : 0xFFFFFFFFu, so_d, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j, pos = i >> 3, c4 = i & 7;
+            if (pos < NH) {
+                u32x2_t hi, lo;
+                W16<T>::split4(rx[j], hi, lo);
+                unsigned short* d = Xs + buf * XB + pos * 32 + c4 * 4;
+                *reinterpret_cast<u32x2_t*>(d) = hi;
+                *reinterpret_cast<u32x2_t*>(d + XH) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j, pp = i >> 3, k4 = i & 7;
+            u32x2_t hi, lo;
+            W16<T>::split4(rd[j] * d_scale, hi, lo);
+            unsigned short* d = Ds + buf * DB + pp * 32 + k4 * 4;
+            *reinterpret_cast<u32x2_t*>(d) = hi;
+            *reinterpret_cast<u32x2_t*>(d + DH) = lo;
+        }
+    };
+
+    // transpose-read addressing of the wide kernel; the wave's 16-pixel run starts at halo position wrun (tap 0, 0)
+    const int u = lane & 15, hh = lane >> 5;
+    const int chan = 16 * ((lane >> 4) & 1) + 4 * (u & 3);
+    const int lp = 8 * hh + (u >> 2);
+    const int wrun = (WD == 32) ? ((wave >> 1) * HPW + 16 * (wave & 1)) : (wave * HPW);
+    const EGZ_LDS unsigned short* Xl = (const EGZ_LDS unsigned short*)(Xs) + (wrun + lp) * 32 + chan;
+    const EGZ_LDS unsigned short* Dl = (const EGZ_LDS unsigned short*)(Ds) + (16 * wave + lp) * 32 + chan;
+    auto xoff = [&](int q, int tap) -> int { return (4 * q + (tap / 3) * HPW + (tap % 3)) * 32; };
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (g0 < g1) {
+        gload(g0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (long g = g0; g < g1; ++g) {
+        const int buf = (int)((g - g0) & 1);
+        if (g + 1 < g1) gload(g + 1);
+        const EGZ_LDS unsigned short* Xb = Xl + buf * XB;
+        const EGZ_LDS unsigned short* Db = Dl + buf * DB;
+        const typename W16<T>::vec8 dh = W16<T>::frag(Db, Db + 4 * 32);
+        const typename W16<T>::vec8 dl = W16<T>::frag(Db + DH, Db + DH + 4 * 32);
+#pragma unroll
+        for (int tr = 0; tr < 3; ++tr) {
+            typename W16<T>::vec8 xh[3], xl[3];
+#pragma unroll
+            for (int ts = 0; ts < 3; ++ts) {
+                const int tap = tr * 3 + ts;
+                xh[ts] = W16<T>::frag(Xb + xoff(0, tap), Xb + xoff(1, tap));
+                xl[ts] = W16<T>::frag(Xb + XH + xoff(0, tap), Xb + XH + xoff(1, tap));
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int ts = 0; ts < 3; ++ts)
+                    acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
+        }
+        if (g + 1 < g1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // the four waves' partial tiles, summed in wave order through LDS (one tap at a time)
+    float* red = reinterpret_cast<float*>(Xs);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[tap][r];
+        __syncthreads();
+        float* out = part + ((long)split * 9 + tap) * C * K;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = tid + 256 * m, r = e >> 6, ln = e & 63;
+            const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+            const int c = egz_acc_row(r, ln), k = ln & 31;
+            if (c < C && k < K) out[(long)c * K + k] = v * d_inv;
+        }
+        __syncthreads();
+    }
+    (void)l31;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Split-half weight gradient of [nearest x2 upsample -> conv3x3] in phase form (4/9 of the MACs of the folded 9-tap form):
 //   dWeff[py][px][a][b][c][k] = sum_{b,y,x} X[y+a+py-1][x+b+px-1][c] * dY[2y+py][2x+px][k]      (LOW-res y, x)
 // One block = one 64(c) x 64(k) tile of BOTH column phases of one row phase py (blockIdx.z): 8 accumulators per wave
@@ -1045,6 +1204,12 @@ int pick_patch_x3(int W, int C, int K, int flags) {
     if (W % 8 == 0) return 8;
     return 0;
 }
+// narrow split-half kernel (C, K <= 32, plain conv): run width of its 64-pixel patch (0 = not applicable)
+int pick_narrow_x3(int W, int C, int K, int flags) {
+    if (!(flags & 0x2000) || (flags & 0x801) || C > 32 || K > 32) return 0;
+    return (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : 0;
+}
+long npatch_x3n(int B, int H, int W, int WD) { return (long)B * ((H + 64 / WD - 1) / (64 / WD)) * (W / WD); }
 #ifndef EGZ_X3_BLOCKS
 #define EGZ_X3_BLOCKS 512
 #endif
@@ -1072,6 +1237,8 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
         if (const int WD = pick_patch_x3(W / 2, C, K, flags))       // phase form on the low-res grid, 16 partial tiles
             return wgrad_ws_floats(pick_splits9(npatch_x3(B, H / 2, W / 2, WD), C, K, X3_BLOCKS / 2), 16L * C * K) * sizeof(float);
     }
+    if (const int WD = pick_narrow_x3(W, C, K, flags))
+        return wgrad_ws_floats(pick_splits9(npatch_x3n(B, H, W, WD), C, K, X3_BLOCKS), n) * sizeof(float);
     if (const int WD = pick_patch_x3(W, C, K, flags))
         return wgrad_ws_floats(pick_splits9(npatch_x3(B, H, W, WD), C, K, X3_BLOCKS), n) * sizeof(float);
     if (flags & 1) {
@@ -1131,6 +1298,19 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
             EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(reduce-ups)");
             return 0;
         }
+    }
+    if (const int WD = pick_narrow_x3(W, C, K, flags)) {  // late-fusion widths: one 32 x 32 tile, waves split the pixels
+        const long np = npatch_x3n(B, H, W, WD);
+        const int S = pick_splits9(np, C, K, X3_BLOCKS);
+        EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
+        const int pps = (int)((np + S - 1) / S);
+        dim3 grid(1, S);
+#define EGZ_W9N(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
+        if (dy_absmax) { if (WD == 32) EGZ_W9N(_Float16, 2, 32); else EGZ_W9N(_Float16, 4, 16); }
+        else           { if (WD == 32) EGZ_W9N(__bf16, 2, 32); else EGZ_W9N(__bf16, 4, 16); }
+#undef EGZ_W9N
+        EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap split, narrow)");
+        return wgrad_reduce(part, dw, C, K, S, st);
     }
     if (const int WD = pick_patch_x3(W, C, K, flags)) {   // split-half (bf16 x3 / f16 x3) on the 16-bit MFMA path
         const long np = npatch_x3(B, H, W, WD);

@@ -94,29 +94,52 @@ __global__ __launch_bounds__(256) void head_bwd_final_kernel(const double* __res
 }
 
 // ---------------------------------------------------------------------------------------------- floss
-// One block per sample: max over the map, then count / row-sum / col-sum of every pixel equal to it.
-// Integer sums are exact, the centroid is their fp64 quotient -- the same value numpy's
-// rows.mean() / cols.mean() yields (floss.py:24-26).
-__global__ __launch_bounds__(256) void floss_centroid_kernel(const float* __restrict__ target, double* __restrict__ cen,
-                                                             int H, int W) {
-    __shared__ float smax[4];
-    __shared__ unsigned long long scnt[4], srow[4], scol[4];
+// One 1024-thread block per sample: max over the map, then count / row-sum / col-sum of every pixel equal to it (two
+// sweeps of 16-byte loads; the map is L2-resident for the second).  Integer sums are exact, the centroid is their fp64
+// quotient -- the same value numpy's rows.mean() / cols.mean() yields (floss.py:24-26).
+template <bool VEC>
+__global__ __launch_bounds__(1024) void floss_centroid_kernel(const float* __restrict__ target, double* __restrict__ cen,
+                                                              int H, int W) {
+    __shared__ float smax[16];
+    __shared__ unsigned long long scnt[16], srow[16], scol[16];
     const float* t = target + (long)blockIdx.x * H * W;
     const int n = H * W, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float mx = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, t[i]);
+    if (VEC) {
+        const float4* t4 = reinterpret_cast<const float4*>(t);
+        for (int i = threadIdx.x; i < n / 4; i += blockDim.x) {
+            const float4 v = t4[i];
+            mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, t[i]);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if (lane == 0) smax[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    mx = smax[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, smax[w]);
     unsigned long long cnt = 0, rs = 0, cs = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-        if (t[i] == mx) {
-            cnt += 1;
-            rs += (unsigned)(i / W);
-            cs += (unsigned)(i % W);
+    auto hit = [&](int i) {
+        cnt += 1;
+        rs += (unsigned)(i / W);
+        cs += (unsigned)(i % W);
+    };
+    if (VEC) {
+        const float4* t4 = reinterpret_cast<const float4*>(t);
+        for (int i = threadIdx.x; i < n / 4; i += blockDim.x) {
+            const float4 v = t4[i];
+            if (v.x == mx) hit(4 * i);
+            if (v.y == mx) hit(4 * i + 1);
+            if (v.z == mx) hit(4 * i + 2);
+            if (v.w == mx) hit(4 * i + 3);
         }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (t[i] == mx) hit(i);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         cnt += __shfl_xor(cnt, o);
@@ -130,9 +153,12 @@ __global__ __launch_bounds__(256) void floss_centroid_kernel(const float* __rest
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long c = scnt[0] + scnt[1] + scnt[2] + scnt[3];
-        const unsigned long long r = srow[0] + srow[1] + srow[2] + srow[3];
-        const unsigned long long q = scol[0] + scol[1] + scol[2] + scol[3];
+        unsigned long long c = 0, r = 0, q = 0;
+        for (int w = 0; w < 16; ++w) {
+            c += scnt[w];
+            r += srow[w];
+            q += scol[w];
+        }
         cen[2 * blockIdx.x + 0] = (double)r / (double)c;
         cen[2 * blockIdx.x + 1] = (double)q / (double)c;
     }
@@ -289,7 +315,10 @@ EGZ_API int egz_floss_fwd(const float* inp, const float* target, float* weights_
     long g = (n + 255) / 256;
     const int grid = (int)(g > LOSS_BLOCKS ? LOSS_BLOCKS : g);
     if (weighted) {
-        hipLaunchKernelGGL(floss_centroid_kernel, dim3(B), dim3(256), 0, st, target, cen, H, W);
+        if ((H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(target) & 15) == 0)
+            hipLaunchKernelGGL(floss_centroid_kernel<true>, dim3(B), dim3(1024), 0, st, target, cen, H, W);
+        else
+            hipLaunchKernelGGL(floss_centroid_kernel<false>, dim3(B), dim3(1024), 0, st, target, cen, H, W);
         EGZ_CHECK_LAUNCH("egz_floss_fwd(centroid)");
         hipLaunchKernelGGL(bce_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, inp, target, cen, weights_out, part, H, W, n);
     } else {

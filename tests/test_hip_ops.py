@@ -119,6 +119,8 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     (2, 16, 32, 64, 64, True), (1, 16, 64, 64, 128, True), (2, 16, 16, 128, 64, True), (1, 10, 48, 64, 64, True),
     # late-fusion widths on the split-half kernel: half c-tile (C = 32) and masked k-tile (K = 32, 8)
     (2, 16, 32, 32, 32, False), (1, 28, 28, 32, 8, False), (2, 9, 7, 32, 32, False), (1, 24, 48, 32, 16, False),
+    # ... and the narrow kernel (one 32 x 32 tile, waves split the 64-pixel patch 2x32 / 4x16): odd / short row counts, C < 32
+    (2, 15, 32, 32, 8, False), (1, 10, 16, 8, 32, False), (1, 33, 224, 32, 32, False), (3, 3, 64, 12, 4, False),
 ])
 def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups):
     """f16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes; dy scaled by its abs-max): patch geometries 1x32 / 2x16 / 4x8,

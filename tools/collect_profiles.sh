@@ -43,3 +43,6 @@ python tools/bench_conv.py --dtype 1 --iters 20 --zero > $O/r02_conv_microbench_
 for t in 8 16 32 64; do timeout 600 python tests/report_cpu_baseline_sweep.py $t 8; done > $O/r02_cpu_baseline_thread_sweep.txt 2>&1
 nproc >> $O/r02_cpu_baseline_thread_sweep.txt; lscpu | grep "Model name" >> $O/r02_cpu_baseline_thread_sweep.txt
 ls -la $O
+
+# 7. LF (config 3): step time with / without the device-side metric, and its kernel stats
+bash tools/collect_lf.sh
