@@ -59,6 +59,10 @@ template <int WM> struct Geo {
     static constexpr int PROWS = BM / 16;                      // patch: PROWS x 16 pixels
     static constexpr int SPP = NTHR / 8;                       // halo slots staged per pass (8 threads x 4 channels per slot)
     static constexpr int NJ = HSLOTS / SPP;                    // halo slots per thread
+#ifndef EGZ_X3S_OCC4
+#define EGZ_X3S_OCC4 3
+#endif
+    static constexpr int OCC = (WM == 4) ? EGZ_X3S_OCC4 : 2;   // resident blocks per CU the register budget is cut for
 };
 
 // workgroup barrier that leaves this wave's global loads (the weight prefetch ring) in flight: __syncthreads() would
@@ -71,7 +75,7 @@ enum { PLAIN = 0, UPSD = 1 };
 // MODE PLAIN: y [B][H][W][K] = conv3x3(x);  MODE UPSD: y [B][H/2][W/2][K] = the data gradient of [nearest x2 upsample ->
 // conv3x3] w.r.t. the LOW-res input, x = the hi-res dy (see the UPSD notes in front of the image loop).
 template <typename T, int WM, int EPI, bool PATCH, int MODE>
-__global__ __launch_bounds__(Geo<WM>::NTHR, 2) void conv3x3_igemm_x3s_kernel(
+__global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
     int mt, int total, const unsigned int* __restrict__ a_absmax, const float* __restrict__ mask_src,

@@ -118,20 +118,25 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
     }
 }
 
-// partial[split][k][kkp] with kkp = c*9 + tap padded to KP (multiple of 32):
-//   sum over the split's pixels of dy[m][k] * x[b][c][y+dy][x+dx]
+// partial[split * NPG + pixel group][k][kkp] with kkp = c*9 + tap padded to KP (multiple of 32):
+//   sum over the group's pixels of dy[m][k] * x[b][c][y+dy][x+dx]
+// Cin = 20: the four waves tile (k half) x (kkp half).  Cin <= 3 has ONE kkp tile (and one or two k tiles), so the spare
+// waves take further 32-pixel groups of a 32 * NPG pixel stage (NPG = 4 / KT) and write their own partial rows.
 template <int NT, int KT>   // NT = KP/32 : 1 (Cin <= 3) or 6 (Cin = 20);  KT = Cout/32
 __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
     int C, long pix_per_split) {
-    constexpr int K = 32 * KT, KP = NT * 32, PKS = 32;
+    constexpr int NPG = (NT == 1) ? 4 / KT : 1;     // pixel groups (one wave each along the reduction)
+    constexpr int K = 32 * KT, KP = NT * 32, PKS = 32 * NPG;
     constexpr int XLD = KP + 1;                     // odd row stride: conflict-free transposing writes
     constexpr int TW = (NT == 1) ? 1 : NT / 2;      // n-tiles per wave
     __shared__ __attribute__((aligned(16))) float Ds[PKS * K];   // [pixel][k]
     __shared__ float Xs[PKS * XLD];                 // [pixel][kkp]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
-    const int wk = wave >> 1, wn = wave & 1;        // k-half (32 filters), kkp-half
+    const int wk = (NT == 1) ? wave / NPG : wave >> 1;     // k tile (32 filters)
+    const int wn = (NT == 1) ? 0 : wave & 1;               // kkp half
+    const int pg = (NT == 1) ? wave % NPG : 0;             // pixel group
     const long HW = (long)H * W, M = (long)B * HW;
     const long mbeg = (long)blockIdx.x * pix_per_split;
     const long mend = (mbeg + pix_per_split < M) ? (mbeg + pix_per_split) : M;
@@ -143,11 +148,10 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    const bool active = (wk < KT) && ((NT != 1) || (wn == 0));   // idle waves when a dimension has one tile
     for (long mb = mbeg; mb < mend; mb += PKS) {
-        // dy tile: 32 pixels x K filters = 8*K float4
+        // dy tile: PKS pixels x K filters
 #pragma unroll
-        for (int j = 0; j < KT; ++j) {
+        for (int j = 0; j < KT * NPG; ++j) {
             const int i = tid + 256 * j;
             const int pp = i / (K / 4), k4 = i % (K / 4);
             const long m = mb + pp;
@@ -155,9 +159,9 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
             if (m < mend) v = *reinterpret_cast<const f32x4*>(dy + m * K + k4 * 4);
             *reinterpret_cast<f32x4*>(Ds + pp * K + k4 * 4) = v;
         }
-        // im2col tile: lanes walk the 32 pixels (consecutive x -> coalesced plane reads)
+        // im2col tile: lanes walk the pixels (consecutive x -> coalesced plane reads)
         {
-            const int pp = tid & 31;
+            const int pp = tid % PKS;
             const long m = mb + pp;
             int yy = -(1 << 20), xx = 0;
             long img = 0;
@@ -168,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
                 xx = rem - yy * W;
                 img = b * C * HW;
             }
-            for (int kk = tid >> 5; kk < KP; kk += 8) {
+#pragma unroll 4
+            for (int kk = tid / PKS; kk < KP; kk += 256 / PKS) {
                 float v = 0.f;
                 if (kk < KK) {
                     const int c = kk / 9, tap = kk - c * 9;
@@ -180,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
             }
         }
         __syncthreads();
-        if (active) {
-            const float* Ab = Ds + hl * K + wk * 32 + l31;
-            const float* Bb = Xs + hl * XLD + wn * (TW * 32) + l31;
+        {
+            const float* Ab = Ds + (pg * 32 + hl) * K + wk * 32 + l31;
+            const float* Bb = Xs + (pg * 32 + hl) * XLD + wn * (TW * 32) + l31;
 #pragma unroll
-            for (int t = 0; t < PKS / 2; ++t) {
+            for (int t = 0; t < 16; ++t) {
                 const float a = Ab[(2 * t) * K];
 #pragma unroll
                 for (int j = 0; j < TW; ++j)
@@ -193,17 +198,15 @@ __global__ __launch_bounds__(256, 2) void conv_first_wgrad_kernel(
         }
         __syncthreads();
     }
-    if (active) {
-        float* out = part + (long)blockIdx.x * K * KP;
+    float* out = part + ((long)blockIdx.x * NPG + pg) * K * KP;
 #pragma unroll
-        for (int j = 0; j < TW; ++j)
+    for (int j = 0; j < TW; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = wk * 32 + egz_acc_row(r, lane);
-                const int kk = wn * (TW * 32) + j * 32 + l31;
-                out[k * KP + kk] = acc[j][r];
-            }
-    }
+        for (int r = 0; r < 16; ++r) {
+            const int k = wk * 32 + egz_acc_row(r, lane);
+            const int kk = wn * (TW * 32) + j * 32 + l31;
+            out[k * KP + kk] = acc[j][r];
+        }
 }
 
 // dw[k][c][tap] (= [k][kk], kk < 9C) = sum_s part[s][k][kk].  32 outputs x 8 split groups per block: group g sums the
@@ -260,7 +263,9 @@ EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias
 }
 
 EGZ_API size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C) {
-    return (size_t)first_splits((long)B * H * W) * 64 * first_kp(C) * sizeof(float);   // sized for Cout = 64
+    // sized for Cout = 64; the one-kkp-tile form (Cin <= 3) writes 4 / (Cout / 32) partial rows per split: 128 filters' worth
+    const int KP = first_kp(C);
+    return (size_t)first_splits((long)B * H * W) * (KP == 32 ? 128 : 64) * KP * sizeof(float);
 }
 
 EGZ_API int egz_conv_first_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
@@ -271,9 +276,10 @@ EGZ_API int egz_conv_first_wgrad(const float* x, const float* dy, float* dw, int
     EGZ_CHECK_ARG(KP == 32 || KP == 192, "egz_conv_first_wgrad: Cin=%d unsupported (1..3 or 18..21)", C);
     const long M = (long)B * H * W;
     const int S = first_splits(M);
-    EGZ_CHECK_ARG(ws_bytes >= (size_t)S * K * KP * sizeof(float), "egz_conv_first_wgrad: workspace too small");
+    const int NPG = (KP == 32) ? 128 / K : 1;          // pixel groups (partial rows) per split
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)S * NPG * K * KP * sizeof(float), "egz_conv_first_wgrad: workspace too small");
     long pps = (M + S - 1) / S;
-    pps = (pps + 31) / 32 * 32;
+    pps = (pps + 127) / 128 * 128;
     float* part = static_cast<float*>(workspace);
     if (K == 64) {
         if (KP == 32) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, 2>), dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
@@ -283,7 +289,7 @@ EGZ_API int egz_conv_first_wgrad(const float* x, const float* dy, float* dw, int
         else          hipLaunchKernelGGL((conv_first_wgrad_kernel<6, 1>), dim3(S), dim3(256), 0, st, x, dy, part, B, H, W, C, pps);
     }
     EGZ_CHECK_LAUNCH("egz_conv_first_wgrad");
-    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(egz_cdiv(K * 9 * C, 32)), dim3(256), 0, st, part, dw, K, 9 * C, KP, S);
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(egz_cdiv(K * 9 * C, 32)), dim3(256), 0, st, part, dw, K, 9 * C, KP, S * NPG);
     EGZ_CHECK_LAUNCH("egz_conv_first_wgrad(reduce)");
     return 0;
 }
