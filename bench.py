@@ -173,10 +173,12 @@ def main():
         at_stream = streams.side_stream("at")
         at_stream.wait_stream(torch.cuda.current_stream())
 
-    def step():
-        # SP: the body of SP.trainSP's loop (SP.py:132-138)
-        output = model(input_s, input_t)
-        loss = criterion(output, target.view(output.size()))
+    def step(staged=None):
+        # SP: the body of SP.trainSP's loop (SP.py:132-138); ``staged`` = (image, flow, gt) of this step when the batch
+        # crosses PCIe inside the step (the untimed PCIe-inclusive leg below), else the HBM-resident synthetic batch
+        x_s, x_t, tgt = staged if staged is not None else (input_s, input_t, target)
+        output = model(x_s, x_t)
+        loss = criterion(output, tgt.view(output.size()))
         loss.backward()
         optimizer.step()
         optimizer.zero_grad()
@@ -213,6 +215,7 @@ def main():
     breakdown = None
     f32_ms = None
     at_ms = None
+    pcie_ms = {}
     if not args.no_roofline:
         # Every rank runs these two extra (untimed) steps -- the gradient all-reduce inside step() is a collective --
         # but only rank 0 reports.  Per-kernel HIP-event timing needs the kernels serialised: the multi-stream
@@ -290,6 +293,35 @@ def main():
             torch.cuda.synchronize()
             f32_ms = (time.perf_counter() - t1) / 3 * 1e3
             H.PRECISION = "split"
+        if world == 1:
+            # PCIe-inclusive step: the batch starts in pinned host memory and is staged inside the step the way SP.trainSP
+            # does it (data.STdatas.stage_batch): raw bytes + device-side normalisation (this build's loader, 38.5 MB per
+            # batch) and the reference loader's normalised fp32 tensors (154 MB per batch).  Untimed leg, never `value`.
+            from egaze_amd.data.STdatas import stage_batch, staged_batches
+            g = torch.Generator().manual_seed(7)
+            shapes = {"image": (args.batch, 3, args.size, args.size), "flow": (args.batch, 20, args.size, args.size),
+                      "gt": (args.batch, 1, args.size, args.size)}
+            for tag in ("u8", "f32"):
+                if tag == "u8":
+                    host = {k: torch.randint(0, 256, sh, dtype=torch.uint8, generator=g).pin_memory() for k, sh in shapes.items()}
+                else:
+                    host = {k: torch.rand(sh, generator=g).pin_memory() for k, sh in shapes.items()}
+                # (a) copied inside the step on the compute stream, as the reference's loop does (SP.py:126-131)
+                for _ in range(2):
+                    step(stage_batch(host, dev))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    step(stage_batch(host, dev)).item()            # the driver reads the loss every step (SP.py:139)
+                pcie_ms[tag + "_in_step"] = (time.perf_counter() - t1) / 5 * 1e3
+                # (b) this build's SP.trainSP: batch k + 1 staged on a copy stream while step k computes
+                t1 = None
+                for k, (_, staged) in enumerate(staged_batches([host] * 7, dev)):
+                    if k == 2:
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                    step(staged).item()
+                pcie_ms[tag + "_prefetched"] = (time.perf_counter() - t1) / 5 * 1e3
         tot = sum(v["ms"] for v in prof.values())
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         breakdown["_sum_kernel_ms"] = round(tot, 3)
@@ -332,7 +364,14 @@ def main():
                       "at_note": ("AT alone (BASELINE config 4 shape): lstmnet T=16, B=%d forward + MSE + backward + Adam, "
                                   "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),
                       "f32_ms_per_step": f32_ms,
-                      "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps"},
+                      "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps",
+                      "pcie_inclusive_ms_per_step": pcie_ms or None,
+                      "pcie_note": ("the step with its batch starting in pinned host memory and the loss read back every step "
+                                    "(SP.trainSP's loop): 'u8' = raw bytes + egz_u8_normalize on the device (38.5 MB/batch), "
+                                    "'f32' = the reference loader's normalised fp32 tensors (154 MB/batch); '_in_step' = "
+                                    "copied on the compute stream inside the step (the reference's loop), '_prefetched' = "
+                                    "batch k+1 staged on a copy stream during step k (data.STdatas.staged_batches, what "
+                                    "SP.trainSP does); 5 untimed-leg steps each")},
         }
         print(json.dumps(out))
     if dist is not None and os.environ.get("EGAZE_DP_CHECK") == "1":

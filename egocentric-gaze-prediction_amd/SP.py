@@ -14,7 +14,7 @@ from . import dp
 from .floss import BCELoss, floss
 from .models.model_SP import model_SP
 from .optim import FusedAdam
-from .data.STdatas import stage_batch
+from .data.STdatas import staged_batches
 from .utils import (AverageMeter, cfg, change_key_names, computeAAEAUC, make_layers, owned_state_dict, plot_loss,
                     save_checkpoint)
 
@@ -111,17 +111,13 @@ class SP():
         print(hipops.precision_banner())
         print('SP module init done!')
 
-    def _batch(self, sample):
-        input_s, input_t, target = stage_batch(sample, self.device)     # u8 -> normalised fp32 on the device if raw
-        return input_s, input_t, target
-
     def trainSP(self):
         self.model.train()
         batch_time, losses = AverageMeter(), AverageMeter()
         end = time.time()
         self.optimizer.zero_grad()
-        for i, sample in _progress(enumerate(self.STTrainLoader)):
-            input_s, input_t, target = self._batch(sample)
+        # batch k + 1 is copied (and normalised) on a copy stream while step k computes: data.STdatas.staged_batches
+        for i, (sample, (input_s, input_t, target)) in _progress(enumerate(staged_batches(self.STTrainLoader, self.device))):
             output = self.model(input_s, input_t)
             loss = self.criterion(output, target.view(output.size()))
             loss.backward()
@@ -142,8 +138,7 @@ class SP():
         batch_time, losses, auc, aae = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
         end = time.time()
         with torch.no_grad():
-            for i, sample in _progress(enumerate(self.STValLoader)):
-                input_s, input_t, target = self._batch(sample)
+            for i, (sample, (input_s, input_t, target)) in _progress(enumerate(staged_batches(self.STValLoader, self.device))):
                 output = self.model(input_s, input_t)
                 target = target.view(output.size())
                 loss = self.criterion(output, target)

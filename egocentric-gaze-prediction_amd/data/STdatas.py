@@ -44,6 +44,45 @@ def stage_batch(sample, device):
             sample['gt'].float().to(device, non_blocking=True))
 
 
+def staged_batches(loader, device):
+    """Iterates ``loader`` one batch ahead: yields ``(sample, (image, flow, gt))`` with the NEXT batch's host-to-device copy
+    and normalisation (stage_batch) already issued on a copy stream, so that batch k + 1 crosses PCIe while step k computes
+    (the reference copies inside the step, SP.py:126-131).  Ordering is by stream events only; the yielded tensors are
+    handed to the consumer's stream (record_stream) so the caching allocator cannot recycle them early.  Falls back to
+    in-step staging when HIP streams are switched off (EGAZE_STREAMS=0) or the device is not a GPU."""
+    from .. import streams
+    device = torch.device(device)
+    if device.type != 'cuda' or not streams.ENABLED:
+        for sample in loader:
+            yield sample, stage_batch(sample, device)
+        return
+    copy = streams.side_stream("h2d")
+
+    def issue(sample):
+        with torch.cuda.stream(copy):
+            staged = stage_batch(sample, device)
+        ev = torch.cuda.Event()
+        ev.record(copy)
+        return sample, staged, ev
+
+    it = iter(loader)
+    try:
+        nxt = issue(next(it))
+    except StopIteration:
+        return
+    while nxt is not None:
+        sample, staged, ev = nxt
+        try:
+            nxt = issue(next(it))          # issued BEFORE the consumer's kernels of this batch: overlaps with them
+        except StopIteration:
+            nxt = None
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for t in staged:
+            t.record_stream(cur)
+        yield sample, staged
+
+
 class STDataset(Dataset):
     def __init__(self, imgPath, imgPath_s, gtPath, listFolders, listTrainFiles, listGtFiles, listfixsacTrain,
                  fixsacPath, raw_u8=False):

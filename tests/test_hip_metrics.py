@@ -90,6 +90,35 @@ def test_u8_normalize_bit_exact():
         H.u8_normalize(im.to(DEV), (0.5,), (0.5,))
 
 
+def test_staged_batches_prefetch_order_and_values():
+    """data.STdatas.staged_batches (batch k + 1 copied on a copy stream while step k computes): every batch arrives, in
+    order, bit-identical to in-step staging, for raw-byte and fp32 loaders, while the consumer stream is kept busy."""
+    from egaze_amd.data.STdatas import stage_batch, staged_batches
+    rs = np.random.RandomState(9)
+    for raw in (True, False):
+        batches = []
+        for k in range(5):
+            im = torch.from_numpy(rs.randint(0, 256, (2, 3, 32, 32)).astype(np.uint8))
+            fl = torch.from_numpy(rs.randint(0, 256, (2, 20, 32, 32)).astype(np.uint8))
+            gt = torch.from_numpy(rs.randint(0, 256, (2, 1, 32, 32)).astype(np.uint8))
+            smp = {'image': im, 'flow': fl, 'gt': gt, 'k': k}
+            if not raw:
+                smp = {'image': im.float(), 'flow': fl.float(), 'gt': gt.float(), 'k': k}
+            batches.append({n: (t.pin_memory() if torch.is_tensor(t) else t) for n, t in smp.items()})
+        busy = torch.randn(2048, 2048, device=DEV)
+        seen = 0
+        for k, (sample, staged) in enumerate(staged_batches(batches, DEV)):
+            assert sample['k'] == k
+            busy = busy @ busy.clamp(-1e-3, 1e-3)                  # consumer-stream work the next copy overlaps with
+            sums = [t.double().sum() for t in staged]              # consume on the current stream
+            ref = stage_batch(batches[k], DEV)
+            for t, r, s_ in zip(staged, ref, sums):
+                assert torch.equal(t, r) and s_.item() == r.double().sum().item()
+            seen += 1
+        assert seen == 5
+    assert list(staged_batches([], DEV)) == []
+
+
 def test_at_glue_kernels_vs_oracle():
     """AT.crop_feature + spatial mean and AT.get_weighted (AT.py:25-39,58-66,229) on the device vs the oracle."""
     from egaze_amd.AT import crop_mean_weight, get_weighted
