@@ -25,6 +25,10 @@ def _split(folder, val_name, task):
     return train, val
 
 
+def _stage_late(sample, device):
+    return tuple(sample[k].float().to(device, non_blocking=True) for k in ('im', 'gt', 'feat'))
+
+
 class LF():
     def __init__(self, pretrained_model=None, save_path='save', late_save_img='loss_late.png',
                  save_name='best_late.pth.tar', device='0', late_pred_path='../new_pred', num_epoch=10,
@@ -64,11 +68,10 @@ class LF():
         print(hipops.precision_banner())
 
     def _run(self, loader, train, every):
+        from .data.STdatas import staged_batches
         losses, auc, aae = AverageMeter(), AverageMeter(), AverageMeter()
-        for i, sample in _progress(enumerate(loader)):
-            im = sample['im'].float().to(self.device)
-            gt = sample['gt'].float().to(self.device)
-            feat = sample['feat'].float().to(self.device)
+        # the three maps of batch k + 1 cross PCIe on a copy stream while step k computes (LF.py:85-89 copies in the step)
+        for i, (sample, (im, gt, feat)) in _progress(enumerate(staged_batches(loader, self.device, _stage_late))):
             out = self.model(feat, im)                       # channel 0 = AT map, channel 1 = SP map (LF.py:90)
             loss = self.criterion(out, gt)
             aae1, auc1, _ = computeAAEAUC(out.detach(), gt)          # device kernel, maps stay in HBM (LF.py:92-94)

@@ -44,23 +44,25 @@ def stage_batch(sample, device):
             sample['gt'].float().to(device, non_blocking=True))
 
 
-def staged_batches(loader, device):
+def staged_batches(loader, device, stage=None):
     """Iterates ``loader`` one batch ahead: yields ``(sample, (image, flow, gt))`` with the NEXT batch's host-to-device copy
     and normalisation (stage_batch) already issued on a copy stream, so that batch k + 1 crosses PCIe while step k computes
     (the reference copies inside the step, SP.py:126-131).  Ordering is by stream events only; the yielded tensors are
     handed to the consumer's stream (record_stream) so the caching allocator cannot recycle them early.  Falls back to
-    in-step staging when HIP streams are switched off (EGAZE_STREAMS=0) or the device is not a GPU."""
+    in-step staging when HIP streams are switched off (EGAZE_STREAMS=0) or the device is not a GPU.  ``stage(sample,
+    device) -> tuple of device tensors`` defaults to stage_batch (the SP / AT sample layout); LF passes its own."""
     from .. import streams
+    stage = stage or stage_batch
     device = torch.device(device)
     if device.type != 'cuda' or not streams.ENABLED:
         for sample in loader:
-            yield sample, stage_batch(sample, device)
+            yield sample, stage(sample, device)
         return
     copy = streams.side_stream("h2d")
 
     def issue(sample):
         with torch.cuda.stream(copy):
-            staged = stage_batch(sample, device)
+            staged = stage(sample, device)
         ev = torch.cuda.Event()
         ev.record(copy)
         return sample, staged, ev
