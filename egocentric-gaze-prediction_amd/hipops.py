@@ -866,6 +866,45 @@ def lstm_seq_bwd(dh_out, dhn, dcn, acts, cs, c0, w_hh_t):
     return dgates, dh0, dc0
 
 
+def _ptr_table(tensors):
+    """Host array of device pointers (None -> NULL) for the C-ABI entry points that take a parameter table."""
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def lstm_b1_fwd(params, inp, h0, c0, want_acts: bool = True):
+    """The whole lstmnet step at T = 1, B = 1 in one call (csrc/lstm_b1.hip).  params: state-dict order, 4L + 2 tensors;
+    inp (C,) raw; h0, c0 (L,H) -> (xt (C,), acts (L,4H) | None, hn (L,H), cn (L,H), out (N,))."""
+    L = (len(params) - 2) // 4
+    for i, t in enumerate(params):
+        _req(t, f"param{i}")
+    _req(inp, "input"); _req(h0, "h0"); _req(c0, "c0")
+    C, Hd, N = params[0].shape[1], params[1].shape[1], params[-2].shape[0]
+    dev = inp.device
+    xt = torch.empty(C, dtype=torch.float32, device=dev)
+    acts = torch.empty((L, 4 * Hd), dtype=torch.float32, device=dev) if want_acts else None
+    hn = torch.empty((L, Hd), dtype=torch.float32, device=dev)
+    cn = torch.empty_like(hn)
+    out = torch.empty(N, dtype=torch.float32, device=dev)
+    check(LIB.egz_lstm_b1_fwd(_ptr_table(params), L, inp.data_ptr(), h0.data_ptr(), c0.data_ptr(), xt.data_ptr(), _p(acts),
+                              hn.data_ptr(), cn.data_ptr(), out.data_ptr(), C, Hd, N, _stream()), "egz_lstm_b1_fwd")
+    return xt, acts, hn, cn, out
+
+
+def lstm_b1_bwd(params, grads, dout, dhn, dcn, xt, acts, h0, c0, hn, cn, out):
+    """Backward of lstm_b1_fwd: fills the tensors in ``grads`` (same order as params; None entries are skipped)."""
+    L = (len(params) - 2) // 4
+    C, Hd, N = params[0].shape[1], params[1].shape[1], params[-2].shape[0]
+    for name, t in (("dout", dout), ("dhn", dhn), ("dcn", dcn)):
+        if t is not None:
+            _req(t, name)
+    nbytes = LIB.egz_lstm_b1_ws_bytes(L, C, Hd)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=out.device)
+    check(LIB.egz_lstm_b1_bwd(_ptr_table(params), _ptr_table(grads), L, dout.data_ptr(), _p(dhn), _p(dcn), xt.data_ptr(),
+                              acts.data_ptr(), h0.data_ptr(), c0.data_ptr(), hn.data_ptr(), cn.data_ptr(), out.data_ptr(),
+                              C, Hd, N, ws.data_ptr(), nbytes, _stream()), "egz_lstm_b1_bwd")
+
+
 def lstm_cell_fwd(gates, c_prev, h_out, c_out, act):
     B, Hd = c_prev.shape
     check(LIB.egz_lstm_cell_fwd(gates.data_ptr(), c_prev.data_ptr(), h_out.data_ptr(), c_out.data_ptr(), _p(act), B, Hd,

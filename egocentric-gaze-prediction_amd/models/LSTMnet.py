@@ -7,12 +7,15 @@ are sequences of C-ABI launches (f32-MFMA GEMMs + fused LSTM-cell kernels).  Qui
 means zeros of batch **1** (module-global ``batch_size``, LSTMnet.py:13,30-31), so a batch > 1 without an
 explicit ``(h, c)`` raises exactly like the reference.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import hipops as H
 
 batch_size = 1
+B1_FUSED = os.environ.get("EGAZE_LSTM_B1", "1") != "0"     # A/B knob: 0 = always the sequence path
 
 
 class _LSTMNetFn(torch.autograd.Function):
@@ -107,6 +110,48 @@ class _LSTMNetFn(torch.autograd.Function):
         return (dinp, dh0 if ng[1] else None, dc0 if ng[2] else None, *grads)
 
 
+class _LSTMNetB1Fn(torch.autograd.Function):
+    """The same network at T = 1, B = 1 -- how the reference itself steps it (AT.py:127-145 per fixation sample, AT.py:246 per
+    frame): ONE C-ABI call per direction (csrc/lstm_b1.hip: matrix-vector kernels, rank-1 weight gradients written straight
+    into the optimizer's buffer) instead of ~25 launches each with a host round trip.  No gradient flows to the input or
+    the initial state on this path (lstmnet.forward routes such calls to the sequence path)."""
+
+    @staticmethod
+    def forward(ctx, inp, h0, c0, *params):
+        train = any(ctx.needs_input_grad)
+        ps = [p.detach() for p in params]
+        h0c = H._req(h0.detach().contiguous(), "h0").view(h0.shape[0], -1)
+        c0c = H._req(c0.detach().contiguous(), "c0").view(c0.shape[0], -1)
+        xt, acts, hn, cn, out = H.lstm_b1_fwd(ps, inp.detach().contiguous().view(-1), h0c, c0c, want_acts=train)
+        ctx.saved = (xt, acts, h0c, c0c, hn, cn, out)
+        ctx.params = list(params)
+        ctx.set_materialize_grads(False)
+        return out.view(1, 1, -1), hn.view(hn.shape[0], 1, -1), cn.view(cn.shape[0], 1, -1)
+
+    @staticmethod
+    def backward(ctx, dout, dhn, dcn):
+        xt, acts, h0c, c0c, hn, cn, out = ctx.saved
+        params = ctx.params
+        if acts is None:
+            raise RuntimeError("lstmnet: backward through a forward pass that ran without gradient tracking")
+        ng = ctx.needs_input_grad
+        if dout is None:
+            dout = torch.empty_like(out)
+            H.fill_zero(dout)
+        sinks = [H.grad_sink(p, ng[3 + i]) for i, p in enumerate(params)]
+        grads = [sinks[i] if sinks[i] is not None else
+                 (torch.empty(p.shape, dtype=torch.float32, device=p.device) if ng[3 + i] else None)
+                 for i, p in enumerate(params)]
+        H.lstm_b1_bwd([p.detach() for p in params], grads, dout.contiguous().view(-1),
+                      None if dhn is None else dhn.contiguous().view(dhn.shape[0], -1),
+                      None if dcn is None else dcn.contiguous().view(dcn.shape[0], -1), xt, acts, h0c, c0c, hn, cn, out)
+        for i, p in enumerate(params):
+            if sinks[i] is not None:
+                H.grad_done(p)
+                grads[i] = None
+        return (None, None, None, *grads)
+
+
 class lstmnet(nn.Module):
     def __init__(self, num_channel=512, num_layer=2):
         super(lstmnet, self).__init__()
@@ -133,5 +178,8 @@ class lstmnet(nn.Module):
             params += [getattr(self.lstm, f"weight_ih_l{l}"), getattr(self.lstm, f"weight_hh_l{l}"),
                        getattr(self.lstm, f"bias_ih_l{l}"), getattr(self.lstm, f"bias_hh_l{l}")]
         params += [self.lin.weight, self.lin.bias]
-        out, hn, cn = _LSTMNetFn.apply(input, h0, c0, *params)
+        # one sample, one step, no gradient wanted for the input / state (the reference's own stepping): the fused path
+        single = (T == 1 and B == 1 and B1_FUSED
+                  and not (torch.is_grad_enabled() and (input.requires_grad or h0.requires_grad or c0.requires_grad)))
+        out, hn, cn = (_LSTMNetB1Fn if single else _LSTMNetFn).apply(input, h0, c0, *params)
         return (out, (hn, cn))

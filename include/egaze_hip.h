@@ -189,6 +189,18 @@ int egz_lstm_seq_fwd(const float* gx, const float* w_hh, const float* h0, const 
 int egz_lstm_seq_bwd(const float* dh_out, const float* dhn, const float* dcn, const float* acts, const float* cs,
                      const float* c0, const float* w_hh_t, float* dgates, float* dh0, float* dc0, int T, int B, int H,
                      hipStream_t stream);
+/* The same network at T = 1, B = 1 -- the reference's own stepping (AT.py:127-145 training loop, AT.py:246 inference): the
+ * whole step in ONE call (L + 1 launches forward, 2L + 1 backward; csrc/lstm_b1.hip).  params / grads: HOST arrays of
+ * 4L + 2 device pointers in state-dict order (w_ih, w_hh, b_ih, b_hh per layer, lin.weight [N][H], lin.bias [N]); a null
+ * grads entry skips that gradient.  inp [C] raw (tanh applied inside, saved to xt); h0, c0, hn, cn [L][H]; acts [L][4H]
+ * (null in no-grad runs); out [N] after ReLU.  No gradient w.r.t. inp / h0 / c0 (the loop detaches them, AT.py:143). */
+size_t egz_lstm_b1_ws_bytes(int L, int C, int H);
+int egz_lstm_b1_fwd(const void* const* params, int L, const float* inp, const float* h0, const float* c0, float* xt,
+                    float* acts, float* hn, float* cn, float* out, int C, int H, int N, hipStream_t stream);
+int egz_lstm_b1_bwd(const void* const* params, void* const* grads, int L, const float* dout, const float* dhn,
+                    const float* dcn, const float* xt, const float* acts, const float* h0, const float* c0,
+                    const float* hn, const float* cn, const float* out, int C, int H, int N, void* workspace,
+                    size_t ws_bytes, hipStream_t stream);
 int egz_tanh_fwd(const float* x, float* y, long n, hipStream_t stream);
 int egz_tanh_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t stream);
 int egz_add(const float* a, const float* b, float* out, long n, hipStream_t stream);

@@ -128,3 +128,61 @@ def test_lstmnet_t16_b32_vs_oracle():
     assert rel(cn.detach().cpu().numpy(), ocn.detach().numpy()) < 2e-5
     for k, p in net.named_parameters():
         assert rel(p.grad.cpu().numpy(), leaves[k].grad.numpy()) < 2e-4, k
+
+
+@pytest.mark.parametrize("through_state", [False, True])
+def test_lstmnet_single_step_fused_vs_oracle(through_state, monkeypatch):
+    """T = 1, B = 1 (the reference's own stepping, AT.py:127-145) runs on the fused one-call path (csrc/lstm_b1.hip): forward,
+    state and EVERY parameter gradient against the oracle -- with the loss on the output only (the AT loop) and with
+    gradients also arriving through the returned (h, c) -- and against the sequence path of the same build."""
+    import egaze_amd.models.LSTMnet as M
+    from egaze_amd.functions import MSELoss
+    sd = synth.synth_state_dict(O.lstm_shapes(), seed=2)
+    inp, tgt = synth.synth_at_batch(1, 1, seed=11)
+    g = torch.Generator().manual_seed(5)
+    h0, c0 = torch.randn(2, 1, 512, generator=g) * 0.3, torch.randn(2, 1, 512, generator=g) * 0.3
+    wh, wc = torch.randn(2, 1, 512, generator=g), torch.randn(2, 1, 512, generator=g)
+
+    def run(fused):
+        monkeypatch.setattr(M, "B1_FUSED", fused)
+        net = build()
+        out, (hn, cn) = net(inp.to(DEV), (h0.to(DEV), c0.to(DEV)))
+        assert type(out.grad_fn).__name__.startswith("_LSTMNetB1Fn" if fused else "_LSTMNetFn")
+        loss = MSELoss.apply(out, torch.tanh(tgt).to(DEV))
+        if through_state:
+            loss = loss + (hn * wh.to(DEV)).sum() * 1e-3 + (cn * wc.to(DEV)).sum() * 1e-3
+        loss.backward()
+        return out.detach().cpu(), hn.detach().cpu(), cn.detach().cpu(), {k: p.grad.cpu() for k, p in net.named_parameters()}
+
+    out, hn, cn, grads = run(True)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oout, (ohn, ocn) = O.lstmnet_forward(leaves, inp, (h0, c0))
+    oloss = O.mse(oout, torch.tanh(tgt))
+    if through_state:
+        oloss = oloss + (ohn * wh).sum() * 1e-3 + (ocn * wc).sum() * 1e-3
+    oloss.backward()
+    assert rel(out.numpy(), oout.detach().numpy()) < 1e-5
+    assert rel(hn.numpy(), ohn.detach().numpy()) < 1e-5 and rel(cn.numpy(), ocn.detach().numpy()) < 1e-5
+    for k in grads:
+        assert rel(grads[k].numpy(), leaves[k].grad.numpy()) < 2e-5, k
+    out2, hn2, cn2, grads2 = run(False)
+    assert rel(out.numpy(), out2.numpy()) < 1e-5 and rel(hn.numpy(), hn2.numpy()) < 1e-5
+    for k in grads:
+        assert rel(grads[k].numpy(), grads2[k].numpy()) < 2e-5, k
+
+
+def test_lstmnet_single_step_routes():
+    """The fused path is taken only when nothing upstream wants a gradient; an input / state that requires grad goes through
+    the sequence path (which produces those gradients), as does any T > 1 or B > 1 call."""
+    net = build()
+    inp, _ = synth.synth_at_batch(1, 1, seed=12)
+    x = inp.to(DEV).requires_grad_(True)
+    out, _ = net(x, None)
+    assert type(out.grad_fn).__name__.startswith("_LSTMNetFn")
+    out.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    out, _ = net(inp.to(DEV), None)
+    assert type(out.grad_fn).__name__.startswith("_LSTMNetB1Fn")
+    with torch.no_grad():
+        o1, (h1, c1) = net(inp.to(DEV), None)
+    assert rel(o1.cpu().numpy(), out.detach().cpu().numpy()) == 0.0
