@@ -8,3 +8,16 @@ python $R/tools/bench_lf.py --steps 50 > $O/r02_lf_step.txt 2>&1
 rm -rf /tmp/lf
 rocprofv3 --kernel-trace --output-format csv -d /tmp/lf -o p -- python $R/tools/bench_lf.py --steps 10 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/lf $O/r02_lf_kernel_stats.txt "python tools/bench_lf.py --steps 10" > /dev/null
+
+# AT.trainLSTM per-sample loop (T = 1, B = 1): fused single-step path vs the sequence path, + kernel stats of the fused path
+{ echo "# python tools/bench_at_loop.py --n 2000   (default: fused single-step path, csrc/lstm_b1.hip)"
+  python $R/tools/bench_at_loop.py --n 2000 2>&1 | grep "AT.trainLSTM"
+  echo "# EGAZE_LSTM_B1=0 python tools/bench_at_loop.py --n 2000   (sequence path)"
+  EGAZE_LSTM_B1=0 python $R/tools/bench_at_loop.py --n 2000 2>&1 | grep "AT.trainLSTM"; } > $O/r02_at_sample_loop.txt
+rm -rf /tmp/atl
+rocprofv3 --kernel-trace --output-format csv -d /tmp/atl -o p -- python $R/tools/bench_at_loop.py --n 200 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/atl /tmp/atl_stats.txt "python tools/bench_at_loop.py --n 200" > /dev/null
+head -24 /tmp/atl_stats.txt >> $O/r02_at_sample_loop.txt
+# config 5 stage timings
+python $R/tools/bench_pipeline.py 2>&1 | grep -v "^/opt\|^begin\|^Finished" > /tmp/pipe.txt
+{ echo "# python tools/bench_pipeline.py (BASELINE config 5 stages on one GPU, synthetic frames in host memory)"; cat /tmp/pipe.txt; } > $O/r02_pipeline_config5.txt
