@@ -13,12 +13,18 @@ import torch
 
 ENABLED = os.environ.get("EGAZE_STREAMS", "1") != "0"
 _SIDE = {}
+# Helper-stream kinds that exist ONCE per device instead of once per parent stream (comma separated).  HIP multiplexes
+# streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; more is 17 % slower, profiles/r02_hw_queues_ab.txt) and streams that
+# share a queue run FIFO.  One weight-gradient stream for both encoders keeps the step at main + encoder_t + wgrad + one
+# more (the AT stream, the H2D copy stream or the RCCL comm stream): the step time is unchanged (35.4 vs 35.3 ms) and the
+# prefetched H2D copy overlaps fully (fp32 loader: 36.2 vs 38.0 ms per step; profiles/r02_hw_queues_ab.txt).
+_SHARED = set(filter(None, os.environ.get("EGAZE_SHARED_STREAMS", "wgrad").split(",")))
 
 
 def side_stream(kind: str) -> torch.cuda.Stream:
     """A persistent helper stream per (current stream, kind)."""
     cur = torch.cuda.current_stream()
-    key = (cur.device.index, cur.cuda_stream, kind)
+    key = (cur.device.index, 0 if kind in _SHARED else cur.cuda_stream, kind)
     st = _SIDE.get(key)
     if st is None:
         st = torch.cuda.Stream(device=cur.device)
