@@ -458,6 +458,201 @@ __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form for the narrowest layers (late_fusion.py:10-12: at most 32 reduction channels AND at most 32 GEMM columns,
+// patch geometry).  With one channel block the kernel above has nothing to pipeline inside a tile (fetch -> split -> barrier ->
+// 108 MFMAs -> store, serially) and every tile re-streams all 36 KB of weight fragments from L2.  Here
+//   * one 256-thread block per CU walks a contiguous range of 16 x 16 pixel tiles of its XCD (so neighbouring halos meet in
+//     one L2);
+//   * the 36 weight fragments (9 taps x 2 k-steps x hi / lo) are loaded ONCE into registers -- 144 VGPRs; the block is
+//     alone on its CU, so a wave has the whole 512-register file;
+//   * the halo of tile i + 1 is fetched (buffer loads with fixed per-thread offsets + one scalar origin + border masks)
+//     before the MFMAs of tile i, split and written to the OTHER LDS image after them: one barrier per tile.
+// Same LDS image, fragment addressing, arithmetic and epilogues (bias / bias + ReLU / bias + BN statistics) as the 32-column
+// configuration (WM = 4) of the kernel above, which stays the path for images that are not multiples of 16.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
+    const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
+    float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, float out_scale, int total,
+    const unsigned int* __restrict__ a_absmax) {
+    using G = Geo<4>;
+    constexpr int BM = G::BM, HSLOTS = G::HSLOTS, NJ = G::NJ, SPP = G::SPP, MR = G::MR, RPW = G::RPW;
+    constexpr int APL = HSLOTS * XLD, ABUF = 2 * APL;
+    static_assert(BM == 256 && MR == 2 && RPW == 64 && G::PROWS == 16, "16 x 16 patch, 64 rows per wave");
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[2 * ABUF];
+    __shared__ double sred[4 * 2 * 32];
+
+    const float a_scale = absmax_scale(a_absmax);
+    out_scale /= a_scale;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
+    const int pw = W >> 4, ppi = (H >> 4) * pw;                 // patches per row / per image
+
+    // this block's tiles: XCD (blockIdx % 8) owns the contiguous range [xcd * per, (xcd + 1) * per)
+    const int per = (total + 7) >> 3, xcd = (int)(blockIdx.x & 7), nbx = (int)(gridDim.x >> 3);
+    const int t_end = ((xcd + 1) * per < total) ? (xcd + 1) * per : total;
+    int tile = xcd * per + (int)(blockIdx.x >> 3);
+    if (tile >= t_end) return;
+
+    // ---- weight fragments: [tap][ks][plane][lane][8 halves], 1 KB pieces, resident in registers for the whole launch
+    const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), 0, 9 * 4096, 0x00020000);
+    u32x4 bq[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[t][c] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, (unsigned)lane * 16u + c * 1024, t * 4096, 0);
+
+    // ---- halo staging map: slot q = (tid >> 3) + SPP j = grid position (hy, hx) of the 18 x 18 halo (pitch 20), 4 channels
+    // (tid & 7) each.  The x resource starts (W + 1) pixels early so that the (-1, -1) corner keeps lane offsets >= 0.
+    const unsigned x_bias = (unsigned)(W + 1) * (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(x)) - x_bias, 0, (int)((unsigned)B * H * W * C * 4u + x_bias), 0x00020000);
+    const int a_c4 = tid & 7;
+    unsigned a_vo[NJ], a_rc[NJ];
+    int a_lds[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = (tid >> 3) + SPP * j;
+        const int hy = q / HPITCH, hx = q - hy * HPITCH;
+        const bool in = hy < 18 && hx < 18 && a_c4 * 4 < C;
+        a_vo[j] = in ? (unsigned)(((hy * W + hx) * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
+        a_rc[j] = (unsigned)(hy << 8 | hx);
+        a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((hx >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
+    }
+    f32x4 ra[NJ];
+    auto gload_a = [&](const int tl) {
+        const int b0 = tl / ppi, rem = tl - b0 * ppi;
+        const int y0 = (rem / pw) * 16, x0 = (rem % pw) * 16;
+        // valid halo rows hy in [rlo, rlo + rn], columns hx in [clo, clo + cn] (source pixel = (y0 - 1 + hy, x0 - 1 + hx))
+        const unsigned rlo = (y0 == 0) ? 1u : 0u, rn = (unsigned)((H - y0 < 17) ? (H - y0) : 17) - rlo;
+        const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((W - x0 < 17) ? (W - x0) : 17) - clo;
+        const unsigned so = (unsigned)((((long)b0 * H + y0) * W + x0) * C * 4);          // + x_bias - x_bias
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool ok = ((a_rc[j] >> 8) - rlo <= rn) && ((a_rc[j] & 255u) - clo <= cn);
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, ok ? a_vo[j] : 0xFFFFFFFFu, so, 0));
+        }
+    };
+    auto lstore_a = [&](const int abuf) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            u32x2 hi, lo;
+            Half<T>::split4(ra[j] * a_scale, hi, lo);
+            unsigned short* d = Ah + abuf * ABUF + a_lds[j];
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + APL) = lo;
+        }
+    };
+
+    // ---- activation fragment addresses (bytes, plane 0, k-step 0, image 0) of the wave's first 32-row group, per tap shift
+    int fa9[9];
+    {
+        const int i = wave * RPW + l31;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const int slot = ((i >> 4) + 1 + dy) * HPITCH + (i & 15) + 1 + dx, col = (i & 15) + 1 + dx;
+            fa9[t] = (slot * XLD + ((hl ^ ((col >> 2) & 3)) << 3)) * 2;
+        }
+    }
+    constexpr int MRSTEP = 2 * HPITCH * XLD * 2;               // bytes between the wave's two row groups (2 grid rows)
+    const char* Ab = reinterpret_cast<const char*>(Ah);
+    const bool nok = l31 < K;
+    const float bz = (bias && nok) ? bias[l31] : 0.f;
+
+    gload_a(tile);
+    lstore_a(0);
+    lds_barrier();
+    int buf = 0;
+    for (;;) {
+        const int nxt = tile + nbx;
+        const bool more = nxt < t_end;                          // block-uniform
+        if (more) gload_a(nxt);
+        f32x16 acc[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 ah[MR], al[MR];
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    const int a = (fa9[t] + buf * (ABUF * 2) + mr * MRSTEP) ^ (ks * 32);
+                    ah[mr] = *reinterpret_cast<const u32x4*>(Ab + a);
+                    al[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + a);
+                }
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr)
+                        acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bq[t][ks * 2 + 1] : bq[t][ks * 2], acc[mr]);
+            }
+        }
+        // ---- epilogue of this tile: the wave owns patch rows 4 wave .. 4 wave + 3 (64 pixels) x 32 columns
+        {
+            const int b0 = tile / ppi, rem = tile - b0 * ppi;
+            const int y0 = (rem / pw) * 16, x0 = (rem % pw) * 16;
+            double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = wave * RPW + mr * 32 + egz_acc_row(r, lane);
+                    const long off = (((long)b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15)) * K;
+                    if (nok) {
+                        float v = acc[mr][r] * out_scale + bz;
+                        if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                        y[off + l31] = v;
+                        if (EPI == EPI_BIAS_STATS) {
+                            s1 += (double)v;
+                            s2 += (double)v * (double)v;
+                        }
+                    }
+                }
+            }
+            if (EPI == EPI_BIAS_STATS) {                       // one partial row per 128 pixels: waves (0, 1) and (2, 3)
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (hl == 0) {
+                    sred[(wave * 2 + 0) * 32 + l31] = s1;
+                    sred[(wave * 2 + 1) * 32 + l31] = s2;
+                }
+                lds_barrier();
+                const long srow = (long)tile * 2 + (wave >> 1);
+                if ((wave & 1) == 0 && hl == 0 && nok) {
+                    stat[(srow * 2 + 0) * K + l31] = s1 + sred[((wave + 1) * 2 + 0) * 32 + l31];
+                    stat[(srow * 2 + 1) * K + l31] = s2 + sred[((wave + 1) * 2 + 1) * 32 + l31];
+                }
+            }
+        }
+        if (!more) break;
+        lstore_a(buf ^ 1);
+        lds_barrier();                                          // everyone has staged its share and is done reading `buf`
+        buf ^= 1;
+        tile = nxt;
+    }
+}
+
+template <typename T>
+int launch_x3p_narrow(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
+                      int W, int C, int K, float out_scale, const unsigned int* a_absmax, hipStream_t st) {
+    const int total = (int)((long)B * H * W / 256);
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    int blocks = (cus / 8) * 8;
+    if (blocks > ((total + 7) / 8) * 8) blocks = ((total + 7) / 8) * 8;
+#define EGZ_X3P(E) hipLaunchKernelGGL((conv3x3_x3p_narrow_kernel<T, E>), dim3(blocks), dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, out_scale, total, a_absmax)
+    if (epi == EPI_BIAS) EGZ_X3P(EPI_BIAS);
+    else if (epi == EPI_BIAS_RELU) EGZ_X3P(EPI_BIAS_RELU);
+    else EGZ_X3P(EPI_BIAS_STATS);
+#undef EGZ_X3P
+    EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed(narrow)");
+    return 0;
+}
+
 template <typename T, int WM, int MODE>
 int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
                int W, int C, int K, float out_scale, const unsigned int* a_absmax, const float* mask_src,
@@ -579,6 +774,13 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
     if (K % 64 == 0) {
         if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
         return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+    }
+#ifndef EGZ_X3P_NARROW
+#define EGZ_X3P_NARROW 1
+#endif
+    if (EGZ_X3P_NARROW && C <= 32 && K <= 32 && H % 16 == 0 && W % 16 == 0 && epi != EPI_MASK_SUMS) {   // persistent narrow form
+        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+        return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
     }
     if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);

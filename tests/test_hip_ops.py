@@ -495,7 +495,11 @@ def test_first_conv_padded_split_path(B, Hh, Ww, C):
     (3, 28, 28, 64, 128), (2, 14, 14, 256, 256), (1, 56, 56, 64, 128), (5, 5, 3, 64, 64), (1, 20, 56, 96, 64),
     (2, 12, 12, 128, 64), (3, 9, 7, 32, 128), (1, 8, 24, 64, 192),
     # 32-column tiles (late-fusion widths): K = 32 / 8 (zero-padded columns), C = 8 (one zero-padded channel block)
-    (2, 16, 16, 32, 32), (1, 20, 56, 32, 8), (2, 12, 12, 8, 32), (1, 32, 48, 32, 32), (3, 28, 28, 16, 40)])
+    (2, 16, 16, 32, 32), (1, 20, 56, 32, 8), (2, 12, 12, 8, 32), (1, 32, 48, 32, 32), (3, 28, 28, 16, 40),
+    # ... of which images that are multiples of 16 with C, K <= 32 run on the persistent narrow kernel (weights resident in
+    # registers, halo of the next tile prefetched): several images (border masks between them), K = 8, C = 8, and more
+    # tiles than blocks (320 tiles on 256 CUs: the per-XCD tile ranges and the double-buffered image switch)
+    (3, 32, 32, 32, 8), (2, 48, 16, 8, 32), (5, 128, 128, 32, 32), (9, 16, 16, 12, 20)])
 def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
     """Streamed-weight halo kernel (fragment-ordered weights L2 -> registers, activation halo through LDS) against an fp64
     reference: forward with all three epilogues (BN partial sums included) and the data gradient, f16 x3 and bf16 x3."""
