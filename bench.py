@@ -233,7 +233,7 @@ def main():
         ig = {"calls": 0, "ms": 0.0, "flops": 0.0}
         # split mode: plain convs run on the streamed-weight kernel (egz_conv3x3_fwd_streamed), the upsample forms on the
         # per-tap gather kernel (egz_conv3x3_fwd_split); their algorithmic FLOPs are noted under one name by hipops
-        entries = ("egz_conv3x3_fwd_split", "egz_conv3x3_fwd_streamed") if split else ("egz_conv3x3_fwd", "egz_conv3x3_ups_dgrad")
+        entries = ("egz_conv3x3_fwd_split", "egz_conv3x3_fwd_streamed", "egz_conv3x3_fwd_streamed_splitk") if split else ("egz_conv3x3_fwd", "egz_conv3x3_ups_dgrad")
         for entry in entries:
             for k2 in ig:
                 ig[k2] += prof.get(entry, {}).get(k2, 0)

@@ -37,6 +37,10 @@ SIGNATURES = {
     "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
     "egz_conv3x3_streamed_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_pack_w3x3_split_frag": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_conv3x3_streamed_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "egz_conv3x3_fwd_streamed_splitk_stat_rows": (c_int, [c_int, c_int, c_int]),
+    "egz_conv3x3_fwd_streamed_splitk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "egz_conv3x3_fwd_streamed_splitk": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, c_int, S]),
     "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
     "egz_absmax_fold": (c_int, [P, c_int, S]),
     "egz_colsum_f64": (c_int, [P, c_int, c_int, c_int, P, P, c_size_t, S]),

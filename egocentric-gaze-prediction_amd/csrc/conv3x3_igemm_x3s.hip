@@ -35,7 +35,10 @@ using namespace x3;
 // layout as y): the epilogue applies the ReLU mask (mask_src > 0), accumulates the per-channel sums of the masked gradient
 // (= the bias gradient of the layer below, plane 0 of the stat rows; plane 1 = 0) and the per-tile max |value| (for the
 // f16 scaling of the next backward kernels) -- the separate ReLU-backward pass of that layer disappears.
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2, EPI_MASK_SUMS = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2, EPI_MASK_SUMS = 3, EPI_PARTIAL = 4 };
+// EPI_PARTIAL: split-K launch (small pixel counts: batch 1 inference, the 14 x 14 / 28 x 28 layers at small batches).  The
+// channel blocks of a tile are divided over `nsplit` blocks; each writes its raw scaled accumulators to
+// y[split][pixel][column] (y = the workspace) and splitk_fixup_kernel sums them in split order and applies the epilogue.
 constexpr int XLD = 32;                 // 16-bit elements per LDS row: 64 B = 32 channels of one plane of one pixel
 constexpr int XBK = 32;                 // channels per block of the reduction
 constexpr int HPITCH = 20;              // patch geometry: halo columns per LDS grid row (18 used)
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
     int mt, int total, const unsigned int* __restrict__ a_absmax, const float* __restrict__ mask_src,
-    unsigned int* __restrict__ absmax_out) {
+    unsigned int* __restrict__ absmax_out, int nsplit) {
     using G = Geo<WM>;
     constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
     constexpr int MR = G::MR, RPW = G::RPW, NTHR = G::NTHR, SPP = G::SPP;
@@ -101,8 +104,10 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     const int ntn = Kp / BN;
     // XCD-aware tile id: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
     const int per = (total + 7) >> 3;
-    const int gt = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (gt >= total) return;
+    const int gts = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);      // total = tiles x splits
+    if (gts >= total) return;
+    const int split = (EPI == EPI_PARTIAL) ? gts % nsplit : 0;
+    const int gt = (EPI == EPI_PARTIAL) ? gts / nsplit : gts;
     const int tile_n = gt % ntn, tile_m = gt / ntn;
     const int n0 = tile_n * BN;
     const int Ho = (MODE == UPSD) ? (H >> 1) : H, Wo = (MODE == UPSD) ? (W >> 1) : W;     // output image
@@ -159,6 +164,10 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 
     // ---- weight fragments: lane-linear 1 KB pieces, [slice][ntile32][ks][plane][lane][8 halves]
     const int nt32 = Kp >> 5, ncb = Cp / XBK, S = ncb * NIMG * NT;
+    // this block's channel blocks [c_lo, c_hi) (all of them unless the launch is split-K) and slice range [., S_hi)
+    const int c_lo = (EPI == EPI_PARTIAL) ? (split * ncb) / nsplit : 0;
+    const int c_hi = (EPI == EPI_PARTIAL) ? ((split + 1) * ncb) / nsplit : ncb;
+    const int S_lo = c_lo * NIMG * NT, S_hi = c_hi * NIMG * NT;
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(wq), 0, (int)((unsigned)S * nt32 * 4096u), 0x00020000);
     const unsigned b_vo = (unsigned)lane * 16u;
@@ -279,22 +288,22 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     };
 
     // ---- prologue
-    gload_b(0, 0);
-    if (NRING > 2) gload_b(S > 1 ? 1 : 0, 1);
-    gload_a(0, 0, 0);
+    gload_b(S_lo, 0);
+    if (NRING > 2) gload_b(S_hi - S_lo > 1 ? S_lo + 1 : S_lo, 1);
+    gload_a(c_lo, 0, 0);
     lstore_a(0, 0);
-    gload_a(0, 0, 1);
+    gload_a(c_lo, 0, 1);
     lstore_a(0, 1);
     lds_barrier();
     read_a0(shift_of(0, 0), 0);
 
     // staging schedule of the NEXT image inside the NT taps of the current one (double-buffered images)
     constexpr int G0 = (NT == 9) ? 1 : 0, L0 = (NT == 9) ? 3 : 1, G1 = (NT == 9) ? 4 : 1, L1 = (NT == 9) ? 6 : 2;
-    for (int c = 0; c < ncb; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) {
-            const int abuf = (G::NABUF == 2) ? ((NIMG == 1) ? (c & 1) : (img & 1)) : 0;
-            const bool more = (img + 1 < NIMG) || (c + 1 < ncb);        // block-uniform
+            const int abuf = (G::NABUF == 2) ? ((NIMG == 1) ? ((c - c_lo) & 1) : (img & 1)) : 0;
+            const bool more = (img + 1 < NIMG) || (c + 1 < c_hi);       // block-uniform
             const int nimg = (img + 1 < NIMG) ? img + 1 : 0;
             const int ncblk = (img + 1 < NIMG) ? c : c + 1;
 #pragma unroll
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                 const int s = (c * NIMG + img) * NT + t, ring = (img * NT + t) % NRING;
                 // the set being refilled was last read by slice s - 1
 #if !(EGZ_X3S_DIAG & 1)
-                gload_b(s + NRING - 1 < S ? s + NRING - 1 : S - 1, (img * NT + t + NRING - 1) % NRING);
+                gload_b(s + NRING - 1 < S_hi ? s + NRING - 1 : S_hi - 1, (img * NT + t + NRING - 1) % NRING);
 #endif
                 u32x4 ah1[MR], al1[MR];
 #pragma unroll
@@ -362,6 +371,10 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long off = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)];
+            if (EPI == EPI_PARTIAL) {                          // raw partial sums of this split; epilogue in the fix-up pass
+                if (off >= 0 && nok) y[(long)split * M * K + off + col] = acc[mr][r] * out_scale;
+                continue;
+            }
             if (off >= 0 && nok) {
                 float v = acc[mr][r] * out_scale + bz;
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
@@ -653,6 +666,97 @@ int launch_x3p_narrow(int epi, const float* x, const unsigned short* wq, const f
     return 0;
 }
 
+// Sum of the nsplit partial results of a split-K launch in split order + the epilogue of the unsplit kernel.
+// One block = 32 pixel rows x 64 columns: thread = 4 columns (one 16-byte load per split) x 2 rows; BN partial sums: one stat
+// row per 32 pixels (egz_conv3x3_fwd_streamed_splitk_stat_rows), reduced over the block's rows through LDS in a fixed order.
+constexpr int FIX_ROWS = 32;
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                           float* __restrict__ y, double* __restrict__ stat, long M, int K,
+                                                           int nsplit) {
+    __shared__ double sred[2][16][64];
+    const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    const int col = blockIdx.y * 64 + c4 * 4;
+    const bool cok = col < K;                                  // K % 4 == 0: a float4 is inside or outside as a whole
+    f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+    if (bias && cok) bz = *reinterpret_cast<const f32x4*>(bias + col);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < FIX_ROWS / 16; ++p) {
+        const long m = (long)blockIdx.x * FIX_ROWS + p * 16 + rr;
+        if (m < M && cok) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(part + m * K + col);
+            for (int sp = 1; sp < nsplit; ++sp) v += *reinterpret_cast<const f32x4*>(part + ((long)sp * M + m) * K + col);
+            v += bz;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
+                if (EPI == EPI_BIAS_STATS) {
+                    s1[e] += (double)v[e];
+                    s2[e] += (double)v[e] * (double)v[e];
+                }
+            }
+            *reinterpret_cast<f32x4*>(y + m * K + col) = v;
+        }
+    }
+    if (EPI == EPI_BIAS_STATS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sred[0][rr][c4 * 4 + e] = s1[e];
+            sred[1][rr][c4 * 4 + e] = s2[e];
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+            double t = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += sred[which][r][c];
+            if (blockIdx.y * 64 + c < K) stat[((long)blockIdx.x * 2 + which) * K + blockIdx.y * 64 + c] = t;
+        }
+    }
+}
+
+// split count for a plain launch on the 128 x 128 tile: > 1 when the tiles fill less than half of one round of resident
+// blocks (2 per CU) and every split keeps at least two channel blocks
+int x3s_splits(int B, int H, int W, int C, int K) {
+    if (K % 128 != 0 || C % 32 != 0) return 1;
+    const long M = (long)B * H * W;
+    const bool patch = (W % 16 == 0) && (H % 8 == 0);
+    const long tiles = (patch ? M / 128 : (M + 127) / 128) * (K / 128);
+    const int ncb = C / 32;
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const long slots = 2L * cus;
+    if (tiles * 2 > slots || ncb < 4) return 1;
+    long ns = slots / tiles;
+    if (ns > ncb / 2) ns = ncb / 2;
+    if (ns > 16) ns = 16;
+    return ns < 2 ? 1 : (int)ns;
+}
+
+template <typename T>
+int launch_x3s_splitk(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
+                      int W, int C, int K, float out_scale, const unsigned int* a_absmax, float* part, int nsplit,
+                      hipStream_t st) {
+    using G = Geo<1>;
+    const long M = (long)B * H * W;
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const bool patch = (W % 16 == 0) && (H % G::PROWS == 0);
+    const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
+    const int total = mt * (Kp / G::BN) * nsplit;
+    const dim3 grid(((total + 7) / 8) * 8);
+    if (patch) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, true, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit);
+    else       hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, false, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit);
+    EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed_splitk");
+    const dim3 fg(egz_cdiv(M, FIX_ROWS), egz_cdiv(K, 64));
+    if (epi == EPI_BIAS) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit);
+    else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_RELU>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit);
+    else hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_STATS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit);
+    EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed_splitk(fixup)");
+    return 0;
+}
+
 template <typename T, int WM, int MODE>
 int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
                int W, int C, int K, float out_scale, const unsigned int* a_absmax, const float* mask_src,
@@ -665,7 +769,7 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
     const int total = mt * (Kp / G::BN);
     const dim3 grid(((total + 7) / 8) * 8);
-#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out)
+#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1)
     if (epi == EPI_MASK_SUMS) {
         EGZ_CHECK_ARG(total <= 8192, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
         if constexpr (WM == 1 || WM == 2) {      // data gradients of the SP decoder: 128- and 64-column 4-wave tiles
@@ -784,4 +888,35 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
     }
     if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+}
+
+// Split-K form of a PLAIN launch for small pixel counts (batch-1 inference, the 14 x 14 / 28 x 28 layers at small batches):
+// egz_conv3x3_streamed_splits recommends the split count (1 = use egz_conv3x3_fwd_streamed) and the workspace holds
+// nsplit x B x H x W x K floats.  epi 0 / 1 / 2 as egz_conv3x3_fwd_streamed; K % 128 == 0, C % 32 == 0.
+EGZ_API int egz_conv3x3_streamed_splits(int B, int H, int W, int C, int K) {
+    if (!egz_conv3x3_streamed_ok(B, H, W, C, K, 0)) return 1;
+    return x3s_splits(B, H, W, C, K);
+}
+// rows of the stat_partial buffer a split-K launch with the BN-statistics epilogue fills (one per 32 output pixels)
+EGZ_API int egz_conv3x3_fwd_streamed_splitk_stat_rows(int B, int H, int W) { return egz_cdiv((long)B * H * W, FIX_ROWS); }
+EGZ_API size_t egz_conv3x3_fwd_streamed_splitk_ws_bytes(int B, int H, int W, int K, int nsplit) {
+    return (size_t)nsplit * B * H * W * K * sizeof(float);
+}
+EGZ_API int egz_conv3x3_fwd_streamed_splitk(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
+                                            int B, int H, int W, int C, int K, int epi, int dtype,
+                                            const unsigned int* x_absmax, void* workspace, size_t ws_bytes, int nsplit,
+                                            hipStream_t st) {
+    EGZ_CHECK_ARG(x && wq && y && workspace, "egz_conv3x3_fwd_streamed_splitk: null pointer");
+    EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, 0) && K % 128 == 0 && C % 32 == 0,
+                  "egz_conv3x3_fwd_streamed_splitk: geometry B=%d H=%d W=%d C=%d K=%d is not covered", B, H, W, C, K);
+    EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && epi >= 0 && epi <= 2, "egz_conv3x3_fwd_streamed_splitk: bad dtype / epilogue");
+    EGZ_CHECK_ARG(epi != EPI_BIAS_STATS || stat_partial, "egz_conv3x3_fwd_streamed_splitk: stats epilogue needs stat_partial");
+    EGZ_CHECK_ARG(nsplit >= 2 && nsplit <= C / 32, "egz_conv3x3_fwd_streamed_splitk: nsplit=%d outside [2, C/32]", nsplit);
+    EGZ_CHECK_ARG(ws_bytes >= egz_conv3x3_fwd_streamed_splitk_ws_bytes(B, H, W, K, nsplit),
+                  "egz_conv3x3_fwd_streamed_splitk: workspace too small");
+    const unsigned short* w16 = static_cast<const unsigned short*>(wq);
+    const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
+    float* part = static_cast<float*>(workspace);
+    if (dtype == 1) return launch_x3s_splitk<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, part, nsplit, st);
+    return launch_x3s_splitk<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, part, nsplit, st);
 }

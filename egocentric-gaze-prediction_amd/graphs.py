@@ -1,0 +1,61 @@
+"""hipGraph capture of a launch-bound forward pass (instead of a tracing compiler).
+
+At small batch the eval-mode SP forward is ~150 short kernels: the device waits for the host to issue them one C-ABI call
+at a time.  Every kernel of this package is launched on torch's current stream, so the whole forward -- including the
+second encoder's side stream, which forks from and joins back into the capturing stream (streams.fork) -- can be captured
+once into a hipGraph and replayed with a single launch.  Inputs are copied into static buffers, the outputs are the
+captured tensors (valid until the next replay).  Only for no-grad forwards of modules whose parameters do not change
+between replays (the packed weights are baked into the graph as pointers, their contents are read at replay time -- a
+repack after an optimizer step would be missed, so GraphedModule checks the package's weight epoch and re-captures).
+"""
+from typing import Sequence
+
+import torch
+
+from . import hipops as H
+
+
+class GraphedModule:
+    def __init__(self, module: torch.nn.Module, example_inputs: Sequence[torch.Tensor], warmup: int = 2):
+        self.module = module
+        self._params = list(module.parameters())
+        self.static_in = [t.clone() for t in example_inputs]
+        self.warmup = warmup
+        self.graph = None
+        self.static_out = None
+        self.epoch = None
+
+    def _signature(self):
+        """Changes whenever a parameter was rewritten (torch version counter, the fused optimizer's per-parameter epoch, a
+        wholesale overwrite) or re-allocated: the packed weights inside the captured graph would then be stale."""
+        v = e = 0
+        for p in self._params:
+            v += p._version
+            e += getattr(p, "_egz_epoch", 0)
+        return (H._WEIGHT_EPOCH[0], v, e, self._params[0].data_ptr() if self._params else 0)
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(side):
+            for _ in range(self.warmup):          # lazy packings, workspaces and helper streams exist before the capture
+                self.module(*self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_out = self.module(*self.static_in)
+        self.epoch = self._signature()
+
+    def __call__(self, *inputs):
+        if self.module.training:
+            raise RuntimeError("GraphedModule replays an eval-mode forward; call module.eval() first")
+        if self.graph is None or self.epoch != self._signature():
+            self._capture()
+        for s, t in zip(self.static_in, inputs):
+            if s.shape != t.shape:
+                raise RuntimeError(f"GraphedModule was captured for inputs of shape {tuple(s.shape)}, got {tuple(t.shape)}")
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.static_out

@@ -59,7 +59,7 @@ class _LibProxy:
         fn = getattr(self._raw, name)
 
         def call(*a):
-            if not PROF.enabled or name.endswith(("_bytes", "_rows", "_elems", "_ok")):   # host-side queries launch nothing
+            if not PROF.enabled or name.endswith(("_bytes", "_rows", "_elems", "_ok", "_splits")):   # host-side queries launch nothing
                 return fn(*a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -218,6 +218,9 @@ STREAMED = _os.environ.get("EGAZE_STREAMED", "1") != "0"      # A/B knob: 0 = ha
 # than the run-to-run noise (35.63 vs 35.60 ms) -- so it is opt-in: EGAZE_TILE8=1 (>= 512 columns), EGAZE_TILE8=all (wherever
 # the geometry allows; tests).
 TILE8 = _os.environ.get("EGAZE_TILE8", "0")
+# Split-K form of the streamed kernel when a launch has too few pixel tiles to fill the chip (egz_conv3x3_streamed_splits):
+# batch-1 inference runs its 28 x 28 / 14 x 14 layers on 8-28 of 512 block slots otherwise.  A/B knob: EGAZE_SPLITK=0.
+SPLITK = _os.environ.get("EGAZE_SPLITK", "1") != "0"
 
 
 def _tile8(B, Ho, Wo, C, gemm_out, mode) -> int:
@@ -407,6 +410,17 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         if ups:
             raise RuntimeError("the streamed-weight kernel covers plain convolutions only")
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        ns = LIB.egz_conv3x3_streamed_splits(B, H, W, C, K) if (SPLITK and epi <= EPI_BIAS_STATS) else 1
+        if ns > 1:      # few pixel tiles (batch-1 inference, 14 x 14 layers at small batches): split the channel blocks
+            if stat is not None:        # the fix-up pass emits one partial row per 32 pixels
+                stat = torch.empty((LIB.egz_conv3x3_fwd_streamed_splitk_stat_rows(B, H, W), 2, K), dtype=torch.float64,
+                                   device=x.device)
+            nb = LIB.egz_conv3x3_fwd_streamed_splitk_ws_bytes(B, H, W, K, ns)
+            ws = workspace(nb, x.device)
+            check(LIB.egz_conv3x3_fwd_streamed_splitk(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W,
+                                                      C, K, epi, dtype, _p(absmax), ws.data_ptr(), nb, ns, _stream()),
+                  "egz_conv3x3_fwd_streamed_splitk")
+            return y, stat
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
                                            epi, dtype, _tile8(B, H, W, C, K, 0), _p(absmax), None, None, _stream()),
               "egz_conv3x3_fwd_split")

@@ -83,6 +83,17 @@ int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, i
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
                              const float* mask_src, unsigned int* absmax_out, hipStream_t stream);
+/* Split-K form of a plain egz_conv3x3_fwd_streamed launch for small pixel counts (batch-1 inference as in
+ * run_spatialstream.py:85-138 / AT.py:216, the 14 x 14 layers at the reference's default --batch_size_sp 8): the channel
+ * blocks of a tile are divided over nsplit blocks (raw partial sums in the workspace, nsplit x B x H x W x K floats) and a
+ * fix-up launch sums them in split order and applies the epilogue (epi 0 / 1 / 2).  egz_conv3x3_streamed_splits recommends
+ * the split count; 1 = use egz_conv3x3_fwd_streamed.  K % 128 == 0, C % 32 == 0. */
+int egz_conv3x3_streamed_splits(int B, int H, int W, int C, int K);
+int egz_conv3x3_fwd_streamed_splitk_stat_rows(int B, int H, int W);   /* rows of stat_partial for epi 2 (one per 32 pixels) */
+size_t egz_conv3x3_fwd_streamed_splitk_ws_bytes(int B, int H, int W, int K, int nsplit);
+int egz_conv3x3_fwd_streamed_splitk(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
+                                    int H, int W, int C, int K, int epi, int dtype, const unsigned int* x_absmax,
+                                    void* workspace, size_t ws_bytes, int nsplit, hipStream_t stream);
 /* helpers of the epi = 3 (ReLU mask + bias-gradient sums + abs-max) form of egz_conv3x3_fwd_streamed, which folds the
  * nn.ReLU backward of a decoder layer (models/model_SP.py:13-29) into the data gradient of the layer above it */
 int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t stream);

@@ -182,11 +182,20 @@ def _full_grads_small(seed):
     return tight, (seed, why)
 
 
-def test_model_sp_vs_oracle_full_grads_small():
-    """Every gradient tensor element-wise against the CPU oracle at 32x32 (seconds on CPU)."""
+def test_model_sp_vs_oracle_full_grads_small(monkeypatch):
+    """Every gradient tensor element-wise against the CPU oracle at 32x32 (seconds on CPU).  Which seeds are flip-free depends
+    on the fp32 summation order of the deep layers, so the tight criterion is pinned to ONE order (the unsplit launches the
+    seeds were characterised with); the split-K order these tiny layers get by default must still pass the per-seed
+    direction / size criterion and the forward bound on every seed (its per-op accuracy is test_conv3x3_streamed_splitk)."""
+    import egaze_amd.hipops as H
+    monkeypatch.setattr(H, "SPLITK", False)
     results = [_full_grads_small(seed) for seed in GRAD_SEEDS]
     print("full-grads (tight on seeds %s):" % [r[1][0] for r in results if r[0]], results)
     assert sum(ok for ok, _ in results) >= 2, results
+    monkeypatch.setattr(H, "SPLITK", True)
+    results = [_full_grads_small(seed) for seed in GRAD_SEEDS]
+    print("full-grads, split-K order (tight on seeds %s):" % [r[1][0] for r in results if r[0]], results)
+    assert sum(ok for ok, _ in results) >= 1, results
 
 
 def _grads_vs_fp64(seed):
@@ -227,9 +236,12 @@ def _grads_vs_fp64(seed):
     return True, (seed, float(np.median(eh)), float(eh.max()))
 
 
-def test_model_sp_grads_vs_fp64():
+def test_model_sp_grads_vs_fp64(monkeypatch):
     """Accuracy, not just agreement: the same train step in fp64 on the CPU oracle is the truth; the HIP
-    path's gradient error must be of the same size as the fp32 CPU reference path's own error."""
+    path's gradient error must be of the same size as the fp32 CPU reference path's own error.  (Summation order pinned
+    to the unsplit launches, like test_model_sp_vs_oracle_full_grads_small: which seeds are flip-free depends on it.)"""
+    import egaze_amd.hipops as H
+    monkeypatch.setattr(H, "SPLITK", False)
     results = [_grads_vs_fp64(seed) for seed in GRAD_SEEDS]
     print("grads-vs-fp64 (tight on seeds %s):" % [r[1][0] for r in results if r[0]], results)
     assert sum(ok for ok, _ in results) >= 2, results
@@ -397,6 +409,7 @@ def test_relu_backward_folded_into_dgrad_above(monkeypatch):
     import egaze_amd.hipops as H
     from egaze_amd.floss import floss
     grads = {}
+    monkeypatch.setattr(H, "SPLITK", False)      # the masked epilogue has no split-K form: same summation order on both sides
     for fuse in (True, False):
         monkeypatch.setattr(H, "MASK_FUSE", fuse)
         H.MASK_FUSE_STATS.update(produced=0, consumed=0)
@@ -417,3 +430,41 @@ def test_relu_backward_folded_into_dgrad_above(monkeypatch):
             assert rel(a.numpy(), b.numpy()) < 2e-6, k
         else:
             assert torch.equal(a, b), k
+
+
+def test_graphed_eval_forward_matches_eager_and_follows_weight_updates():
+    """egaze_amd.graphs.GraphedModule: the eval-mode SP forward captured into one hipGraph (both encoder streams, the
+    split-K launches of the small layers, lazy weight packings built before the capture) replays bit-identically to the
+    eager launches, accepts new inputs through its static buffers, and re-captures after the parameters changed."""
+    from egaze_amd.graphs import GraphedModule
+    from egaze_amd.floss import floss
+    from egaze_amd.optim import FusedAdam
+    model, _ = build_model()
+    model.eval()
+    xs = [synth.synth_sp_batch(1, 64, seed=70 + i) for i in range(2)]
+    a = [t.to(DEV) for t in xs[0][:2]]
+    b = [t.to(DEV) for t in xs[1][:2]]
+    with torch.no_grad():
+        ea, eb = model(*a).clone(), model(*b).clone()
+    g = GraphedModule(model, a)
+    assert torch.equal(g(*a), ea)
+    assert torch.equal(g(*b), eb)                      # new input through the static buffers
+    assert torch.equal(g(*a), ea)
+    with pytest.raises(RuntimeError):
+        g(a[0][:, :, :32], a[1][:, :, :32])            # other shape than the captured one
+    # one optimizer step changes the weights: the packed copies inside the graph are stale -> re-capture
+    model.train()
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    opt.zero_grad()
+    gt = xs[0][2].to(DEV)
+    out = model(*a)
+    floss().to(DEV)(out, gt.view(out.size())).backward()
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        ea2 = model(*a).clone()
+    assert not torch.equal(ea2, ea)
+    assert torch.equal(g(*a), ea2)
+    model.train()
+    with pytest.raises(RuntimeError):
+        g(*a)

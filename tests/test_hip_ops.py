@@ -515,8 +515,9 @@ def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
         want = F.relu(ref) if epi == 1 else ref
         y, stat = h.conv3x3_fwd(xd, wp, b.to(DEV), K, epi=epi, dtype=dtype, streamed=True)
         assert rel(nchw(y), want) < tol, epi
-        if epi == 2:
-            assert stat.shape[0] == (B * Hh * Ww + 127) // 128
+        if epi == 2:      # one partial row per 128 pixels, or per 32 when the launch ran split-K (few pixel tiles)
+            per = 32 if h.LIB.egz_conv3x3_streamed_splits(B, Hh, Ww, C, K) > 1 else 128
+            assert stat.shape[0] == (B * Hh * Ww + per - 1) // per
             assert rel(stat.sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
             assert rel(stat.sum(0)[1].cpu(), (ref * ref).sum(dim=(0, 2, 3))) < 1e-5
     if C % 32 == 0 and K % 64 == 0:      # same values as the LDS-DMA halo kernel up to fp32 summation order
@@ -530,6 +531,46 @@ def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
         assert st
         dx = h.conv3x3_dgrad(dyd, wq, C, dtype=dtype, streamed=True)
         assert rel(nchw(dx), dref) < tol
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C,K", [(1, 28, 28, 512, 512), (1, 14, 14, 256, 512), (2, 16, 16, 128, 128),
+                                         (1, 56, 56, 128, 256), (3, 14, 14, 512, 128), (1, 7, 9, 160, 128)])
+def test_conv3x3_streamed_splitk(B, Hh, Ww, C, K, monkeypatch):
+    """Split-K form of the streamed kernel (few pixel tiles: batch-1 inference, 14 x 14 layers): the channel blocks of a tile
+    are divided over several blocks and a fix-up pass sums them and applies the epilogue.  All three epilogues and the data
+    gradient against fp64 and against the unsplit launch (same values up to fp32 summation order, same BN partial sums)."""
+    h = H()
+    ns = h.LIB.egz_conv3x3_streamed_splits(B, Hh, Ww, C, K)
+    assert ns >= 2, "geometry expected to be split"
+    x = rnd(B, C, Hh, Ww, seed=91)
+    w = rnd(K, C, 3, 3, seed=92, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=93, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    wd, xd = w.to(DEV), nhwc(x)
+    wp, st = h.conv_weight(wd, "fwd", 1, xd, K)
+    assert st
+    for epi in (0, 1, 2):
+        want = F.relu(ref) if epi == 1 else ref
+        monkeypatch.setattr(h, "SPLITK", True)
+        y, stat = h.conv3x3_fwd(xd, wp, b.to(DEV), K, epi=epi, dtype=1, streamed=True)
+        monkeypatch.setattr(h, "SPLITK", False)
+        y0, stat0 = h.conv3x3_fwd(xd, wp, b.to(DEV), K, epi=epi, dtype=1, streamed=True)
+        assert rel(nchw(y), want) < 2e-6, epi
+        assert rel(y, y0) < 2e-6, epi
+        if epi == 2:
+            assert stat.shape[0] == (B * Hh * Ww + 31) // 32 and stat0.shape[0] == (B * Hh * Ww + 127) // 128
+            assert rel(stat.sum(0), stat0.sum(0)) < 1e-6
+            assert rel(stat.sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
+            assert rel(stat.sum(0)[1].cpu(), (ref * ref).sum(dim=(0, 2, 3))) < 1e-5
+    if K % 32 == 0 and C % 128 == 0 and h.LIB.egz_conv3x3_streamed_splits(B, Hh, Ww, K, C) >= 2:
+        monkeypatch.setattr(h, "SPLITK", True)
+        dy = rnd(B, K, Hh, Ww, seed=94, scale=1e-4)                 # small gradients: the abs-max scaling path
+        dref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), padding=1)
+        dyd = nhwc(dy)
+        wq, st = h.conv_weight(wd, "dgrad", 1, dyd, C)
+        assert st
+        dx = h.conv3x3_dgrad(dyd, wq, C, dtype=1, streamed=True)
+        assert rel(nchw(dx), dref) < 2e-6
 
 
 def test_conv3x3_streamed_tile8(monkeypatch):
