@@ -70,12 +70,14 @@ def toim(ten):
     return (ten.squeeze().cpu().numpy() * 255).astype(np.uint8)
 
 
-def predict(model, lf, im_bgr_u8, device):
-    """One iteration of the reference's loop body (run_spatialstream.py:123-139). Returns a dict of stages."""
+def predict(model, lf, im_bgr_u8, device, graphed=None):
+    """One iteration of the reference's loop body (run_spatialstream.py:123-139). Returns a dict of stages.
+    ``graphed``: a graphs.GraphedModule of ``model`` (one hipGraph replay instead of ~100 launches for the batch-1 forward;
+    its outputs are static buffers, valid until the next call)."""
     from scipy import ndimage
     im = totensor(im_bgr_u8).to(device)
     with torch.no_grad():
-        out, feat = model(im)
+        out, feat = graphed(im) if graphed is not None else model(im)
     imq = toim(out)
     predicted = ndimage.center_of_mass(imq)
     vec = crop_feature1(feat, predicted, 3)
@@ -96,6 +98,7 @@ def main(argv=None):
     p.add_argument('--trained_late', default='models/late.pth.tar', required=False)
     p.add_argument('--dir', required=True)
     p.add_argument('--device', default='0', help='GPU index')
+    p.add_argument('--hipgraph', action='store_true', help='replay the batch-1 forward as one captured hipGraph')
     args = p.parse_args(argv)
     device = torch.device('cuda:' + args.device)
     model = VGG(make_layers(cfg['D'], 3))
@@ -104,9 +107,13 @@ def main(argv=None):
     lf = late_fusion()
     lf.load_state_dict(torch.load(args.trained_late, map_location='cpu', weights_only=False)['state_dict'])
     lf.to(device).eval()
+    graphed = None
+    if args.hipgraph:
+        from .graphs import GraphedModule
+        graphed = GraphedModule(model, (torch.zeros(1, 3, 224, 224, device=device),))
     for imname in [k for k in os.listdir(args.dir) if 'img' in k]:
         im0 = imread(os.path.join(args.dir, imname))
-        res = predict(model, lf, resize(im0, (224, 224)), device)
+        res = predict(model, lf, resize(im0, (224, 224)), device, graphed)
         fin = resize(toim(res["fin"]), (im0.shape[1], im0.shape[0]))
         try:
             import cv2

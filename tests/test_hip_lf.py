@@ -135,3 +135,10 @@ def test_config1_run_spatialstream_on_hip():
     assert rel(r["vec"].cpu().numpy(), gold["vec"]) < 1e-4
     assert rel(r["weighted"].cpu().numpy(), gold["weighted"]) < 1e-4
     assert rel(r["fin"].cpu().numpy(), gold["fin"]) < 1e-4
+    # the same iteration with the batch-1 forward replayed as one captured hipGraph (--hipgraph): identical stages
+    from egaze_amd.graphs import GraphedModule
+    g = GraphedModule(model, (torch.zeros(1, 3, 224, 224, device=DEV),))
+    r2 = predict(model, lf, im_u8, DEV, g)
+    for k in ("out", "feat", "weighted", "fin"):
+        assert torch.equal(r2[k], r[k]), k
+    assert np.array_equal(r2["imq"], r["imq"])
