@@ -108,7 +108,7 @@ class ConvBNReLUPool(torch.autograd.Function):
             coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
                                  running_var, momentum, eps, nbt)
         else:
-            coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+            coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
         ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta)
         ctx.cfg = (training, pool, first, C, K, padded)
@@ -245,7 +245,7 @@ class FusionBlock(torch.autograd.Function):
             coef = H.bn_finalize(H.channel_stats(z), float(B * Hh * Ww), gamma.detach(), beta.detach(),
                                  running_mean, running_var, momentum, eps, nbt)
         else:
-            coef = H.bn_eval_coeffs(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+            coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(z, coef, False)
         ctx.save_for_backward(x2, y2, z, coef, weight, bias, gamma, beta)
         ctx.cfg = (training, C, K)

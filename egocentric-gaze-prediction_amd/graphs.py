@@ -18,7 +18,7 @@ from . import hipops as H
 class GraphedModule:
     def __init__(self, module: torch.nn.Module, example_inputs: Sequence[torch.Tensor], warmup: int = 2):
         self.module = module
-        self._params = list(module.parameters())
+        self._params = list(module.parameters()) + list(module.buffers())      # BN running statistics feed cached coefficients
         self.static_in = [t.clone() for t in example_inputs]
         self.warmup = warmup
         self.graph = None

@@ -582,6 +582,8 @@ def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, run
     dev = stat.device
     coef = torch.empty((4, K), dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
     ws = workspace(LIB.egz_bn_ws_bytes(K), dev)
+    if running_mean is not None:        # written behind torch's back: invalidate what is cached on it (bn_eval_coeffs)
+        running_mean._egz_epoch = getattr(running_mean, "_egz_epoch", 0) + 1
     check(LIB.egz_bn_finalize(stat.data_ptr(), rows, K, float(count), _p(gamma), _p(beta), _p(running_mean),
                               _p(running_var), momentum, eps, coef[0].data_ptr(), coef[1].data_ptr(),
                               coef[2].data_ptr(), coef[3].data_ptr(), _p(num_batches_tracked), ws.data_ptr(), ws.numel(),
@@ -590,11 +592,32 @@ def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, run
 
 
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps: float):
+    """Eval-mode (scale, shift) rows of a BatchNorm.  Pass the module's own parameter / buffer objects: the result is cached
+    on ``running_mean`` and reused until any of the four tensors changed (torch version counters for in-place torch
+    writes such as load_state_dict or a broadcast, the per-tensor epoch for writes behind torch's back: bn_finalize's
+    running-statistics update, the fused optimizer's step) -- at batch 1 the two launches per layer were a quarter of the
+    device time of a captured forward."""
+    key = (_tag(running_mean), _tag(running_var), None if gamma is None else _tag(gamma), None if beta is None else _tag(beta),
+           float(eps), _stream_device(running_mean))
+    hit = getattr(running_mean, "_egz_evalcoef", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
     K = running_mean.numel()
     coef = torch.zeros((4, K), dtype=torch.float32, device=running_mean.device)
-    check(LIB.egz_bn_eval_coeffs(K, _p(gamma), _p(beta), running_mean.data_ptr(), running_var.data_ptr(), eps,
+    g = None if gamma is None else gamma.detach()
+    b = None if beta is None else beta.detach()
+    check(LIB.egz_bn_eval_coeffs(K, _p(g), _p(b), running_mean.data_ptr(), running_var.data_ptr(), eps,
                                  coef[2].data_ptr(), coef[3].data_ptr(), _stream()), "egz_bn_eval_coeffs")
+    # the cached rows are read by later launches on whatever stream is current then: make them safe to read from any
+    # stream by finishing the two small launches first (once per weight change, not per forward)
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().synchronize()
+        running_mean._egz_evalcoef = (key, coef)
     return coef
+
+
+def _stream_device(t):
+    return t.device.index or 0
 
 
 def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
