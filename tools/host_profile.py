@@ -1,6 +1,5 @@
-"""How long does the HOST need to issue one SP training step (all launches, no synchronisation) vs the GPU time of the step?
-If the two are close the step is launch-bound and a captured hipGraph would pay."""
-import os, sys, time
+"""cProfile of the host side of the SP training step at a small batch (where the step is host-bound)."""
+import cProfile, os, pstats, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import egaze_amd  # noqa
@@ -14,8 +13,7 @@ dev = torch.device("cuda", 0)
 model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20)).to(dev).train()
 crit = floss().to(dev)
 opt = FusedAdam(model.parameters(), lr=1e-7)
-BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-b = synthetic.sp_batch(BATCH, 224, dev, seed=100)
+b = synthetic.sp_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 4, 224, dev, seed=100)
 def step():
     out = model(b["image"], b["flow"])
     loss = crit(out, b["gt"].view(out.size()))
@@ -23,16 +21,15 @@ def step():
     opt.step()
     opt.zero_grad()
 opt.zero_grad()
-for _ in range(3):
+for _ in range(5):
     step()
 torch.cuda.synchronize()
-host = []
-t0 = time.perf_counter()
-for _ in range(10):
-    h0 = time.perf_counter()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
     step()
-    host.append(time.perf_counter() - h0)
 torch.cuda.synchronize()
-tot = (time.perf_counter() - t0) / 10
-print("host issue per step: first %.2f ms, min %.2f ms, median %.2f ms; wall per step %.2f ms" %
-      (host[0] * 1e3, min(host) * 1e3, sorted(host)[5] * 1e3, tot * 1e3))
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(35)
+st.sort_stats("cumtime").print_stats(45)
