@@ -107,6 +107,74 @@ def get_weighted(chn_weight, feature):
     return feature / torch.max(feature)
 
 
+AT_GRAPH = os.environ.get("EGAZE_AT_GRAPH", "1") != "0"      # A/B knob: 0 = issue every sample step launch by launch
+
+
+class _GraphedSampleStep:
+    """One training step of AT.trainLSTM's loop captured into a hipGraph (the reference issues it per fixation sample,
+    AT.py:127-145; ~20 launches plus autograd and optimizer bookkeeping on the host every time):
+
+        pred, (h, c) = lstm(inp, (h, c));  loss = MSE(pred, tanh(target));  zero_grad;  backward;  Adam step
+
+    The reference scores the prediction made from sample i-1 against target i and only then steps the network on sample i,
+    so the forward pass of sample i-1 is deferred until target i is known -- the parameters it sees are the same (those
+    after the update of iteration i-1) and so is every loss, every update and the carried state.  Inputs, state and loss live
+    in static buffers; the Adam step counter lives on the device (FusedAdam.set_capturable).  The first ``WARM`` steps run
+    eagerly through the same function (they are real training steps), then the step is captured once and replayed."""
+    WARM = 3
+
+    def __init__(self, lstm, criterion, optimizer, device, width):
+        self.lstm, self.criterion, self.opt = lstm, criterion, optimizer
+        self.both = torch.zeros((2, 1, 1, width), device=device)          # (input, target) of the step: ONE host copy fills it
+        self.state = torch.zeros((2, lstm.num_layer, 1, lstm.num_channel), device=device)      # (h, c)
+        self.loss = None                     # the loss tensor of the last step (a graph-owned tensor once captured)
+        self.graph, self.calls = None, 0
+        self.opt.set_capturable(True)
+
+    def _unit(self):
+        pred, (hn, cn) = self.lstm(self.both[0], (self.state[0], self.state[1]))
+        loss = self.criterion(pred, torch.tanh(self.both[1]))
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        # (hn, cn) share one buffer on the single-step path: one copy carries the state over -- after the backward pass,
+        # which reads the incoming state
+        base = getattr(hn, "_base", None)
+        if base is not None and base is getattr(cn, "_base", None) and base.numel() == self.state.numel():
+            self.state.copy_(base.detach().view_as(self.state))
+        else:
+            self.state[0].copy_(hn.detach())
+            self.state[1].copy_(cn.detach())
+        self.loss = loss.detach()
+
+    def reset_state(self):
+        self.state.zero_()
+
+    def step(self, host_pair):
+        """host_pair: pinned (2, width) tensor = (input of the deferred sample, target of the current one) -> loss (0-d)."""
+        self.both.copy_(host_pair.view_as(self.both), non_blocking=True)
+        self.calls += 1
+        if self.graph is None and self.calls <= self.WARM:
+            self._unit()
+        elif self.graph is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            count = self.opt.step_count
+            with torch.cuda.graph(g):
+                self._unit()
+            self.opt.step_count = count        # the capture ran the host side of step() without executing anything
+            self.graph = g
+            g.replay()
+            self.opt.note_replays(1)
+        else:
+            self.graph.replay()
+            self.opt.note_replays(1)
+        return self.loss
+
+    def close(self):
+        self.opt.set_capturable(False)
+
+
 class AT():
     def __init__(self, pretrained_model=None, pretrained_lstm=None, extract_lstm=False, crop_size=3,
                  num_epoch_lstm=30, lstm_save_img='loss_lstm.png', save_path='save', save_name='best_lstm.pth.tar',
@@ -144,7 +212,37 @@ class AT():
         self.lstm.load_state_dict(merged)
         print('loaded pretrained lstm from ' + pretrained_lstm)
 
+    def _epoch_graphed(self, loader):
+        """trainLSTM's loop with the per-sample step replayed from a hipGraph (_GraphedSampleStep)."""
+        losses = AverageMeter()
+        runner, stage, prev_inp, reset = None, None, None, True
+        try:
+            for i, sample in enumerate(loader):
+                n = sample['input'].numel()
+                if stage is None:
+                    stage = torch.empty((2, 2, n), dtype=torch.float32).pin_memory()
+                    runner = _GraphedSampleStep(self.lstm, self.criterion_lstm, self.optimizer_lstm, self.device, n)
+                same = int(sample['same'])
+                if prev_inp is not None:
+                    # step on the previous sample's input (forward) scored against THIS sample's target
+                    slot = stage[i & 1]
+                    slot[0].copy_(prev_inp)
+                    slot[1].copy_(sample['gt'].reshape(-1))
+                    if reset:
+                        runner.reset_state()
+                    losses.update(runner.step(slot).item())
+                    reset = False
+                if same == 0:                       # the state is reset before THIS sample's forward pass (AT.py:129-130)
+                    reset = True
+                prev_inp = sample['input'].reshape(-1).clone()
+        finally:
+            if runner is not None:
+                runner.close()
+        return losses.avg
+
     def _epoch(self, loader, train):
+        if train and AT_GRAPH and self.device.type == 'cuda':
+            return self._epoch_graphed(loader)
         losses = AverageMeter()
         hidden, pred_chn_weight, stage = None, None, None
         for i, sample in enumerate(loader):

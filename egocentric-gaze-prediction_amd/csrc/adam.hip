@@ -39,7 +39,63 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p[t] = p[t] - step_size * (mm / (sqrtf(vq) / bc2_sqrt + eps));
     }
 }
+// Step count on the device (hipGraph-captured training steps: a replay cannot receive a new host scalar).  The bias
+// corrections are formed in fp64 from *step + 1 exactly as the host form does; adam_bump_kernel increments the counter after
+// the update (a separate launch: every block of the update reads the same value).
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, double lr, double beta1, double beta2,
+                                                       float eps, const int* __restrict__ step, float grad_scale) {
+    const double t = (double)(*step + 1);
+    const float omb1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2);
+    const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gv[e] * grad_scale;
+            mv[e] = mv[e] + omb1 * (ge - mv[e]);
+            vv[e] = vv[e] * b2 + omb2 * ge * ge;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pv[e] = pv[e] - step_size * (mv[e] / denom);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    const long tl = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (tl < n) {
+        const float ge = g[tl] * grad_scale;
+        const float mm = m[tl] + omb1 * (ge - m[tl]);
+        const float vq = v[tl] * b2 + omb2 * ge * ge;
+        m[tl] = mm;
+        v[tl] = vq;
+        p[tl] = p[tl] - step_size * (mm / (sqrtf(vq) / bc2_sqrt + eps));
+    }
+}
+__global__ void adam_bump_kernel(int* step) { *step += 1; }
 }  // namespace
+
+// egz_adam_step with the (0-based, completed-steps) counter on the device: applies step *step + 1 and increments *step.
+EGZ_API int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                              double eps, int* step, double grad_scale, hipStream_t st) {
+    EGZ_CHECK_ARG(p && g && m && v && step && n > 0, "egz_adam_step_dev: bad arguments");
+    EGZ_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                  "egz_adam_step_dev: buffers must be 16-byte aligned");
+    long g4 = (n / 4 + 255) / 256;
+    if (g4 < 1) g4 = 1;
+    const int grid = (int)(g4 > 8192 ? 8192 : g4);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, (float)eps, step,
+                       (float)grad_scale);
+    EGZ_CHECK_LAUNCH("egz_adam_step_dev");
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, step);
+    EGZ_CHECK_LAUNCH("egz_adam_step_dev(bump)");
+    return 0;
+}
 
 // Hyper-parameters are doubles (Python floats) so 1-beta keeps its precision.  step: 1-based step count.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
 EGZ_API int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,

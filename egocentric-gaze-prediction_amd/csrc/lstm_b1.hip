@@ -144,23 +144,29 @@ __global__ __launch_bounds__(128) void outer_b1_kernel(const float* __restrict__
 // dh[j] = sum_s part[s][j] (+ dhn[j]); cell backward of one step with no later step: dc = dcn[j] + dh * o * (1 - tanh(c)^2)
 //   di = dc * g * i (1 - i), df = dc * c_prev * f (1 - f), dg = dc * i * (1 - g^2), do = dh * tanh(c) * o (1 - o)
 // dh_prev / dc_prev are not produced here: the caller's hidden state carries no gradient on this path.
-__global__ __launch_bounds__(64) void cell_bwd_b1_kernel(const float* __restrict__ part, int nstrips,
+// Block = 32 hidden units x 8 strip groups: group q sums strips q, q + 8, ... (independent loads in flight), the eight group
+// sums are combined in group order through LDS (fixed order: deterministic), then 32 threads do the cell arithmetic.
+__global__ __launch_bounds__(256) void cell_bwd_b1_kernel(const float* __restrict__ part, int nstrips,
                                                           const float* __restrict__ dhn, const float* __restrict__ dcn,
                                                           const float* __restrict__ act, const float* __restrict__ c_new,
                                                           const float* __restrict__ c_prev, float* __restrict__ dgates,
                                                           int H) {
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= H) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= nstrips; s += 4) {
-        a0 += part[(long)s * H + j];
-        a1 += part[(long)(s + 1) * H + j];
-        a2 += part[(long)(s + 2) * H + j];
-        a3 += part[(long)(s + 3) * H + j];
+    __shared__ float red[8][32];
+    const int jl = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + jl;
+    float a0 = 0.f, a1 = 0.f;
+    if (j < H) {
+        int s = q;
+        for (; s + 8 < nstrips; s += 16) {
+            a0 += part[(long)s * H + j];
+            a1 += part[(long)(s + 8) * H + j];
+        }
+        if (s < nstrips) a0 += part[(long)s * H + j];
     }
-    for (; s < nstrips; ++s) a0 += part[(long)s * H + j];
-    float dh = (a0 + a1) + (a2 + a3);
+    red[q][jl] = a0 + a1;
+    __syncthreads();
+    if (q != 0 || j >= H) return;
+    float dh = ((red[0][jl] + red[1][jl]) + (red[2][jl] + red[3][jl])) + ((red[4][jl] + red[5][jl]) + (red[6][jl] + red[7][jl]));
     if (dhn) dh += dhn[j];
     const float ig = act[j], fg = act[H + j], gg = act[2 * H + j], og = act[3 * H + j];
     const float tc = tanhf(c_new[j]);
@@ -225,7 +231,7 @@ EGZ_API int egz_lstm_b1_bwd(const void* const* params, void* const* grads, int L
     EGZ_CHECK_LAUNCH("egz_lstm_b1_bwd(lin)");
     for (int l = L - 1; l >= 0; --l) {
         float* dg = dgates + (long)l * 4 * H;
-        hipLaunchKernelGGL(cell_bwd_b1_kernel, dim3((H + 63) / 64), dim3(64), 0, st, part, strips,
+        hipLaunchKernelGGL(cell_bwd_b1_kernel, dim3((H + 31) / 32), dim3(256), 0, st, part, strips,
                            dhn ? dhn + (long)l * H : nullptr, dcn ? dcn + (long)l * H : nullptr, acts + (long)l * 4 * H,
                            cn + (long)l * H, c0 + (long)l * H, dg, H);
         EGZ_CHECK_LAUNCH("egz_lstm_b1_bwd(cell)");

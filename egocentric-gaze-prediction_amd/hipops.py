@@ -826,6 +826,12 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
                             int(step), grad_scale, _stream()), "egz_adam_step")
 
 
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
+    """Adam step whose counter of completed steps lives on the device (int32 tensor): usable inside a captured hipGraph."""
+    check(LIB.egz_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                                step_dev.data_ptr(), grad_scale, _stream()), "egz_adam_step_dev")
+
+
 # ----------------------------------------------------------------------------- AT: GEMM + LSTM cell
 def gemm(a: torch.Tensor, b: torch.Tensor, M: int, N: int, K: int, a_strides, b_strides, out: torch.Tensor = None,
          bias: torch.Tensor = None, accumulate: bool = False, relu: bool = False) -> torch.Tensor:
@@ -927,8 +933,8 @@ def lstm_b1_fwd(params, inp, h0, c0, want_acts: bool = True):
     dev = inp.device
     xt = torch.empty(C, dtype=torch.float32, device=dev)
     acts = torch.empty((L, 4 * Hd), dtype=torch.float32, device=dev) if want_acts else None
-    hn = torch.empty((L, Hd), dtype=torch.float32, device=dev)
-    cn = torch.empty_like(hn)
+    hc = torch.empty((2, L, Hd), dtype=torch.float32, device=dev)     # (hn, cn) in one buffer: a caller can copy both at once
+    hn, cn = hc[0], hc[1]
     out = torch.empty(N, dtype=torch.float32, device=dev)
     check(LIB.egz_lstm_b1_fwd(_ptr_table(params), L, inp.data_ptr(), h0.data_ptr(), c0.data_ptr(), xt.data_ptr(), _p(acts),
                               hn.data_ptr(), cn.data_ptr(), out.data_ptr(), C, Hd, N, _stream()), "egz_lstm_b1_fwd")

@@ -68,6 +68,21 @@ class FusedAdam:
                 p._egz_sink = H.GradSink(self.flat_g[o:o + n], self)
         H.bump_weight_epoch()
         self.pre_step_hooks = []          # dp.GradReducer registers its wait() here
+        self.capturable = False
+        self.step_dev = None
+
+    def set_capturable(self, on: bool = True):
+        """Keep the step counter on the device (egz_adam_step_dev), so that step() can sit inside a captured hipGraph.  Every
+        replay advances the device counter; the owner of the graph adds the replays to ``step_count`` (note_replays)."""
+        if on:
+            self.step_dev = torch.tensor([self.step_count], dtype=torch.int32, device=self.flat_p.device)
+        elif self.capturable:
+            self.step_count = int(self.step_dev.item())
+        self.capturable = on
+
+    def note_replays(self, n: int = 1):
+        """A captured graph containing step() was replayed n times: the host-side count follows the device counter."""
+        self.step_count += n
 
     # -- torch.optim.Optimizer surface used by the drivers
     def zero_grad(self, set_to_none: bool = False):
@@ -86,10 +101,19 @@ class FusedAdam:
             hook()
         # gradients are written in place by kernels on several HIP streams (encoder / wgrad helper streams, streams.py);
         # autograd only orders the streams its own AccumulateGrad nodes ran on, so order all of them here
-        streams.join_all_into_current()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:             # (a capture holds exactly the streams that forked from it; nothing else may be joined)
+            streams.join_all_into_current()
         self.step_count += 1
-        H.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
-                    self.eps, self.step_count, self.grad_scale)
+        if self.capturable:
+            # the step counter lives on the device so that a captured step can be replayed (set_capturable)
+            H.adam_step_dev(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
+                            self.eps, self.step_dev, self.grad_scale)
+        else:
+            if capturing:
+                raise RuntimeError("FusedAdam.step() inside a hipGraph capture needs set_capturable(True)")
+            H.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
+                        self.eps, self.step_count, self.grad_scale)
         H.touch_params(self.params)
         if _MULTIPACK:
             H.repack_params(self.params)  # every cached split-half weight packing, one launch
@@ -130,6 +154,8 @@ class FusedAdam:
                 self.flat_m[o:o + n].copy_(st["exp_avg"].reshape(-1))
                 self.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_count = int(float(st["step"]))
+        if self.capturable:
+            self.step_dev.fill_(self.step_count)
 
 
 Adam = FusedAdam

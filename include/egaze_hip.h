@@ -220,6 +220,10 @@ int egz_add(const float* a, const float* b, float* out, long n, hipStream_t stre
  *      grad_scale multiplies the gradient first (1/world_size after the RCCL sum all-reduce). */
 int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                   double eps, int step, double grad_scale, hipStream_t stream);
+/* the same step with the counter of COMPLETED steps on the device (applies step *step + 1, then increments *step): for
+ * optimizer steps inside a captured hipGraph, where a replay cannot receive a new host scalar */
+int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
+                      double eps, int* step, double grad_scale, hipStream_t stream);
 
 /* utils.computeAAEAUC (utils.py:96-140) per sample on the device: res (B,6) doubles = (AAE deg, fp = #{z > z[gp]}, gaze row,
  * gaze col, centroid row, centroid col); gw = the 2R+1 weights of scipy's gaussian kernel (sigma 14, R = 56),

@@ -186,3 +186,76 @@ def test_lstmnet_single_step_routes():
     with torch.no_grad():
         o1, (h1, c1) = net(inp.to(DEV), None)
     assert rel(o1.cpu().numpy(), out.detach().cpu().numpy()) == 0.0
+
+
+def _at_shell(net, opt):
+    """An AT driver object with just what _epoch needs (the constructor wants a trained SP checkpoint and dataset folders)."""
+    from egaze_amd.AT import AT
+    from egaze_amd.functions import MSELoss
+    at = AT.__new__(AT)
+    at.lstm, at.optimizer_lstm, at.criterion_lstm, at.device = net, opt, MSELoss.apply, torch.device(DEV)
+    return at
+
+
+def test_at_epoch_graphed_matches_golden_and_eager(monkeypatch):
+    """AT.trainLSTM's loop with the per-sample step replayed from a captured hipGraph (AT._epoch_graphed: deferred forward,
+    static buffers, device-side Adam counter): the reference's own 5-sample replay fixture (video break included), and a
+    24-sample run against the launch-by-launch loop of the same build -- same mean loss, same final parameters, same
+    optimizer step count."""
+    import egaze_amd.AT as at_mod
+    from egaze_amd.optim import FusedAdam
+    gold = np.load(os.path.join(GOLDEN, "lstmnet.npz"))
+    ins, tgts = synth.synth_at_batch(5, 1, seed=6)
+    same = [1, 1, 1, 0, 1]
+    loader = [{"input": ins[i], "gt": tgts[i], "same": torch.tensor([same[i]])} for i in range(5)]
+    monkeypatch.setattr(at_mod, "AT_GRAPH", True)
+    net = build()
+    opt = FusedAdam(net.parameters(), lr=1e-4)
+    mean_loss = _at_shell(net, opt)._epoch(loader, True)
+    assert abs(mean_loss - float(np.mean(gold["replay_losses"]))) < 1e-4 * abs(float(np.mean(gold["replay_losses"])))
+    assert rel(net.lin.bias.detach().cpu().numpy(), gold["replay_lin_bias"]) < 1e-4
+    ws = np.array([p.detach().double().sum().item() for p in net.parameters()])
+    assert np.allclose(ws, gold["replay_w_sum"], rtol=1e-4, atol=1e-5)
+    assert opt.step_count == 4 and not opt.capturable
+
+    g = torch.Generator().manual_seed(8)
+    n = 24
+    flags = [1] * n
+    flags[9] = flags[17] = 0
+    loader = [{"input": torch.randn(1, 512, generator=g), "gt": torch.rand(1, 512, generator=g), "same": torch.tensor([flags[i]])}
+              for i in range(n)]
+    res = {}
+    for graphed in (True, False):
+        monkeypatch.setattr(at_mod, "AT_GRAPH", graphed)
+        net = build()
+        opt = FusedAdam(net.parameters(), lr=1e-4)
+        loss = _at_shell(net, opt)._epoch(loader, True)
+        res[graphed] = (loss, {k: p.detach().cpu().clone() for k, p in net.named_parameters()}, opt.step_count)
+    assert res[True][2] == res[False][2] == n - 1
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0])
+    for k in res[True][1]:
+        assert rel(res[True][1][k].numpy(), res[False][1][k].numpy()) < 1e-5, k
+
+
+def test_fused_adam_device_step_counter():
+    """egz_adam_step_dev (counter on the device, for captured steps) against the host-counter form over several steps."""
+    from egaze_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    w0 = torch.randn(1000, generator=g)
+    grads = [torch.randn(1000, generator=g) for _ in range(6)]
+    out = {}
+    for cap in (False, True):
+        p = torch.nn.Parameter(w0.clone().to(DEV))
+        opt = FusedAdam([p], lr=1e-2)
+        if cap:
+            opt.set_capturable(True)
+        for gr in grads:
+            opt.zero_grad()
+            p.grad.copy_(gr.to(DEV))
+            opt.step()
+        if cap:
+            assert int(opt.step_dev.item()) == 6
+            opt.set_capturable(False)
+        assert opt.step_count == 6
+        out[cap] = p.detach().cpu()
+    assert rel(out[True].numpy(), out[False].numpy()) < 1e-6

@@ -9,11 +9,14 @@ rm -rf /tmp/lf
 rocprofv3 --kernel-trace --output-format csv -d /tmp/lf -o p -- python $R/tools/bench_lf.py --steps 10 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/lf $O/r02_lf_kernel_stats.txt "python tools/bench_lf.py --steps 10" > /dev/null
 
-# AT.trainLSTM per-sample loop (T = 1, B = 1): fused single-step path vs the sequence path, + kernel stats of the fused path
-{ echo "# python tools/bench_at_loop.py --n 2000   (default: fused single-step path, csrc/lstm_b1.hip)"
+# AT.trainLSTM per-sample loop (T = 1, B = 1): hipGraph replay / launch by launch on the fused single-step kernels / on the
+# sequence kernels, + kernel stats of the default
+{ echo "# python tools/bench_at_loop.py --n 2000   (default: one hipGraph replay per sample)"
   python $R/tools/bench_at_loop.py --n 2000 2>&1 | grep "AT.trainLSTM"
-  echo "# EGAZE_LSTM_B1=0 python tools/bench_at_loop.py --n 2000   (sequence path)"
-  EGAZE_LSTM_B1=0 python $R/tools/bench_at_loop.py --n 2000 2>&1 | grep "AT.trainLSTM"; } > $O/r02_at_sample_loop.txt
+  echo "# EGAZE_AT_GRAPH=0   (launch by launch, fused single-step kernels csrc/lstm_b1.hip)"
+  EGAZE_AT_GRAPH=0 python $R/tools/bench_at_loop.py --n 2000 2>&1 | grep "AT.trainLSTM"
+  echo "# EGAZE_AT_GRAPH=0 EGAZE_LSTM_B1=0   (launch by launch, sequence kernels)"
+  EGAZE_AT_GRAPH=0 EGAZE_LSTM_B1=0 python $R/tools/bench_at_loop.py --n 2000 2>&1 | grep "AT.trainLSTM"; } > $O/r02_at_sample_loop.txt
 rm -rf /tmp/atl
 rocprofv3 --kernel-trace --output-format csv -d /tmp/atl -o p -- python $R/tools/bench_at_loop.py --n 200 > /dev/null 2>&1
 python $R/tools/prof_summary.py /tmp/atl /tmp/atl_stats.txt "python tools/bench_at_loop.py --n 200" > /dev/null
