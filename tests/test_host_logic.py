@@ -180,3 +180,20 @@ def test_align_window_weights_equal_interpolate_crop_mean():
             assert abs(W.sum() - 1.0) < 1e-12
             got = (feat[0].double().numpy() * W[None]).sum((1, 2))
             assert np.abs(got - ref).max() < 1e-6, (size, gp)
+
+
+def test_staged_batches_cpu_fallback_keeps_order_and_values():
+    """data.STdatas.staged_batches without a GPU (or with EGAZE_STREAMS=0): plain in-loop staging, every batch once, in
+    order, through the caller's staging function when one is given (the LF loop's)."""
+    import torch
+    from egaze_amd.data.STdatas import staged_batches
+    batches = [{'image': torch.full((1, 3, 4, 4), float(k)), 'flow': torch.full((1, 20, 4, 4), float(k)),
+                'gt': torch.full((1, 1, 4, 4), float(k)), 'k': k} for k in range(4)]
+    seen = []
+    for sample, (im, fl, gt) in staged_batches(batches, 'cpu'):
+        assert float(im.mean()) == float(fl.mean()) == float(gt.mean()) == sample['k']
+        seen.append(sample['k'])
+    assert seen == [0, 1, 2, 3]
+    out = list(staged_batches(batches, 'cpu', stage=lambda s, d: (s['gt'] + 1,)))
+    assert [float(t[0].mean()) for _, t in out] == [1.0, 2.0, 3.0, 4.0]
+    assert list(staged_batches([], 'cpu')) == []
