@@ -648,3 +648,53 @@ def test_conv3x3_streamed_ups_dgrad(B, Hl, Wl, C, K, dtype, tol):
     assert rel(nchw(dx), x.grad) < tol
     dg = h.conv3x3_ups_dgrad(dyd, h.packed_weight(wd, "ups_dgrad", dtype), C, dtype=dtype)
     assert rel(dx, dg) < (2e-6 if dtype == 1 else 3e-5)
+
+
+def test_cabi_argument_errors_are_loud():
+    """Error behaviour of the boundary: bad arguments never launch -- the C-ABI returns a non-zero code with a message
+    (egz_last_error) and the Python layer raises RuntimeError, as the reference's torch ops would (empty batch, wrong
+    layout, host tensors, a geometry an entry point does not cover, an undersized workspace)."""
+    h = H()
+    w = rnd(64, 64, 3, 3, seed=1).to(DEV)
+    x = nhwc(rnd(2, 64, 16, 16, seed=2))
+    wp = h.packed_weight(w, "fwd", 0)
+    with pytest.raises(RuntimeError):                                  # empty batch
+        h.conv3x3_fwd(torch.empty((0, 16, 16, 64), device=DEV), wp, None, 64)
+    with pytest.raises(RuntimeError):                                  # non-contiguous operand
+        h.conv3x3_fwd(x.transpose(1, 2), wp, None, 64)
+    with pytest.raises(RuntimeError):                                  # host tensor
+        h.conv3x3_fwd(x.cpu(), wp, None, 64)
+    with pytest.raises(RuntimeError):                                  # fp64 operand
+        h.conv3x3_fwd(x.double(), wp, None, 64)
+    # a geometry the streamed kernel does not cover is refused by the entry point itself, not silently mis-run
+    assert h.LIB.egz_conv3x3_streamed_ok(2, 16, 16, 30, 64, 0) == 0
+    y = torch.empty((2, 16, 16, 64), device=DEV)
+    rc = h.LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, 2, 16, 16, 30, 64, 0, 1, 0,
+                                        None, None, None, h._stream())
+    assert rc != 0
+    with pytest.raises(RuntimeError, match="egz_conv3x3_fwd_streamed"):
+        h.check(rc, "egz_conv3x3_fwd_streamed")
+    # split-K needs its workspace
+    xs = nhwc(rnd(1, 256, 14, 14, seed=3))
+    ws_ = rnd(512, 256, 3, 3, seed=4).to(DEV)
+    wq, st = h.conv_weight(ws_, "fwd", 1, xs, 512)
+    ns = h.LIB.egz_conv3x3_streamed_splits(1, 14, 14, 256, 512)
+    assert st and ns >= 2
+    yo = torch.empty((1, 14, 14, 512), device=DEV)
+    small = torch.empty(16, device=DEV)
+    rc = h.LIB.egz_conv3x3_fwd_streamed_splitk(xs.data_ptr(), wq.data_ptr(), None, yo.data_ptr(), None, 1, 14, 14, 256, 512, 0, 1,
+                                               None, small.data_ptr(), 64, ns, h._stream())
+    assert rc != 0
+    with pytest.raises(RuntimeError, match="workspace"):
+        h.check(rc, "egz_conv3x3_fwd_streamed_splitk")
+
+
+def test_large_operand_routes_to_the_64bit_addressed_kernels(monkeypatch):
+    """Operands of 4 GiB or more cannot use the split-half kernels' 32-bit buffer offsets: conv_dtype sends them to the
+    exact-f32 kernels (64-bit addressing).  The threshold is lowered here so that an ordinary tensor takes that route, and
+    the result is checked against the default route."""
+    h = H()
+    x = nhwc(rnd(2, 64, 32, 32, seed=5))
+    assert h.conv_dtype("fwd", 128, 64, x) == h.F16X3
+    monkeypatch.setattr(h, "_SPLIT_MAX_BYTES", 1024)
+    assert h.conv_dtype("fwd", 128, 64, x) == h.F32 and h.conv_dtype("dgrad", 64, 128, x) == h.F32
