@@ -38,6 +38,34 @@ def kernel_src_sha():
     return h.hexdigest()[:16]
 
 
+def mfma_power_probe(dev, ms_target=30.0):
+    """Sustained v_mfma_f32_32x32x16_f16 rate of THIS chip on random operand bits (csrc/probe.hip): register operands, no
+    memory traffic.  MI355X manages its matrix cores against a power budget -- ~1.5 PFLOP/s on random bits vs 2.4 on zeros
+    (profiles/r02_mfma_power_probe.txt) and the figure differs by several per cent from chip to chip -- so the bench line
+    carries the ceiling of the box it ran on: roofline.power_ceiling_tflops (MFMA TFLOP/s; one algorithmic MAC of the
+    split-half kernels costs 3 MFMA MACs) and the effective clock it implies (1024 flop / cycle / SIMD, 1024 SIMDs)."""
+    import egaze_amd.hipops as H
+    frag = torch.randn(16 * 64 * 8, device=dev).to(torch.float16)
+    blocks = 2048
+    out = torch.empty(blocks * 256, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        H.check(H._RAW_LIB.egz_mfma_probe(frag.data_ptr(), out.data_ptr(), blocks, iters, st), "egz_mfma_probe")
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    run(200)
+    t = run(1000)
+    iters = max(1000, int(1000 * ms_target / max(t, 1e-3)))
+    ms = run(iters)
+    tf = blocks * 4 * iters * 8 * 32768.0 / (ms * 1e-3) / 1e12
+    return {"tflops": tf, "ms": ms, "effective_clock_ghz": tf * 1e12 / (1024 * 1024 * 1e9)}
+
+
 def cpu_baseline(batch=8, size=224, threads=16, timed_steps=3):
     """The reference's CPU algorithm (oracle/, pinned to the reference by golden vectors) on the host cores:
     one warm-up + one timed SP train step (fwd + floss + bwd + Adam) at a bounded batch."""
@@ -62,8 +90,8 @@ def cpu_baseline(batch=8, size=224, threads=16, timed_steps=3):
             "sample": f"oracle SP train step (fwd+floss+bwd+Adam; the reference's PyTorch-CPU algorithm), batch "
                       f"{batch}, {size}x{size}, 1 warm-up + {timed_steps} timed steps, {dt:.2f} s/step, torch-CPU "
                       f"fp32 on {cores} threads (best of an 8/16/32/64 sweep, profiles/r02_cpu_baseline_thread_sweep.txt; host has "
-                      f"{avail}); frames/s is batch-independent here (a batch-32 step takes 4x as long), so it is also the "
-                      f"batch-32 figure"}
+                      f"{avail}); the same oracle step at batch 32 was measured once per round on a GPU box "
+                      f"(profiles/r03_cpu_baseline_b32.txt) -- batch 8 is the bounded sample, and the faster of the two per frame"}
 
 
 def main():
@@ -109,9 +137,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # EGAZE_DP_FORCE=1 at N = 1: a process group of ONE rank over RCCL -- the timed step then runs the data-parallel code
+    # path (bucket hooks, async all-reduce from the comm stream, the joins in front of Adam) on the one GPU of the box
+    dp_forced = world == 1 and os.environ.get("EGAZE_DP_FORCE") == "1"
+    if world > 1 or dp_forced:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if dp_forced and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -134,7 +170,7 @@ def main():
     model.train()
     criterion = floss().to(dev)
     optimizer = FusedAdam(model.parameters(), lr=1e-7)          # gaze_full.py --lr default
-    if world > 1:
+    if dist is not None:
         dp.attach(optimizer)
     batch = synthetic.sp_batch(args.batch, args.size, dev, seed=100 + rank)
     input_s, input_t, target = batch["image"], batch["flow"], batch["gt"]
@@ -148,7 +184,7 @@ def main():
         lstm = lstmnet().to(dev)
         lstm.train()
         opt_at = FusedAdam(lstm.parameters(), lr=1e-4)          # AT.py:84
-        if world > 1:
+        if dist is not None:
             dp.attach(opt_at)
         atb = synthetic.at_batch(T_AT, args.batch, dev, seed=200 + rank)
         at_in, at_tgt = atb["input"], torch.tanh(atb["gt"])
@@ -190,6 +226,11 @@ def main():
                 at_step()
         return loss
 
+    probe = None
+    if rank == 0 and not args.no_roofline:
+        probe = mfma_power_probe(dev)
+        print(f"[bench] bare-MFMA probe (f16 32x32x16, random bits): {probe['tflops']:.0f} TFLOP/s "
+              f"= {probe['effective_clock_ghz']:.2f} GHz effective", file=sys.stderr, flush=True)
     optimizer.zero_grad()
     for _ in range(args.warmup):
         step()
@@ -210,12 +251,14 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = args.batch * world * args.steps / elapsed
     last_loss = loss.item()
+    del loss            # the last graph (and its AccumulateGrad nodes, bound to this leg's streams) dies here
 
     roofline = None
     breakdown = None
     f32_ms = None
     at_ms = None
     pcie_ms = {}
+    rccl = None
     if not args.no_roofline:
         # Every rank runs these two extra (untimed) steps -- the gradient all-reduce inside step() is a collective --
         # but only rank 0 reports.  Per-kernel HIP-event timing needs the kernels serialised: the multi-stream
@@ -271,6 +314,13 @@ def main():
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
                         "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
                         "algorithmic_flop_per_step": ig["flops"]}
+            if probe is not None and split:
+                # this box's own ceiling: bare MFMA rate on random bits / 3 MFMA MACs per algorithmic MAC
+                roofline.update({"power_ceiling_tflops": probe["tflops"], "effective_clock_ghz": probe["effective_clock_ghz"],
+                                 "frac_of_power_ceiling": achieved / (probe["tflops"] / 3.0),
+                                 "power_ceiling_note": "egz_mfma_probe (csrc/probe.hip) run for ~30 ms before the timed region: "
+                                                       "sustained v_mfma_f32_32x32x16_f16 TFLOP/s on random operand bits; "
+                                                       "frac_of_power_ceiling = achieved / (ceiling / 3)"})
         if use_at:
             # config 4 standalone: the AT step alone (lstmnet T=16, B=32 forward + MSE + backward + Adam), untimed leg
             torch.cuda.synchronize()
@@ -322,6 +372,43 @@ def main():
                         t1 = time.perf_counter()
                     step(staged).item()
                 pcie_ms[tag + "_prefetched"] = (time.perf_counter() - t1) / 5 * 1e3
+        if world == 1 and dist is None:
+            # The data-parallel code path on this one GPU (untimed leg): a process group of ONE rank over RCCL, the gradient
+            # reducer attached to the live optimizers -- bucket hooks fired from the gradient sinks during backward, async
+            # all-reduces issued from the comm stream, handles joined in front of Adam -- against the same steps without it.
+            try:
+                import socket
+                import torch.distributed as tdist
+                def _timed(n):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(n):
+                        step()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t1) / n * 1e3
+                step()
+                plain_ms = _timed(5)
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    port = s_.getsockname()[1]
+                tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                reds = [(dp.attach(optimizer, force=True), optimizer)]
+                if use_at:
+                    reds.append((dp.attach(opt_at, force=True), opt_at))
+                step()
+                step()
+                rccl_ms = _timed(5)
+                nb = len(reds[0][0].buckets)
+                inb = reds[0][0].stats["launched_in_backward"] / max(reds[0][0].stats["steps"], 1)
+                for red, o in reds:
+                    red.detach(o)
+                tdist.destroy_process_group()
+                rccl = {"ms_per_step": rccl_ms, "ms_per_step_without": plain_ms, "delta_ms": rccl_ms - plain_ms,
+                        "buckets": nb, "buckets_issued_inside_backward_per_step": inb,
+                        "note": "untimed leg: 5 steps with dp.GradReducer forced on over the nccl (RCCL) backend at world size 1 "
+                                "vs 5 steps without; the timed region above runs without it at N = 1"}
+            except Exception as e:       # a box without a working RCCL must not lose the bench line
+                rccl = {"error": repr(e)[:300]}
         tot = sum(v["ms"] for v in prof.values())
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         breakdown["_sum_kernel_ms"] = round(tot, 3)
@@ -349,12 +436,16 @@ def main():
                                    + (f"; + AT lstmnet forward + MSE + backward + Adam over T=16, B={args.batch} "
                                       f"512-vectors per step" if use_at else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "collective": (None if world == 1 else
+                       "collective": ("gradient all-reduce over rccl at world size 1 (EGAZE_DP_FORCE=1: the data-parallel code "
+                                      "path on one GPU)" if dp_forced else None if world == 1 else
                                       f"gradient all-reduce, backend {'rccl' if backend == 'nccl' else backend}, "
                                       f"{'ALL RANKS ON ONE GPU (functional run, not a scaling number)' if shared_device else 'one GPU per rank'}"),
                        "precision": (f"split-half f16x3 MFMA for conv fwd, {'f16x3' if H.GRAD_SPLIT == 'f16' else 'bf16x3'} "
-                                     "for dgrad / wgrad (fp32-class accuracy, gaze map within 1e-5 of the reference; "
-                                     "8-step training trajectory within 1e-3 of the CPU reference path, tests/test_hip_model_sp.py)"
+                                     "for dgrad / wgrad, operands abs-max scaled (fp32-class accuracy: gaze map within 1e-5 of "
+                                     "the reference at batch 2 and batch 32; an 8-step lr 1e-4 training trajectory stays inside "
+                                     "2x the CPU fp32 path's own distance from an fp64 run of the same steps -- such a trajectory "
+                                     "is chaotic at the 1e-3 level for any fp32 implementation, profiles/r03_training_trajectory.txt; "
+                                     "tests/test_hip_model_sp.py)"
                                      if H.PRECISION == "split" else "exact f32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "roofline": roofline, "cpu_baseline": cpu,
             "step_mfma_frac": step_flops / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
@@ -365,6 +456,7 @@ def main():
                                   "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),
                       "f32_ms_per_step": f32_ms,
                       "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps",
+                      "rccl_world1": rccl,
                       "pcie_inclusive_ms_per_step": pcie_ms or None,
                       "pcie_note": ("the step with its batch starting in pinned host memory and the loss read back every step "
                                     "(SP.trainSP's loop): 'u8' = raw bytes + egz_u8_normalize on the device (38.5 MB/batch), "

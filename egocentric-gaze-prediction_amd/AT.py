@@ -297,10 +297,15 @@ class AT():
     def extract_late(self, st_loader, pred_folder='../new_pred/', feat_folder='../new_feat/', chunk=32):
         """pred = SP gaze map, feat = AT-weighted conv5_3 map, both written as uint8 PNGs (AT.py:199-253).
 
-        Same per-frame results and the same sequential LSTM state as the reference's batch-1 loop, but the frames of the
-        (batch-1) loader are gathered ``chunk`` at a time: the SP forward (eval mode, every sample independent), the uint8
-        quantisation, the gaze-point metric and the crop means run once per chunk on the device; only the recurrent step,
-        the weighted map and the image hand-over stay per frame.  ``chunk=1`` is the reference's schedule."""
+        The same sequential LSTM state as the reference's batch-1 loop, but the frames of the (batch-1) loader are gathered
+        ``chunk`` at a time: the SP forward (eval mode, every sample independent), the uint8 quantisation, the gaze-point
+        metric and the crop means run once per chunk on the device; only the recurrent step, the weighted map and the image
+        hand-over stay per frame.  ``chunk=1`` is the reference's schedule.  A batched forward is NOT bitwise equal to a
+        batch-1 forward (the conv launches pick tile / split-K geometry by batch size, i.e. another fp32 summation order),
+        and ``(255 * output).to(uint8)`` truncates: a 1-ulp difference next to an integer flips that pixel by one level.
+        Against the reference's own output the chunked path differs by +-1 LSB on < 0.2 % of the pixels
+        (tests/test_hip_config5.py), the same class of difference as chunk=1 vs the reference's CPU arithmetic; pass
+        ``chunk=1`` when the written PNGs must not depend on the batching."""
         print('begin to extract files for training LF module ...')
         os.makedirs(pred_folder, exist_ok=True)
         os.makedirs(feat_folder, exist_ok=True)

@@ -22,6 +22,7 @@ S = c_void_p          # hipStream_t
 SIGNATURES = {
     "egz_version": (c_char_p, []),
     "egz_last_error": (c_char_p, []),
+    "egz_mfma_probe": (c_int, [P, P, c_int, c_int, S]),
     # --- 3x3 conv, implicit GEMM on f32 MFMA
     "egz_pack_w3x3_elems": (c_size_t, [c_int, c_int, c_int]),
     "egz_pack_w3x3_ups_fwd": (c_int, [P, P, c_int, c_int, S]),
@@ -34,18 +35,18 @@ SIGNATURES = {
     "egz_pack_w3x3_split": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "egz_pack_w3x3_split_multi": (c_int, [P, c_int, c_int, S]),
     "egz_conv3x3_fwd_split_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
+    "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, S]),
     "egz_conv3x3_streamed_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_pack_w3x3_split_frag": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
     "egz_conv3x3_streamed_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd_streamed_splitk_stat_rows": (c_int, [c_int, c_int, c_int]),
     "egz_conv3x3_fwd_streamed_splitk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv3x3_fwd_streamed_splitk": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, c_int, S]),
+    "egz_conv3x3_fwd_streamed_splitk": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, c_int, P, S]),
     "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
     "egz_absmax_fold": (c_int, [P, c_int, S]),
     "egz_colsum_f64": (c_int, [P, c_int, c_int, c_int, P, P, c_size_t, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, S]),
+    "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, S]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)
     "egz_conv_first_stat_rows": (c_int, [c_int, c_int, c_int]),
     "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
@@ -56,7 +57,7 @@ SIGNATURES = {
     "egz_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P, P,
                                 c_size_t, S]),
     "egz_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P, S]),
-    "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
+    "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_bn_relu_pool_bwd_ws_bytes": (c_size_t, [c_int]),
     "egz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
                                      c_size_t, P, S]),
@@ -91,7 +92,7 @@ SIGNATURES = {
     "egz_lstm_cell_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, S]),
     "egz_lstm_seq_fwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, S]),
     "egz_lstm_seq_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, S]),
-    "egz_lstm_b1_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "egz_lstm_b1_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "egz_lstm_b1_fwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, S]),
     "egz_lstm_b1_bwd": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_size_t, S]),
     "egz_tanh_fwd": (c_int, [P, P, c_long, S]),

@@ -87,15 +87,61 @@ __global__ void bn_eval_coeffs_kernel(int K, const float* __restrict__ gamma, co
     shift[k] = (beta ? beta[k] : 0.f) - rm[k] * sc;
 }
 
+// max |v| of everything the launch wrote, without atomics (tens of thousands of device-scope atomics on one address cost
+// milliseconds): every block stores the bit pattern of its own maximum into absmax[1 + blockIdx.x] and a one-block
+// epilogue kernel folds the <= EGZ_ABSMAX_PARTIALS partials into absmax[0].  Bit patterns of non-negative floats order like
+// unsigned ints and max is exact and order independent: the result is deterministic.  No zero-initialisation is needed.
+constexpr int ABSMAX_PARTIALS = 16384;
+__device__ __forceinline__ void block_absmax_commit(float m, unsigned int* __restrict__ absmax) {
+    if (!absmax) return;                                  // uniform
+    __shared__ float s_am[16];
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_am[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, s_am[w]);
+        absmax[1 + blockIdx.x] = __float_as_uint(m);
+    }
+}
+__global__ __launch_bounds__(256) void absmax_final_kernel(unsigned int* __restrict__ absmax, int nblocks) {
+    __shared__ unsigned int s[256];
+    unsigned int m = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) m = max(m, absmax[1 + i]);
+    s[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) s[threadIdx.x] = max(s[threadIdx.x], s[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) absmax[0] = s[0];
+}
+int absmax_finish(unsigned int* absmax, int nblocks, hipStream_t st, const char* what) {
+    if (!absmax) return 0;
+    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, absmax, nblocks);
+    EGZ_CHECK_LAUNCH(what);
+    return 0;
+}
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n4, unsigned int* __restrict__ absmax) {
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    block_absmax_commit(m, absmax);
+}
+
 // ------------------------------------------------------------------ BN-apply + ReLU (+pool) forward
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
-                                                               float* __restrict__ out, int B, int H, int W, int K) {
+                                                               float* __restrict__ out, int B, int H, int W, int K,
+                                                               unsigned int* __restrict__ absmax) {
     const int K4 = K >> 2;
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const long n = (long)B * Ho * Wo * K4;
+    float amx = 0.f;                                      // max of what this thread wrote (outputs are >= 0)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % K4);
         const long pix = i / K4;
@@ -124,7 +170,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
             }
         }
         *reinterpret_cast<f32x4*>(out + pix * K + c4 * 4) = r;
+        amx = fmaxf(amx, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
     }
+    block_absmax_commit(amx, absmax);
 }
 
 // dz at the four (or one) input positions of an output pixel: ReLU mask and first-max-wins pool routing
@@ -227,50 +275,6 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int npar
     if (dgamma) dgamma[k] = (float)s2;
     mdz[k] = (float)(s1 / count);
     mdzx[k] = (float)(s2 / count);
-}
-
-// max |v| of everything the launch wrote, without atomics (tens of thousands of device-scope atomics on one address cost
-// milliseconds): every block stores the bit pattern of its own maximum into absmax[1 + blockIdx.x] and a one-block
-// epilogue kernel folds the <= EGZ_ABSMAX_PARTIALS partials into absmax[0].  Bit patterns of non-negative floats order like
-// unsigned ints and max is exact and order independent: the result is deterministic.  No zero-initialisation is needed.
-constexpr int ABSMAX_PARTIALS = 8192;
-__device__ __forceinline__ void block_absmax_commit(float m, unsigned int* __restrict__ absmax) {
-    if (!absmax) return;                                  // uniform
-    __shared__ float s_am[16];
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if ((threadIdx.x & 63) == 0) s_am[wave] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < nw; ++w) m = fmaxf(m, s_am[w]);
-        absmax[1 + blockIdx.x] = __float_as_uint(m);
-    }
-}
-__global__ __launch_bounds__(256) void absmax_final_kernel(unsigned int* __restrict__ absmax, int nblocks) {
-    __shared__ unsigned int s[256];
-    unsigned int m = 0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) m = max(m, absmax[1 + i]);
-    s[threadIdx.x] = m;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) s[threadIdx.x] = max(s[threadIdx.x], s[threadIdx.x + st]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) absmax[0] = s[0];
-}
-int absmax_finish(unsigned int* absmax, int nblocks, hipStream_t st, const char* what) {
-    if (!absmax) return 0;
-    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, absmax, nblocks);
-    EGZ_CHECK_LAUNCH(what);
-    return 0;
-}
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n4, unsigned int* __restrict__ absmax) {
-    float m = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-    }
-    block_absmax_commit(m, absmax);
 }
 
 // ------------------------------------------------------------------ BN backward, pass 2: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
@@ -543,16 +547,17 @@ EGZ_API int egz_bn_eval_coeffs(int K, const float* gamma, const float* beta, con
 }
 
 // out = relu(y*scale + shift), optionally followed by MaxPool2d(2,2) (out is then [B][H/2][W/2][K]).
+// absmax (optional): receives max |out| (egz_absmax layout) -- the f16 x3 scaling of the convolution that consumes `out`.
 EGZ_API int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, float* out, int B, int H,
-                                 int W, int K, int pool, hipStream_t st) {
+                                 int W, int K, int pool, unsigned int* absmax, hipStream_t st) {
     EGZ_CHECK_ARG(y && scale && shift && out, "egz_bn_relu_pool_fwd: null pointer");
     EGZ_CHECK_ARG(K % 4 == 0, "egz_bn_relu_pool_fwd: K=%d must be a multiple of 4", K);
     EGZ_CHECK_ARG(!pool || (H % 2 == 0 && W % 2 == 0), "egz_bn_relu_pool_fwd: pooled map must be even");
     const long n = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (K / 4);
-    if (pool) hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K);
-    else      hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K);
+    if (pool) hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, absmax);
+    else      hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, absmax);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_fwd");
-    return 0;
+    return absmax_finish(absmax, ew_grid(n), st, "egz_bn_relu_pool_fwd(absmax)");
 }
 
 EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {

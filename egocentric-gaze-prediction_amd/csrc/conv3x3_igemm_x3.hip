@@ -20,6 +20,9 @@
 #include "x3_split.h"
 #include <type_traits>
 
+EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st);      // bn_pool.hip
+EGZ_API int egz_absmax(const float* x, long n, unsigned int* absmax, hipStream_t st);
+
 namespace {
 
 constexpr int XBM = 128, XBK = 32;
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
     float out_scale, int mt, int tile_base, int nsplit, int pass, float* __restrict__ ws,
-    const unsigned int* __restrict__ a_absmax) {
+    const unsigned int* __restrict__ a_absmax, unsigned int* __restrict__ absmax_out) {
     // pass 0: whole tile (all K-slices + epilogue).  pass 1: split-K part blockIdx.y of nsplit -> raw accumulators to ws.
     // pass 2: sum the nsplit partials of the tile in a fixed order, then the normal epilogue (launch_x3: tail tiles).
     const float a_scale = absmax_scale(a_absmax);
@@ -317,6 +320,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
 
     // ---- epilogue (same as the fp32 kernel; out_scale undoes the weight pre-scaling of the f16 path exactly)
     double* red = reinterpret_cast<double*>(As);   // [2 (wm)][2 (sum, sumsq)][128] doubles = 4 KB
+    __shared__ float samax[4];
+    float amx = 0.f;                               // EPI_BIAS_RELU: max of the activation this thread wrote
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int col = wn * WN + nr * 32 + l31;
@@ -330,7 +335,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
                 const long off = Ro[wm * 64 + mr * 32 + egz_acc_row(r, lane)];
                 if (off >= 0 && nok) {
                     float v = acc[mr][nr][r] * out_scale + bz;
-                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    if (EPI == EPI_BIAS_RELU) {
+                        v = fmaxf(v, 0.f);
+                        amx = fmaxf(amx, v);
+                    }
                     y[off + n0 + col] = v;
                     if (EPI == EPI_BIAS_STATS) {
                         s1 += (double)v;
@@ -347,6 +355,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
                 red[(wm * 2 + 1) * XBN + col] = s2;
             }
         }
+    }
+    if (EPI == EPI_BIAS_RELU && absmax_out && pass == 0) {                    // block-uniform: per-block partial, folded by the launcher
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+        if (lane == 0) samax[wave] = amx;
+        __syncthreads();
+        if (tid == 0) absmax_out[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
     }
     if (EPI == EPI_BIAS_STATS) {
         __syncthreads();
@@ -381,7 +396,7 @@ template <typename T, int XBN, int EPI>
 __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wp, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp,
-    float out_scale, int mt, int patch, const unsigned int* __restrict__ a_absmax) {
+    float out_scale, int mt, int patch, const unsigned int* __restrict__ a_absmax, unsigned int* __restrict__ absmax_out) {
     const float a_scale = absmax_scale(a_absmax);
     out_scale /= a_scale;
     constexpr int NR = XBN / 64, WN = XBN / 2, BLD = XBN / 64;
@@ -651,6 +666,8 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
 
     // ---- epilogue (as conv3x3_igemm_x3_kernel)
     double* red = reinterpret_cast<double*>(Ah);
+    __shared__ float samax[4];
+    float amx = 0.f;
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int col = wn * WN + nr * 32 + l31;
@@ -664,7 +681,10 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
                 const long off = Ro[wm * 64 + mr * 32 + egz_acc_row(r, lane)];
                 if (off >= 0 && nok) {
                     float v = acc[mr][nr][r] * out_scale + bz;
-                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    if (EPI == EPI_BIAS_RELU) {
+                        v = fmaxf(v, 0.f);
+                        amx = fmaxf(amx, v);
+                    }
                     y[off + n0 + col] = v;
                     if (EPI == EPI_BIAS_STATS) {
                         s1 += (double)v;
@@ -681,6 +701,13 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
                 red[(wm * 2 + 1) * XBN + col] = s2;
             }
         }
+    }
+    if (EPI == EPI_BIAS_RELU && absmax_out) {                    // block-uniform: per-block partial, folded by the launcher
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+        if (lane == 0) samax[wave] = amx;
+        __syncthreads();
+        if (tid == 0) absmax_out[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
     }
     if (EPI == EPI_BIAS_STATS) {
         __syncthreads();
@@ -823,8 +850,13 @@ long x3_rows(int mode, int B, int H, int W) { return (mode >= UPS_PHASE) ? (long
 template <typename T, int XBN, int MODE>
 int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bias, float* y, double* stat, int B, int H,
               int W, int C, int K, float out_scale, int flags, float* ws, size_t ws_bytes, const unsigned int* a_absmax,
-              hipStream_t st) {
+              unsigned int* absmax_out, hipStream_t st) {
     const long M = x3_rows(MODE, B, H, W);
+    if (epi != EPI_BIAS_RELU || MODE == UPS_DGRAD) absmax_out = nullptr;
+    // max |y| of a bias + ReLU launch (the f16 x3 scaling of the next convolution): per-block partials from the epilogue when
+    // the launch is one plain grid of at most 16384 blocks, else one extra pass over y
+    const long ny = (long)B * H * W * K;
+    auto absmax_pass = [&]() -> int { return absmax_out ? egz_absmax(y, ny, absmax_out, st) : 0; };
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
     if constexpr (MODE == PLAIN) {
         // halo-tile kernel: 8 x 16 patches, or raster runs for narrow images; flag 0x2000 forces the per-tap gather kernel
@@ -832,19 +864,22 @@ int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bi
         if (!(flags & 0x2000) && (patch || (W <= 56 && XBM + 2 * W + 2 <= HZERO))) {
             const int mt = egz_cdiv(M, XBM);
             dim3 grid(mt * (Kp / XBN));
-#define EGZ_X3H(E) hipLaunchKernelGGL((conv3x3_igemm_x3h_kernel<T, XBN, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, patch ? 1 : 0, a_absmax)
+            unsigned int* amo = (grid.x <= 16384) ? absmax_out : nullptr;
+#define EGZ_X3H(E) hipLaunchKernelGGL((conv3x3_igemm_x3h_kernel<T, XBN, E>), grid, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, patch ? 1 : 0, a_absmax, amo)
             if (epi == EPI_BIAS) EGZ_X3H(EPI_BIAS);
             else if (epi == EPI_BIAS_RELU) EGZ_X3H(EPI_BIAS_RELU);
             else EGZ_X3H(EPI_BIAS_STATS);
 #undef EGZ_X3H
             EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_split(halo)");
-            return 0;
+            if (amo) return egz_absmax_fold(amo, (int)grid.x, st);
+            return absmax_pass();
         }
     }
     const X3Plan p = x3_plan(M, Cp, Kp, XBN, MODE, flags);
     EGZ_CHECK_ARG(!p.tail || (ws && ws_bytes >= (size_t)p.tail * p.nsplit * XBM * XBN * sizeof(float)),
                   "egz_conv3x3_fwd_split: workspace too small (%zu bytes; see egz_conv3x3_fwd_split_ws_bytes)", ws_bytes);
-#define EGZ_X3L(E, GRID, BASE, NS, PASS) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, XBN, MODE, E>), GRID, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, p.mt, BASE, NS, PASS, ws, a_absmax)
+    unsigned int* amo = (!p.tail && p.main <= 16384) ? absmax_out : nullptr;
+#define EGZ_X3L(E, GRID, BASE, NS, PASS) hipLaunchKernelGGL((conv3x3_igemm_x3_kernel<T, XBN, MODE, E>), GRID, dim3(256), 0, st, x, wp, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, p.mt, BASE, NS, PASS, ws, a_absmax, amo)
 #define EGZ_X3(E)                                                                  \
     do {                                                                           \
         if (p.main) EGZ_X3L(E, dim3(p.main), 0, 1, 0);                             \
@@ -859,7 +894,8 @@ int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bi
 #undef EGZ_X3
 #undef EGZ_X3L
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_split");
-    return 0;
+    if (amo) return egz_absmax_fold(amo, p.main, st);
+    return absmax_pass();
 }
 
 }  // namespace
@@ -908,7 +944,7 @@ EGZ_API size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K,
 // launch on MI355X for the SP shapes -- lone tail blocks already run ~1.7x faster -- so it is opt-in).
 EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial,
                                   int B, int H, int W, int C, int K, int flags, int dtype, void* workspace,
-                                  size_t ws_bytes, const unsigned int* x_absmax, hipStream_t st) {
+                                  size_t ws_bytes, const unsigned int* x_absmax, unsigned int* absmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && wp && y, "egz_conv3x3_fwd_split: null pointer");
     EGZ_CHECK_ARG(K % 64 == 0 && C % 32 == 0 && C > 0, "egz_conv3x3_fwd_split: needs Cout %% 64 == 0 and Cin %% 32 == 0 (got %d, %d)", K, C);
     EGZ_CHECK_ARG(dtype == 1 || dtype == 2, "egz_conv3x3_fwd_split: dtype must be 1 (f16) or 2 (bf16)");
@@ -926,10 +962,10 @@ EGZ_API int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* b
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
     float* ws = static_cast<float*>(workspace);
 #define EGZ_MODE(T, N)                                                                                          \
-    if (flags & 4) return launch_x3<T, N, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st); \
-    if (ups == 3) return launch_x3<T, N, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st);  \
-    if (ups == 1) return launch_x3<T, N, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st);   \
-    return launch_x3<T, N, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, st)
+    if (flags & 4) return launch_x3<T, N, UPS_DGRAD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, absmax_out, st); \
+    if (ups == 3) return launch_x3<T, N, UPS_PHASE>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, absmax_out, st);  \
+    if (ups == 1) return launch_x3<T, N, UPS_FOLD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, absmax_out, st);   \
+    return launch_x3<T, N, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, flags, ws, ws_bytes, x_absmax, absmax_out, st)
     if (K % 128 == 0) {
         if (dtype == 1) { EGZ_MODE(_Float16, 128); }
         EGZ_MODE(__bf16, 128);

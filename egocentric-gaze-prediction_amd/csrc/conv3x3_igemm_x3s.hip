@@ -28,6 +28,8 @@
 #define EGZ_X3S_DIAG 0        // fragment reads, 4 no halo restaging
 #endif
 
+EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st);      // bn_pool.hip
+
 namespace {
 using namespace x3;
 
@@ -378,18 +380,17 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             if (off >= 0 && nok) {
                 float v = acc[mr][r] * out_scale + bz;
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                if (EPI == EPI_MASK_SUMS) {
-                    v = (mask_src[off + col] > 0.f) ? v : 0.f;
-                    amx = fmaxf(amx, fabsf(v));
-                }
+                if (EPI == EPI_MASK_SUMS) v = (mask_src[off + col] > 0.f) ? v : 0.f;
+                if (EPI == EPI_MASK_SUMS || EPI == EPI_BIAS_RELU) amx = fmaxf(amx, fabsf(v));
                 y[off + col] = v;
                 if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS) s1 += (double)v;
                 if (EPI == EPI_BIAS_STATS) s2 += (double)v * (double)v;
             }
         }
     }
-    if (EPI == EPI_MASK_SUMS) {
-        // per-tile max |value| -> absmax_out[1 + tile] (bit pattern; folded by egz_absmax_fold, no atomics)
+    if ((EPI == EPI_MASK_SUMS || EPI == EPI_BIAS_RELU) && absmax_out) {           // block-uniform
+        // per-tile max |value| -> absmax_out[1 + tile] (bit pattern; folded by egz_absmax_fold, no atomics).  EPI_BIAS_RELU:
+        // the result is a post-ReLU activation that the next convolution splits into f16 halves -- its abs-max scales that split
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
         if (lane == 0) samax[wave] = amx;
@@ -673,8 +674,10 @@ constexpr int FIX_ROWS = 32;
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restrict__ part, const float* __restrict__ bias,
                                                            float* __restrict__ y, double* __restrict__ stat, long M, int K,
-                                                           int nsplit) {
+                                                           int nsplit, unsigned int* __restrict__ absmax_out) {
     __shared__ double sred[2][16][64];
+    __shared__ float samax[4];
+    float amx = 0.f;
     const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;
     const int col = blockIdx.y * 64 + c4 * 4;
     const bool cok = col < K;                                  // K % 4 == 0: a float4 is inside or outside as a whole
@@ -690,7 +693,10 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restri
             v += bz;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (EPI == EPI_BIAS_RELU) v[e] = fmaxf(v[e], 0.f);
+                if (EPI == EPI_BIAS_RELU) {
+                    v[e] = fmaxf(v[e], 0.f);
+                    amx = fmaxf(amx, v[e]);
+                }
                 if (EPI == EPI_BIAS_STATS) {
                     s1[e] += (double)v[e];
                     s2[e] += (double)v[e] * (double)v[e];
@@ -698,6 +704,15 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restri
             }
             *reinterpret_cast<f32x4*>(y + m * K + col) = v;
         }
+    }
+    if (EPI == EPI_BIAS_RELU && absmax_out) {                   // block-uniform: per-block max of the activation written
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
+        if ((threadIdx.x & 63) == 0) samax[threadIdx.x >> 6] = amx;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            absmax_out[1 + blockIdx.y * gridDim.x + blockIdx.x] =
+                __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
     }
     if (EPI == EPI_BIAS_STATS) {
 #pragma unroll
@@ -739,7 +754,7 @@ int x3s_splits(int B, int H, int W, int C, int K) {
 template <typename T>
 int launch_x3s_splitk(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
                       int W, int C, int K, float out_scale, const unsigned int* a_absmax, float* part, int nsplit,
-                      hipStream_t st) {
+                      unsigned int* absmax_out, hipStream_t st) {
     using G = Geo<1>;
     const long M = (long)B * H * W;
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
@@ -751,10 +766,13 @@ int launch_x3s_splitk(int epi, const float* x, const unsigned short* wq, const f
     else       hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, false, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit);
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed_splitk");
     const dim3 fg(egz_cdiv(M, FIX_ROWS), egz_cdiv(K, 64));
-    if (epi == EPI_BIAS) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit);
-    else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_RELU>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit);
-    else hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_STATS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit);
+    if (epi == EPI_BIAS_RELU && absmax_out)
+        EGZ_CHECK_ARG((long)fg.x * fg.y <= 16384, "egz_conv3x3_fwd_streamed_splitk: %ld fix-up blocks exceed the abs-max partial slots", (long)fg.x * fg.y);
+    if (epi == EPI_BIAS) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit, nullptr);
+    else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_RELU>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit, absmax_out);
+    else hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_STATS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit, nullptr);
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed_splitk(fixup)");
+    if (epi == EPI_BIAS_RELU && absmax_out) return egz_absmax_fold(absmax_out, (int)(fg.x * fg.y), st);
     return 0;
 }
 
@@ -771,8 +789,9 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const int total = mt * (Kp / G::BN);
     const dim3 grid(((total + 7) / 8) * 8);
 #define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1)
+    if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS) absmax_out = nullptr;
+    if (absmax_out) EGZ_CHECK_ARG(total <= 16384, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
     if (epi == EPI_MASK_SUMS) {
-        EGZ_CHECK_ARG(total <= 8192, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
         if constexpr (WM == 1 || WM == 2) {      // data gradients of the SP decoder: 128- and 64-column 4-wave tiles
             if (patch) EGZ_X3S(EPI_MASK_SUMS, true); else EGZ_X3S(EPI_MASK_SUMS, false);
         } else {
@@ -790,6 +809,7 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     }
 #undef EGZ_X3S
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed");
+    if (epi == EPI_BIAS_RELU && absmax_out) return egz_absmax_fold(absmax_out, total, st);     // (epi 3: the caller folds)
     return 0;
 }
 
@@ -883,6 +903,8 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
 #ifndef EGZ_X3P_NARROW
 #define EGZ_X3P_NARROW 1
 #endif
+    EGZ_CHECK_ARG(!(absmax_out && epi == EPI_BIAS_RELU), "egz_conv3x3_fwd_streamed: the abs-max epilogue exists for 64- and "
+                  "128-column tiles only (K %% 64 == 0)");
     if (EGZ_X3P_NARROW && C <= 32 && K <= 32 && H % 16 == 0 && W % 16 == 0 && epi != EPI_MASK_SUMS) {   // persistent narrow form
         if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
         return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
@@ -906,7 +928,7 @@ EGZ_API size_t egz_conv3x3_fwd_streamed_splitk_ws_bytes(int B, int H, int W, int
 EGZ_API int egz_conv3x3_fwd_streamed_splitk(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
                                             int B, int H, int W, int C, int K, int epi, int dtype,
                                             const unsigned int* x_absmax, void* workspace, size_t ws_bytes, int nsplit,
-                                            hipStream_t st) {
+                                            unsigned int* absmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y && workspace, "egz_conv3x3_fwd_streamed_splitk: null pointer");
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, 0) && K % 128 == 0 && C % 32 == 0,
                   "egz_conv3x3_fwd_streamed_splitk: geometry B=%d H=%d W=%d C=%d K=%d is not covered", B, H, W, C, K);
@@ -918,6 +940,6 @@ EGZ_API int egz_conv3x3_fwd_streamed_splitk(const float* x, const void* wq, cons
     const unsigned short* w16 = static_cast<const unsigned short*>(wq);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
     float* part = static_cast<float*>(workspace);
-    if (dtype == 1) return launch_x3s_splitk<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, part, nsplit, st);
-    return launch_x3s_splitk<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, part, nsplit, st);
+    if (dtype == 1) return launch_x3s_splitk<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, part, nsplit, absmax_out, st);
+    return launch_x3s_splitk<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, part, nsplit, absmax_out, st);
 }

@@ -333,9 +333,11 @@ __device__ __forceinline__ void wgrad_block(int& tile, int& split) {
 template <typename T, bool UPS, int R, int WD>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
-    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax) {
+    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax,
+    const unsigned int* __restrict__ x_absmax) {
     static_assert(R * WD == 32 && (WD == 32 || WD == 16 || WD == 8), "patch = 32 pixels");
     const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
+    const float x_scale = W16<T>::scale(x_absmax), x_inv = 1.f / x_scale;      // the activation operand, scaled the same way
     constexpr int NP = R * WD, KS = NP / 16;
     constexpr int HPW = WD + 2, NH = (R + 2) * HPW;            // halo row width / halo pixels
     constexpr int XH = NH * 32 + ((NH & 1) ? 0 : 32);          // channel-half stride (elements): bytes % 128 == 64
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4(rx[j], hi, lo);
+                W16<T>::split4(rx[j] * x_scale, hi, lo);
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);
             const int k = k0 + wk * 32 + l31;
-            if (c < C && k < K) out[(long)c * K + k] = acc[tap][r] * d_inv;
+            if (c < C && k < K) out[(long)c * K + k] = acc[tap][r] * d_inv * x_inv;
         }
     }
 }
@@ -532,9 +534,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 template <typename T, int R, int WD>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
-    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax) {
+    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax,
+    const unsigned int* __restrict__ x_absmax) {
     static_assert(R * WD == 64 && (WD == 32 || WD == 16), "patch = 64 pixels in rows of 16-pixel runs");
     const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
+    const float x_scale = W16<T>::scale(x_absmax), x_inv = 1.f / x_scale;      // the activation operand, scaled the same way
     constexpr int NP = R * WD;
     constexpr int HPW = WD + 2, NH = (R + 2) * HPW;            // halo row width / halo pixels
     constexpr int XH = NH * 32 + 32, DH = NP * 32 + 32;        // plane strides (elements)
@@ -600,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
             const int i = tid + 256 * j, pos = i >> 3, c4 = i & 7;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4(rx[j], hi, lo);
+                W16<T>::split4(rx[j] * x_scale, hi, lo);
                 unsigned short* d = Xs + buf * XB + pos * 32 + c4 * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + XH) = lo;
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
             const int e = tid + 256 * m, r = e >> 6, ln = e & 63;
             const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
             const int c = egz_acc_row(r, ln), k = ln & 31;
-            if (c < C && k < K) out[(long)c * K + k] = v * d_inv;
+            if (c < C && k < K) out[(long)c * K + k] = v * d_inv * x_inv;
         }
         __syncthreads();
     }
@@ -692,9 +696,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
 template <typename T, int R, int WD>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
-    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax) {
+    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax,
+    const unsigned int* __restrict__ x_absmax) {
     static_assert(R * WD == 32 && (WD == 32 || WD == 16 || WD == 8), "patch = 32 low-res pixels");
     const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
+    const float x_scale = W16<T>::scale(x_absmax), x_inv = 1.f / x_scale;      // the activation operand, scaled the same way
     constexpr int NP = R * WD, KS = NP / 16;
     constexpr int HPW = WD + 2, NH = (R + 1) * HPW;
     constexpr int XH = NH * 32 + ((NH & 1) ? 0 : 32);          // channel-half stride (elements): bytes % 128 == 64
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4(rx_[j], hi, lo);
+                W16<T>::split4(rx_[j] * x_scale, hi, lo);
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
         for (int r = 0; r < 16; ++r) {
             const int c = c0 + wc * 32 + egz_acc_row(r, lane);
             const int k = k0 + wk * 32 + l31;
-            out[(long)c * K + k] = acc[t][r] * d_inv;
+            out[(long)c * K + k] = acc[t][r] * d_inv * x_inv;
         }
     }
 }
@@ -1254,11 +1260,13 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 // flags: bit0 = the conv input was the nearest-x2 upsampling of x ([B][H/2][W/2][C]); 0x100 forces 64 tiles;
 //        0x800 forces the per-tap kernel, 0x1000 the folded 9-tap form of an upsampled conv (A/B benchmarking);
 //        0x2000 = split-half arithmetic on the 16-bit MFMA path (C, K multiples of 64; else exact f32): bf16 x3 (16 bits,
-//        no scaling) when dy_absmax is NULL, f16 x3 (22 bits) with dy scaled by absmax_scale(*dy_absmax) when it is given.
+//        no scaling) when dy_absmax is NULL, f16 x3 (22 bits) with dy scaled by absmax_scale(*dy_absmax) when it is given;
+//        x_absmax (optional, f16 x3 only): max |x| -- x is scaled the same way (activations outside [2^-3, 6e4] otherwise
+//        leave the f16 pair's 22-bit domain).
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
 EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
                               int flags, void* workspace, size_t ws_bytes, const unsigned int* dy_absmax,
-                              hipStream_t st) {
+                              const unsigned int* x_absmax, hipStream_t st) {
     EGZ_CHECK_ARG(x && dy && dw && workspace, "egz_conv3x3_wgrad: null pointer");
     EGZ_CHECK_ARG(C % 4 == 0 && K % 4 == 0 && C > 0 && K > 0, "egz_conv3x3_wgrad: C=%d K=%d must be multiples of 4", C, K);
     const bool ups = flags & 1;
@@ -1279,7 +1287,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
             EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, n16) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
             const int pps = (int)((np + S - 1) / S);
             dim3 grid((C / 64) * (K / 64), S, 2);
-#define EGZ_WUX(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
+#define EGZ_WUX(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
             if (dy_absmax) { if (WD == 32) EGZ_WUX(_Float16, 1, 32); else if (WD == 16) EGZ_WUX(_Float16, 2, 16); else EGZ_WUX(_Float16, 4, 8); }
             else           { if (WD == 32) EGZ_WUX(__bf16, 1, 32); else if (WD == 16) EGZ_WUX(__bf16, 2, 16); else EGZ_WUX(__bf16, 4, 8); }
 #undef EGZ_WUX
@@ -1305,7 +1313,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int pps = (int)((np + S - 1) / S);
         dim3 grid(1, S);
-#define EGZ_W9N(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
+#define EGZ_W9N(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
         if (dy_absmax) { if (WD == 32) EGZ_W9N(_Float16, 2, 32); else EGZ_W9N(_Float16, 4, 16); }
         else           { if (WD == 32) EGZ_W9N(__bf16, 2, 32); else EGZ_W9N(__bf16, 4, 16); }
 #undef EGZ_W9N
@@ -1318,7 +1326,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int pps = (int)((np + S - 1) / S);
         dim3 grid(((C + 63) / 64) * ((K + 63) / 64), S);
-#define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax)
+#define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
 #define EGZ_W9T(TT)                                                                                                    \
         if (ups) { if (WD == 32) EGZ_W9X(TT, true, 1, 32); else if (WD == 16) EGZ_W9X(TT, true, 2, 16); else EGZ_W9X(TT, true, 4, 8); } \
         else     { if (WD == 32) EGZ_W9X(TT, false, 1, 32); else if (WD == 16) EGZ_W9X(TT, false, 2, 16); else EGZ_W9X(TT, false, 4, 8); }

@@ -180,9 +180,12 @@ __global__ __launch_bounds__(256) void cell_bwd_b1_kernel(const float* __restric
 
 }  // namespace
 
+#define P_ALIGNED(p) ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)
+
 // Workspace floats of the backward call: per-strip partial columns of the widest transposed product + the gate gradients.
-EGZ_API size_t egz_lstm_b1_ws_bytes(int L, int C, int H) {
-    const int strips = (4 * H + STRIP - 1) / STRIP;
+EGZ_API size_t egz_lstm_b1_ws_bytes(int L, int C, int H, int N) {
+    const int rows = 4 * H > N ? 4 * H : N;                  // the Linear head's launch writes ceil(N / STRIP) strips of H floats
+    const int strips = (rows + STRIP - 1) / STRIP;
     const int wide = C > H ? C : H;
     return ((size_t)strips * wide + (size_t)L * 4 * H) * sizeof(float);
 }
@@ -194,6 +197,10 @@ EGZ_API int egz_lstm_b1_fwd(const void* const* params, int L, const float* inp, 
                             float* acts, float* hn, float* cn, float* out, int C, int H, int N, hipStream_t st) {
     EGZ_CHECK_ARG(params && inp && h0 && c0 && xt && hn && cn && out && L >= 1, "egz_lstm_b1_fwd: null pointer");
     EGZ_CHECK_ARG(C % 4 == 0 && H % 4 == 0 && C > 0 && H > 0 && N > 0, "egz_lstm_b1_fwd: C=%d H=%d must be multiples of 4", C, H);
+    for (int i = 0; i < 4 * L + 2; ++i) {                   // the kernels use 16-byte loads on the parameter rows
+        EGZ_CHECK_ARG(P_ALIGNED(reinterpret_cast<const float* const*>(params)[i]), "egz_lstm_b1_fwd: parameter %d is not 16-byte aligned", i);
+    }
+    EGZ_CHECK_ARG(P_ALIGNED(inp) && P_ALIGNED(h0) && P_ALIGNED(xt) && P_ALIGNED(hn), "egz_lstm_b1_fwd: inp / h0 / xt / hn must be 16-byte aligned");
     for (int l = 0; l < L; ++l) {
         const float* const* p = reinterpret_cast<const float* const*>(params) + 4 * l;
         const float* xin = l ? hn + (long)(l - 1) * H : nullptr;
@@ -218,10 +225,14 @@ EGZ_API int egz_lstm_b1_bwd(const void* const* params, void* const* grads, int L
     EGZ_CHECK_ARG(params && grads && dout && xt && acts && h0 && c0 && hn && cn && out && workspace && L >= 1,
                   "egz_lstm_b1_bwd: null pointer");
     EGZ_CHECK_ARG(C % 4 == 0 && H % 4 == 0, "egz_lstm_b1_bwd: C=%d H=%d must be multiples of 4", C, H);
-    EGZ_CHECK_ARG(ws_bytes >= egz_lstm_b1_ws_bytes(L, C, H), "egz_lstm_b1_bwd: workspace too small");
+    EGZ_CHECK_ARG(ws_bytes >= egz_lstm_b1_ws_bytes(L, C, H, N), "egz_lstm_b1_bwd: workspace too small");
     float* part = static_cast<float*>(workspace);
     const int wide = C > H ? C : H;
-    float* dgates = part + (size_t)((4 * H + STRIP - 1) / STRIP) * wide;           // [L][4H]
+    float* dgates = part + (size_t)(((4 * H > N ? 4 * H : N) + STRIP - 1) / STRIP) * wide;       // [L][4H], behind the widest partial region
+    for (int i = 0; i < 4 * L + 2; ++i) {                   // the kernels use 16-byte loads on the parameter rows
+        EGZ_CHECK_ARG(P_ALIGNED(reinterpret_cast<const float* const*>(params)[i]), "egz_lstm_b1_bwd: parameter %d is not 16-byte aligned", i);
+    }
+    EGZ_CHECK_ARG(P_ALIGNED(xt) && P_ALIGNED(h0) && P_ALIGNED(hn) && P_ALIGNED(dout), "egz_lstm_b1_bwd: xt / h0 / hn / dout must be 16-byte aligned");
     const float* const* P = reinterpret_cast<const float* const*>(params);
     float* const* G = reinterpret_cast<float* const*>(grads);
     // Linear + ReLU head: dW = dpre x h_top, db = dpre, partial columns of W^T dpre

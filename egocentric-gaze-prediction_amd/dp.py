@@ -16,6 +16,7 @@ Works with any torch.distributed backend ('nccl' = RCCL on ROCm; 'gloo' in the C
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -24,10 +25,22 @@ import torch.distributed as dist
 
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, params: Sequence[torch.nn.Parameter], offsets: Sequence[int],
-                 bucket_bytes: int = 25 * 1024 * 1024, group=None, flat_param: Optional[torch.Tensor] = None):
+                 bucket_bytes: int = 25 * 1024 * 1024, group=None, flat_param: Optional[torch.Tensor] = None,
+                 force: Optional[bool] = None, record_events: bool = False):
+        """``force``: install the hooks and issue the collectives even at world size 1 (default: EGAZE_DP_FORCE=1) -- a
+        1-rank RCCL all-reduce is legal and runs the same code path (comm stream, async handles, the joins in front of
+        the optimizer step), which is how the ``nccl`` path is exercised on a one-GPU box (tests/test_hip_rccl.py,
+        ``bench.py`` extra.rccl_world1).  ``record_events``: keep a HIP event per bucket launch (tests)."""
         self.flat_grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if force is None:
+            force = os.environ.get("EGAZE_DP_FORCE", "0") == "1"
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
+        self.record_events = record_events
+        self.events = []                            # (bucket, event recorded on the comm stream behind its collective)
+        self.stats = {"launched_in_backward": 0, "launched_in_wait": 0, "steps": 0}
+        self._in_wait = False
         self.buckets: List[List[int]] = []          # [start, end, n_params]
         self.bucket_of = {}
         self._pending: List[int] = []
@@ -49,7 +62,7 @@ class GradReducer:
             self.buckets.append([cur_start, cur_end, cur_n])
         self._reset()
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             if flat_param is not None:
                 dist.broadcast(flat_param, src=0, group=group)       # identical replicas to start from
             for i, p in enumerate(params):
@@ -64,10 +77,13 @@ class GradReducer:
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        if getattr(self, "events", None):
+            self.last_events, self.events = self.events, []      # the finished step's bucket events (record_events)
 
     def _launch(self, b: int):
         start, end, _ = self.buckets[b]
         self._launched[b] = True
+        self.stats["launched_in_wait" if self._in_wait else "launched_in_backward"] += 1
         if self.flat_grad.is_cuda:
             # A bucket holds gradients written on several HIP streams (the two encoders, the detached weight-gradient
             # streams: streams.py).  The collective is issued from a dedicated comm stream that waits for ALL of them; the
@@ -80,6 +96,13 @@ class GradReducer:
             with torch.cuda.stream(comm):
                 self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
+                if self.record_events:
+                    # the library runs the collective on its own stream, ordered after `comm`; the handle's wait() orders a
+                    # stream after the collective -- make `comm` wait and mark that point
+                    self._handles[-1].wait()
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(comm)
+                    self.events.append((b, ev))
             return
         self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True))
@@ -97,30 +120,52 @@ class GradReducer:
             self._pending[b] -= 1
             if self._pending[b] == 0 and not self._launched[b]:
                 self._launch(b)
+        hook._egz_reducer = self
         return hook
 
     def wait(self):
         """Join all bucket all-reduces of this step (launching any whose parameters got no gradient)."""
-        if self.world == 1:
+        if not self.active:
             return
-        for b in range(len(self.buckets)):
-            if not self._launched[b]:
-                self._launch(b)
+        self._in_wait = True
+        try:
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)
+        finally:
+            self._in_wait = False
         for h in self._handles:
             h.wait()
+        self.stats["steps"] += 1
         self._reset()
 
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
+    def detach(self, optimizer=None):
+        """Remove the hooks again (bench.py's untimed RCCL leg attaches a reducer to the live optimizer and takes it off)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in getattr(optimizer, "params", []):
+            sink = getattr(p, "_egz_sink", None)
+            if sink is not None:
+                sink.hooks = [k for k in sink.hooks if getattr(k, "_egz_reducer", None) is not self]
+        if optimizer is not None and self.wait in optimizer.pre_step_hooks:
+            optimizer.pre_step_hooks.remove(self.wait)
+            optimizer.grad_scale = 1.0
+        self.active = False
 
-def attach(optimizer, bucket_bytes: int = 25 * 1024 * 1024, group=None) -> GradReducer:
+
+def attach(optimizer, bucket_bytes: int = 25 * 1024 * 1024, group=None, force: Optional[bool] = None,
+           record_events: bool = False) -> GradReducer:
     """Wire a GradReducer to a FusedAdam: reduce before the step, average inside the Adam kernel."""
-    red = GradReducer(optimizer.flat_g, optimizer.params, optimizer.offsets, bucket_bytes, group, optimizer.flat_p)
+    red = GradReducer(optimizer.flat_g, optimizer.params, optimizer.offsets, bucket_bytes, group, optimizer.flat_p,
+                      force=force, record_events=record_events)
     optimizer.pre_step_hooks.append(red.wait)
     optimizer.grad_scale = red.grad_scale
-    if red.world > 1:
+    if red.active:
         from . import hipops
         hipops.bump_weight_epoch()          # parameters were overwritten by the broadcast
     return red

@@ -16,22 +16,27 @@ from __future__ import annotations
 import torch
 
 from . import hipops as H
+from . import streams
 from .streams import fork
 
 
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
-    """Logical (B,C,H,W) tensor -> contiguous (B,H,W,C) buffer (zero-copy when already channels_last)."""
+    """Logical (B,C,H,W) tensor -> contiguous (B,H,W,C) buffer (zero-copy when already channels_last).  The abs-max scalar
+    the producing kernel attached to ``x`` (hipops.carry_absmax) follows the values."""
+    am = getattr(x, "_egz_absmax", None)
     x = x.detach()
     xp = x.permute(0, 2, 3, 1)
-    if xp.is_contiguous():
-        return xp
-    if not x.is_contiguous():
-        x = x.contiguous()
-    return H.nchw_to_nhwc(x)
+    if not xp.is_contiguous():
+        if not x.is_contiguous():
+            x = x.contiguous()
+        xp = H.nchw_to_nhwc(x)
+    if am is not None:
+        xp._egz_absmax = am
+    return xp
 
 
 def from_nhwc(y: torch.Tensor) -> torch.Tensor:
-    return y.permute(0, 3, 1, 2)
+    return H.carry_absmax(y.permute(0, 3, 1, 2), y)
 
 
 DETACH_WGRAD = __import__("os").environ.get("EGAZE_DETACH_WGRAD", "1") != "0"      # A/B knob
@@ -52,8 +57,34 @@ def _close_fork(f, sink, dw, *inputs):
     gradient tensor goes back to autograd and the streams are joined."""
     if sink is not None and DETACH_WGRAD:
         f.detach(*inputs)
+        _join_at_end_of_backward()
     else:
         f.join(dw)
+
+
+_JOIN_QUEUED = [False]
+
+
+def _join_at_end_of_backward():
+    """A detached weight-gradient stream is unknown to the autograd engine, so ``loss.backward()`` would return with
+    ``p.grad`` still being written on it: reading a gradient, clipping, or ``zero_grad()`` without a ``step()`` in between
+    would race.  The first detach of a backward pass queues ONE engine callback that makes the stream
+    ``backward()`` was called on wait for every helper stream once the whole graph has been issued -- the same join the
+    optimizer step performs, so the step itself is unchanged (measured), but gradients are ordinary stream-ordered tensors
+    again when ``backward()`` returns.  Skipped inside a hipGraph capture (a capture may only join streams forked from it)."""
+    if _JOIN_QUEUED[0] or not streams.ENABLED:
+        return
+    _JOIN_QUEUED[0] = True
+
+    def _join():
+        _JOIN_QUEUED[0] = False
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            streams.join_all_into_current(include_comm=False)
+
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_join)
+    except RuntimeError:          # not inside a backward pass (a test calling a backward function by hand)
+        _JOIN_QUEUED[0] = False
 
 
 def _finish(param, sink, grad):
@@ -110,13 +141,15 @@ class ConvBNReLUPool(torch.autograd.Function):
         else:
             coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
-        ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta)
+        # max |xin| (left on xin by its producer, or by the conv launch above): the weight gradient scales x with it
+        ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta, getattr(xin, "_egz_absmax", None))
         ctx.cfg = (training, pool, first, C, K, padded)
         return from_nhwc(out)
 
     @staticmethod
     def backward(ctx, dout):
-        xin, y, coef, weight, bias, gamma, beta = ctx.saved_tensors
+        xin, y, coef, weight, bias, gamma, beta, xam = ctx.saved_tensors
+        H.carry_absmax(xin, xam)
         training, pool, first, C, K, padded = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path "
@@ -169,13 +202,14 @@ class ConvReLU(torch.autograd.Function):
         wp, st = (H.packed_weight(weight, "ups_fwd", dt), False) if ups else H.conv_weight(weight, "fwd", dt, xin, K)
         y, _ = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
                              epi=H.EPI_BIAS_RELU, dtype=dt, streamed=st)
-        ctx.save_for_backward(xin, y, weight, bias)
+        ctx.save_for_backward(xin, y, weight, bias, getattr(xin, "_egz_absmax", None))
         ctx.cfg = (ups, C, K, bool(relu_below))
         return from_nhwc(y)
 
     @staticmethod
     def backward(ctx, dout):
-        xin, y, weight, bias = ctx.saved_tensors
+        xin, y, weight, bias, xam = ctx.saved_tensors
+        H.carry_absmax(xin, xam)
         ups, C, K, relu_below = ctx.cfg
         ng = ctx.needs_input_grad
         dx = dw = db = None
@@ -247,13 +281,14 @@ class FusionBlock(torch.autograd.Function):
         else:
             coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(z, coef, False)
-        ctx.save_for_backward(x2, y2, z, coef, weight, bias, gamma, beta)
+        ctx.save_for_backward(x2, y2, z, coef, weight, bias, gamma, beta, getattr(x2, "_egz_absmax", None))
         ctx.cfg = (training, C, K)
         return from_nhwc(out)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, y2, z, coef, weight, bias, gamma, beta = ctx.saved_tensors
+        x2, y2, z, coef, weight, bias, gamma, beta, xam = ctx.saved_tensors
+        H.carry_absmax(x2, xam)
         training, C, K = ctx.cfg
         if not training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path")

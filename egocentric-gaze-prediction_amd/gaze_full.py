@@ -57,6 +57,43 @@ def _split(folder, val_name):
     return sorted(k for k in names if val_name not in k), sorted(k for k in names if val_name in k)
 
 
+def _at_stage(args, STTrainData, STValData):
+    from .AT import AT
+    att = AT(pretrained_model=args.pretrained_model, pretrained_lstm=args.pretrained_lstm,
+             extract_lstm=args.extract_lstm, crop_size=args.crop_size, num_epoch_lstm=args.num_epoch_lstm,
+             lstm_save_img=args.lstm_save_img, save_path=args.save_path, save_name=args.save_lstm,
+             device=args.device, lstm_data_path=args.extract_lstm_path, traindata=STTrainData, valdata=STValData,
+             task=args.task, align=args.align)
+    if args.train_lstm:
+        att.train()
+    if args.extract_late:
+        if not args.train_lstm:
+            att.reload_LSTM(os.path.join(args.save_path, args.save_lstm))
+        for data in (STValData, STTrainData):
+            att.extract_late(DataLoader(dataset=data, batch_size=1, shuffle=False, num_workers=1, pin_memory=True),
+                             args.extract_late_pred_folder, args.extract_late_feat_folder)
+
+
+def _wait_for_rank0(key, poll_s=5.0):
+    """Host-side rendezvous after a rank-0-only stage: rank 0 sets ``key`` in the default process group's store when it is
+    done (or ``key + '/failed'`` on its way out of an exception), the others poll with sleep.  No device collective runs
+    while waiting, and a failure of rank 0 ends the other ranks instead of leaving them in a barrier."""
+    import time
+    from . import dp
+    if dp.world_size() == 1:
+        return
+    store = torch.distributed.distributed_c10d._get_default_store()
+    if dp.is_main():
+        store.set(key, "1")
+        return
+    while True:
+        if store.check([key + "/failed"]):
+            raise RuntimeError("rank 0 failed in its sequential stage (%s)" % key)
+        if store.check([key]):
+            return
+        time.sleep(poll_s)
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     from .AT import AT
@@ -68,9 +105,11 @@ def main(argv=None):
         import datetime
         args.device = os.environ['LOCAL_RANK']
         torch.cuda.set_device(int(args.device))
-        # the AT stage below is sequential (rank 0 only) and takes hours: the other ranks wait at a barrier
+        # the AT stage below is sequential (rank 0 only) and takes hours: the other ranks wait for it on the HOST
+        # (_wait_for_rank0: a key in the process group's store, polled with sleep) -- not inside a device collective, which
+        # would spin for hours and need a multi-day collective timeout that also hides real hangs of the SP / LF all-reduces
         torch.distributed.init_process_group(os.environ.get('EGAZE_DIST_BACKEND', 'nccl'),
-                                             timeout=datetime.timedelta(days=7))
+                                             timeout=datetime.timedelta(minutes=30))
     listFolders = sorted(os.listdir(args.flowPath))
     listGtFiles, listValGtFiles = _split(args.gtPath, args.val_name)
     print('num of training samples: ', len(listGtFiles))
@@ -93,20 +132,13 @@ def main(argv=None):
     # dataset (AT.py:127-145, 199-253): it does not shard without changing its results, so under torch.distributed it
     # runs on rank 0 only (which also owns every file it writes) while the other ranks wait.
     if dp.is_main():
-        att = AT(pretrained_model=args.pretrained_model, pretrained_lstm=args.pretrained_lstm,
-                 extract_lstm=args.extract_lstm, crop_size=args.crop_size, num_epoch_lstm=args.num_epoch_lstm,
-                 lstm_save_img=args.lstm_save_img, save_path=args.save_path, save_name=args.save_lstm,
-                 device=args.device, lstm_data_path=args.extract_lstm_path, traindata=STTrainData, valdata=STValData,
-                 task=args.task, align=args.align)
-        if args.train_lstm:
-            att.train()
-        if args.extract_late:
-            if not args.train_lstm:
-                att.reload_LSTM(os.path.join(args.save_path, args.save_lstm))
-            for data in (STValData, STTrainData):
-                att.extract_late(DataLoader(dataset=data, batch_size=1, shuffle=False, num_workers=1, pin_memory=True),
-                                 args.extract_late_pred_folder, args.extract_late_feat_folder)
-    dp.barrier()
+        try:
+            _at_stage(args, STTrainData, STValData)
+        except BaseException:
+            if dp.world_size() > 1:       # let the waiting ranks go down with this one instead of polling for ever
+                torch.distributed.distributed_c10d._get_default_store().set("at_stage_done/failed", "1")
+            raise
+    _wait_for_rank0("at_stage_done")
     lf = LF(pretrained_model=args.pretrained_late, save_path=args.save_path, late_save_img=args.late_save_img,
             save_name=args.save_late, device=args.device, late_pred_path=args.extract_late_pred_folder,
             num_epoch=args.num_epoch, late_feat_path=args.extract_late_feat_folder, gt_path=args.gtPath,

@@ -377,6 +377,27 @@ def _want_absmax() -> bool:
     return PRECISION == "split" and GRAD_SPLIT == "f16"
 
 
+# Forward activations get the same treatment as gradients: the pass that WRITES a post-ReLU activation (BN apply + ReLU
+# [+ pool], the bias + ReLU epilogue of a decoder conv) also emits max |a|, and the consuming convolution (forward operand)
+# and weight gradient (x operand) multiply by the matching power of two before the f16 split -- without it the pair's 22 bits
+# only hold for max |a| in [2^-3, 65504] (lo goes subnormal below, hi saturates above).  A/B knob: EGAZE_FWD_SCALE=0.
+FWD_SCALE = _os.environ.get("EGAZE_FWD_SCALE", "1") != "0"
+ABSMAX_STATS = {"standalone": 0}         # standalone egz_absmax passes (an operand arrived without its producer's abs-max)
+
+
+def _want_fwd_absmax() -> bool:
+    return PRECISION == "split" and FWD_SCALE
+
+
+def carry_absmax(dst: torch.Tensor, src) -> torch.Tensor:
+    """Hand the abs-max scalar of ``src`` (a tensor or the scalar buffer itself) on to ``dst`` -- a view / re-layout of the same
+    values (permutes and detaches create new tensor objects, which drop Python attributes)."""
+    am = getattr(src, "_egz_absmax", None) if isinstance(src, torch.Tensor) and src.dtype != torch.int32 else src
+    if am is not None:
+        dst._egz_absmax = am
+    return dst
+
+
 def absmax_of(x: torch.Tensor) -> torch.Tensor:
     """The abs-max scalar of a gradient tensor: the one its producer kernel attached (bn_relu_pool_bwd, relu_bwd_bias,
     pairmax_bwd compute it in their own pass), else a standalone reduction (egz_absmax)."""
@@ -384,9 +405,16 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
     if am is None:
         _req(x, "x")
         am = _new_absmax(x.device)
+        ABSMAX_STATS["standalone"] += 1
         check(LIB.egz_absmax(x.data_ptr(), x.numel(), am.data_ptr(), _stream()), "egz_absmax")
         x._egz_absmax = am
     return am
+
+
+def _streamed_tiles(B, H, W, K) -> int:
+    """Tiles of a plain streamed launch (128 x 128 when K % 128 == 0, else 256 x 64): its abs-max epilogue has 16384 slots."""
+    bm, bn = (128, 128) if K % 128 == 0 else (256, 64)
+    return ((B * H * W + bm - 1) // bm) * ((K + bn - 1) // bn)
 
 
 # ----------------------------------------------------------------------------- convolutions
@@ -401,6 +429,12 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     H, W = (2 * Hin, 2 * Win) if ups else (Hin, Win)
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
     stat = None
+    if dtype == F16X3 and absmax is None and FWD_SCALE:
+        absmax = absmax_of(x)               # forward operand: the producer's max |x| (or one standalone pass)
+    amo = None                              # max |y| of a bias + ReLU launch, for the convolution that consumes y
+    if dtype and epi == EPI_BIAS_RELU and _want_fwd_absmax() and K % 64 == 0:
+        amo = _new_absmax(x.device)
+        y._egz_absmax = amo
     uflag = 0 if not ups else (1 if ups == "fold" else 3)
     flags = uflag | (epi << 4) | (0x200 if dtype else (tile_flag or _TILE_FLAG))      # split kernels: 128-row tiles
     if epi == EPI_BIAS_STATS:
@@ -417,12 +451,19 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
                                    device=x.device)
             nb = LIB.egz_conv3x3_fwd_streamed_splitk_ws_bytes(B, H, W, K, ns)
             ws = workspace(nb, x.device)
+            if amo is not None and ((B * H * W + 31) // 32) * ((K + 63) // 64) > 16384:
+                amo = None
+                del y._egz_absmax
             check(LIB.egz_conv3x3_fwd_streamed_splitk(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W,
-                                                      C, K, epi, dtype, _p(absmax), ws.data_ptr(), nb, ns, _stream()),
+                                                      C, K, epi, dtype, _p(absmax), ws.data_ptr(), nb, ns, _p(amo), _stream()),
                   "egz_conv3x3_fwd_streamed_splitk")
             return y, stat
+        t8 = _tile8(B, H, W, C, K, 0)
+        if amo is not None and (t8 or _streamed_tiles(B, H, W, K) > 16384):
+            amo = None                      # no epilogue slot for this launch: the consumer runs a standalone abs-max pass
+            del y._egz_absmax
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, _tile8(B, H, W, C, K, 0), _p(absmax), None, None, _stream()),
+                                           epi, dtype, t8, _p(absmax), None, _p(amo), _stream()),
               "egz_conv3x3_fwd_split")
         return y, stat
     if dtype:
@@ -431,7 +472,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         nb = LIB.egz_conv3x3_fwd_split_ws_bytes(B, H, W, C, K, sflags)
         ws = workspace(nb, x.device) if nb else None
         check(LIB.egz_conv3x3_fwd_split(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                        sflags, dtype, _p(ws), nb, _p(absmax), _stream()), "egz_conv3x3_fwd_split")
+                                        sflags, dtype, _p(ws), nb, _p(absmax), _p(amo), _stream()), "egz_conv3x3_fwd_split")
         return y, stat
     PROF.note_flops("egz_conv3x3_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_fwd(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K, flags,
@@ -466,7 +507,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         ws = workspace(nb, dy.device) if nb else None
         am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_split(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                        4, dtype, _p(ws), nb, _p(am), _stream()), "egz_conv3x3_fwd_split(ups_dgrad)")
+                                        4, dtype, _p(ws), nb, _p(am), None, _stream()), "egz_conv3x3_fwd_split(ups_dgrad)")
         return dx
     PROF.note_flops("egz_conv3x3_ups_dgrad", 2.0 * B * H * W * K * 9 * C)     # algorithmic (reference) FLOPs
     check(LIB.egz_conv3x3_ups_dgrad(dy.data_ptr(), wp_ups_dgrad.data_ptr(), dx.data_ptr(), B, H, W, C, K,
@@ -532,17 +573,19 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
     C = x.shape[3]
     dw = _out(out, (K, C, 3, 3), x.device)
     flags = (1 if ups else 0) | variant_flag
-    am = None
+    am = xam = None
     prec = precision or PRECISION
     if prec in ("split", "split_bf16", "split_f16"):
         flags |= WGRAD_SPLIT
         if prec == "split_f16" or (prec == "split" and GRAD_SPLIT == "f16"):
             am = absmax_of(dy)             # f16 x3 with dy scaled by its abs-max; bf16 x3 otherwise
+            if FWD_SCALE:
+                xam = absmax_of(x)         # ... and the activation operand by its own (the forward pass left it on x)
     nb = LIB.egz_conv3x3_wgrad_ws_bytes(B, H, W, C, K, flags)
     ws = workspace(nb, x.device)
     PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, C, K, flags, ws.data_ptr(),
-                                ws.numel(), _p(am), _stream()), "egz_conv3x3_wgrad")
+                                ws.numel(), _p(am), _p(xam), _stream()), "egz_conv3x3_wgrad")
     return dw
 
 
@@ -624,8 +667,11 @@ def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool, out: Optio
     _req(y, "y")
     B, H, W, K = y.shape
     out = _out(out, (B, H // 2, W // 2, K) if pool else (B, H, W, K), y.device)
+    am = _new_absmax(y.device) if _want_fwd_absmax() else None
     check(LIB.egz_bn_relu_pool_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), out.data_ptr(), B, H, W, K,
-                                   int(pool), _stream()), "egz_bn_relu_pool_fwd")
+                                   int(pool), _p(am), _stream()), "egz_bn_relu_pool_fwd")
+    if am is not None:
+        out._egz_absmax = am      # max |out|, folded into the same pass: scales the f16 split of the consuming convolution
     return out
 
 
@@ -948,7 +994,7 @@ def lstm_b1_bwd(params, grads, dout, dhn, dcn, xt, acts, h0, c0, hn, cn, out):
     for name, t in (("dout", dout), ("dhn", dhn), ("dcn", dcn)):
         if t is not None:
             _req(t, name)
-    nbytes = LIB.egz_lstm_b1_ws_bytes(L, C, Hd)
+    nbytes = LIB.egz_lstm_b1_ws_bytes(L, C, Hd, N)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=out.device)
     check(LIB.egz_lstm_b1_bwd(_ptr_table(params), _ptr_table(grads), L, dout.data_ptr(), _p(dhn), _p(dcn), xt.data_ptr(),
                               acts.data_ptr(), h0.data_ptr(), c0.data_ptr(), hn.data_ptr(), cn.data_ptr(), out.data_ptr(),

@@ -49,15 +49,20 @@ class _LSTMNetFn(torch.autograd.Function):
             H.copy_into(hn[l], hs[T - 1])
             H.copy_into(cn[l], cs[T - 1])
         lin_w, lin_b = params[-2].detach(), params[-1].detach()
-        out = H.linear_fwd(layer_in, lin_w, bias=lin_b, relu=True).view(T, B, lin_w.shape[0])
-        ctx.saved = (x, h0c, c0c, saved_layers, out)
+        out2d = H.linear_fwd(layer_in, lin_w, bias=lin_b, relu=True)
+        # the node keeps the 2-D base and hands out a VIEW: the returned tensor (whose grad_fn is this node) must not be
+        # stored on the node itself -- that reference cycle runs through C++ and is never collected, leaking the
+        # saved T*B*4H activations of every step and keeping the step's AccumulateGrad nodes alive into the next one
+        ctx.saved = (x, h0c, c0c, saved_layers, out2d)
         ctx.params = list(params)
         ctx.dims = (T, B, C, Hd, L)
         ctx.set_materialize_grads(False)
-        return out, hn, cn
+        return out2d.view(T, B, lin_w.shape[0]), hn, cn
 
     @staticmethod
     def backward(ctx, dout, dhn, dcn):
+        if ctx.saved is None:
+            raise RuntimeError("lstmnet: backward a second time through the same forward pass (activations were freed)")
         x, h0c, c0c, saved_layers, out = ctx.saved
         params = ctx.params
         T, B, C, Hd, L = ctx.dims
@@ -107,6 +112,7 @@ class _LSTMNetFn(torch.autograd.Function):
             if sinks[i] is not None:
                 H.grad_done(p)
                 grads[i] = None
+        ctx.saved = None              # activations are dead after one backward pass (as with save_for_backward)
         return (dinp, dh0 if ng[1] else None, dc0 if ng[2] else None, *grads)
 
 

@@ -75,21 +75,23 @@ class fork:
                         am.record_stream(self.side)
 
 
-def join_all_into(target: torch.cuda.Stream):
+def join_all_into(target: torch.cuda.Stream, include_comm: bool = True):
     """Make ``target`` wait for every helper stream created so far, the current stream and the default stream."""
     cur = torch.cuda.current_stream()
     seen = {target.cuda_stream}
-    for st in list(_SIDE.values()) + [cur, torch.cuda.default_stream(target.device)]:
+    side = [st for key, st in _SIDE.items() if include_comm or key[2] != "comm"]
+    for st in side + [cur, torch.cuda.default_stream(target.device)]:
         if st.device == target.device and st.cuda_stream not in seen:
             target.wait_stream(st)
             seen.add(st.cuda_stream)
 
 
-def join_all_into_current():
+def join_all_into_current(include_comm: bool = True):
     """Make the current stream wait for every helper stream created so far (the optimizer step: gradients are written in
-    place by kernels on several streams)."""
+    place by kernels on several streams).  ``include_comm=False`` leaves the collective stream out (the end-of-backward
+    join: the gradient buckets still in flight are joined by the reducer's wait() in front of the optimizer step)."""
     if torch.cuda.is_available():
-        join_all_into(torch.cuda.current_stream())
+        join_all_into(torch.cuda.current_stream(), include_comm)
 
 
 _COMM = {}

@@ -70,8 +70,11 @@ int egz_pack_w3x3_split_multi(const void* table, int nrows, int total_blocks, hi
 size_t egz_conv3x3_fwd_split_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, float* y, double* stat_partial, int B,
                           int H, int W, int C, int K, int flags, int dtype, void* workspace, size_t ws_bytes,
-                          const unsigned int* x_absmax, hipStream_t stream);
-/* Streamed-weight form of the plain split-half conv (csrc/conv3x3_igemm_x3s.hip): the weights are packed in MFMA
+                          const unsigned int* x_absmax, unsigned int* absmax_out, hipStream_t stream);
+/* absmax_out (optional; bias + ReLU epilogue, forward forms): receives max |y| in the egz_absmax layout -- the f16 x3
+ * scaling of the convolution that consumes y (per-block partials from the epilogue + one fold launch, no extra pass over y
+ * for launches of at most 16384 blocks).
+ * Streamed-weight form of the plain split-half conv (csrc/conv3x3_igemm_x3s.hip): the weights are packed in MFMA
  * fragment order (kind 4 = forward, 5 = data gradient of the same nn.Conv2d: utils.py:66, models/model_SP.py:13-29) and go
  * L2 -> registers, the activation halo goes through LDS.  egz_conv3x3_streamed_ok: 1 when a geometry is covered
  * (C = reduction channels % 32 == 0, K = GEMM columns % 64 == 0).  mode 0 = plain conv; mode 1 = data gradient of
@@ -83,7 +86,8 @@ int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, i
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
                              const float* mask_src, unsigned int* absmax_out, hipStream_t stream);
-/* Split-K form of a plain egz_conv3x3_fwd_streamed launch for small pixel counts (batch-1 inference as in
+/* epi 1 (bias + ReLU) with absmax_out != NULL (K % 64 == 0, at most 16384 tiles): absmax_out receives max |y|, folded.
+ * Split-K form of a plain egz_conv3x3_fwd_streamed launch for small pixel counts (batch-1 inference as in
  * run_spatialstream.py:85-138 / AT.py:216, the 14 x 14 layers at the reference's default --batch_size_sp 8): the channel
  * blocks of a tile are divided over nsplit blocks (raw partial sums in the workspace, nsplit x B x H x W x K floats) and a
  * fix-up launch sums them in split order and applies the epilogue (epi 0 / 1 / 2).  egz_conv3x3_streamed_splits recommends
@@ -93,7 +97,8 @@ int egz_conv3x3_fwd_streamed_splitk_stat_rows(int B, int H, int W);   /* rows of
 size_t egz_conv3x3_fwd_streamed_splitk_ws_bytes(int B, int H, int W, int K, int nsplit);
 int egz_conv3x3_fwd_streamed_splitk(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                                     int H, int W, int C, int K, int epi, int dtype, const unsigned int* x_absmax,
-                                    void* workspace, size_t ws_bytes, int nsplit, hipStream_t stream);
+                                    void* workspace, size_t ws_bytes, int nsplit, unsigned int* absmax_out,
+                                    hipStream_t stream);
 /* helpers of the epi = 3 (ReLU mask + bias-gradient sums + abs-max) form of egz_conv3x3_fwd_streamed, which folds the
  * nn.ReLU backward of a decoder layer (models/model_SP.py:13-29) into the data gradient of the layer above it */
 int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t stream);
@@ -102,7 +107,8 @@ int egz_colsum_f64(const double* part, int rows, int cols, int ncols_out, float*
 /* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
 size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,
-                      void* workspace, size_t ws_bytes, const unsigned int* dy_absmax, hipStream_t stream);
+                      void* workspace, size_t ws_bytes, const unsigned int* dy_absmax, const unsigned int* x_absmax,
+                      hipStream_t stream);
 
 /* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
  *      per data/STdatas.py:50-73) and Conv2d(2,32) (models/late_fusion.py:10).  K in {64, 32}. */
@@ -124,7 +130,7 @@ int egz_bn_finalize(const double* stat_partial, int rows, int K, double count, c
 int egz_bn_eval_coeffs(int K, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
 int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W,
-                         int K, int pool, hipStream_t stream);
+                         int K, int pool, unsigned int* absmax, hipStream_t stream);   /* absmax: optional, max |out| */
 size_t egz_bn_relu_pool_bwd_ws_bytes(int K);
 int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift, const float* mean,
                          const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int K,
@@ -205,7 +211,7 @@ int egz_lstm_seq_bwd(const float* dh_out, const float* dhn, const float* dcn, co
  * 4L + 2 device pointers in state-dict order (w_ih, w_hh, b_ih, b_hh per layer, lin.weight [N][H], lin.bias [N]); a null
  * grads entry skips that gradient.  inp [C] raw (tanh applied inside, saved to xt); h0, c0, hn, cn [L][H]; acts [L][4H]
  * (null in no-grad runs); out [N] after ReLU.  No gradient w.r.t. inp / h0 / c0 (the loop detaches them, AT.py:143). */
-size_t egz_lstm_b1_ws_bytes(int L, int C, int H);
+size_t egz_lstm_b1_ws_bytes(int L, int C, int H, int N);
 int egz_lstm_b1_fwd(const void* const* params, int L, const float* inp, const float* h0, const float* c0, float* xt,
                     float* acts, float* hn, float* cn, float* out, int C, int H, int N, hipStream_t stream);
 int egz_lstm_b1_bwd(const void* const* params, void* const* grads, int L, const float* dout, const float* dhn,
@@ -246,6 +252,10 @@ int egz_window_mean(const float* feat, const int* win, float* out, int B, int H,
  * x16-upsampled map is a linear functional of the map -- out[b][c] = sum_p wmap[b][p] * feat[b][p][c] */
 int egz_pixel_weighted_sum(const float* feat, const float* wmap, float* out, int B, int HW, int C, hipStream_t stream);
 int egz_weighted_minmax(const float* feat, const float* w, float* out, int B, int HW, int C, hipStream_t stream);
+
+/* ---- measurement aid (bench.py): sustained v_mfma_f32_32x32x16_f16 rate of this chip on the given operand bits; frag =
+ *      16 x 64 x 16 bytes, out = blocks x 256 floats; executes blocks x 4 x iters x 8 MFMAs of 32768 flop. */
+int egz_mfma_probe(const void* frag, float* out, int blocks, int iters, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,46 @@ def test_model_sp_train_step(tag, size):
     assert int(sd["features_s.1.num_batches_tracked"]) == 1
 
 
+def test_model_sp_train_step_headline_size():
+    """The headline configuration itself (BASELINE config 2: batch 32, 224 x 224, train-mode BN): one literal SP.trainSP
+    iteration (SP.py:126-138) on the HIP path vs the CPU oracle on the same synthetic batch.  The goldens are batch 2; at
+    batch 32 the launch geometry differs (3136 / 6272 tiles per launch, split counts, buffers up to 411 MB, the weight
+    gradient's split-K depth), which only shape fuzz at small sizes covered so far.  Bounds as for the golden step: gaze map
+    1e-4 (bar 1e-3), loss 1e-4, gradient norms 5e-3 (2x the fp32 reference's own distance from the fp64 gradient, see
+    test_model_sp_train_step), BN running statistics 1e-4.  ~15-30 s of oracle time on the GPU box's host cores."""
+    from egaze_amd.floss import floss
+    from egaze_amd.optim import FusedAdam
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    model, sd0 = build_model()
+    x_s, x_t, gt, _ = synth.synth_sp_batch(32, 224, seed=3)
+    model.train()
+    criterion = floss().to(DEV)
+    optimizer = FusedAdam(model.parameters(), lr=1e-7)
+    optimizer.zero_grad()
+    output = model(x_s.to(DEV), x_t.to(DEV))
+    loss = criterion(output, gt.to(DEV).view(output.size()))
+    loss.backward()
+    got = {k: p.grad.detach().double().norm().item() for k, p in model.named_parameters()}
+    out_hip, loss_hip = output.detach().cpu(), loss.item()
+    sd_hip = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if "running" in k}
+    del output, loss
+    sd = {k: v.clone() for k, v in sd0.items()}
+    loss_ref, out_ref, grads = O.sp_train_step(sd, {}, 1, x_s, x_t, gt, 0.0)
+    r = rel(out_hip.numpy(), out_ref.numpy())
+    print(f"B=32 224x224: gaze map {r:.2e}, loss {loss_hip:.6f} vs {loss_ref.item():.6f}")
+    assert r < TOL_TIGHT, r
+    assert abs(loss_hip - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+    gmax = max(g.double().norm().item() for g in grads.values())
+    worst = 0.0
+    for k, g in grads.items():
+        want = g.double().norm().item()
+        worst = max(worst, abs(got[k] - want) / (want + 1e-5 * gmax))
+        assert abs(got[k] - want) <= 5e-3 * want + 1e-5 * gmax, (k, got[k], want)
+    print(f"B=32 224x224: worst gradient-norm deviation {worst:.2e} over {len(grads)} tensors")
+    for k, v in sd_hip.items():
+        assert rel(v.numpy(), sd[k].numpy()) < 1e-4, k
+
+
 # Element-wise gradient checks at 32 x 32.  The encoders end at 2 x 2 (B = 3: twelve samples per channel), so ONE
 # post-BN value that lands within ~1e-5 of zero makes two implementations take different (equally valid) ReLU
 # subgradients at the TOP of a 13-layer chain, which moves every gradient below it by ~2 % -- measured with
@@ -145,7 +185,7 @@ def test_model_sp_train_step(tag, size):
 #     indexing bug breaks this on every input, a subgradient flip does not;
 #   * at least two of the three seeds are flip-free and then match tightly (98 % of the entries within 2e-3 / the
 #     fp32-class bound); the test prints which.
-GRAD_SEEDS = (5, 6, 7)
+GRAD_SEEDS = (4, 5, 6)      # flip-free in BOTH summation orders (survey of seeds 0-11: profiles/r03_grad_seed_survey.txt)
 
 
 def cos_norm(a, b):
@@ -195,7 +235,7 @@ def test_model_sp_vs_oracle_full_grads_small(monkeypatch):
     monkeypatch.setattr(H, "SPLITK", True)
     results = [_full_grads_small(seed) for seed in GRAD_SEEDS]
     print("full-grads, split-K order (tight on seeds %s):" % [r[1][0] for r in results if r[0]], results)
-    assert sum(ok for ok, _ in results) >= 1, results
+    assert sum(ok for ok, _ in results) >= 2, results
 
 
 def _grads_vs_fp64(seed):
@@ -333,6 +373,12 @@ def _bn_stats_dev(sd, truth):
     return worst
 
 
+# Where the run ENDS (final eval-mode gaze map, BN running statistics) every mode must be within 2x the CPU fp32 path's own
+# distance from the fp64 run -- observed 0.85 - 1.3x (profiles/r03_training_trajectory.txt).  The per-step loss sequence keeps
+# the factor 4: the EXACT-f32 MFMA mode -- same arithmetic class as the reference, another summation order -- itself reaches
+# 3.3x the envelope at step 8 (2.9e-2 vs 8.9e-3; f16 x3: 2.4x), so a tighter per-step bound would test the summation order of
+# a chaotic trajectory, not the precision of the kernels.
+END_FACTOR = 2.0
 # (PRECISION, GRAD_SPLIT, envelope factor).  The default mode and the exact-f32 mode must stay within 4x the reference
 # path's own fp32-vs-fp64 envelope.  bf16 x3 gradients (16-bit operands in the backward pass, opt-in with
 # EGAZE_GRAD_SPLIT=bf16) DO drift more -- measured 4.4x the envelope at step 8 (3.95e-2 vs 8.9e-3) -- which is why f16 x3
@@ -395,10 +441,10 @@ def test_training_trajectory_vs_oracle(precision, grad_split, factor, monkeypatc
     r_hip = rel(ev.cpu().numpy(), truth["eval_out"])
     r_cpu = rel(ref32["eval_out"], truth["eval_out"])
     print(f"{tag} final eval gaze map vs fp64: HIP {r_hip:.2e}, CPU fp32 {r_cpu:.2e}")
-    assert r_hip <= factor * r_cpu + 1e-4, (r_hip, r_cpu)
+    assert r_hip <= END_FACTOR * r_cpu + 1e-4, (r_hip, r_cpu)
     b_hip, b_cpu = _bn_stats_dev(model.state_dict(), truth["sd"]), _bn_stats_dev(ref32["sd"], truth["sd"])
     print(f"{tag} BN running stats vs fp64: HIP {b_hip:.2e}, CPU fp32 {b_cpu:.2e}")
-    assert b_hip <= factor * b_cpu + 1e-4, (b_hip, b_cpu)
+    assert b_hip <= END_FACTOR * b_cpu + 1e-4, (b_hip, b_cpu)
 
 
 def test_relu_backward_folded_into_dgrad_above(monkeypatch):

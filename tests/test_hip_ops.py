@@ -460,6 +460,87 @@ def test_gradient_absmax_scaling(mag):
     assert torch.equal(dy2._egz_absmax[:1].view(torch.float32).cpu(), want)
 
 
+@pytest.mark.parametrize("mag", [1e-5, 1e-2, 1.0, 1e3, 2e5])
+def test_forward_activation_scaling(mag):
+    """f16 x3 forward operands of ANY magnitude (round-3 parity item): the pass that writes a post-ReLU activation also
+    emits max |a| (BN apply + ReLU [+ pool]; the bias + ReLU epilogue of the streamed / phase-upsample conv kernels) and the
+    consuming convolution -- forward operand, weight-gradient x operand -- scales by the matching power of two before the
+    split.  Unscaled, activations above 65504 overflow the hi half and below ~0.125 push the lo half into f16 subnormals;
+    the reference's fp32 Conv2d (utils.py:70, models/model_SP.py:13-29) has no such domain.  Bound: 2e-6 of max |ref| vs fp64,
+    the same bound as at magnitude 1."""
+    h = H()
+    assert h.FWD_SCALE
+    keep = h.PRECISION
+    h.PRECISION = "split"
+    try:
+        B, Hh, Ww, C, K = 2, 16, 32, 64, 128
+        # ---- producer 1: BN apply + ReLU + pool writes the activation and its abs-max in one pass
+        ypre = rnd(B, 2 * Hh, 2 * Ww, C, seed=71).to(DEV)
+        coef = torch.zeros(4, C, device=DEV)
+        coef[2] = mag
+        coef[3] = 0.1 * mag
+        a = h.bn_relu_pool_fwd(ypre, coef, True)
+        am = a._egz_absmax
+        assert torch.equal(am[:1].view(torch.float32).cpu(), a.max().reshape(1).cpu())          # exact max, as a bit pattern
+        a_ref = a.permute(0, 3, 1, 2).double().cpu()
+        w = rnd(K, C, 3, 3, seed=72, scale=(2.0 / (9 * C)) ** 0.5)
+        b = rnd(K, seed=73, scale=0.1 * mag)
+        wd = torch.nn.Parameter(w.to(DEV))
+        ref = F.relu(F.conv2d(a_ref, w.double(), b.double(), padding=1))
+        before = h.ABSMAX_STATS["standalone"]
+        wq, st = h.conv_weight(wd, "fwd", h.F16X3, a, K)
+        assert st
+        y, _ = h.conv3x3_fwd(a, wq, b.to(DEV), K, epi=h.EPI_BIAS_RELU, dtype=h.F16X3, streamed=True)
+        assert h.ABSMAX_STATS["standalone"] == before          # the producer's scalar was used, no extra pass
+        assert rel(nchw(y), ref) < 2e-6
+        # ---- producer 2: the conv's own bias + ReLU epilogue emitted max |y| for the next layer
+        assert torch.equal(y._egz_absmax[:1].view(torch.float32).cpu(), y.max().reshape(1).cpu())
+        # ---- the gather-kernel family (phase-upsample forward) scales the same way and emits its abs-max too
+        w2 = rnd(64, K, 3, 3, seed=74, scale=(2.0 / (9 * K)) ** 0.5)
+        w2d = torch.nn.Parameter(w2.to(DEV))
+        y_ref = nchw(y).double()
+        ref2 = F.relu(F.conv2d(F.interpolate(y_ref, scale_factor=2, mode="nearest"), w2.double(), None, padding=1))
+        y2, _ = h.conv3x3_fwd(y, h.packed_weight(w2d, "ups_fwd", h.F16X3), None, 64, ups="phase", epi=h.EPI_BIAS_RELU,
+                              dtype=h.F16X3)
+        assert h.ABSMAX_STATS["standalone"] == before
+        assert rel(nchw(y2), ref2) < 2e-6
+        assert torch.equal(y2._egz_absmax[:1].view(torch.float32).cpu(), y2.max().reshape(1).cpu())
+        # ---- weight gradient: the x operand is scaled by its abs-max, dy by its own
+        dy = rnd(B, K, Hh, Ww, seed=75)
+        wref = torch.nn.grad.conv2d_weight(a_ref, w.shape, dy.double(), padding=1)
+        dw = h.conv3x3_wgrad(a, nhwc(dy), precision="split_f16")
+        assert rel(dw.cpu(), wref) < 2e-6
+        wref2 = torch.nn.grad.conv2d_weight(F.interpolate(y_ref, scale_factor=2, mode="nearest"), w2.shape,
+                                            rnd(B, 64, 2 * Hh, 2 * Ww, seed=76).double(), padding=1)
+        dw2 = h.conv3x3_wgrad(y, nhwc(rnd(B, 64, 2 * Hh, 2 * Ww, seed=76)), ups=True, precision="split_f16")
+        assert rel(dw2.cpu(), wref2) < 2e-6
+        # ---- an operand without a producer scalar (network input, user tensor): one standalone pass, same bound
+        a2 = a.clone()
+        before = h.ABSMAX_STATS["standalone"]
+        y3, _ = h.conv3x3_fwd(a2, wq, b.to(DEV), K, epi=h.EPI_BIAS, dtype=h.F16X3, streamed=True)
+        assert h.ABSMAX_STATS["standalone"] == before + 1
+        assert rel(nchw(y3), F.conv2d(a_ref, w.double(), b.double(), padding=1)) < 2e-6
+    finally:
+        h.PRECISION = keep
+
+
+def test_forward_scaling_off_loses_the_small_range(monkeypatch):
+    """The knob that switches the forward scaling off (EGAZE_FWD_SCALE=0, A/B runs) shows what it is for: at max |a| = 1e-5
+    the unscaled f16 pair is two orders of magnitude less accurate than the scaled one."""
+    h = H()
+    B, Hh, Ww, C, K = 1, 16, 16, 64, 128
+    a = (torch.rand(B, Hh, Ww, C, generator=torch.Generator().manual_seed(5)) * 1e-5).to(DEV)
+    w = rnd(K, C, 3, 3, seed=6, scale=(2.0 / (9 * C)) ** 0.5)
+    wd = torch.nn.Parameter(w.to(DEV))
+    ref = F.conv2d(a.permute(0, 3, 1, 2).double().cpu(), w.double(), None, padding=1)
+    wq, st = h.conv_weight(wd, "fwd", h.F16X3, a, K)
+    y_on, _ = h.conv3x3_fwd(a, wq, None, K, epi=h.EPI_BIAS, dtype=h.F16X3, streamed=st)
+    monkeypatch.setattr(h, "FWD_SCALE", False)
+    y_off, _ = h.conv3x3_fwd(a.clone(), wq, None, K, epi=h.EPI_BIAS, dtype=h.F16X3, streamed=st)
+    e_on, e_off = rel(nchw(y_on), ref), rel(nchw(y_off), ref)
+    assert e_on < 2e-6 and e_off > 20 * e_on, (e_on, e_off)
+
+
 @pytest.mark.parametrize("B,Hh,Ww,C", [(2, 16, 32, 20), (1, 24, 28, 20), (2, 9, 7, 17)])
 def test_first_conv_padded_split_path(B, Hh, Ww, C):
     """The flow-stack first conv (Cin = 20, SP.py:53) on the split-half kernels after zero-padding Cin to 32:
@@ -683,7 +764,7 @@ def test_cabi_argument_errors_are_loud():
     yo = torch.empty((1, 14, 14, 512), device=DEV)
     small = torch.empty(16, device=DEV)
     rc = h.LIB.egz_conv3x3_fwd_streamed_splitk(xs.data_ptr(), wq.data_ptr(), None, yo.data_ptr(), None, 1, 14, 14, 256, 512, 0, 1,
-                                               None, small.data_ptr(), 64, ns, h._stream())
+                                               None, small.data_ptr(), 64, ns, None, h._stream())
     assert rc != 0
     with pytest.raises(RuntimeError, match="workspace"):
         h.check(rc, "egz_conv3x3_fwd_streamed_splitk")
