@@ -24,8 +24,15 @@
 #include "egz_common.h"
 #include "x3_split.h"
 
+#ifndef EGZ_UPSD_PIPE         // A/B knob: 1 = both halves of an upsample-dgrad image fetched at tap 0 into two register sets
+                              // (measured: no gain, 675 vs 678 us -- the staging latency is already covered; costs 12 VGPRs)
+#define EGZ_UPSD_PIPE 0
+#endif
+#ifndef EGZ_WAVE_SCALAR       // A/B knob: 0 = wave index left in a VGPR (weight-fragment loads in waterfall loops)
+#define EGZ_WAVE_SCALAR 1
+#endif
 #ifndef EGZ_X3S_DIAG          // timing diagnostics (WRONG RESULTS): 1 no weight loads in the loop, 2 half the activation
-#define EGZ_X3S_DIAG 0        // fragment reads, 4 no halo restaging
+#define EGZ_X3S_DIAG 0        // fragment reads, 4 no halo restaging, 8 no barrier between images
 #endif
 
 EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st);      // bn_pool.hip
@@ -101,7 +108,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 
     const float a_scale = absmax_scale(a_absmax);
     out_scale /= a_scale;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is wave-uniform: telling the compiler (readfirstlane -> SGPR) keeps everything derived from it scalar --
+    // in particular the soffset of the weight-fragment loads, which otherwise is wrapped in a waterfall loop per load
+    const int tid = threadIdx.x, lane = tid & 63, wave = EGZ_WAVE_SCALAR ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN, hl = lane >> 5, l31 = lane & 31;
     const int ntn = Kp / BN;
     // XCD-aware tile id: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
@@ -241,19 +250,24 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         return tap;
     };
 
-    f32x4 ra[NJ / 2];
+    // staging registers: one half of an image at a time (PLAIN: its nine taps leave two taps between a fetch and its split),
+    // or -- UPSD, where an image only lasts four taps -- both halves in flight at once, fetched at tap 0 and split at taps 2
+    // and 3: one tap of distance (~0.4 us per wave) did not cover the HBM latency of the strided polyphase fetch, and the
+    // four upsample data gradients ran at half the rate of the plain convolutions (profiles/r02_conv_microbench.txt)
+    constexpr int RAOFF = (MODE == UPSD && EGZ_UPSD_PIPE) ? NJ / 2 : 0;
+    f32x4 ra[NJ / 2 + RAOFF];
     auto gload_a = [&](int cblk, const int img, const int half) {
         const unsigned so = (unsigned)(cblk * XBK * 4) +
                             ((MODE == UPSD) ? (unsigned)(((img >> 1) * W + (img & 1)) * C * 4) : 0u);
 #pragma unroll
         for (int j = 0; j < NJ / 2; ++j)
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[half * (NJ / 2) + j], so, 0));
+            ra[half * RAOFF + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[half * (NJ / 2) + j], so, 0));
     };
     auto lstore_a = [&](const int abuf, const int half) {
 #pragma unroll
         for (int j = 0; j < NJ / 2; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4(ra[j] * a_scale, hi, lo);
+            Half<T>::split4(ra[half * RAOFF + j] * a_scale, hi, lo);
             unsigned short* d = Ah + abuf * ABUF + a_lds[half * (NJ / 2) + j];
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -300,7 +314,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     read_a0(shift_of(0, 0), 0);
 
     // staging schedule of the NEXT image inside the NT taps of the current one (double-buffered images)
-    constexpr int G0 = (NT == 9) ? 1 : 0, L0 = (NT == 9) ? 3 : 1, G1 = (NT == 9) ? 4 : 1, L1 = (NT == 9) ? 6 : 2;
+    constexpr bool UP2 = (NT == 4) && EGZ_UPSD_PIPE;             // both halves fetched at tap 0 (two register sets)
+    constexpr int G0 = (NT == 9) ? 1 : 0, L0 = (NT == 9) ? 3 : (UP2 ? 2 : 1), G1 = (NT == 9) ? 4 : (UP2 ? 0 : 1),
+                  L1 = (NT == 9) ? 6 : (UP2 ? 3 : 2);
     for (int c = c_lo; c < c_hi; ++c) {
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) {
@@ -340,7 +356,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                     if (t < NT - 1) {
                         read_a0(shift_of(img, t + 1), abuf);
                     } else if (more) {
+#if !(EGZ_X3S_DIAG & 8)
                         lds_barrier();                         // every wave has staged its share and is done reading
+#endif
                         read_a0(shift_of(nimg, 0), abuf ^ 1);
                     }
                 } else {

@@ -144,6 +144,7 @@ def test_model_sp_train_step_headline_size():
     test_model_sp_train_step), BN running statistics 1e-4.  ~15-30 s of oracle time on the GPU box's host cores."""
     from egaze_amd.floss import floss
     from egaze_amd.optim import FusedAdam
+    keep_threads = torch.get_num_threads()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     model, sd0 = build_model()
     x_s, x_t, gt, _ = synth.synth_sp_batch(32, 224, seed=3)
@@ -160,6 +161,7 @@ def test_model_sp_train_step_headline_size():
     del output, loss
     sd = {k: v.clone() for k, v in sd0.items()}
     loss_ref, out_ref, grads = O.sp_train_step(sd, {}, 1, x_s, x_t, gt, 0.0)
+    torch.set_num_threads(keep_threads)
     r = rel(out_hip.numpy(), out_ref.numpy())
     print(f"B=32 224x224: gaze map {r:.2e}, loss {loss_hip:.6f} vs {loss_ref.item():.6f}")
     assert r < TOL_TIGHT, r
@@ -345,12 +347,17 @@ def test_train_step_is_bitwise_deterministic():
 
 # ----------------------------------------------------------------------------- multi-step training trajectory
 TRAJ_STEPS, TRAJ_SIZE, TRAJ_B, TRAJ_LR = 8, 64, 4, 1e-4
+TRAJ_THREADS = (8, 2, 16)
 _TRAJ_ORACLE = {}
 
 
-def _oracle_trajectory(dtype):
+def _oracle_trajectory(dtype, threads=None):
     """TRAJ_STEPS literal SP.trainSP iterations (SP.py:126-138) on the CPU oracle in ``dtype``, fresh batch per step."""
-    if dtype not in _TRAJ_ORACLE:
+    key = (dtype, threads)
+    if key not in _TRAJ_ORACLE:
+        keep = torch.get_num_threads()
+        if threads:
+            torch.set_num_threads(threads)
         cast = lambda v: v.to(dtype) if v.is_floating_point() else v.clone()
         sd = {k: cast(v) for k, v in synth.synth_state_dict(O.sp_shapes(), seed=1, head_gain=0.25).items()}
         opt, losses = {}, []
@@ -361,8 +368,9 @@ def _oracle_trajectory(dtype):
         x_s, x_t, _, _ = synth.synth_sp_batch(TRAJ_B, TRAJ_SIZE, seed=99)
         with torch.no_grad():
             ev, _ = O.sp_forward(sd, cast(x_s), cast(x_t), training=False)
-        _TRAJ_ORACLE[dtype] = dict(losses=losses, sd=sd, eval_out=ev.double().numpy())
-    return _TRAJ_ORACLE[dtype]
+        torch.set_num_threads(keep)
+        _TRAJ_ORACLE[key] = dict(losses=losses, sd=sd, eval_out=ev.double().numpy())
+    return _TRAJ_ORACLE[key]
 
 
 def _bn_stats_dev(sd, truth):
@@ -406,7 +414,10 @@ def test_training_trajectory_vs_oracle(precision, grad_split, factor, monkeypatc
     from egaze_amd.optim import FusedAdam
     monkeypatch.setattr(H, "PRECISION", precision)
     monkeypatch.setattr(H, "GRAD_SPLIT", grad_split)
-    ref32, truth = _oracle_trajectory(torch.float32), _oracle_trajectory(torch.float64)
+    # the reference path in THREE summation orders (2, 8 and 16 host threads): its own run-to-run variability is part of
+    # the envelope -- with a single order the envelope itself moved from 8.9e-3 to 6.9e-3 between two hosts (round 3)
+    refs32 = [_oracle_trajectory(torch.float32, t) for t in TRAJ_THREADS]
+    ref32, truth = refs32[0], _oracle_trajectory(torch.float64, TRAJ_THREADS[0])
     model, _ = build_model()
     model.train()
     crit = floss().to(DEV)
@@ -423,8 +434,10 @@ def test_training_trajectory_vs_oracle(precision, grad_split, factor, monkeypatc
         losses.append(loss.item())
     tag = f"[{precision}/{grad_split}]"
     dev_hip = [abs(a - b) / abs(b) for a, b in zip(losses, truth["losses"])]
-    dev_cpu = [abs(a - b) / abs(b) for a, b in zip(ref32["losses"], truth["losses"])]
-    vs32 = [abs(a - b) / abs(b) for a, b in zip(losses, ref32["losses"])]
+    dev_cpu = [max(abs(r["losses"][i] - b) / abs(b) for r in refs32) for i, b in enumerate(truth["losses"])]
+    vs32 = [min(abs(a - r["losses"][i]) / abs(r["losses"][i]) for r in refs32) for i, a in enumerate(losses)]
+    for r, t in zip(refs32, TRAJ_THREADS):
+        print(tag, f"CPU fp32 on {t:2d} threads vs fp64:", ["%.1e" % (abs(a - b) / abs(b)) for a, b in zip(r["losses"], truth["losses"])])
     print(tag, "loss dev vs fp64 : HIP", ["%.1e" % v for v in dev_hip])
     print(tag, "                   CPU fp32", ["%.1e" % v for v in dev_cpu])
     print(tag, "loss dev vs CPU fp32:", ["%.1e" % v for v in vs32])
@@ -439,10 +452,10 @@ def test_training_trajectory_vs_oracle(precision, grad_split, factor, monkeypatc
     with torch.no_grad():
         ev = model(x_s.to(DEV), x_t.to(DEV))
     r_hip = rel(ev.cpu().numpy(), truth["eval_out"])
-    r_cpu = rel(ref32["eval_out"], truth["eval_out"])
+    r_cpu = max(rel(r["eval_out"], truth["eval_out"]) for r in refs32)
     print(f"{tag} final eval gaze map vs fp64: HIP {r_hip:.2e}, CPU fp32 {r_cpu:.2e}")
     assert r_hip <= END_FACTOR * r_cpu + 1e-4, (r_hip, r_cpu)
-    b_hip, b_cpu = _bn_stats_dev(model.state_dict(), truth["sd"]), _bn_stats_dev(ref32["sd"], truth["sd"])
+    b_hip, b_cpu = _bn_stats_dev(model.state_dict(), truth["sd"]), max(_bn_stats_dev(r["sd"], truth["sd"]) for r in refs32)
     print(f"{tag} BN running stats vs fp64: HIP {b_hip:.2e}, CPU fp32 {b_cpu:.2e}")
     assert b_hip <= END_FACTOR * b_cpu + 1e-4, (b_hip, b_cpu)
 
