@@ -38,6 +38,22 @@ def kernel_src_sha():
     return h.hexdigest()[:16]
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner straight to file descriptor 1 when its first communicator comes up; the contract of this
+    script is ONE JSON line on stdout, so descriptor 1 points at stderr while a process group is initialised / first used."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def mfma_power_probe(dev, ms_target=30.0):
     """Sustained v_mfma_f32_32x32x16_f16 rate of THIS chip on random operand bits (csrc/probe.hip): register operands, no
     memory traffic.  MI355X manages its matrix cores against a power budget -- ~1.5 PFLOP/s on random bits vs 2.4 on zeros
@@ -148,10 +164,12 @@ def main():
             with socket.socket() as s_:
                 s_.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier()               # the first collective creates the communicator (and prints RCCL's banner)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
         if rank == 0:
             print(f"[bench] {'RCCL' if backend == 'nccl' else backend} ranks: {dist.get_world_size()}"
@@ -376,6 +394,8 @@ def main():
             # The data-parallel code path on this one GPU (untimed leg): a process group of ONE rank over RCCL, the gradient
             # reducer attached to the live optimizers -- bucket hooks fired from the gradient sinks during backward, async
             # all-reduces issued from the comm stream, handles joined in front of Adam -- against the same steps without it.
+            redirect = stdout_to_stderr()
+            redirect.__enter__()
             try:
                 import socket
                 import torch.distributed as tdist
@@ -409,6 +429,8 @@ def main():
                                 "vs 5 steps without; the timed region above runs without it at N = 1"}
             except Exception as e:       # a box without a working RCCL must not lose the bench line
                 rccl = {"error": repr(e)[:300]}
+            finally:
+                redirect.__exit__()
         tot = sum(v["ms"] for v in prof.values())
         breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         breakdown["_sum_kernel_ms"] = round(tot, 3)

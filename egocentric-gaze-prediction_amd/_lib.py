@@ -23,6 +23,8 @@ SIGNATURES = {
     "egz_version": (c_char_p, []),
     "egz_last_error": (c_char_p, []),
     "egz_mfma_probe": (c_int, [P, P, c_int, c_int, S]),
+    "egz_u8_center_of_mass": (c_int, [P, c_int, c_int, c_int, P, P, P, S]),
+    "egz_bilinear_up": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_long, S]),
     # --- 3x3 conv, implicit GEMM on f32 MFMA
     "egz_pack_w3x3_elems": (c_size_t, [c_int, c_int, c_int]),
     "egz_pack_w3x3_ups_fwd": (c_int, [P, P, c_int, c_int, S]),

@@ -6,6 +6,7 @@
 // Channel reductions: every block keeps fp64 per-channel partials, writes them to a small workspace and a
 // second tiny kernel sums them in a fixed order (deterministic, no atomics).
 #include "egz_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -495,9 +496,23 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     }
 }
 
+// Grid of the element-wise passes: n float4 items over 256-thread blocks, grid-stride, capped.  The cap is the experiment knob
+// EGZ_EW_CAP (default 8192): a conv kernel's two resident blocks per CU take the whole register file, so a streaming pass from
+// another HIP stream only gets the slots conv blocks free -- a narrower grid holds fewer of those slots (for longer).
+inline int ew_cap() {
+    static int cap = 0;
+    if (!cap) {
+        const char* e = getenv("EGZ_EW_CAP");
+        cap = e ? atoi(e) : 8192;
+        if (cap < 64) cap = 64;
+        if (cap > 8192) cap = 8192;
+    }
+    return cap;
+}
 inline int ew_grid(long n) {
     long g = (n + 255) / 256;
-    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+    const int cap = ew_cap();
+    return (int)(g > cap ? cap : (g < 1 ? 1 : g));
 }
 
 constexpr int BWD_BLOCKS = 1024;
@@ -579,6 +594,7 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
     const long npix = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W);
     int blocks = (int)((npix + rpb - 1) / rpb);
     if (blocks > BWD_BLOCKS) blocks = BWD_BLOCKS;
+    if (blocks > ew_cap()) blocks = ew_cap();
     const size_t need = egz_bn_relu_pool_bwd_ws_bytes(K);
     EGZ_CHECK_ARG(ws_bytes >= need, "egz_bn_relu_pool_bwd: workspace too small (%zu < %zu)", ws_bytes, need);
     double* part = static_cast<double*>(workspace);
@@ -692,6 +708,7 @@ EGZ_API int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, fl
     const int rpb = threads / K4;
     int blocks = (int)((rows + rpb - 1) / rpb);
     if (blocks > BWD_BLOCKS) blocks = BWD_BLOCKS;
+    if (blocks > ew_cap()) blocks = ew_cap();
     double* part = static_cast<double*>(workspace);
     double* part2 = part + (size_t)BWD_BLOCKS * K;
     hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3(blocks), dim3(threads), (size_t)rpb * K * sizeof(double), st, out,

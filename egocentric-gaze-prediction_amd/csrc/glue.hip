@@ -94,6 +94,70 @@ __global__ __launch_bounds__(256) void weighted_minmax_kernel(const float* __res
     for (int p = tid; p < HW; p += 256) out[(long)b * HW + p] = (vals[p] - mn) / den;
 }
 
+
+// one block per image: the reference's host glue  `im = (out * 255).astype(uint8); ndimage.center_of_mass(im)`
+// (run_spatialstream.py:99-104,130-131) on the device.  q = (unsigned char)(v * 255.f) is numpy's truncating cast of the fp32
+// product; scipy forms sum(q * row) / sum(q) in float64 from integer-valued terms, i.e. the correctly rounded quotient of two
+// exact integers -- reproduced bit for bit with 64-bit integer sums and ONE double division.  gp = floor(com) (what
+// `np.array(predicted) // 16` then divides); an all-zero image (0 / 0 in the reference) yields com = NaN, gp = 0.
+__global__ __launch_bounds__(256) void u8_center_of_mass_kernel(const float* __restrict__ map, int H, int W,
+                                                                double* __restrict__ com, int* __restrict__ gp,
+                                                                unsigned char* __restrict__ q8) {
+    __shared__ unsigned long long red[3][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* m = map + (long)b * H * W;
+    unsigned long long s0 = 0, sy = 0, sx = 0;
+    for (int p = tid; p < H * W; p += 256) {
+        const unsigned int q = (unsigned int)(unsigned char)(m[p] * 255.f);
+        if (q8) q8[(long)b * H * W + p] = (unsigned char)q;
+        const int y = p / W, x = p - y * W;
+        s0 += q;
+        sy += (unsigned long long)q * (unsigned)y;
+        sx += (unsigned long long)q * (unsigned)x;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off);
+        sy += __shfl_xor(sy, off);
+        sx += __shfl_xor(sx, off);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = sy; red[2][tid >> 6] = sx; }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const unsigned long long ty = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const unsigned long long tx = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const double cy = t0 ? (double)ty / (double)t0 : NAN, cx = t0 ? (double)tx / (double)t0 : NAN;
+        com[2 * b] = cy;
+        com[2 * b + 1] = cx;
+        gp[2 * b] = t0 ? (int)floor(cy) : 0;
+        gp[2 * b + 1] = t0 ? (int)floor(cx) : 0;
+    }
+}
+
+// nn.functional.interpolate(x, scale_factor=s, mode='bilinear') of (B, h, w) maps -- torch's upsample_bilinear2d arithmetic in
+// fp32: source index r * (dst + 0.5) - 0.5 clamped at 0 with r = 1 / s (align_corners=False, run_spatialstream.py:136) or
+// r * dst with r = (h - 1) / (H - 1) (align_corners=True, nn.functional.upsample_bilinear: AT.py:47, extractLSTMw.py:33);
+// value = l0y (l0x v00 + l1x v01) + l1y (l0x v10 + l1x v11).  dst rows of sample b start at dst + b * dst_bstride (so the
+// result can land in one plane of a wider tensor, e.g. channel 1 of late_fusion's (B, 2, H, W) input).
+__global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h,
+                                                          int w, int H, int W, float rh, float rw, int align, long dst_bstride) {
+    const long n = (long)B * H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H), b = (int)(t / H);
+        float sy = align ? rh * (float)y : rh * ((float)y + 0.5f) - 0.5f;
+        float sx = align ? rw * (float)x : rw * ((float)x + 0.5f) - 0.5f;
+        if (!align) { sy = sy < 0.f ? 0.f : sy; sx = sx < 0.f ? 0.f : sx; }
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int yp = (y0 < h - 1) ? 1 : 0, xp = (x0 < w - 1) ? 1 : 0;
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+        const float* s = src + ((long)b * h + y0) * w + x0;
+        dst[(long)b * dst_bstride + (long)y * W + x] =
+            ly0 * (lx0 * s[0] + lx1 * s[xp]) + ly1 * (lx0 * s[(long)yp * w] + lx1 * s[(long)yp * w + xp]);
+    }
+}
+
 }  // namespace
 
 // src: n bytes laid out [...][C][plane]; dst: n floats, same order.  mean / std: C floats on the device.
@@ -143,5 +207,30 @@ EGZ_API int egz_weighted_minmax(const float* feat, const float* w, float* out, i
     EGZ_CHECK_ARG(HW <= 4096, "egz_weighted_minmax: map of %d pixels does not fit the LDS stage", HW);
     hipLaunchKernelGGL(weighted_minmax_kernel, dim3(B), dim3(256), (size_t)(HW + 512) * sizeof(float), st, feat, w, out, HW, C);
     EGZ_CHECK_LAUNCH("egz_weighted_minmax");
+    return 0;
+}
+
+// map: (B, H, W) fp32 in [0, 1]; com: (B, 2) doubles (row, col) = scipy.ndimage.center_of_mass of (map * 255).astype(uint8);
+// gp: (B, 2) int32 = floor(com) (feeds egz_crop_mean); q8 (optional): the (B, H, W) uint8 image itself.
+EGZ_API int egz_u8_center_of_mass(const float* map, int B, int H, int W, double* com, int* gp, unsigned char* q8,
+                                  hipStream_t st) {
+    EGZ_CHECK_ARG(map && com && gp && B > 0 && H > 0 && W > 0 && (long)H * W < (1L << 24), "egz_u8_center_of_mass: bad arguments");
+    hipLaunchKernelGGL(u8_center_of_mass_kernel, dim3(B), dim3(256), 0, st, map, H, W, com, gp, q8);
+    EGZ_CHECK_LAUNCH("egz_u8_center_of_mass");
+    return 0;
+}
+
+// src: (B, h, w) fp32 -> dst: B maps of (h * scale) x (w * scale), sample b at dst + b * dst_bstride floats.
+EGZ_API int egz_bilinear_up(const float* src, float* dst, int B, int h, int w, int scale, int align_corners, long dst_bstride,
+                            hipStream_t st) {
+    EGZ_CHECK_ARG(src && dst && B > 0 && h > 0 && w > 0 && scale >= 1 && dst_bstride >= (long)h * w * scale * scale,
+                  "egz_bilinear_up: bad arguments");
+    const int H = h * scale, W = w * scale;
+    const float rh = align_corners ? (H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f) : 1.f / (float)scale;
+    const float rw = align_corners ? (W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f) : 1.f / (float)scale;
+    const long n = (long)B * H * W;
+    const int g = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(bilinear_up_kernel, dim3(g), dim3(256), 0, st, src, dst, B, h, w, H, W, rh, rw, align_corners ? 1 : 0, dst_bstride);
+    EGZ_CHECK_LAUNCH("egz_bilinear_up");
     return 0;
 }

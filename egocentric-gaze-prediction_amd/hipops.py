@@ -1091,7 +1091,10 @@ def crop_mean(feat_nhwc: torch.Tensor, gp, size: int, cell: int = 16) -> torch.T
     """feat_nhwc: (B,H,W,C) fp32; gp: B gaze points (row, col) in input pixels -> chn_weight (B, C)."""
     _req(feat_nhwc, "feature")
     B, Hh, Ww, C = feat_nhwc.shape
-    g = torch.as_tensor(gp, dtype=torch.int32).reshape(B, 2).to(feat_nhwc.device)
+    if isinstance(gp, torch.Tensor) and gp.is_cuda and gp.dtype == torch.int32 and gp.is_contiguous() and gp.numel() == 2 * B:
+        g = gp                           # already on the device (u8_center_of_mass): no host round trip
+    else:
+        g = torch.as_tensor(gp, dtype=torch.int32).reshape(B, 2).to(feat_nhwc.device)
     out = torch.empty((B, C), dtype=torch.float32, device=feat_nhwc.device)
     check(LIB.egz_crop_mean(feat_nhwc.data_ptr(), g.data_ptr(), out.data_ptr(), B, Hh, Ww, C, int(size), int(cell),
                             _stream()), "egz_crop_mean")
@@ -1130,4 +1133,33 @@ def weighted_minmax(feat_nhwc: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     out = torch.empty((B, Hh, Ww), dtype=torch.float32, device=feat_nhwc.device)
     check(LIB.egz_weighted_minmax(feat_nhwc.data_ptr(), w.data_ptr(), out.data_ptr(), B, Hh * Ww, C, _stream()),
           "egz_weighted_minmax")
+    return out
+
+
+def u8_center_of_mass(maps: torch.Tensor, want_u8: bool = False):
+    """maps: (B, H, W) fp32 in [0, 1] -> (com (B, 2) float64, gp (B, 2) int32 = floor(com)[, q (B, H, W) uint8]): the
+    reference's ``ndimage.center_of_mass((map * 255).astype(np.uint8))`` (run_spatialstream.py:99-104,130-131), bit for bit."""
+    _req(maps, "map")
+    B, Hh, Ww = maps.shape
+    com = torch.empty((B, 2), dtype=torch.float64, device=maps.device)
+    gp = torch.empty((B, 2), dtype=torch.int32, device=maps.device)
+    q = torch.empty((B, Hh, Ww), dtype=torch.uint8, device=maps.device) if want_u8 else None
+    check(LIB.egz_u8_center_of_mass(maps.data_ptr(), B, Hh, Ww, com.data_ptr(), gp.data_ptr(), _p(q), _stream()),
+          "egz_u8_center_of_mass")
+    return (com, gp, q) if want_u8 else (com, gp)
+
+
+def bilinear_up(src: torch.Tensor, scale: int, align_corners: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src: (B, h, w) -> (B, h*scale, w*scale), ``nn.functional.interpolate(mode='bilinear')`` with either align_corners
+    convention.  ``out``: a (B, H, W) destination whose samples may be strided (e.g. ``x[:, 1]`` of a (B, 2, H, W) tensor --
+    channel 1 of late_fusion's input) but whose rows are dense."""
+    _req(src, "src")
+    B, h, w = src.shape
+    Hh, Ww = h * scale, w * scale
+    if out is None:
+        out = torch.empty((B, Hh, Ww), dtype=torch.float32, device=src.device)
+    if tuple(out.shape) != (B, Hh, Ww) or out.dtype != torch.float32 or not out.is_cuda or out.stride(2) != 1 or out.stride(1) != Ww:
+        raise RuntimeError(f"bilinear_up: destination {tuple(out.shape)} / strides {out.stride()} does not fit {(B, Hh, Ww)}")
+    check(LIB.egz_bilinear_up(src.data_ptr(), out.data_ptr(), B, h, w, int(scale), int(bool(align_corners)),
+                              out.stride(0) if B > 1 else Hh * Ww, _stream()), "egz_bilinear_up")
     return out

@@ -5,8 +5,9 @@ weighted map -> bilinear x16 -> ``late_fusion(out, weighted)`` (:121-138).
 
 The reference script parses argv and runs at import; here the same pieces are importable (``VGG``, ``crop_feature1``,
 ``get_weighted``, ``totensor``, ``toim``, ``predict``) and ``main()`` keeps the CLI (--trained_model, --trained_late,
---dir, --device).  Encoder, decoder and late fusion run on the HIP kernels; the tiny glue between them (centre of
-mass on the host like the reference, crop / mean / bilinear resize through torch) is SURVEY.md section 8(f-2) "next".
+--dir, --device).  Encoder, decoder, late fusion AND the glue between them run on HIP kernels (``SpatialPipeline``:
+uint8 centre of mass, crop mean, weighted min-max map, bilinear x16 -- no host round trip, capturable as one hipGraph);
+``predict`` keeps the reference's host-side glue (scipy centre of mass, torch slicing) as the comparison path.
 """
 import argparse
 import math
@@ -70,6 +71,44 @@ def toim(ten):
     return (ten.squeeze().cpu().numpy() * 255).astype(np.uint8)
 
 
+class SpatialPipeline(nn.Module):
+    """The whole loop body of run_spatialstream.py:125-138 after the image upload as ONE device-resident forward:
+    VGG -> uint8 centre of mass -> 3 x 3 crop mean of conv5_3 -> channel-weighted, min-max normalised map -> bilinear x16 ->
+    ``late_fusion(out, weighted)``.  Every stage is a HIP kernel of this package on the current stream -- no device-to-host
+    copy, no scipy, no tensor-library kernel (the reference does a D2H copy + ndimage.center_of_mass + torch slicing / mean /
+    upsample per frame) -- so ``graphs.GraphedModule(SpatialPipeline(model, lf), ...)`` replays a frame as one hipGraph.
+    Returns (out, feat, com, vec, weighted, fin); com = (1, 2) float64 (row, col) on the device."""
+
+    def __init__(self, model, lf, crop_size=3):
+        super().__init__()
+        self.model, self.lf, self.crop_size = model, lf, crop_size
+
+    def forward(self, im):
+        from . import hipops as H
+        from .functions import to_nhwc
+        out, feat = self.model(im)                                   # (B,1,224,224), (B,512,14,14) channels_last
+        B, _, Hh, Ww = out.shape
+        com, gp = H.u8_center_of_mass(out.reshape(B, Hh, Ww))        # `toim` + ndimage.center_of_mass
+        fn = to_nhwc(feat)
+        vec = H.crop_mean(fn, gp, self.crop_size, Hh // fn.shape[1])  # crop_feature1 + mean -> chn_weight (B, 512)
+        wmap = H.weighted_minmax(fn, vec)                            # get_weighted -> (B, 14, 14)
+        fused = torch.empty((B, 2, Hh, Ww), dtype=torch.float32, device=out.device)     # late_fusion's cat((f, g), 1)
+        for b in range(B):
+            H.copy_into(fused[b, 0], out[b, 0])
+        H.bilinear_up(wmap, Hh // wmap.shape[1], align_corners=False, out=fused[:, 1])
+        fin = self.lf.fusion(fused, fuse_sigmoid=True)               # late_fusion.forward without the cat kernel
+        return out, feat, com, vec, fused[:, 1:2], fin
+
+
+def predict_device(pipeline, im_bgr_u8, device):
+    """`predict` with the glue on the device: ``pipeline`` = SpatialPipeline or a GraphedModule of one."""
+    im = totensor(im_bgr_u8).to(device)
+    with torch.no_grad():
+        out, feat, com, vec, weighted, fin = pipeline(im)
+    return {"out": out, "feat": feat, "imq": toim(out), "predicted": com[0].cpu().numpy(), "vec": vec[0],
+            "weighted": weighted, "fin": fin}
+
+
 def predict(model, lf, im_bgr_u8, device, graphed=None):
     """One iteration of the reference's loop body (run_spatialstream.py:123-139). Returns a dict of stages.
     ``graphed``: a graphs.GraphedModule of ``model`` (one hipGraph replay instead of ~100 launches for the batch-1 forward;
@@ -98,7 +137,7 @@ def main(argv=None):
     p.add_argument('--trained_late', default='models/late.pth.tar', required=False)
     p.add_argument('--dir', required=True)
     p.add_argument('--device', default='0', help='GPU index')
-    p.add_argument('--hipgraph', action='store_true', help='replay the batch-1 forward as one captured hipGraph')
+    p.add_argument('--hipgraph', action='store_true', help='replay the whole per-frame pipeline as one captured hipGraph')
     args = p.parse_args(argv)
     device = torch.device('cuda:' + args.device)
     model = VGG(make_layers(cfg['D'], 3))
@@ -107,13 +146,13 @@ def main(argv=None):
     lf = late_fusion()
     lf.load_state_dict(torch.load(args.trained_late, map_location='cpu', weights_only=False)['state_dict'])
     lf.to(device).eval()
-    graphed = None
+    pipeline = SpatialPipeline(model, lf).eval()
     if args.hipgraph:
         from .graphs import GraphedModule
-        graphed = GraphedModule(model, (torch.zeros(1, 3, 224, 224, device=device),))
+        pipeline = GraphedModule(pipeline, (torch.zeros(1, 3, 224, 224, device=device),))
     for imname in [k for k in os.listdir(args.dir) if 'img' in k]:
         im0 = imread(os.path.join(args.dir, imname))
-        res = predict(model, lf, resize(im0, (224, 224)), device, graphed)
+        res = predict_device(pipeline, resize(im0, (224, 224)), device)
         fin = resize(toim(res["fin"]), (im0.shape[1], im0.shape[0]))
         try:
             import cv2

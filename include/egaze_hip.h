@@ -253,6 +253,15 @@ int egz_window_mean(const float* feat, const int* win, float* out, int B, int H,
 int egz_pixel_weighted_sum(const float* feat, const float* wmap, float* out, int B, int HW, int C, hipStream_t stream);
 int egz_weighted_minmax(const float* feat, const float* w, float* out, int B, int HW, int C, hipStream_t stream);
 
+/* Config-1 glue (run_spatialstream.py:99-104,130-136): centre of mass of the uint8-quantised gaze map exactly as
+ * scipy.ndimage.center_of_mass((map * 255).astype(uint8)) computes it (com (B,2) doubles, gp = floor(com) (B,2) int32, q8
+ * optional (B,H,W) uint8 image), and nn.functional.interpolate(mode='bilinear', scale_factor=scale) of (B,h,w) maps with either
+ * align_corners convention (False: run_spatialstream.py:136; True: upsample_bilinear at AT.py:47, extractLSTMw.py:33); sample b
+ * of the result starts at dst + b * dst_bstride floats. */
+int egz_u8_center_of_mass(const float* map, int B, int H, int W, double* com, int* gp, unsigned char* q8, hipStream_t stream);
+int egz_bilinear_up(const float* src, float* dst, int B, int h, int w, int scale, int align_corners, long dst_bstride,
+                    hipStream_t stream);
+
 /* ---- measurement aid (bench.py): sustained v_mfma_f32_32x32x16_f16 rate of this chip on the given operand bits; frag =
  *      16 x 64 x 16 bytes, out = blocks x 256 floats; executes blocks x 4 x iters x 8 MFMAs of 32768 flop. */
 int egz_mfma_probe(const void* frag, float* out, int blocks, int iters, hipStream_t stream);

@@ -142,3 +142,57 @@ def test_config1_run_spatialstream_on_hip():
     for k in ("out", "feat", "weighted", "fin"):
         assert torch.equal(r2[k], r[k]), k
     assert np.array_equal(r2["imq"], r["imq"])
+
+
+def test_config1_glue_on_device_matches_host_glue_and_golden():
+    """The per-frame loop body of run_spatialstream.py:125-138 with its glue on the device (SpatialPipeline: uint8 centre of
+    mass, crop mean, weighted min-max, bilinear x16, no cat kernel) vs the reference golden and vs ``predict`` (host glue:
+    scipy + torch), eager and as ONE captured hipGraph."""
+    from egaze_amd.run_spatialstream import VGG, SpatialPipeline, predict, predict_device
+    from egaze_amd.graphs import GraphedModule
+    from egaze_amd.utils import make_layers, cfg
+    gold = np.load(os.path.join(GOLDEN, "config1.npz"))
+    model = VGG(make_layers(cfg['D'], 3))
+    model.load_state_dict(synth.synth_state_dict(O.spatial_vgg_shapes(), seed=4, head_gain=0.25))
+    model.to(DEV).eval()
+    lf = build().eval()
+    im_u8 = np.random.RandomState(21).randint(0, 256, (224, 224, 3)).astype(np.uint8)
+    host = predict(model, lf, im_u8, DEV)
+    pipe = SpatialPipeline(model, lf).eval()
+    r = predict_device(pipe, im_u8, DEV)
+    assert np.array_equal(r["predicted"], host["predicted"])            # scipy's float64 centre of mass, bit for bit
+    assert np.allclose(r["predicted"], gold["predicted"], atol=0.05)
+    assert torch.equal(r["out"], host["out"])
+    assert rel(r["vec"].cpu().numpy(), gold["vec"]) < 1e-4
+    assert rel(r["weighted"].cpu().numpy(), gold["weighted"]) < 1e-4
+    assert rel(r["weighted"].cpu().numpy(), host["weighted"].cpu().numpy()) < 1e-5
+    assert rel(r["fin"].cpu().numpy(), gold["fin"]) < 1e-4
+    g = GraphedModule(pipe, (torch.zeros(1, 3, 224, 224, device=DEV),))
+    r2 = predict_device(g, im_u8, DEV)
+    for k in ("out", "weighted", "fin", "vec"):
+        assert torch.equal(r2[k], r[k]), k
+    assert np.array_equal(r2["predicted"], r["predicted"])
+    im2 = np.random.RandomState(22).randint(0, 256, (224, 224, 3)).astype(np.uint8)     # the replay follows its input
+    r3, h3 = predict_device(g, im2, DEV), predict(model, lf, im2, DEV)
+    assert np.array_equal(r3["predicted"], h3["predicted"]) and rel(r3["fin"].cpu().numpy(), h3["fin"].cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("align", [False, True])
+def test_bilinear_up_and_u8_center_of_mass(align):
+    import egaze_amd.hipops as H
+    from scipy import ndimage
+    g = torch.Generator().manual_seed(3)
+    src = torch.rand(3, 14, 14, generator=g)
+    ref = torch.nn.functional.interpolate(src.unsqueeze(1), scale_factor=16, mode="bilinear", align_corners=align).squeeze(1)
+    wide = torch.zeros(3, 2, 224, 224, device=DEV)
+    got = H.bilinear_up(src.to(DEV), 16, align_corners=align, out=wide[:, 1])
+    assert rel(got.cpu().numpy(), ref.numpy()) < 2e-6 and float(wide[:, 0].abs().max()) == 0.0
+    maps = torch.rand(3, 224, 224, generator=g)
+    maps[1] *= 0.02                                                # nearly black image: tiny integer sums (levels 0 .. 5)
+    com, gp, q = H.u8_center_of_mass(maps.to(DEV), want_u8=True)
+    for b in range(3):
+        imq = (maps[b].numpy() * 255).astype(np.uint8)
+        assert np.array_equal(q[b].cpu().numpy(), imq)
+        want = np.array(ndimage.center_of_mass(imq))
+        assert np.array_equal(com[b].cpu().numpy(), want), (com[b], want)
+        assert np.array_equal(gp[b].cpu().numpy(), np.floor(want).astype(np.int32))
