@@ -40,12 +40,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 // Step count on the device (hipGraph-captured training steps: a replay cannot receive a new host scalar).  The bias
-// corrections are formed in fp64 from *step + 1 exactly as the host form does; adam_bump_kernel increments the counter after
-// the update (a separate launch: every block of the update reads the same value).
+// corrections are formed in fp64 from step[0] + 1 exactly as the host form does; adam_bump_kernel increments the counter after
+// the update (a separate launch: every block of the update reads the same value).  Round 3 tried to let the LAST block to finish
+// do the increment (a ticket in step[1]): one device-scope atomic per block on one address costs ~45 ns each -- 2048 blocks
+// took the kernel from 23 to 112 us, 512 blocks (23 tickets-us) cost as much as they saved in bandwidth -- so the 4.9 us bump
+// launch stays.  step[1] is reserved (0).
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, double lr, double beta1, double beta2,
-                                                       float eps, const int* __restrict__ step, float grad_scale) {
-    const double t = (double)(*step + 1);
+                                                       float eps, int* __restrict__ step, float grad_scale) {
+    const double t = (double)(*static_cast<volatile int*>(step) + 1);
     const float omb1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2);
     const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
     const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, t));
@@ -80,7 +83,8 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 __global__ void adam_bump_kernel(int* step) { *step += 1; }
 }  // namespace
 
-// egz_adam_step with the (0-based, completed-steps) counter on the device: applies step *step + 1 and increments *step.
+// egz_adam_step with the (0-based, completed-steps) counter on the device: applies step step[0] + 1 and increments step[0].
+// step points at TWO ints: {completed steps, reserved 0}.
 EGZ_API int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                               double eps, int* step, double grad_scale, hipStream_t st) {
     EGZ_CHECK_ARG(p && g && m && v && step && n > 0, "egz_adam_step_dev: bad arguments");

@@ -775,9 +775,29 @@ EGZ_API int egz_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, i
 // Stream-ordered device copy / zero fill (hipMemcpyAsync / hipMemsetAsync on the caller's stream): plumbing for the
 // host side where the reference writes torch.cat((x_s, x_t), 2) (models/model_SP.py:39) and optimizer.zero_grad()
 // (SP.py:138) -- no kernels of the tensor library in the step.
+// Both are plain kernels when the buffers are 16-byte aligned (float4 grid-stride; 5-6 TB/s on large buffers, ~2 us on the
+// small state / gradient buffers of the AT per-sample step, where the runtime's blit kernels behind hipMemcpyAsync /
+// hipMemsetAsync were a quarter of a replayed graph's device time -- profiles/r02_at_sample_loop.txt); the runtime calls
+// remain for unaligned buffers.
+namespace {
+__global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void zero16_kernel(f32x4* __restrict__ dst, long n4) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) dst[i] = z;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+}  // namespace
 EGZ_API int egz_copy(const float* src, float* dst, long n, hipStream_t st) {
     EGZ_CHECK_ARG(src && dst && n >= 0, "egz_copy: bad arguments");
     if (n == 0) return 0;
+    if (al16(src) && al16(dst) && n % 4 == 0) {
+        hipLaunchKernelGGL(copy16_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src),
+                           reinterpret_cast<f32x4*>(dst), n / 4);
+        EGZ_CHECK_LAUNCH("egz_copy");
+        return 0;
+    }
     hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, st);
     EGZ_CHECK_ARG(e == hipSuccess, "egz_copy: %s", hipGetErrorString(e));
     return 0;
@@ -785,6 +805,11 @@ EGZ_API int egz_copy(const float* src, float* dst, long n, hipStream_t st) {
 EGZ_API int egz_fill_zero(void* dst, size_t bytes, hipStream_t st) {
     EGZ_CHECK_ARG(dst || bytes == 0, "egz_fill_zero: null pointer");
     if (bytes == 0) return 0;
+    if (al16(dst) && bytes % 16 == 0) {
+        hipLaunchKernelGGL(zero16_kernel, dim3(ew_grid((long)(bytes / 16))), dim3(256), 0, st, static_cast<f32x4*>(dst), (long)(bytes / 16));
+        EGZ_CHECK_LAUNCH("egz_fill_zero");
+        return 0;
+    }
     hipError_t e = hipMemsetAsync(dst, 0, bytes, st);
     EGZ_CHECK_ARG(e == hipSuccess, "egz_fill_zero: %s", hipGetErrorString(e));
     return 0;

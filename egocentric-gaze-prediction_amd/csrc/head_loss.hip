@@ -224,12 +224,13 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ 
 }
 
 // mean squared error (nn.MSELoss, AT.py:83,138) forward partials and backward
+// tanh_b: the target is tanh(b) (AT.py:138: `criterion(pred, tanh(target))` -- the tanh pass of the reference folded in)
 __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                      double* __restrict__ part, long n) {
+                                                      double* __restrict__ part, long n, int tanh_b) {
     __shared__ double red[4];
     double acc = 0.0;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float d = a[i] - b[i];
+        const float d = a[i] - (tanh_b ? tanhf(b[i]) : b[i]);
         acc += (double)(d * d);
     }
 #pragma unroll
@@ -239,10 +240,28 @@ __global__ __launch_bounds__(256) void mse_fwd_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                      const float* __restrict__ gout, float* __restrict__ da, long n) {
+                                                      const float* __restrict__ gout, float* __restrict__ da, long n,
+                                                      int tanh_b) {
     const float s = (gout ? gout[0] : 1.f) * 2.f / (float)n;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        da[i] = s * (a[i] - b[i]);
+        da[i] = s * (a[i] - (tanh_b ? tanhf(b[i]) : b[i]));
+}
+
+// small n (the AT per-sample step: 512 values): partial sums and the final division in ONE block, one launch instead of two.
+// Same summation tree as the two-kernel form would use with a single partial (fp64 throughout).
+__global__ __launch_bounds__(256) void mse_small_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ loss, long n, int tanh_b) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float d = a[i] - (tanh_b ? tanhf(b[i]) : b[i]);
+        acc += (double)(d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
 }
 
 constexpr int LOSS_BLOCKS = 1024;
@@ -341,22 +360,28 @@ EGZ_API int egz_floss_bwd(const float* inp, const float* target, const float* we
 }
 
 EGZ_API int egz_mse_fwd(const float* a, const float* b, float* loss_out, long n, void* workspace, size_t ws_bytes,
-                        hipStream_t st) {
+                        int tanh_b, hipStream_t st) {
     EGZ_CHECK_ARG(a && b && loss_out && workspace && n > 0, "egz_mse_fwd: bad arguments");
     EGZ_CHECK_ARG(ws_bytes >= LOSS_BLOCKS * sizeof(double), "egz_mse_fwd: workspace too small");
+    if (n <= 4096) {
+        hipLaunchKernelGGL(mse_small_kernel, dim3(1), dim3(256), 0, st, a, b, loss_out, n, tanh_b);
+        EGZ_CHECK_LAUNCH("egz_mse_fwd(small)");
+        return 0;
+    }
     double* part = static_cast<double*>(workspace);
     long g = (n + 255) / 256;
     const int grid = (int)(g > LOSS_BLOCKS ? LOSS_BLOCKS : g);
-    hipLaunchKernelGGL(mse_fwd_kernel, dim3(grid), dim3(256), 0, st, a, b, part, n);
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(grid), dim3(256), 0, st, a, b, part, n, tanh_b);
     EGZ_CHECK_LAUNCH("egz_mse_fwd");
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, part, grid, (double)n, loss_out);
     EGZ_CHECK_LAUNCH("egz_mse_fwd(final)");
     return 0;
 }
-EGZ_API int egz_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, long n, hipStream_t st) {
+EGZ_API int egz_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, long n, int tanh_b,
+                        hipStream_t st) {
     EGZ_CHECK_ARG(a && b && da && n > 0, "egz_mse_bwd: bad arguments");
     long g = (n + 255) / 256;
-    hipLaunchKernelGGL(mse_bwd_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, a, b, grad_out, da, n);
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((int)(g > 4096 ? 4096 : g)), dim3(256), 0, st, a, b, grad_out, da, n, tanh_b);
     EGZ_CHECK_LAUNCH("egz_mse_bwd");
     return 0;
 }

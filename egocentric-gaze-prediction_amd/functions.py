@@ -365,14 +365,18 @@ class FlossLoss(torch.autograd.Function):
 
 
 class MSELoss(torch.autograd.Function):
+    """nn.MSELoss (AT.py:83).  ``tanh_target``: the loss against tanh(target) -- the reference's
+    ``criterion(pred, tanh(target))`` (AT.py:138) without a separate tanh pass over the target."""
+
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, tanh_target=False):
         a_ = H._req(a.detach().contiguous(), "input")
         b_ = H._req(b.detach().contiguous(), "target")
         ctx.save_for_backward(a_, b_)
-        return H.mse_fwd(a_, b_)
+        ctx.tanh_target = bool(tanh_target)
+        return H.mse_fwd(a_, b_, ctx.tanh_target)
 
     @staticmethod
     def backward(ctx, gout):
         a_, b_ = ctx.saved_tensors
-        return H.mse_bwd(a_, b_, gout.detach().contiguous()), None
+        return H.mse_bwd(a_, b_, gout.detach().contiguous(), ctx.tanh_target), None, None

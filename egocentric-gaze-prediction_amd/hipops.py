@@ -851,18 +851,19 @@ def floss_bwd(inp, target, weights, grad_out: Optional[torch.Tensor]) -> torch.T
     return dinp
 
 
-def mse_fwd(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def mse_fwd(a: torch.Tensor, b: torch.Tensor, tanh_target: bool = False) -> torch.Tensor:
+    """mean((a - b)^2), or mean((a - tanh(b))^2) with ``tanh_target`` (AT.py:138 in one pass)."""
     _req(a, "a"); _req(b, "b")
     loss = torch.empty((), dtype=torch.float32, device=a.device)
     ws = workspace(1024 * 8, a.device)
     check(LIB.egz_mse_fwd(a.data_ptr(), b.data_ptr(), loss.data_ptr(), a.numel(), ws.data_ptr(), ws.numel(),
-                          _stream()), "egz_mse_fwd")
+                          int(tanh_target), _stream()), "egz_mse_fwd")
     return loss
 
 
-def mse_bwd(a, b, grad_out) -> torch.Tensor:
+def mse_bwd(a, b, grad_out, tanh_target: bool = False) -> torch.Tensor:
     da = torch.empty_like(a)
-    check(LIB.egz_mse_bwd(a.data_ptr(), b.data_ptr(), _p(grad_out), da.data_ptr(), a.numel(), _stream()),
+    check(LIB.egz_mse_bwd(a.data_ptr(), b.data_ptr(), _p(grad_out), da.data_ptr(), a.numel(), int(tanh_target), _stream()),
           "egz_mse_bwd")
     return da
 

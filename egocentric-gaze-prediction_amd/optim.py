@@ -75,9 +75,10 @@ class FusedAdam:
         """Keep the step counter on the device (egz_adam_step_dev), so that step() can sit inside a captured hipGraph.  Every
         replay advances the device counter; the owner of the graph adds the replays to ``step_count`` (note_replays)."""
         if on:
-            self.step_dev = torch.tensor([self.step_count], dtype=torch.int32, device=self.flat_p.device)
+            # {completed steps, reserved}
+            self.step_dev = torch.tensor([self.step_count, 0], dtype=torch.int32, device=self.flat_p.device)
         elif self.capturable:
-            self.step_count = int(self.step_dev.item())
+            self.step_count = int(self.step_dev[0].item())
         self.capturable = on
 
     def note_replays(self, n: int = 1):
@@ -85,8 +86,13 @@ class FusedAdam:
         self.step_count += n
 
     # -- torch.optim.Optimizer surface used by the drivers
-    def zero_grad(self, set_to_none: bool = False):
-        if os.environ.get('EGAZE_TORCH_ZERO') == '1':
+    def zero_grad(self, set_to_none: bool = False, all_overwritten: bool = False):
+        """``all_overwritten``: the caller guarantees that the coming backward pass writes EVERY parameter's gradient in full
+        through the gradient sinks (the AT single-sample step: rank-1 weight gradients and bias gradients written by
+        csrc/lstm_b1.hip) -- the flat gradient buffer then needs no zero fill, only a new generation."""
+        if all_overwritten:
+            pass
+        elif os.environ.get('EGAZE_TORCH_ZERO') == '1':
             self.flat_g.zero_()
         else:
             H.fill_zero(self.flat_g)
@@ -155,7 +161,7 @@ class FusedAdam:
                 self.flat_v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_count = int(float(st["step"]))
         if self.capturable:
-            self.step_dev.fill_(self.step_count)
+            self.step_dev[0] = self.step_count
 
 
 Adam = FusedAdam

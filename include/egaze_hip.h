@@ -185,9 +185,10 @@ int egz_floss_fwd(const float* inp, const float* target, float* weights_out, flo
                   int weighted, void* workspace, size_t ws_bytes, hipStream_t stream);
 int egz_floss_bwd(const float* inp, const float* target, const float* weights, const float* grad_out, float* dinp,
                   long n, hipStream_t stream);
-int egz_mse_fwd(const float* a, const float* b, float* loss_out, long n, void* workspace, size_t ws_bytes,
+/* nn.MSELoss (AT.py:83); tanh_b != 0: the target is tanh(b), i.e. `criterion(pred, tanh(target))` of AT.py:138 in one pass */
+int egz_mse_fwd(const float* a, const float* b, float* loss_out, long n, void* workspace, size_t ws_bytes, int tanh_b,
                 hipStream_t stream);
-int egz_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, long n, hipStream_t stream);
+int egz_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, long n, int tanh_b, hipStream_t stream);
 
 /* ---- AT: nn.LSTM(512,512,2) + nn.Linear + tanh (models/LSTMnet.py:18-37) from a strided f32-MFMA GEMM and fused
  *      cell kernels.  egz_gemm: C[M][N] (row stride ldc) = op(A) op(B) (+C if flags&1) (+bias[n]) (ReLU if flags&2),
@@ -226,8 +227,9 @@ int egz_add(const float* a, const float* b, float* out, long n, hipStream_t stre
  *      grad_scale multiplies the gradient first (1/world_size after the RCCL sum all-reduce). */
 int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                   double eps, int step, double grad_scale, hipStream_t stream);
-/* the same step with the counter of COMPLETED steps on the device (applies step *step + 1, then increments *step): for
- * optimizer steps inside a captured hipGraph, where a replay cannot receive a new host scalar */
+/* the same step with the counter of COMPLETED steps on the device (applies step step[0] + 1, then increments step[0]): for
+ * optimizer steps inside a captured hipGraph, where a replay cannot receive a new host scalar.  step -> TWO ints {completed
+ * steps, reserved (0)} */
 int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
                       double eps, int* step, double grad_scale, hipStream_t stream);
 

@@ -254,7 +254,7 @@ def test_fused_adam_device_step_counter():
             p.grad.copy_(gr.to(DEV))
             opt.step()
         if cap:
-            assert int(opt.step_dev.item()) == 6
+            assert int(opt.step_dev[0].item()) == 6 and int(opt.step_dev[1].item()) == 0
             opt.set_capturable(False)
         assert opt.step_count == 6
         out[cap] = p.detach().cpu()

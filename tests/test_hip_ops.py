@@ -278,6 +278,26 @@ def test_mse():
     ad, bd = a.detach().to(DEV), b.to(DEV)
     assert abs(h.mse_fwd(ad, bd).item() - ref.item()) < 1e-6 * abs(ref.item())
     assert rel(h.mse_bwd(ad, bd, None).cpu(), a.grad) < 1e-6
+    # criterion(pred, tanh(target)) of AT.py:138 as one kernel, through the autograd node
+    from egaze_amd.functions import MSELoss
+    a2 = a.detach().clone().requires_grad_(True)
+    ref2 = ((a2 - torch.tanh(b)) ** 2).mean()
+    ref2.backward()
+    a3 = a.detach().to(DEV).requires_grad_(True)
+    l3 = MSELoss.apply(a3, bd, True)
+    l3.backward(gradient=torch.ones((), device=DEV))
+    assert abs(l3.item() - ref2.item()) < 2e-6 * abs(ref2.item()) and rel(a3.grad.cpu(), a2.grad) < 2e-6
+    # the stream-ordered copy / zero helpers are plain kernels for aligned buffers, the runtime calls otherwise
+    src = torch.randn(1031, device=DEV)
+    dst = torch.full((1031,), 7.0, device=DEV)
+    h.copy_into(dst[:1028], src[:1028])
+    assert torch.equal(dst[:1028], src[:1028]) and float(dst[1028]) == 7.0
+    h.copy_into(dst[1:1030], src[2:1031])                    # unaligned: hipMemcpyAsync route
+    assert torch.equal(dst[1:1030], src[2:1031])
+    h.fill_zero(dst[:512])
+    assert float(dst[:512].abs().max()) == 0.0 and float(dst[512]) == float(src[513])
+    h.fill_zero(dst[513:])                                   # unaligned start
+    assert float(dst[513:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("dtype,tol", [(1, 2e-6), (2, 3e-5)])
