@@ -28,6 +28,9 @@
                               // (measured: no gain, 675 vs 678 us -- the staging latency is already covered; costs 12 VGPRs)
 #define EGZ_UPSD_PIPE 0
 #endif
+#ifndef EGZ_X3S_FINE_ALL      // A/B knob: 1 = the instruction-level interleave of the one-wave-per-SIMD tile on every
+#define EGZ_X3S_FINE_ALL 1    // double-buffered configuration (the default 128 x 128 tile too): fwd -1 %, dgrad -3 % (r03_x3s_fine.txt)
+#endif
 #ifndef EGZ_WAVE_SCALAR       // A/B knob: 0 = wave index left in a VGPR (weight-fragment loads in waterfall loops)
 #define EGZ_WAVE_SCALAR 1
 #endif
@@ -59,22 +62,26 @@ constexpr int HPITCH = 20;              // patch geometry: halo columns per LDS 
 //   8: 8 waves 2 x 4, tile 256 x 128, one 512-thread block per CU.  The two waves of a column share their weight fragments:
 //      they issue the same 1 KB loads at the same time and the second is served by the CU's vector L1 instead of L2 -- the
 //      weight-fragment stream is the largest non-MFMA cost of this kernel (profiles/r02_x3s_diag.txt: -21 % without it).
+//  16: 4 waves 1 x 4, tile 256 x 128, every wave 256 rows x 32 columns = EIGHT accumulator tiles, ONE wave per SIMD (the
+//      accumulators live in AGPRs; 512 registers per wave).  A 1 KB weight fragment feeds 24 MFMAs instead of 12: the
+//      weight-fragment stream L2 -> registers, the largest non-MFMA cost of this kernel (-20 % without it,
+//      profiles/r03_x3s_diag.txt), is halved per MFMA -- without the duplicate loads of the 8-wave tile.
 template <int WM> struct Geo {
-    static constexpr int WMM = (WM == 8) ? 2 : WM;             // waves along the pixel dimension
-    static constexpr int NWN = (WM == 8) ? 4 : 4 / WM;         // waves along the columns
+    static constexpr int WMM = (WM == 8) ? 2 : (WM == 16) ? 1 : WM;         // waves along the pixel dimension
+    static constexpr int NWN = (WM == 8 || WM == 16) ? 4 : 4 / WM;         // waves along the columns
     static constexpr int NTHR = 64 * WMM * NWN;
-    static constexpr int MR = (WM == 4) ? 2 : 4;               // 32-row groups (accumulator tiles) per wave
+    static constexpr int MR = (WM == 4) ? 2 : (WM == 16) ? 8 : 4;          // 32-row groups (accumulator tiles) per wave
     static constexpr int RPW = 32 * MR;                        // pixel rows per wave
     static constexpr int BM = RPW * WMM, BN = 32 * NWN;
     static constexpr int HSLOTS = (WM == 1) ? 256 : 384, HZERO = HSLOTS - 1;
-    static constexpr int NABUF = (WM == 1 || WM == 8) ? 2 : 1;
+    static constexpr int NABUF = (WM == 1 || WM == 8 || WM == 16) ? 2 : 1;
     static constexpr int PROWS = BM / 16;                      // patch: PROWS x 16 pixels
     static constexpr int SPP = NTHR / 8;                       // halo slots staged per pass (8 threads x 4 channels per slot)
     static constexpr int NJ = HSLOTS / SPP;                    // halo slots per thread
 #ifndef EGZ_X3S_OCC4
 #define EGZ_X3S_OCC4 3
 #endif
-    static constexpr int OCC = (WM == 4) ? EGZ_X3S_OCC4 : 2;   // resident blocks per CU the register budget is cut for
+    static constexpr int OCC = (WM == 4) ? EGZ_X3S_OCC4 : (WM == 16) ? 1 : 2;     // waves per SIMD the register budget is cut for
 };
 
 // workgroup barrier that leaves this wave's global loads (the weight prefetch ring) in flight: __syncthreads() would
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     constexpr int NIMG = (MODE == UPSD) ? 4 : 1;               // staged images per channel block
     constexpr int NT = (MODE == UPSD) ? 4 : 9;                 // taps per staged image
     constexpr int NRING = (MODE == UPSD) ? 2 : 3;              // weight-fragment register sets (NIMG * NT % NRING == 0)
-    static_assert(MODE == PLAIN || WM == 1 || WM == 8, "the upsample data gradient is built for the 128-column tiles only");
+    static_assert(MODE == PLAIN || WM == 1 || WM == 8 || WM == 16, "the upsample data gradient is built for the 128-column tiles only");
     __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
     __shared__ long Ro[BM];
     __shared__ double sred[(RPW < 128) ? 4 * 2 * 32 : 1];       // BN partial sums of the waves that share a 128-row stat row
@@ -254,7 +261,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // or -- UPSD, where an image only lasts four taps -- both halves in flight at once, fetched at tap 0 and split at taps 2
     // and 3: one tap of distance (~0.4 us per wave) did not cover the HBM latency of the strided polyphase fetch, and the
     // four upsample data gradients ran at half the rate of the plain convolutions (profiles/r02_conv_microbench.txt)
-    constexpr int RAOFF = (MODE == UPSD && EGZ_UPSD_PIPE) ? NJ / 2 : 0;
+    constexpr bool FINE = (G::NABUF == 2) && (WM == 16 || EGZ_X3S_FINE_ALL);   // instruction-level interleave of a slice (main loop)
+    // (the interleaved loop fetches half 1 of an upsample-dgrad image in the same tap that splits half 0: two register sets)
+    constexpr int RAOFF = (MODE == UPSD && (EGZ_UPSD_PIPE || FINE)) ? NJ / 2 : 0;
     f32x4 ra[NJ / 2 + RAOFF];
     auto gload_a = [&](int cblk, const int img, const int half) {
         const unsigned so = (unsigned)(cblk * XBK * 4) +
@@ -327,6 +336,73 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int s = (c * NIMG + img) * NT + t, ring = (img * NT + t) % NRING;
+                if constexpr (FINE) {
+                    // ---- one wave per SIMD: nothing else fills the matrix pipe while this wave fetches, so every non-MFMA
+                    // instruction of the slice is issued in the ~24 free issue cycles behind ONE MFMA (sched_barrier after each
+                    // pair pins the order).  Group 0 = the 3 MR MFMAs of k-step 0, carrying the k-step-1 fragment reads, the
+                    // weight prefetch and the halo fetch; group 1 = k-step 1, carrying the next tap's fragment reads, the halo
+                    // split + LDS stores and (last tap of an image) the barrier.
+                    constexpr int NM = 3 * MR, NH = NJ / 2;
+                    const int ringn = (img * NT + t + NRING - 1) % NRING;
+                    const int sn = s + NRING - 1 < S_hi ? s + NRING - 1 : S_hi - 1;
+                    const unsigned bso = (unsigned)sn * (unsigned)nt32 * 4096u + b_tile;
+                    const unsigned aso = (unsigned)(ncblk * XBK * 4) +
+                                         ((MODE == UPSD) ? (unsigned)(((nimg >> 1) * W + (nimg & 1)) * C * 4) : 0u);
+                    const int ghalf = (t == G0) ? 0 : 1;
+                    const bool gl = more && (t == G0 || t == G1);
+                    u32x4 ah1[MR], al1[MR];
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        const int term = i / MR, mr = i % MR;
+                        acc[mr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bq[ring][1] : bq[ring][0], acc[mr]);
+                        if (i < MR) {
+                            ah1[i] = *reinterpret_cast<const u32x4*>(Ab + (cur[i] ^ 32));
+                            al1[i] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[i] ^ 32));
+                        } else if (i < MR + 4) {
+                            bq[ringn][i - MR] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo + (i - MR) * 1024, bso, 0);
+                        } else if (gl && i - MR - 4 < NH) {
+                            const int j = i - MR - 4;
+                            ra[ghalf * RAOFF + j] = __builtin_bit_cast(
+                                f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[ghalf * NH + j], aso, 0));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    static_assert(!FINE || (MR + 4 + NJ / 2 <= 3 * MR), "group 0 has too few MFMAs for its side work");
+                    static_assert(!FINE || (L1 < NT - 1 && L0 < NT - 1), "the last tap of an image carries the barrier, not a split");
+                    const int lhalf = (t == L0) ? 0 : 1;
+                    const bool ls = more && (t == L0 || t == L1);
+                    const bool last = (t == NT - 1);
+                    if (!last) tap_addr(shift_of(img, t + 1), abuf, cur);
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        const int term = i / MR, mr = i % MR;
+                        acc[mr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bq[ring][3] : bq[ring][2], acc[mr]);
+                        if (!last && i < MR) {
+                            ah0[i] = *reinterpret_cast<const u32x4*>(Ab + cur[i]);
+                            al0[i] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[i]);
+                        } else if (ls && i >= MR && i - MR < NH) {
+                            const int j = i - MR;
+                            u32x2 hi, lo;
+                            Half<T>::split4(ra[lhalf * RAOFF + j] * a_scale, hi, lo);
+                            unsigned short* d = Ah + (abuf ^ 1) * ABUF + a_lds[lhalf * NH + j];
+                            *reinterpret_cast<u32x2*>(d) = hi;
+                            *reinterpret_cast<u32x2*>(d + APL) = lo;
+                        } else if (last && more) {
+                            // the image boundary: every wave has staged its share (taps L0, L1) and read its last fragments
+                            // (group 0); the first fragments of the next image ride on the remaining MFMAs of this group
+                            if (i == 1) {
+                                lds_barrier();
+                                tap_addr(shift_of(nimg, 0), abuf ^ 1, cur);
+                            }
+                            if (i >= 2 && i - 2 < MR) {
+                                ah0[i - 2] = *reinterpret_cast<const u32x4*>(Ab + cur[i - 2]);
+                                al0[i - 2] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[i - 2]);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    continue;
+                }
                 // the set being refilled was last read by slice s - 1
 #if !(EGZ_X3S_DIAG & 1)
                 gload_b(s + NRING - 1 < S_hi ? s + NRING - 1 : S_hi - 1, (img * NT + t + NRING - 1) % NRING);
@@ -384,10 +460,17 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     const int col = n0 + wn * 32 + l31;
     const bool nok = col < K;
     const float bz = (bias && nok) ? bias[col] : 0.f;
-    double s1 = 0.0, s2 = 0.0;
+    constexpr int SR = (RPW > 128) ? RPW / 128 : 1;            // 128-row stat rows a wave owns (2 on the 256-row waves)
+    double s1 = 0.0, s2 = 0.0, s1b[SR], s2b[SR];
     float amx = 0.f;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
+        if (SR > 1 && (mr & 3) == 0 && mr) {                    // a 128-row group is complete: park its sums
+            s1b[mr / 4 - 1] = s1;
+            s2b[mr / 4 - 1] = s2;
+            s1 = 0.0;
+            s2 = 0.0;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long off = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)];
@@ -424,7 +507,23 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         // one partial row per 128 pixel rows (the granularity egz_conv3x3_stat_rows promises)
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
-        if (RPW == 128) {                                      // the wave's own row
+        if (RPW > 128) {                                       // the wave's own SR rows
+            s1b[SR - 1] = s1;
+            s2b[SR - 1] = s2;
+#pragma unroll
+            for (int q = 0; q + 1 < SR; ++q) {
+                s1b[q] += __shfl_xor(s1b[q], 32);
+                s2b[q] += __shfl_xor(s2b[q], 32);
+            }
+#pragma unroll
+            for (int q = 0; q < SR; ++q) {
+                const long srow = ((long)tile_m * G::WMM + wm) * SR + q;
+                if (hl == 0 && nok && srow * 128 < M) {
+                    stat[(srow * 2 + 0) * K + col] = s1b[q];
+                    stat[(srow * 2 + 1) * K + col] = s2b[q];
+                }
+            }
+        } else if (RPW == 128) {                               // the wave's own row
             const long srow = (long)tile_m * G::WMM + wm;
             if (hl == 0 && nok && srow * 128 < M) {
                 stat[(srow * 2 + 0) * K + col] = s1;
@@ -836,10 +935,11 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 // 1 when the streamed-weight kernel covers this geometry (C = reduction channels: a multiple of 32, or a multiple of 4
 // below 32; K = GEMM columns: any).
 // mode 0: plain conv over an H x W image; mode 1: data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res
-// input, H x W = the hi-res gradient image (both even), 128-column tiles only; mode | 0x10: on the 8-wave 256 x 128 tile.  Needs the split-half channel constraints
+// input, H x W = the hi-res gradient image (both even), 128-column tiles only; mode | 0x10: on the 8-wave 256 x 128 tile; mode | 0x20: on the 4-wave 256 x 128 tile with one wave
+// per SIMD (8 accumulator tiles per wave).  Needs the split-half channel constraints
 // and either the patch geometry or a raster run whose halo fits the LDS image (on the OUTPUT image: H/2 x W/2 in mode 1).
 EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode) {
-    const bool tile8 = (mode & 0x10) != 0;                              // the 8-wave 256 x 128 tile (K % 128 == 0 only)
+    const bool tile8 = (mode & 0x30) != 0;                              // a 256 x 128 tile: 0x10 = 8 waves, 0x20 = 4 waves x 8 accumulators (K % 128 == 0 only)
     mode &= 0xF;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || mode < 0 || mode > 1) return 0;
     if (tile8 && K % 128 != 0) return 0;
@@ -897,6 +997,15 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                   "mask_src and absmax_out and takes no bias");
     const unsigned short* w16 = static_cast<const unsigned short*>(wq);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
+    if (mode & 0x20) {                                                  // 4-wave 256 x 128 tile, one wave per SIMD
+        EGZ_CHECK_ARG(epi != EPI_MASK_SUMS, "egz_conv3x3_fwd_streamed: the mask epilogue runs on the two-waves-per-SIMD tiles");
+        if ((mode & 0xF) == 1) {
+            if (dtype == 1) return launch_x3s<_Float16, 16, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+            return launch_x3s<__bf16, 16, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        }
+        if (dtype == 1) return launch_x3s<_Float16, 16, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        return launch_x3s<__bf16, 16, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+    }
     if (mode & 0x10) {                                                  // 8-wave 256 x 128 tile
         EGZ_CHECK_ARG(epi != EPI_MASK_SUMS, "egz_conv3x3_fwd_streamed: the mask epilogue runs on the 4-wave tiles");
         if ((mode & 0xF) == 1) {

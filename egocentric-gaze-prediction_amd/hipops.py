@@ -223,8 +223,18 @@ TILE8 = _os.environ.get("EGAZE_TILE8", "0")
 SPLITK = _os.environ.get("EGAZE_SPLITK", "1") != "0"
 
 
+# 4-wave 256 x 128 tile with ONE wave per SIMD and eight accumulator tiles per wave (csrc Geo<16>): every weight fragment feeds
+# twice the MFMAs.  EGAZE_TILE16=1: where the launch has at least one tile per CU; =all: wherever the geometry allows (tests).
+TILE16 = _os.environ.get("EGAZE_TILE16", "0")
+
+
 def _tile8(B, Ho, Wo, C, gemm_out, mode) -> int:
-    """0x10 when the launch should run on the 8-wave tile."""
+    """0x10 when the launch should run on the 8-wave tile, 0x20 for the 4-wave / 8-accumulator tile."""
+    if TILE16 != "0" and gemm_out % 128 == 0:
+        if TILE16 == "all" or ((B * Ho * Wo + 255) // 256) * (gemm_out // 128) >= 256:
+            H_, W_ = (2 * Ho, 2 * Wo) if mode else (Ho, Wo)
+            if LIB.egz_conv3x3_streamed_ok(B, H_, W_, C, gemm_out, mode | 0x20):
+                return 0x20
     if TILE8 == "0" or gemm_out % 128 != 0:
         return 0
     if TILE8 != "all" and (gemm_out < 512 or ((B * Ho * Wo + 255) // 256) * (gemm_out // 128) < 256):

@@ -702,6 +702,44 @@ def test_conv3x3_streamed_tile8(monkeypatch):
         assert rel(d1, d0) < 2e-6, (B, Hl, Wl, C, K)
 
 
+def test_conv3x3_streamed_tile16(monkeypatch):
+    """The 4-wave 256 x 128 tile with one wave per SIMD and eight accumulator tiles per wave (EGAZE_TILE16): plain launches with
+    every epilogue (bias, bias + ReLU + abs-max... via the fold, bias + BN partial sums incl. the two 128-row stat rows a wave
+    owns) and the upsample data gradient against the default tiles and against fp64."""
+    h = H()
+    for (B, Hh, Ww, C, K) in [(2, 16, 32, 64, 128), (3, 28, 28, 64, 256), (1, 56, 56, 32, 128), (2, 14, 14, 128, 512),
+                              (5, 13, 9, 32, 128), (2, 48, 16, 32, 128)]:
+        xc = rnd(B, C, Hh, Ww, seed=81)
+        x = nhwc(xc)
+        wc = rnd(K, C, 3, 3, seed=82, scale=(2.0 / (9 * C)) ** 0.5)
+        w = wc.to(DEV)
+        bc = rnd(K, seed=83, scale=0.1)
+        b = bc.to(DEV)
+        ref = F.conv2d(xc.double(), wc.double(), bc.double(), padding=1)
+        wp, st = h.conv_weight(w, "fwd", 1, x, K)
+        assert st
+        monkeypatch.setattr(h, "TILE16", "0")
+        y0, s0 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
+        monkeypatch.setattr(h, "TILE16", "all")
+        assert h._tile8(B, Hh, Ww, C, K, 0) == 0x20
+        y1, s1 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
+        assert rel(nchw(y1), ref) < 2e-6, (B, Hh, Ww, C, K)
+        assert rel(y1, y0) < 2e-6 and rel(s1.sum(0), s0.sum(0)) < 1e-6, (B, Hh, Ww, C, K)
+        assert s1.shape == s0.shape                                            # one stat row per 128 output pixels, both tiles
+        y2, _ = h.conv3x3_fwd(x, wp, b, K, epi=1, dtype=1, streamed=True)
+        assert rel(nchw(y2), F.relu(ref)) < 2e-6
+    for (B, Hl, Wl, C, K) in [(2, 16, 32, 128, 64), (3, 28, 28, 128, 64)]:
+        w = rnd(K, C, 3, 3, seed=84, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
+        dy = nhwc(rnd(B, K, 2 * Hl, 2 * Wl, seed=85))
+        wq, st = h.conv_weight(w, "ups_dgrad", 1, dy, C)
+        assert st
+        monkeypatch.setattr(h, "TILE16", "0")
+        d0 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
+        monkeypatch.setattr(h, "TILE16", "all")
+        d1 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
+        assert rel(d1, d0) < 2e-6, (B, Hl, Wl, C, K)
+
+
 def test_conv3x3_streamed_shape_fuzz():
     """Random geometries through the streamed kernel wherever egz_conv3x3_streamed_ok accepts them, against the exact-f32
     kernels: patch / run selection, ragged tiles, XCD tile map with tile counts that are not multiples of 8."""
