@@ -385,11 +385,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     }
 
     f32x4 rx[NX], rd[ND];
-    auto gload = [&](long g) {
-        const int x0 = (int)(g % cpr) * WD;
-        const long t = g / cpr;
-        const int y0 = (int)(t % rpi) * R;
-        const long b = t / rpi;
+    // patch cursor of the NEXT fetch, advanced by one patch per call (stages are consecutive patches): three scalar adds and
+    // compares per stage instead of four 64-bit divisions on the vector ALU (which also made the scalar offsets of the buffer
+    // loads look divergent, wrapping every load in a waterfall loop)
+    int nx0 = (int)(g0 % cpr) * WD, ny0 = (int)((g0 / cpr) % rpi) * R, nb = (int)((g0 / cpr) / rpi);
+    auto gload = [&]() {
+        const int x0 = nx0, y0 = ny0;
+        const unsigned b = (unsigned)nb;
+        nx0 += WD;
+        if (nx0 >= cpr * WD) {
+            nx0 = 0;
+            ny0 += R;
+            if (ny0 >= rpi * R) {
+                ny0 = 0;
+                ++nb;
+            }
+        }
         if constexpr (!UPS) {
             // valid halo rows hr in [rlo, rhi], cols hx in [clo, chi]  (source pixel = (y0 + hr - 1, x0 + hx - 1))
             const unsigned rlo = (y0 == 0) ? 1u : 0u, rn = (unsigned)((H - y0 < R + 1) ? (H - y0) : (R + 1)) - rlo;
@@ -479,13 +490,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (g0 < g1) {
-        gload(g0);
+        gload();
         lstore(0);
     }
     __syncthreads();
     for (long g = g0; g < g1; ++g) {
         const int buf = (int)((g - g0) & 1);
-        if (g + 1 < g1) gload(g + 1);
+        if (g + 1 < g1) gload();
         const EGZ_LDS unsigned short* Xb = Xl + buf * XB;
         const EGZ_LDS unsigned short* Db = Dl + buf * DB;
 #pragma unroll
@@ -577,11 +588,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
         d_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
     }
     f32x4 rx[NX], rd[ND];
-    auto gload = [&](long g) {
-        const int x0 = (int)(g % cpr) * WD;
-        const long t = g / cpr;
-        const int y0 = (int)(t % rpi) * R;
-        const long b = t / rpi;
+    // patch cursor of the NEXT fetch, advanced by one patch per call (stages are consecutive patches): three scalar adds and
+    // compares per stage instead of four 64-bit divisions on the vector ALU (which also made the scalar offsets of the buffer
+    // loads look divergent, wrapping every load in a waterfall loop)
+    int nx0 = (int)(g0 % cpr) * WD, ny0 = (int)((g0 / cpr) % rpi) * R, nb = (int)((g0 / cpr) / rpi);
+    auto gload = [&]() {
+        const int x0 = nx0, y0 = ny0;
+        const unsigned b = (unsigned)nb;
+        nx0 += WD;
+        if (nx0 >= cpr * WD) {
+            nx0 = 0;
+            ny0 += R;
+            if (ny0 >= rpi * R) {
+                ny0 = 0;
+                ++nb;
+            }
+        }
         const unsigned rlo = (y0 == 0) ? 1u : 0u, rn = (unsigned)((H - y0 < R + 1) ? (H - y0) : (R + 1)) - rlo;
         const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((W - x0 < WD + 1) ? (W - x0) : (WD + 1)) - clo;
         const unsigned so_x = (unsigned)((((b * H + y0) * W + x0) * C) * 4);
@@ -636,13 +658,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (g0 < g1) {
-        gload(g0);
+        gload();
         lstore(0);
     }
     __syncthreads();
     for (long g = g0; g < g1; ++g) {
         const int buf = (int)((g - g0) & 1);
-        if (g + 1 < g1) gload(g + 1);
+        if (g + 1 < g1) gload();
         const EGZ_LDS unsigned short* Xb = Xl + buf * XB;
         const EGZ_LDS unsigned short* Db = Dl + buf * DB;
         const typename W16<T>::vec8 dh = W16<T>::frag(Db, Db + 4 * 32);
@@ -746,11 +768,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
     }
 
     f32x4 rx_[NX], rd[ND];
-    auto gload = [&](long g) {
-        const int x0 = (int)(g % cpr) * WD;
-        const long t = g / cpr;
-        const int y0 = (int)(t % rpi) * R;
-        const long b = t / rpi;
+    // patch cursor of the NEXT fetch, advanced by one patch per call (stages are consecutive patches): three scalar adds and
+    // compares per stage instead of four 64-bit divisions on the vector ALU (which also made the scalar offsets of the buffer
+    // loads look divergent, wrapping every load in a waterfall loop)
+    int nx0 = (int)(g0 % cpr) * WD, ny0 = (int)((g0 / cpr) % rpi) * R, nb = (int)((g0 / cpr) / rpi);
+    auto gload = [&]() {
+        const int x0 = nx0, y0 = ny0;
+        const unsigned b = (unsigned)nb;
+        nx0 += WD;
+        if (nx0 >= cpr * WD) {
+            nx0 = 0;
+            ny0 += R;
+            if (ny0 >= rpi * R) {
+                ny0 = 0;
+                ++nb;
+            }
+        }
         // halo row hr <-> low-res row y0 + py - 1 + hr, halo col hx <-> x0 - 1 + hx
         const int ytop = y0 + py;                                            // low-res row of hr = 1
         const unsigned rlo = (ytop == 0) ? 1u : 0u, rn = (unsigned)((Hl - ytop < R) ? (Hl - ytop) : R) - rlo;
@@ -811,13 +844,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (g0 < g1) {
-        gload(g0);
+        gload();
         lstore(0);
     }
     __syncthreads();
     for (long g = g0; g < g1; ++g) {
         const int buf = (int)((g - g0) & 1);
-        if (g + 1 < g1) gload(g + 1);
+        if (g + 1 < g1) gload();
         const EGZ_LDS unsigned short* Xb = Xl + buf * XB;
         const EGZ_LDS unsigned short* Db = Dl + buf * DB;
 #pragma unroll
