@@ -277,6 +277,7 @@ def main():
     at_ms = None
     pcie_ms = {}
     rccl = None
+    lf_block = None
     if not args.no_roofline:
         # Every rank runs these two extra (untimed) steps -- the gradient all-reduce inside step() is a collective --
         # but only rank 0 reports.  Per-kernel HIP-event timing needs the kernels serialised: the multi-stream
@@ -303,7 +304,7 @@ def main():
         # -> tools/pmc_traffic.py; gfx950 FETCH half-count corrected).  The profile is stamped with a hash of the kernel
         # sources it was taken from: if the kernels changed since, the number is NOT quoted (traffic = null).
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if not split or tj.get("kernel_src_sha") == kernel_src_sha():
@@ -326,7 +327,7 @@ def main():
                                    "launches, exact-f32 MFMA)") +
                                   "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
                                   "timed with HIP events on the launch stream with stream concurrency off, as in "
-                                  "profiles/r02_bench_b32_kernel_stats_streams0.txt",
+                                  "profiles/r03_bench_b32_kernel_stats_streams0.txt",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
@@ -347,6 +348,42 @@ def main():
                 at_step()
             torch.cuda.synchronize()
             at_ms = (time.perf_counter() - t1) / 20 * 1e3
+        if world == 1:
+            # BASELINE config 5's last stage beside the headline (untimed leg): one LF.trainLate iteration (late_fusion forward
+            # + floss + backward + Adam, LF.py:90-100) at the same batch, HBM-bound -- 88 MB of algorithmic traffic per frame
+            # (every conv reads its input and writes its output once, BN / ReLU fused) against the 8 TB/s roof
+            try:
+                from egaze_amd.models.late_fusion import late_fusion
+                lfm = late_fusion().to(dev)
+                lfm.train()
+                lfo = FusedAdam(lfm.parameters(), lr=1e-4)
+                lfb = [torch.rand(args.batch, 1, args.size, args.size, device=dev) for _ in range(3)]
+
+                def lf_step():
+                    o = lfm(lfb[0], lfb[1])
+                    l_ = criterion(o, lfb[2])
+                    lfo.zero_grad()
+                    l_.backward()
+                    lfo.step()
+                for _ in range(3):
+                    lf_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    lf_step()
+                torch.cuda.synchronize()
+                lf_ms = (time.perf_counter() - t1) / 20 * 1e3
+                lf_bytes = 88e6 * args.batch * (args.size / 224.0) ** 2
+                lf_block = {"ms_per_step": lf_ms, "frames_per_s": args.batch / (lf_ms * 1e-3),
+                            "roofline": {"bound": "hbm", "achieved": lf_bytes / (lf_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": lf_bytes / (lf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                         "algorithmic_bytes_per_frame": 88e6},
+                            "note": "LF.trainLate iteration at this batch, 20 untimed-leg steps; the three train-mode BatchNorm "
+                                    "layers are still passes of their own (9 of the step's HBM passes), which is what separates "
+                                    "it from the roof"}
+                del lfm, lfo, lfb
+            except Exception as e:
+                lf_block = {"error": repr(e)[:300]}
         if split and not args.no_f32_leg:
             # the same step on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), untimed leg, reported beside the headline
             H.PRECISION = "f32"
@@ -474,6 +511,14 @@ def main():
             "step_hbm_frac": BYTES_PER_FRAME * args.batch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "loss": last_loss, "kernel_ms_breakdown": breakdown,
             "extra": {"at_ms_per_step": at_ms,
+                      "at_roofline": (None if not at_ms else
+                                      {"bound": "latency (batched f32-MFMA GEMMs + T dependent [recurrent product + cell] launches)",
+                                       "achieved": 3 * 4.56e9 * (args.batch / 32.0) / (at_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": 3 * 4.56e9 * (args.batch / 32.0) / (at_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                       "samples_per_s": 16 * args.batch / (at_ms * 1e-3),
+                                       "note": "config 4 shape, T=16: 4.56 GFLOP forward, x3 for forward + backward (SURVEY.md 8d); "
+                                               "the step is ~150 dependent launches, not a matrix-core workload"}),
+                      "lf_step": lf_block,
                       "at_note": ("AT alone (BASELINE config 4 shape): lstmnet T=16, B=%d forward + MSE + backward + Adam, "
                                   "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),
                       "f32_ms_per_step": f32_ms,

@@ -14,6 +14,8 @@ from .optim import FusedAdam
 from .utils import AverageMeter, computeAAEAUC, owned_state_dict, plot_loss
 from .SP import _progress
 
+LF_GRAPH = os.environ.get("EGAZE_LF_GRAPH", "1") != "0"      # A/B knob: 0 = issue every LF training step launch by launch
+
 
 def _split(folder, val_name, task):
     names = os.listdir(folder)
@@ -71,7 +73,29 @@ class LF():
         from .data.STdatas import staged_batches
         losses, auc, aae = AverageMeter(), AverageMeter(), AverageMeter()
         # the three maps of batch k + 1 cross PCIe on a copy stream while step k computes (LF.py:85-89 copies in the step)
+        # The training step (forward + loss + zero_grad + backward + Adam, ~110 launches for ~1.4 ms of kernels) is captured
+        # once and replayed (graphs.GraphedTrainStep); single process only -- the gradient reducer's hooks are host code.
+        graphed = None
+        use_graph = train and LF_GRAPH and dp.world_size() == 1 and self.device.type == 'cuda'
         for i, (sample, (im, gt, feat)) in _progress(enumerate(staged_batches(loader, self.device, _stage_late))):
+            if use_graph and graphed is None:
+                from .graphs import GraphedTrainStep
+
+                def fwd_loss(feat_, im_, gt_):
+                    o = self.model(feat_, im_)
+                    return self.criterion(o, gt_), o
+                graphed = GraphedTrainStep(fwd_loss, self.optimizer, (feat, im, gt))
+            if graphed is not None and feat.shape == graphed.static_in[0].shape:
+                loss, out = graphed(feat, im, gt)             # one replay = one LF.trainLate iteration (LF.py:90-100)
+                aae1, auc1, _ = computeAAEAUC(out, gt)
+                auc.update(auc1)
+                aae.update(aae1)
+                losses.update(loss.item())
+                if (i + 1) % every == 0:
+                    print('Epoch: [{0}][{1}/{2}]\t''AUCAAE_late {auc.avg:.3f} ({aae.avg:.3f})\t'
+                          'Loss {loss.val:.4f} ({loss.avg:.4f})\t'.format(self.epochnow, i + 1, len(loader) + 1, auc=auc,
+                                                                          loss=losses, aae=aae))
+                continue
             out = self.model(feat, im)                       # channel 0 = AT map, channel 1 = SP map (LF.py:90)
             loss = self.criterion(out, gt)
             aae1, auc1, _ = computeAAEAUC(out.detach(), gt)          # device kernel, maps stay in HBM (LF.py:92-94)
@@ -86,6 +110,8 @@ class LF():
                 print('Epoch: [{0}][{1}/{2}]\t''AUCAAE_late {auc.avg:.3f} ({aae.avg:.3f})\t'
                       'Loss {loss.val:.4f} ({loss.avg:.4f})\t'.format(self.epochnow, i + 1, len(loader) + 1, auc=auc,
                                                                       loss=losses, aae=aae))
+        if graphed is not None:
+            graphed.close()
         if dp.world_size() > 1:                      # global averages so that every rank agrees on the best epoch
             return tuple(dp.reduce_meters((losses.sum, losses.count), (auc.sum, auc.count), (aae.sum, aae.count)))
         return losses.avg, auc.avg, aae.avg

@@ -315,10 +315,26 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // ---- prologue
     gload_b(S_lo, 0);
     if (NRING > 2) gload_b(S_hi - S_lo > 1 ? S_lo + 1 : S_lo, 1);
-    gload_a(c_lo, 0, 0);
-    lstore_a(0, 0);
-    gload_a(c_lo, 0, 1);
-    lstore_a(0, 1);
+    // both halves of the first image in flight together (the second into registers that are dead until the main loop): one
+    // exposed global round trip per tile instead of two -- on the 64-channel layers, whose tiles only run 18 K-slices, the
+    // second one was a tenth of a tile's time
+    f32x4 rp[NJ / 2];
+    {
+        const unsigned so0 = (unsigned)(c_lo * XBK * 4);
+        gload_a(c_lo, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NJ / 2; ++j)
+            rp[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[NJ / 2 + j], so0, 0));
+        lstore_a(0, 0);
+#pragma unroll
+        for (int j = 0; j < NJ / 2; ++j) {
+            u32x2 hi, lo;
+            Half<T>::split4(rp[j] * a_scale, hi, lo);
+            unsigned short* d = Ah + a_lds[NJ / 2 + j];
+            *reinterpret_cast<u32x2*>(d) = hi;
+            *reinterpret_cast<u32x2*>(d + APL) = lo;
+        }
+    }
     lds_barrier();
     read_a0(shift_of(0, 0), 0);
 
@@ -444,7 +460,10 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                 __builtin_amdgcn_sched_barrier(0);
                 mfma12(ah1, al1, bq[ring][2], bq[ring][3]);
                 if (G::NABUF == 1 && t == NT - 1 && more) {
-                    // single image: everyone finishes reading, then the two halves are restaged in place
+                    // single image: everyone finishes reading, then the two halves are restaged in place.  (Fetching the second
+                    // half into spare registers half a tap early, so that its round trip overlaps the first half's, was tried in
+                    // round 3: the 64-column configuration sits at 256 VGPRs and the extra live range spilled inside the loop --
+                    // enc3 forward 520 -> 595 us.)
                     lds_barrier();
                     lstore_a(0, 0);
                     gload_a(ncblk, nimg, 1);

@@ -55,11 +55,11 @@ def _close_fork(f, sink, dw, *inputs):
     helper stream is left running (streams.fork.detach): the weight gradient of layer L then overlaps the HBM-bound
     BN / ReLU backward pass and the data gradient of layer L-1 instead of holding the chain up.  Without a sink the
     gradient tensor goes back to autograd and the streams are joined."""
-    if sink is not None and DETACH_WGRAD:
+    if sink is not None and DETACH_WGRAD and not (f.enabled and torch.cuda.is_current_stream_capturing()):
         f.detach(*inputs)
         _join_at_end_of_backward()
     else:
-        f.join(dw)
+        f.join(dw)            # (inside a hipGraph capture every fork joins back: a capture must end with one open stream)
 
 
 _JOIN_QUEUED = [False]

@@ -196,3 +196,49 @@ def test_bilinear_up_and_u8_center_of_mass(align):
         want = np.array(ndimage.center_of_mass(imq))
         assert np.array_equal(com[b].cpu().numpy(), want), (com[b], want)
         assert np.array_equal(gp[b].cpu().numpy(), np.floor(want).astype(np.int32))
+
+
+def test_lf_train_step_graphed_matches_eager():
+    """LF.trainLate's iteration (LF.py:90-100) captured into one hipGraph (graphs.GraphedTrainStep) vs the same steps issued
+    launch by launch: identical losses, outputs, parameters, BN running statistics and Adam state after five steps -- the
+    capture changes how the step is issued (every weight-gradient fork joins back), not what it computes."""
+    from egaze_amd.floss import floss
+    from egaze_amd.graphs import GraphedTrainStep
+    from egaze_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(11)
+    batches = [tuple(torch.rand(4, 1, 224, 224, generator=g).to(DEV) for _ in range(3)) for _ in range(5)]
+    results = []
+    for graphed in (False, True):
+        torch.manual_seed(5)
+        model = build()
+        model.train()
+        crit = floss().to(DEV)
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        losses = []
+        if graphed:
+            def fwd_loss(f, i, t):
+                o = model(f, i)
+                return crit(o, t), o
+            step = GraphedTrainStep(fwd_loss, opt, batches[0], warm=2)
+            for f, i, t in batches:
+                l, o = step(f, i, t)
+                losses.append(l.item())
+            assert step.graph is not None and opt.step_count == 5
+            step.close()
+            assert opt.step_count == 5
+        else:
+            for f, i, t in batches:
+                o = model(f, i)
+                l = crit(o, t)
+                opt.zero_grad()
+                l.backward()
+                opt.step()
+                losses.append(l.item())
+        torch.cuda.synchronize()
+        results.append((losses, o.detach().clone(), opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_v.clone(),
+                        {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "tracked" in k}))
+    (l0, o0, p0, m0, v0, b0), (l1, o1, p1, m1, v1, b1) = results
+    assert l0 == l1, (l0, l1)
+    assert torch.equal(o0, o1) and torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    for k in b0:
+        assert torch.equal(b0[k], b1[k]), k

@@ -35,3 +35,21 @@ for metric in (False, True):
     for _ in range(a.steps): step(metric)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     print(f"LF step B={a.batch} metric={'device AAE/AUC' if metric else 'off'}: {dt*1e3:.2f} ms  {a.batch/dt:.0f} frames/s")
+
+# the same step captured into one hipGraph and replayed (graphs.GraphedTrainStep; what LF._run does by default)
+from egaze_amd.graphs import GraphedTrainStep
+def fwd_loss(feat_, im_, gt_):
+    o = model(feat_, im_)
+    return crit(o, gt_), o
+g = GraphedTrainStep(fwd_loss, opt, (feat, im, gt))
+for metric in (False, True):
+    for _ in range(4): 
+        l, o = g(feat, im, gt)
+        if metric: computeAAEAUC(o, gt)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps):
+        l, o = g(feat, im, gt)
+        if metric: computeAAEAUC(o, gt)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+    print(f"LF step B={a.batch} metric={'device AAE/AUC' if metric else 'off'} hipGraph replay: {dt*1e3:.2f} ms  {a.batch/dt:.0f} frames/s")
+g.close()
