@@ -149,8 +149,23 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
     const int a_c4 = tid & 7;
+    // The single-image configurations (64- and 32-column tiles) run at the register limit: their LDS staging addresses are
+    // recomputed at each use from an opaque copy of the slot base (12 registers less; ~10 integer ops per staged slot, twelve
+    // slots per channel block) instead of living in registers across the MFMA loop.
+    constexpr bool LDS_RECOMP = (G::NABUF == 1);
     unsigned a_vo[NJ];
-    int a_lds[NJ];
+    int a_lds[LDS_RECOMP ? 1 : NJ];
+    auto lds_slot = [&](const int j) -> int {
+        if constexpr (!LDS_RECOMP) {
+            return a_lds[j];
+        } else {
+            int tq = tid >> 3;
+            asm volatile("" : "+v"(tq));                       // keeps the compiler from hoisting the twelve addresses again
+            const int q = tq + SPP * j;
+            const int col = PATCH ? q - (q / HPITCH) * HPITCH : q;
+            return q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
+        }
+    };
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = (tid >> 3) + SPP * j;
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             pix = (MODE == UPSD) ? ((long)ib * H + 2 * iy) * W + 2 * ix : ((long)ib * H + iy) * W + ix;
         if (a_c4 * 4 >= C) pix = -1;                           // C < 32 (one zero-padded channel block): channels past C read zeros
         a_vo[j] = (pix >= 0) ? (unsigned)((pix * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
-        a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
+        if constexpr (!LDS_RECOMP) a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
     }
 
     // ---- weight fragments: lane-linear 1 KB pieces, [slice][ntile32][ks][plane][lane][8 halves]
@@ -235,7 +250,16 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // addresses of the four row groups for shift t9 in image `abuf` -> fa[0..3]
     auto tap_addr = [&](const int t9, const int abuf, int* fa) {
         if (PATCH) {
-            int f = fa9[t9] + abuf * (ABUF * 2);
+            int f;
+            if constexpr (LDS_RECOMP) {                        // (register-limited configurations: the table entry is recomputed)
+                int i = wm * RPW + l31;
+                asm volatile("" : "+v"(i));
+                const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+                const int col = (i & 15) + 1 + dx, slot = ((i >> 4) + 1 + dy) * HPITCH + col;
+                f = (slot * XLD + ((hl ^ ((col >> 2) & 3)) << 3)) * 2 + abuf * (ABUF * 2);
+            } else {
+                f = fa9[t9] + abuf * (ABUF * 2);
+            }
             asm volatile("" : "+v"(f));
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) fa[mr] = f + mr * MRSTEP;
@@ -277,7 +301,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         for (int j = 0; j < NJ / 2; ++j) {
             u32x2 hi, lo;
             Half<T>::split4(ra[half * RAOFF + j] * a_scale, hi, lo);
-            unsigned short* d = Ah + abuf * ABUF + a_lds[half * (NJ / 2) + j];
+            unsigned short* d = Ah + abuf * ABUF + lds_slot(half * (NJ / 2) + j);
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
         }
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         for (int j = 0; j < NJ / 2; ++j) {
             u32x2 hi, lo;
             Half<T>::split4(rp[j] * a_scale, hi, lo);
-            unsigned short* d = Ah + a_lds[NJ / 2 + j];
+            unsigned short* d = Ah + lds_slot(NJ / 2 + j);
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
         }
@@ -400,7 +424,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                             const int j = i - MR;
                             u32x2 hi, lo;
                             Half<T>::split4(ra[lhalf * RAOFF + j] * a_scale, hi, lo);
-                            unsigned short* d = Ah + (abuf ^ 1) * ABUF + a_lds[lhalf * NH + j];
+                            unsigned short* d = Ah + (abuf ^ 1) * ABUF + lds_slot(lhalf * NH + j);
                             *reinterpret_cast<u32x2*>(d) = hi;
                             *reinterpret_cast<u32x2*>(d + APL) = lo;
                         } else if (last && more) {
