@@ -316,6 +316,10 @@ template <> struct W16<_Float16> {
 #ifndef EGZ_WGRAD_XCD
 #define EGZ_WGRAD_XCD 1
 #endif
+#ifndef EGZ_WGRAD_FINE        // A/B knob: 1 = the split + LDS stores of the next stage issued piecewise behind the last 18 MFMAs of
+#define EGZ_WGRAD_FINE 0      // the current one.  Measured slower (4.14 vs 3.82 ms over the 12 layer shapes): the pieces wait for their
+#endif                        // global loads earlier and the longer live ranges spill (68 B / lane) -- unlike the forward kernel, whose
+                              // staging registers are loaded two taps ahead.  The block form stays.
 __device__ __forceinline__ void wgrad_block(int& tile, int& split) {
     tile = blockIdx.x;
     split = blockIdx.y;
@@ -369,20 +373,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         const_cast<char*>(reinterpret_cast<const char*>(x)) - x_bias, 0, (int)((unsigned)B * H * W * C * 4u + x_bias), 0x00020000);
     const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(dy), 0, (int)((unsigned)B * H * W * K * 4u), 0x00020000);
-    unsigned x_vo[NX], x_rc[NX], d_vo[ND], d_rc[ND];      // byte offsets; (row << 8 | col) of the slot inside the patch
+    unsigned x_vo[NX], d_vo[ND];                          // byte offsets of the slot inside the patch
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         const int i = tid + 256 * j, pos = i >> 4, c4 = i & 15;
         const int hr = pos / HPW, hx = pos - hr * HPW;
         x_vo[j] = (pos < NH && c0 + c4 * 4 < C) ? (unsigned)((hr * W + hx) * C * 4 + c4 * 16) : 0xFFFFFFFFu;   // C = 32: half tile
-        x_rc[j] = (unsigned)(hr << 8 | hx);
     }
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
         const int i = tid + 256 * j, pp = i >> 4, k4 = i & 15;
         d_vo[j] = (k0 + k4 * 4 < K) ? (unsigned)(((pp / WD) * W + pp % WD) * K * 4 + k4 * 16) : 0xFFFFFFFFu;   // K < 64: masked k-tile
-        d_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
     }
+    // (row << 8 | col) of a slot inside the patch, for the border tests: recomputed per stage from an opaque copy of the thread
+    // index (a few integer ops per load) instead of held in registers across the MFMA loop -- the kernel sits at 256 VGPRs and
+    // every register kept out of the loop is a spill reload less in it
+    // (only where it pays: the 2 x 16 patch variant spilled 60 bytes per lane and its 112 x 112 layers ran 16 % slower for
+    // it; the other variants fit and keep the codes in registers -- recomputing costs them 2-5 %)
+    constexpr bool RC_RECOMP = (R == 2 && WD == 16);
+    unsigned x_rc[RC_RECOMP ? 1 : NX], d_rc[RC_RECOMP ? 1 : ND];
+    if constexpr (!RC_RECOMP) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int pos = (tid + 256 * j) >> 4, hr = pos / HPW;
+            x_rc[j] = (unsigned)(hr << 8 | (pos - hr * HPW));
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int pp = (tid + 256 * j) >> 4;
+            d_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
+        }
+    }
+    auto x_rc_of = [&](const int j) -> unsigned {
+        if constexpr (!RC_RECOMP) {
+            return x_rc[j];
+        } else {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int pos = (t_ + 256 * j) >> 4, hr = pos / HPW;
+            return (unsigned)(hr << 8 | (pos - hr * HPW));
+        }
+    };
+    auto d_rc_of = [&](const int j) -> unsigned {
+        if constexpr (!RC_RECOMP) {
+            return d_rc[j];
+        } else {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int pp = (t_ + 256 * j) >> 4;
+            return (unsigned)((pp / WD) << 8 | (pp % WD));
+        }
+    };
 
     f32x4 rx[NX], rd[ND];
     // patch cursor of the NEXT fetch, advanced by one patch per call (stages are consecutive patches): three scalar adds and
@@ -409,13 +450,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const unsigned so_d = (unsigned)((((b * H + y0) * W + x0) * K + k0) * 4);
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
-                const bool ok = ((x_rc[j] >> 8) - rlo <= rn) && ((x_rc[j] & 255u) - clo <= cn);
+                const unsigned rc = x_rc_of(j);
+                const bool ok = ((rc >> 8) - rlo <= rn) && ((rc & 255u) - clo <= cn);
                 rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? x_vo[j] : 0xFFFFFFFFu, so_x, 0));
             }
             const unsigned rmax = (unsigned)(H - y0), cmax = (unsigned)(W - x0);              // py < rmax, px < cmax
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
-                const bool ok = ((d_rc[j] >> 8) < rmax) && ((d_rc[j] & 255u) < cmax);
+                const unsigned rc = d_rc_of(j);
+                const bool ok = ((rc >> 8) < rmax) && ((rc & 255u) < cmax);
                 rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, ok ? d_vo[j] : 0xFFFFFFFFu, so_d, 0));
             }
             return;
@@ -470,6 +513,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         }
     };
 
+    // one staged float4 of the next stage: split + two LDS stores (piece p < NX: halo slot, else dY) -- issued one at a time
+    // in the shadow of the last MFMAs of the stage (EGZ_WGRAD_FINE) instead of as a block behind them
+    static_assert(NX + ND <= 9, "the last 18 MFMAs of a stage carry at most 9 staging pieces");
+    auto lstore_piece = [&](int buf, const int p) {
+        if (p < NX) {
+            const int i = tid + 256 * p;
+            const int pos = i >> 4, c4 = i & 15;
+            if (pos < NH) {
+                u32x2_t hi, lo;
+                W16<T>::split4(rx[p] * x_scale, hi, lo);
+                unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
+                *reinterpret_cast<u32x2_t*>(d) = hi;
+                *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
+            }
+        } else if (p < NX + ND) {
+            const int j = p - NX;
+            const int i = tid + 256 * j;
+            const int pp = i >> 4, k4 = i & 15;
+            u32x2_t hi, lo;
+            W16<T>::split4(rd[j] * d_scale, hi, lo);
+            unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
+            *reinterpret_cast<u32x2_t*>(d) = hi;
+            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
+        }
+    };
+
     // transpose-read addressing: 16-lane group g = lane >> 4 covers channels 16 * (g & 1) .. +15 of the wave's half and
     // reduction elements 8 * (g >> 1) .. +7 (two reads of 4 pixels); lane u of the group hands in pixel (u >> 2),
     // channel chunk (u & 3)
@@ -513,6 +582,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                     xh[ts] = W16<T>::frag(Xb + xoff(ks, 0, tap), Xb + xoff(ks, 1, tap));
                     xl[ts] = W16<T>::frag(Xb + 2 * XH + xoff(ks, 0, tap), Xb + 2 * XH + xoff(ks, 1, tap));
                 }
+                if (EGZ_WGRAD_FINE && ks == KS - 1 && tr >= 1) {
+                    // the last 18 MFMAs of the stage carry the split + LDS stores of the next stage, one piece per two MFMAs
+                    const bool nxt = g + 1 < g1;                // block-uniform
+#pragma unroll
+                    for (int m = 0; m < 9; ++m) {
+                        const int term = m / 3, ts = m % 3;
+                        acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
+                        const int mm = (tr - 1) * 9 + m;
+                        if (nxt && (mm & 1) == 0) lstore_piece(buf ^ 1, mm >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -520,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                         acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
             }
         }
-        if (g + 1 < g1) lstore(buf ^ 1);
+        if (!EGZ_WGRAD_FINE && g + 1 < g1) lstore(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
