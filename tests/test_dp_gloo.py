@@ -212,3 +212,92 @@ def test_grad_sinks_report_once_per_bucket():
         assert n_buckets >= 3
         assert not early, "a bucket was all-reduced before all of its gradients had landed"
         assert summed
+
+
+def _wait_worker(rank, world, port, q, fail):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    import egaze_amd  # noqa: F401
+    from egaze_amd.gaze_full import _wait_for_rank0
+    t0 = time.time()
+    try:
+        if rank == 0:
+            time.sleep(1.0)                                    # the sequential rank-0 stage (AT training / extraction)
+            if fail:
+                dist.distributed_c10d._get_default_store().set("stage/failed", "1")
+                q.put((rank, "failed-flag-set", time.time() - t0))
+                return
+        _wait_for_rank0("stage", poll_s=0.1)
+        q.put((rank, "released", time.time() - t0))
+    except RuntimeError as e:
+        q.put((rank, "raised: " + str(e), time.time() - t0))
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_wait_for_rank0_is_a_host_side_rendezvous(fail):
+    """gaze_full's wait for the rank-0-only AT stage: a store key polled on the host (no device collective, no multi-day
+    timeout).  Rank 1 is released once rank 0 sets the key -- and is ENDED, not left hanging, when rank 0 fails."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wait_worker, args=(r, 2, port, q, fail)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(2):
+        r, what, dt = q.get(timeout=120)
+        res[r] = (what, dt)
+    for p in procs:
+        p.join(30)
+    if fail:
+        assert res[1][0].startswith("raised: rank 0 failed"), res
+    else:
+        assert res[0][0] == "released" and res[1][0] == "released" and res[1][1] >= 0.9, res
+
+
+def _forced_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import egaze_amd  # noqa: F401
+    from egaze_amd.dp import GradReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 50), torch.nn.ReLU(), torch.nn.Linear(50, 3))
+    params = list(net.parameters())
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    flat_g = torch.zeros(off)
+    for p, o in zip(params, offsets):
+        p.grad = flat_g[o:o + p.numel()].view(p.shape)
+    x = torch.randn(4, 37)
+    (net(x) ** 2).sum().backward()
+    plain = flat_g.clone()
+    idle = GradReducer(flat_g, params, offsets, bucket_bytes=512)              # world 1, not forced: a no-op
+    assert not idle.active
+    red = GradReducer(flat_g, params, offsets, bucket_bytes=512, force=True)
+    assert red.active and red.world == 1 and len(red.buckets) >= 2
+    flat_g.zero_()
+    (net(x) ** 2).sum().backward()
+    in_bwd = red.stats["launched_in_backward"]
+    red.wait()
+    q.put((torch.equal(flat_g, plain), in_bwd, red.stats["launched_in_wait"], len(red.buckets), red.grad_scale))
+    red.detach()
+    assert not red.active
+
+
+def test_reducer_forced_at_world_one():
+    """dp.GradReducer(force=True) at world size 1 (how the RCCL path is exercised on a one-GPU box): hooks fire, every bucket
+    is all-reduced (a 1-rank sum = identity), gradients unchanged, scale 1."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    same, in_bwd, in_wait, nb, scale = q.get(timeout=120)
+    p.join(30)
+    assert same and in_bwd + in_wait == nb and in_bwd >= 1 and scale == 1.0
