@@ -188,6 +188,7 @@ def main():
     model.train()
     criterion = floss().to(dev)
     optimizer = FusedAdam(model.parameters(), lr=1e-7)          # gaze_full.py --lr default
+    optimizer.overlap_with_backward(True)       # step() follows backward() directly (SP.py:136-137): bucketed Adam under the backward
     if dist is not None:
         dp.attach(optimizer)
     batch = synthetic.sp_batch(args.batch, args.size, dev, seed=100 + rank)

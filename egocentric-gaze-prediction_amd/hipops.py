@@ -129,6 +129,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 # ----------------------------------------------------------------------------- packed weights
 _WEIGHT_EPOCH = [0]
 _PACKED = {}
+_USED = set()                     # packings requested by a launch since their last rebuild (refresh_packings)
 
 
 def bump_weight_epoch():
@@ -270,6 +271,7 @@ def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
     tag = _tag(w)
     hit = _PACKED.get(key)
     if hit is not None and hit[0] == tag:
+        _USED.add(key)
         return hit[1]
     fname, ekind, kidx = _PACK_FN[kind]
     buf = hit[1] if hit is not None else torch.empty(LIB.egz_pack_w3x3_elems(C, K, ekind), dtype=torch.float32,
@@ -284,7 +286,26 @@ def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
     else:
         check(getattr(LIB, fname)(w.data_ptr(), buf.data_ptr(), C, K, _stream()), fname)
     _PACKED[key] = (tag, buf, weakref.ref(w))
+    _USED.add(key)
     return buf
+
+
+def refresh_packings(params) -> int:
+    """Rebuild every cached packing of these parameters NOW, on the current stream (the bucketed optimizer tail calls this
+    on its side stream right after the bucket's Adam kernel, so that the ~70 small pack launches of a step run under the rest
+    of the backward pass instead of in front of the next forward's convolutions).  Returns the number of packings refreshed."""
+    uids = {getattr(p, "_egz_uid", None): p for p in params}
+    uids.pop(None, None)
+    n = 0
+    for key, ent in list(_PACKED.items()):
+        uid, kind, dtype = key
+        w = uids.get(uid)
+        if w is None or ent[2]() is not w or key not in _USED:      # only packings a launch asked for since their last rebuild
+            continue
+        packed_weight(w, kind, dtype)
+        _USED.discard(key)
+        n += 1
+    return n
 
 
 _PACK_PER_BLOCK = 2048
@@ -878,9 +899,14 @@ def mse_bwd(a, b, grad_out, tanh_target: bool = False) -> torch.Tensor:
     return da
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
-    check(LIB.egz_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
-                            int(step), grad_scale, _stream()), "egz_adam_step")
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, lo: int = 0, hi: Optional[int] = None):
+    """One Adam step over the flat buffers, or over their slice [lo, hi) (element offsets, multiples of 4)."""
+    hi = p.numel() if hi is None else hi
+    if hi <= lo:
+        return
+    o = 4 * lo
+    check(LIB.egz_adam_step(p.data_ptr() + o, g.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, hi - lo, lr, beta1, beta2,
+                            eps, int(step), grad_scale, _stream()), "egz_adam_step")
 
 
 def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):

@@ -18,7 +18,7 @@ _SIDE = {}
 # share a queue run FIFO.  One weight-gradient stream for both encoders keeps the step at main + encoder_t + wgrad + one
 # more (the AT stream, the H2D copy stream or the RCCL comm stream): the step time is unchanged (35.4 vs 35.3 ms) and the
 # prefetched H2D copy overlaps fully (fp32 loader: 36.2 vs 38.0 ms per step; profiles/r02_hw_queues_ab.txt).
-_SHARED = set(filter(None, os.environ.get("EGAZE_SHARED_STREAMS", "wgrad").split(",")))
+_SHARED = set(filter(None, os.environ.get("EGAZE_SHARED_STREAMS", "wgrad,adam").split(",")))
 
 
 def side_stream(kind: str) -> torch.cuda.Stream:
