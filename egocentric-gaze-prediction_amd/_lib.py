@@ -44,13 +44,15 @@ SIGNATURES = {
     "egz_conv3x3_fwd_streamed_splitk_stat_rows": (c_int, [c_int, c_int, c_int]),
     "egz_conv3x3_fwd_streamed_splitk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd_streamed_splitk": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, c_int, P, S]),
-    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
+    "egz_conv3x3_streamed_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, S]),
     "egz_absmax_fold": (c_int, [P, c_int, S]),
     "egz_colsum_f64": (c_int, [P, c_int, c_int, c_int, P, P, c_size_t, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, S]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)
     "egz_conv_first_stat_rows": (c_int, [c_int, c_int, c_int]),
+    "egz_conv_first_stat_rows_for": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
     "egz_conv_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "egz_conv_first_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
@@ -62,7 +64,9 @@ SIGNATURES = {
     "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_bn_relu_pool_bwd_ws_bytes": (c_size_t, [c_int]),
     "egz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
-                                     c_size_t, P, S]),
+                                     c_size_t, P, P, c_int, S]),
+    "egz_bn_bwd_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int]),
+    "egz_bn_bwd_first_wgrad": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_int, S]),
     "egz_pairmax_fwd": (c_int, [P, P, c_long, S]),
     "egz_pairmax_bwd": (c_int, [P, P, P, c_long, P, S]),
     "egz_absmax_elems": (c_int, []),

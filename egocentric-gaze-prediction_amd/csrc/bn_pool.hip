@@ -301,14 +301,52 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int npar
     mdzx[k] = (float)(s2 / count);
 }
 
+// The finalize step inside a consumer kernel (K <= 64): every block sums the few partial rows ([nrows][2][K] fp64, written by
+// the 256 blocks of the persistent narrow data-gradient kernel) itself, in a fixed order -- identical values in every block --
+// and block 0 also writes dgamma / dbeta.  The two tiny launches this replaces (column sums + finalize) would each wait for a
+// CU slot behind the weight-gradient kernel running on the helper stream (100 us apiece in the late-fusion backward pass,
+// profiles/r03_lf_timeline.txt).  fm[0][k] = mean(dz), fm[1][k] = mean(dz * xhat).
+__device__ inline void bn_bwd_finalize_in_block(const double* __restrict__ rows, int nrows, int K, double count,
+                                                float* __restrict__ dgamma, float* __restrict__ dbeta, double (*fsum)[128],
+                                                float (*fm)[64]) {
+    const int cols = 2 * K, ngrp = 256 / cols;                 // K = 32: 4 row groups of 64 columns
+    const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
+    if (grp < ngrp) {
+        double s = 0.0;
+        for (int r = grp; r < nrows; r += ngrp) s += rows[(long)r * cols + col];
+        fsum[grp][col] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < cols) {
+        double t = 0.0;
+        for (int g = 0; g < ngrp; ++g) t += fsum[g][threadIdx.x];
+        const int k = threadIdx.x % K, plane = threadIdx.x / K;
+        fm[plane][k] = (float)(t / count);
+        if (blockIdx.x == 0) {
+            float* dst = plane ? dgamma : dbeta;
+            if (dst) dst[k] = (float)t;
+        }
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------ BN backward, pass 2: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
-template <bool POOL>
+template <bool POOL, bool FIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ mdz, const float* __restrict__ mdzx,
+                                                           const float* mdz, const float* mdzx,
                                                            float* __restrict__ dy, int B, int H, int W, int K,
-                                                           unsigned int* __restrict__ absmax) {
+                                                           unsigned int* __restrict__ absmax, const double* __restrict__ rows = nullptr,
+                                                           int nrows = 0, double count = 1.0, float* __restrict__ dgamma = nullptr,
+                                                           float* __restrict__ dbeta = nullptr) {
+    __shared__ double fsum[FIN ? 16 : 1][128];
+    __shared__ float fm[2][64];
+    if (FIN) {          // FIN: mdz / mdzx are not inputs -- this block derives them from the partial rows (K <= 64)
+        bn_bwd_finalize_in_block(rows, nrows, K, count, dgamma, dbeta, fsum, fm);
+        mdz = fm[0];
+        mdzx = fm[1];
+    }
     const int K4 = K >> 2;
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const long n = (long)B * Ho * Wo * K4;
@@ -539,6 +577,15 @@ inline int ew_grid(long n) {
 }
 
 constexpr int BWD_BLOCKS = 1024;
+constexpr int FIN_MAX_ROWS = 512, FIN_GRID = 2048;     // in-kernel finalize: at most this many partial rows / blocks re-summing them
+inline bool fin_in_kernel() {                            // A/B knob EGZ_BN_FIN_FUSE=0: separate column-sum + finalize launches
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EGZ_BN_FIN_FUSE");
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on != 0;
+}
 
 }  // namespace
 
@@ -607,8 +654,11 @@ EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {
 EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
                                  int B, int H, int W, int K, int pool, void* workspace, size_t ws_bytes,
-                                 unsigned int* absmax, hipStream_t st) {
+                                 unsigned int* absmax, const double* sums, int sums_rows, hipStream_t st) {
+    // sums (optional): [sums_rows][2][K] partial rows of (sum dz, sum dz * xhat) already accumulated by the producer of dout
+    // (egz_conv3x3_fwd_streamed epi 5): the reduce pass over y and dout is skipped.
     EGZ_CHECK_ARG(y && dout && scale && shift && mean && invstd && dy && workspace, "egz_bn_relu_pool_bwd: null pointer");
+    EGZ_CHECK_ARG(!sums || (sums_rows > 0 && !pool), "egz_bn_relu_pool_bwd: precomputed sums need sums_rows > 0 and no pooling");
     EGZ_CHECK_ARG(K % 4 == 0 && K <= 1024, "egz_bn_relu_pool_bwd: K=%d must be a multiple of 4, <= 1024", K);
     EGZ_CHECK_ARG(!pool || (H % 2 == 0 && W % 2 == 0), "egz_bn_relu_pool_bwd: pooled map must be even");
     const int K4 = K / 4;
@@ -625,9 +675,23 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
     float* mdz = reinterpret_cast<float*>(part2 + (size_t)RED_ROWS * 2 * K);
     float* mdzx = mdz + K;
     const size_t shm = (size_t)rpb * 2 * K * sizeof(double);
-    if (pool) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
-    else      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
-    EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(reduce)");
+    if (sums && sums_rows <= FIN_MAX_ROWS && K <= 64 && 256 % (2 * K) == 0 && fin_in_kernel()) {
+        // few partial rows (persistent narrow kernel): the apply pass sums them itself -- no column-sum / finalize launches
+        const long n = npix * K4;
+        const int grid = ew_grid(n) < FIN_GRID ? ew_grid(n) : FIN_GRID;
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(grid), dim3(256), 0, st, y, dout, scale, shift, mean, invstd,
+                           (const float*)nullptr, (const float*)nullptr, dy, B, H, W, K, absmax, sums, sums_rows, (double)B * H * W, dgamma, dbeta);
+        EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(finalize + apply)");
+        return absmax_finish(absmax, grid, st, "egz_bn_relu_pool_bwd(absmax)");
+    }
+    if (sums) {
+        part = const_cast<double*>(sums);
+        blocks = sums_rows;
+    } else {
+        if (pool) hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
+        else      hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(threads), shm, st, y, dout, scale, shift, mean, invstd, part, B, H, W, K);
+        EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(reduce)");
+    }
     const double* fin = part;
     int nfin = blocks;
     if (blocks > RED_ROWS) {            // two-stage: keep the serial per-channel tail at <= RED_ROWS terms
@@ -646,6 +710,220 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
     return absmax_finish(absmax, ew_grid(n), st, "egz_bn_relu_pool_bwd(absmax)");
 }
 
+
+namespace {
+// ------------------------------------------------------------------ first block of a narrow stack: BN backward + weight gradient in one pass
+// late_fusion.py:10-12 starts with Conv2d(2 -> 32) -> BatchNorm2d -> ReLU on the (B, 2, H, W) network input, which needs no data
+// gradient: the gradient w.r.t. the conv output, dy = scale * (dz - mean(dz) - xhat * mean(dz xhat)), is consumed by the weight
+// gradient only.  This kernel computes dy in registers (same arithmetic as bn_bwd_apply_kernel) and accumulates
+//   dw[k][c][tap] = sum_pixels dy[pixel][k] * x[b][c][py + tap / 3 - 1][px + tap % 3 - 1]
+// straight away: the 205 MB dy tensor (B = 32, 224 x 224) is neither written nor re-read, and the generic first-layer weight
+// gradient (built for 3 / 20 -> 64 channels on fp32 MFMA) leaves the end of the LF backward pass.
+// Thread = (pixel lane pl = tid >> 3, channel quad k4 = tid & 7): one 16-byte load of dout and y per pixel, CIN * 9 taps of the
+// NCHW input (the eight channel quads of a pixel read the same address), CIN * 9 * 4 fp32 accumulators.  A block walks a
+// contiguous pixel range 32 pixels at a time; its partial sums are reduced over the pixel lanes with wave shuffles and over the
+// four waves through LDS, in a fixed order, and written as one partial row; first_wgrad_rows_kernel sums the rows in fp64.
+constexpr int FWG_BLOCKS = 1024;
+template <int CIN, int PX, bool FIN>      // PX = horizontally adjacent pixels per thread (4 when W % 4 == 0, see conv_first_direct_kernel)
+__global__ __launch_bounds__(256) void bn_bwd_first_wgrad_kernel(
+    const float* __restrict__ y, const float* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* mdz, const float* mdzx,
+    const float* __restrict__ x, float* __restrict__ part, int B, int H, int W, int ppb, const double* __restrict__ rows,
+    int nrows, double count, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int K = 32, NT = CIN * 9;
+    __shared__ float red[4][8][NT * 4];
+    __shared__ double fsum[FIN ? 4 : 1][128];
+    __shared__ float fm[2][64];
+    if (FIN) {                                                  // the BatchNorm finalize step, redone by every block (see above)
+        bn_bwd_finalize_in_block(rows, nrows, K, count, dgamma, dbeta, fsum, fm);
+        mdz = fm[0];
+        mdzx = fm[1];
+    }
+    const int tid = threadIdx.x, k4 = tid & 7, pl = tid >> 3, lane = tid & 63, wave = tid >> 6;
+    const int HW = H * W, M = B * HW;
+    const int m0 = blockIdx.x * ppb, m1 = (m0 + ppb < M) ? m0 + ppb : M;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + k4 * 4), sh = *reinterpret_cast<const f32x4*>(shift + k4 * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + k4 * 4), is = *reinterpret_cast<const f32x4*>(invstd + k4 * 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(mdz + k4 * 4), a2 = *reinterpret_cast<const f32x4*>(mdzx + k4 * 4);
+    float acc[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+    int m = m0 + pl * PX;                                      // first of the thread's PX pixels (same image row: W % PX == 0)
+    int b = m / HW, py = (m - b * HW) / W, px = m - b * HW - py * W;          // advanced by 32 PX pixels per iteration below
+    for (; m < m1; m += 32 * PX) {
+        f32x4 g[PX], v[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            g[p] = *reinterpret_cast<const f32x4*>(dout + (long)(m + p) * K + k4 * 4);
+            v[p] = *reinterpret_cast<const f32x4*>(y + (long)(m + p) * K + k4 * 4);
+        }
+        float xw[CIN][3][PX + 2];
+        const float* xb = x + (long)b * CIN * HW + (long)py * W + px;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const bool rok = (unsigned)(py + r - 1) < (unsigned)H;
+#pragma unroll
+            for (int j = 0; j < PX + 2; ++j) {
+                const bool ok = rok && (unsigned)(px + j - 1) < (unsigned)W;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) xw[c][r][j] = ok ? xb[(long)c * HW + (r - 1) * W + (j - 1)] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z = v[p][e] * sc[e] + sh[e];
+                const float dz = z > 0.f ? g[p][e] : 0.f;
+                const float xh = (v[p][e] - mu[e]) * is[e];
+                r[e] = sc[e] * (dz - a1[e] - xh * a2[e]);
+            }
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[c * 9 + t][e] += r[e] * xw[c][t / 3][p + t % 3];
+        }
+        px += 32 * PX;
+        while (px >= W) {
+            px -= W;
+            if (++py == H) {
+                py = 0;
+                ++b;
+            }
+        }
+    }
+    // pixel lanes of a wave: lane = (pl & 7) * 8 + k4
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = acc[t][e];
+            a += __shfl_xor(a, 8);
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            if (lane < 8) red[wave][lane][t * 4 + e] = a;
+        }
+    __syncthreads();
+    // part[block][k][c * 9 + tap]
+    for (int i = tid; i < K * NT; i += 256) {
+        const int k = i / NT, t = i - k * NT;
+        const int q = k >> 2, e = k & 3;
+        part[(long)blockIdx.x * K * NT + i] = ((red[0][q][t * 4 + e] + red[1][q][t * 4 + e]) + red[2][q][t * 4 + e]) + red[3][q][t * 4 + e];
+    }
+}
+
+// dw[i] = sum over the partial rows in fp64: a block = 16 outputs x 16 row lanes (row lane q sums rows q, q + 16, ... with
+// four independent chains), the sixteen lane sums added in lane order
+__global__ __launch_bounds__(256) void first_wgrad_rows_kernel(const float* __restrict__ part, float* __restrict__ dw, int rows, int n) {
+    __shared__ double red[16][17];
+    const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < n) {
+        int r = q;
+        for (; r + 48 < rows; r += 64) {
+            s0 += (double)part[(long)r * n + i];
+            s1 += (double)part[(long)(r + 16) * n + i];
+            s2 += (double)part[(long)(r + 32) * n + i];
+            s3 += (double)part[(long)(r + 48) * n + i];
+        }
+        for (; r < rows; r += 16) s0 += (double)part[(long)r * n + i];
+    }
+    red[q][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][o];
+        dw[i] = (float)t;
+    }
+}
+
+}  // namespace
+
+EGZ_API size_t egz_bn_bwd_first_wgrad_ws_bytes(int C, int K) {
+    return egz_bn_relu_pool_bwd_ws_bytes(K) + (size_t)FWG_BLOCKS * K * C * 9 * sizeof(float);
+}
+
+// Backward of the FIRST block [Conv2d(C -> 32, 3x3) -> BN(train) -> ReLU] of a narrow stack (late_fusion.py:10-12; C <= 3):
+// dgamma / dbeta of the BatchNorm and dw (K, C, 3, 3) of the conv, without materialising the gradient w.r.t. the conv output.
+// y: pre-BN conv output [B][H][W][32], dout: gradient w.r.t. the block output (same layout), x: the block input [B][C][H][W]
+// (NCHW, as the reference loader yields it).  sums (optional): as for egz_bn_relu_pool_bwd.
+EGZ_API int egz_bn_bwd_first_wgrad(const float* y, const float* dout, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const float* x, float* dw, float* dgamma, float* dbeta, int B, int H,
+                                   int W, int C, int K, void* workspace, size_t ws_bytes, const double* sums, int sums_rows,
+                                   hipStream_t st) {
+    EGZ_CHECK_ARG(y && dout && scale && shift && mean && invstd && x && dw && workspace, "egz_bn_bwd_first_wgrad: null pointer");
+    EGZ_CHECK_ARG(K == 32 && C >= 1 && C <= 3, "egz_bn_bwd_first_wgrad: covers C <= 3 input channels and 32 filters (got %d -> %d)", C, K);
+    EGZ_CHECK_ARG(B > 0 && H > 0 && W > 0 && (long)B * H * W * 32 < (1l << 31), "egz_bn_bwd_first_wgrad: bad shape");
+    EGZ_CHECK_ARG(!sums || sums_rows > 0, "egz_bn_bwd_first_wgrad: sums need sums_rows > 0");
+    const size_t need = egz_bn_bwd_first_wgrad_ws_bytes(C, K);
+    EGZ_CHECK_ARG(ws_bytes >= need, "egz_bn_bwd_first_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    const int K4 = K / 4, threads = 256, rpb = threads / K4;
+    const long npix = (long)B * H * W;
+    int blocks = (int)((npix + rpb - 1) / rpb);
+    if (blocks > BWD_BLOCKS) blocks = BWD_BLOCKS;
+    if (blocks > ew_cap()) blocks = ew_cap();
+    double* part = static_cast<double*>(workspace);
+    double* part2 = part + (size_t)BWD_BLOCKS * 2 * K;
+    float* mdz = reinterpret_cast<float*>(part2 + (size_t)RED_ROWS * 2 * K);
+    float* mdzx = mdz + K;
+    float* wpart = reinterpret_cast<float*>(static_cast<char*>(workspace) + egz_bn_relu_pool_bwd_ws_bytes(K));
+    const bool fin_fused = sums && sums_rows <= FIN_MAX_ROWS && fin_in_kernel();
+    if (sums) {
+        part = const_cast<double*>(sums);
+        blocks = sums_rows;
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(blocks), dim3(threads), (size_t)rpb * 2 * K * sizeof(double), st, y, dout,
+                           scale, shift, mean, invstd, part, B, H, W, K);
+        EGZ_CHECK_LAUNCH("egz_bn_bwd_first_wgrad(reduce)");
+    }
+    if (!fin_fused) {
+        const double* fin = part;
+        int nfin = blocks;
+        if (blocks > RED_ROWS) {
+            int rc = colsum_partial<double>(part, part2, blocks, 2 * K, st);
+            if (rc) return rc;
+            fin = part2;
+            nfin = RED_ROWS;
+        }
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K, (double)npix, dgamma, dbeta, mdz, mdzx);
+        EGZ_CHECK_LAUNCH("egz_bn_bwd_first_wgrad(finalize)");
+    }
+    const int step = (W % 4 == 0) ? 128 : 32;                  // pixels per block iteration (4 / 1 per thread)
+    int ppb = (int)((npix + FWG_BLOCKS - 1) / FWG_BLOCKS);
+    ppb = (ppb + step - 1) / step * step;
+    const int nb = (int)((npix + ppb - 1) / ppb);
+#define EGZ_FWG2(CC, PP)                                                                                                         \
+    do {                                                                                                                         \
+        if (fin_fused)                                                                                                           \
+            hipLaunchKernelGGL((bn_bwd_first_wgrad_kernel<CC, PP, true>), dim3(nb), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, \
+                               (const float*)nullptr, (const float*)nullptr, x, wpart, B, H, W, ppb, sums, sums_rows, (double)npix, dgamma, dbeta); \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((bn_bwd_first_wgrad_kernel<CC, PP, false>), dim3(nb), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, \
+                               mdz, mdzx, x, wpart, B, H, W, ppb, (const double*)nullptr, 0, 1.0, (float*)nullptr, (float*)nullptr); \
+    } while (0)
+#define EGZ_FWG(CC)                                                                                                              \
+    do {                                                                                                                         \
+        if (W % 4 == 0) EGZ_FWG2(CC, 4);                                                                                         \
+        else EGZ_FWG2(CC, 1);                                                                                                    \
+    } while (0)
+    if (C == 1) EGZ_FWG(1);
+    else if (C == 2) EGZ_FWG(2);
+    else EGZ_FWG(3);
+#undef EGZ_FWG
+#undef EGZ_FWG2
+    EGZ_CHECK_LAUNCH("egz_bn_bwd_first_wgrad(apply + wgrad)");
+    const int n = K * C * 9;
+    hipLaunchKernelGGL(first_wgrad_rows_kernel, dim3(egz_cdiv(n, 16)), dim3(256), 0, st, wpart, dw, nb, n);
+    EGZ_CHECK_LAUNCH("egz_bn_bwd_first_wgrad(rows)");
+    return 0;
+}
 
 // y2: [2][n] (stream s then stream t), z: [n];  n must be a multiple of 4.
 EGZ_API int egz_pairmax_fwd(const float* y2, float* z, long n, hipStream_t st) {

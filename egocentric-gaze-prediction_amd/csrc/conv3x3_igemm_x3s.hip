@@ -47,7 +47,12 @@ using namespace x3;
 // layout as y): the epilogue applies the ReLU mask (mask_src > 0), accumulates the per-channel sums of the masked gradient
 // (= the bias gradient of the layer below, plane 0 of the stat rows; plane 1 = 0) and the per-tile max |value| (for the
 // f16 scaling of the next backward kernels) -- the separate ReLU-backward pass of that layer disappears.
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2, EPI_MASK_SUMS = 3, EPI_PARTIAL = 4 };
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_BIAS_STATS = 2, EPI_MASK_SUMS = 3, EPI_PARTIAL = 4, EPI_BNSUMS = 5 };
+// EPI_BNSUMS (persistent narrow kernel, data gradients): the result is the gradient w.r.t. the OUTPUT of a train-mode
+// BatchNorm + ReLU below (late_fusion.py:10-12: conv -> BN -> ReLU -> conv).  The epilogue also reads that layer's pre-BN conv
+// output `bn_y` (same layout as y) and accumulates the two per-channel sums its BatchNorm backward needs -- sum dz and
+// sum dz * xhat with dz = (bn_y * scale + shift > 0) ? v : 0 -- into the stat rows (planes 0 / 1, one row per block):
+// the separate reduce pass of that BatchNorm (two reads of 205 MB tensors at 224 x 224 x 32) disappears.
 // EPI_PARTIAL: split-K launch (small pixel counts: batch 1 inference, the 14 x 14 / 28 x 28 layers at small batches).  The
 // channel blocks of a tile are divided over `nsplit` blocks; each writes its raw scaled accumulators to
 // y[split][pixel][column] (y = the workspace) and splitk_fixup_kernel sums them in split order and applies the epilogue.
@@ -648,7 +653,7 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, float out_scale, int total,
-    const unsigned int* __restrict__ a_absmax) {
+    const unsigned int* __restrict__ a_absmax, const float* __restrict__ bn_y, const float* __restrict__ bn_coef) {
     using G = Geo<4>;
     constexpr int BM = G::BM, HSLOTS = G::HSLOTS, NJ = G::NJ, SPP = G::SPP, MR = G::MR, RPW = G::RPW;
     constexpr int APL = HSLOTS * XLD, ABUF = 2 * APL;
@@ -665,7 +670,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     const int per = (total + 7) >> 3, xcd = (int)(blockIdx.x & 7), nbx = (int)(gridDim.x >> 3);
     const int t_end = ((xcd + 1) * per < total) ? (xcd + 1) * per : total;
     int tile = xcd * per + (int)(blockIdx.x >> 3);
-    if (tile >= t_end) return;
+    if (tile >= t_end) {                                        // (a block without tiles still owns its row of partial sums)
+        if ((EPI == EPI_BIAS_STATS || EPI == EPI_BNSUMS) && tid < 2 * K) stat[(long)blockIdx.x * 2 * K + tid] = 0.0;
+        return;
+    }
 
     // ---- weight fragments: [tap][ks][plane][lane][8 halves], 1 KB pieces, resident in registers for the whole launch
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(wq), 0, 9 * 4096, 0x00020000);
@@ -732,6 +740,26 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     const char* Ab = reinterpret_cast<const char*>(Ah);
     const bool nok = l31 < K;
     const float bz = (bias && nok) ? bias[l31] : 0.f;
+    // EPI_BNSUMS: (mean, invstd, scale, shift) of this lane's channel of the BatchNorm below (bn_coef: 4 rows of K floats)
+    const float bn_mu = (EPI == EPI_BNSUMS && nok) ? bn_coef[l31] : 0.f, bn_is = (EPI == EPI_BNSUMS && nok) ? bn_coef[K + l31] : 0.f;
+    const float bn_sc = (EPI == EPI_BNSUMS && nok) ? bn_coef[2 * K + l31] : 0.f, bn_sh = (EPI == EPI_BNSUMS && nok) ? bn_coef[3 * K + l31] : 0.f;
+
+    double s1 = 0.0, s2 = 0.0;                                  // partial sums of the block's tiles: ONE stat row per block
+    // output (and EPI_BNSUMS: bn_y) addressing: buffer stores / loads with a fixed per-thread byte offset inside the 16 x 16
+    // patch + one scalar patch origin; lanes beyond K get an out-of-range offset (dropped / zero).  No per-lane branches: the
+    // tile body stays ONE basic block, so the bn_y requests issued in front of the MFMAs are not sunk to their use and the
+    // stores are not serialised by per-block wait counts.
+    const int obytes = (int)((unsigned)B * H * W * K * 4u);
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bn_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == EPI_BNSUMS ? bn_y : y), 0, obytes, 0x00020000);
+    unsigned o_vo[MR][16];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = wave * RPW + mr * 32 + egz_acc_row(r, lane);
+            o_vo[mr][r] = nok ? (unsigned)((((i >> 4) * W + (i & 15)) * K + l31) * 4) : 0xFFFFFFFFu;
+        }
 
     gload_a(tile);
     lstore_a(0);
@@ -741,6 +769,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
         const int nxt = tile + nbx;
         const bool more = nxt < t_end;                          // block-uniform
         if (more) gload_a(nxt);
+        // EPI_BNSUMS: this tile's values of the pre-BN tensor below, requested now and consumed in the epilogue (one wave per
+        // SIMD: nothing else hides a load issued there -- fetched in the epilogue the launch took 3x as long)
+        float byp[MR][16];
+        if (EPI == EPI_BNSUMS) {
+            const int b0 = tile / ppi, rem = tile - b0 * ppi;
+            const int y0 = (rem / pw) * 16, x0 = (rem % pw) * 16;
+            const unsigned so = (unsigned)((((long)b0 * H + y0) * W + x0) * K * 4);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    byp[mr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bn_rs, o_vo[mr][r], so, 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f32x16 acc[MR];
 #pragma unroll
         for (int i = 0; i < MR; ++i)
@@ -768,37 +810,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
         {
             const int b0 = tile / ppi, rem = tile - b0 * ppi;
             const int y0 = (rem / pw) * 16, x0 = (rem % pw) * 16;
-            double s1 = 0.0, s2 = 0.0;
+            const unsigned so = (unsigned)((((long)b0 * H + y0) * W + x0) * K * 4);
+            {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int i = wave * RPW + mr * 32 + egz_acc_row(r, lane);
-                    const long off = (((long)b0 * H + y0 + (i >> 4)) * W + x0 + (i & 15)) * K;
-                    if (nok) {
-                        float v = acc[mr][r] * out_scale + bz;
+                    {
+                        float v = acc[mr][r] * out_scale + bz;         // (lanes beyond K: zero columns, bz = 0 -> v = 0)
                         if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                        y[off + l31] = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, o_vo[mr][r], so, 0);
                         if (EPI == EPI_BIAS_STATS) {
                             s1 += (double)v;
                             s2 += (double)v * (double)v;
                         }
+                        if (EPI == EPI_BNSUMS) {
+                            const float yp = byp[mr][r];
+                            const float dz = (yp * bn_sc + bn_sh > 0.f) ? v : 0.f;
+                            s1 += (double)dz;
+                            s2 += (double)(dz * ((yp - bn_mu) * bn_is));
+                        }
                     }
                 }
             }
-            if (EPI == EPI_BIAS_STATS) {                       // one partial row per 128 pixels: waves (0, 1) and (2, 3)
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (hl == 0) {
-                    sred[(wave * 2 + 0) * 32 + l31] = s1;
-                    sred[(wave * 2 + 1) * 32 + l31] = s2;
-                }
-                lds_barrier();
-                const long srow = (long)tile * 2 + (wave >> 1);
-                if ((wave & 1) == 0 && hl == 0 && nok) {
-                    stat[(srow * 2 + 0) * K + l31] = s1 + sred[((wave + 1) * 2 + 0) * 32 + l31];
-                    stat[(srow * 2 + 1) * K + l31] = s2 + sred[((wave + 1) * 2 + 1) * 32 + l31];
-                }
             }
         }
         if (!more) break;
@@ -807,20 +841,56 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
         buf ^= 1;
         tile = nxt;
     }
+    if (EPI == EPI_BIAS_STATS || EPI == EPI_BNSUMS) {            // row blockIdx.x: the four waves' sums in wave order
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (hl == 0) {
+            sred[(wave * 2 + 0) * 32 + l31] = s1;
+            sred[(wave * 2 + 1) * 32 + l31] = s2;
+        }
+        lds_barrier();
+        if (wave == 0 && hl == 0 && nok) {
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                t1 += sred[(w * 2 + 0) * 32 + l31];
+                t2 += sred[(w * 2 + 1) * 32 + l31];
+            }
+            stat[((long)blockIdx.x * 2 + 0) * K + l31] = t1;
+            stat[((long)blockIdx.x * 2 + 1) * K + l31] = t2;
+        }
+    }
 }
 
-template <typename T>
-int launch_x3p_narrow(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
-                      int W, int C, int K, float out_scale, const unsigned int* a_absmax, hipStream_t st) {
+#ifndef EGZ_X3P_NARROW
+#define EGZ_X3P_NARROW 1
+#endif
+// geometry of the persistent narrow kernel (the output is addressed through a 32-bit buffer resource)
+bool x3p_narrow_ok(int B, int H, int W, int C, int K) {
+    return EGZ_X3P_NARROW && C <= 32 && K <= 32 && H % 16 == 0 && W % 16 == 0 && 4ull * B * H * W * K < (1ull << 32);
+}
+
+// blocks of a persistent narrow launch = rows of its partial-sum buffer (epi 2 / 5): one block per CU, a multiple of 8 (XCDs)
+int x3p_narrow_blocks(int B, int H, int W) {
     const int total = (int)((long)B * H * W / 256);
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     int blocks = (cus / 8) * 8;
     if (blocks > ((total + 7) / 8) * 8) blocks = ((total + 7) / 8) * 8;
-#define EGZ_X3P(E) hipLaunchKernelGGL((conv3x3_x3p_narrow_kernel<T, E>), dim3(blocks), dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, out_scale, total, a_absmax)
+    return blocks;
+}
+
+template <typename T>
+int launch_x3p_narrow(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
+                      int W, int C, int K, float out_scale, const unsigned int* a_absmax, const float* bn_y, const float* bn_coef,
+                      hipStream_t st) {
+    const int total = (int)((long)B * H * W / 256);
+    const int blocks = x3p_narrow_blocks(B, H, W);
+#define EGZ_X3P(E) hipLaunchKernelGGL((conv3x3_x3p_narrow_kernel<T, E>), dim3(blocks), dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, out_scale, total, a_absmax, bn_y, bn_coef)
     if (epi == EPI_BIAS) EGZ_X3P(EPI_BIAS);
     else if (epi == EPI_BIAS_RELU) EGZ_X3P(EPI_BIAS_RELU);
+    else if (epi == EPI_BNSUMS) EGZ_X3P(EPI_BNSUMS);
     else EGZ_X3P(EPI_BIAS_STATS);
 #undef EGZ_X3P
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed(narrow)");
@@ -1000,6 +1070,14 @@ EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode)
     return (bm + 2 * W + 2 <= hzero) ? 1 : 0;
 }
 
+// rows of the fp64 partial-sum buffer (stat_partial) of an epi 2 / 5 launch of egz_conv3x3_fwd_streamed (mode 0): one per
+// 128 output pixels, except on the persistent narrow kernel (C, K <= 32, H and W multiples of 16), whose blocks each
+// write one row.
+EGZ_API int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K) {
+    if (x3p_narrow_ok(B, H, W, C, K)) return x3p_narrow_blocks(B, H, W);
+    return (int)(((long)B * H * W + 127) / 128);
+}
+
 // Fragment-ordered split packing for the streamed kernel.  kind 4: forward of a (K, C, 3, 3) weight (GEMM columns = K,
 // reduction = C); kind 5: its data gradient (columns = C, reduction = K, taps flipped); kind 6: the data gradient of
 // [upsample x2 -> conv] w.r.t. the low-res input (columns = C, reduction = K, 16 polyphase taps).  dtype 1 = f16 (values
@@ -1022,16 +1100,26 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
 // x [B][H][W][C] (the gathered operand), y [B][H'][W'][K].  mode 0: plain conv (forward: kind-4 packing; data gradient: the
 // caller passes dy as x, C = Cout, K = Cin and the kind-5 packing), H' x W' = H x W.  mode 1: data gradient of an
 // upsample-fused conv w.r.t. its low-res input (x = hi-res dy, kind-6 packing, H' x W' = H/2 x W/2).
-// epi: 0 bias, 1 bias + ReLU, 2 bias + per-channel (sum, sumsq) partials, one row per 128 output pixels as
-// egz_conv3x3_stat_rows(B, H', W', K, 0x200) promises; 3 (data gradients, 128- / 64-column tiles): y = result where
+// epi: 0 bias, 1 bias + ReLU, 2 bias + per-channel (sum, sumsq) partials in egz_conv3x3_streamed_stat_rows(B, H, W, C, K)
+// rows (one per 128 output pixels; one per block on the persistent narrow kernel); 3 (data gradients, 128- / 64-column tiles): y = result where
 // mask_src > 0 else 0 (mask_src: [B][H'][W'][K], the post-ReLU activation whose gradient this is), stat rows = per-channel
 // sums of the masked result (plane 0; the bias gradient of the layer below), absmax_out[1 + tile] = per-tile max |y| (fold
 // with egz_absmax_fold(absmax_out, tiles)).  Only for geometries egz_conv3x3_streamed_ok accepts.
 EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
                                      int B, int H, int W, int C, int K, int epi, int dtype, int mode,
                                      const unsigned int* x_absmax, const float* mask_src, unsigned int* absmax_out,
-                                     hipStream_t st) {
+                                     const float* bn_coef, hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
+    if (epi == EPI_BNSUMS) {       // data gradient + the BatchNorm-backward sums of the layer below (persistent narrow kernel only)
+        EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && mode == 0 && mask_src && bn_coef && stat_partial && !bias &&
+                      x3p_narrow_ok(B, H, W, C, K) && egz_conv3x3_streamed_ok(B, H, W, C, K, 0),
+                      "egz_conv3x3_fwd_streamed: epi 5 (BatchNorm sums) needs the narrow geometry (C, K <= 32, H and W multiples of 16), "
+                      "mask_src = the pre-BN conv output of the layer below, bn_coef, stat_partial and no bias");
+        const unsigned short* w16b = static_cast<const unsigned short*>(wq);
+        const float osb = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
+        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, st);
+        return launch_x3p_narrow<__bf16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, st);
+    }
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, mode), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d "
                   "mode=%d is not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K, mode);
     EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && epi >= 0 && epi <= 3, "egz_conv3x3_fwd_streamed: bad dtype / epilogue");
@@ -1070,14 +1158,11 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
         return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
-#ifndef EGZ_X3P_NARROW
-#define EGZ_X3P_NARROW 1
-#endif
     EGZ_CHECK_ARG(!(absmax_out && epi == EPI_BIAS_RELU), "egz_conv3x3_fwd_streamed: the abs-max epilogue exists for 64- and "
                   "128-column tiles only (K %% 64 == 0)");
-    if (EGZ_X3P_NARROW && C <= 32 && K <= 32 && H % 16 == 0 && W % 16 == 0 && epi != EPI_MASK_SUMS) {   // persistent narrow form
-        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
-        return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, st);
+    if (x3p_narrow_ok(B, H, W, C, K) && epi != EPI_MASK_SUMS) {   // persistent narrow form
+        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, nullptr, st);
+        return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, nullptr, st);
     }
     if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);

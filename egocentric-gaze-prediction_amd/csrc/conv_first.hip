@@ -118,6 +118,128 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
     }
 }
 
+// Direct form for the first late-fusion conv (late_fusion.py:10: Conv2d(2 -> 32) on the (B, 2, 224, 224) pair of maps; CIN <= 3,
+// 32 filters).  With 18-27 MACs per output the layer is a 205 MB write (B = 32) and nothing else; the im2col + fp32-MFMA kernel
+// above (built for 3 / 20 -> 64 channels) spent 110-120 us on it (1.8 TB/s).  Here thread = (pixel lane pl = tid >> 3, filter
+// quad k4 = tid & 7): its CIN * 9 * 4 weights live in registers, the CIN * 9 taps of the NCHW input are read once per pixel
+// (the eight quads of a pixel share the address), and the eight 16-byte stores of a pixel form one 128-byte line of the NHWC
+// output.  A block walks a contiguous pixel range 32 pixels at a time and writes ONE row of fp64 BN partial sums at the end
+// (pixel lanes reduced with wave shuffles, the four waves through LDS, fixed order).
+constexpr int FD_BLOCKS = 2048;
+// PX = horizontally adjacent pixels per thread (4 when W % 4 == 0: the 3 x (PX + 2) input window of a channel is read once for
+// the four of them -- 9 instead of 18 tap loads, bounds checks and address computations per pixel; the one-pixel form spent
+// more issue slots on those than on the 72 FMAs and ran at 1.9 TB/s).
+template <int CIN, int PX, bool STATS>
+__global__ __launch_bounds__(256) void conv_first_direct_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+    double* __restrict__ stat, int B, int H, int W, int ppb) {
+    constexpr int K = 32, NT = CIN * 9;
+    __shared__ double red[4][8][8];
+    const int tid = threadIdx.x, k4 = tid & 7, pl = tid >> 3, lane = tid & 63, wave = tid >> 6;
+    const int HW = H * W, M = B * HW;
+    const int m0 = blockIdx.x * ppb, m1 = (m0 + ppb < M) ? m0 + ppb : M;
+    float wr[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wr[t][e] = w[(long)(k4 * 4 + e) * NT + t];          // w: (32, CIN, 3, 3)
+    f32x4 bz = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bz = *reinterpret_cast<const f32x4*>(bias + k4 * 4);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    int m = m0 + pl * PX;                                      // first of the thread's PX pixels (same image row: W % PX == 0)
+    int b = m / HW, py = (m - b * HW) / W, px = m - b * HW - py * W;
+    for (; m < m1; m += 32 * PX) {
+        float xw[CIN][3][PX + 2];
+        const float* xb = x + (long)b * CIN * HW + (long)py * W + px;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const bool rok = (unsigned)(py + r - 1) < (unsigned)H;
+#pragma unroll
+            for (int j = 0; j < PX + 2; ++j) {
+                const bool ok = rok && (unsigned)(px + j - 1) < (unsigned)W;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) xw[c][r][j] = ok ? xb[(long)c * HW + (r - 1) * W + (j - 1)] : 0.f;
+            }
+        }
+        float q1[4] = {0.f, 0.f, 0.f, 0.f}, q2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += xw[c][t / 3][p + t % 3] * wr[c * 9 + t][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += bz[e];
+            *reinterpret_cast<f32x4*>(y + (long)(m + p) * K + k4 * 4) = acc;
+            if (STATS) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (PX == 1) {
+                        s1[e] += (double)acc[e];
+                        s2[e] += (double)acc[e] * (double)acc[e];
+                    } else {                                     // the PX pixels in fp32, then one fp64 add per iteration
+                        q1[e] += acc[e];
+                        q2[e] += acc[e] * acc[e];
+                    }
+                }
+            }
+        }
+        if (STATS && PX > 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += (double)q1[e];
+                s2[e] += (double)q2[e];
+            }
+        }
+        px += 32 * PX;
+        while (px >= W) {
+            px -= W;
+            if (++py == H) {
+                py = 0;
+                ++b;
+            }
+        }
+    }
+    if (STATS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            double a = s1[e], q = s2[e];
+            a += __shfl_xor(a, 8);  q += __shfl_xor(q, 8);
+            a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+            if (lane < 8) {
+                red[wave][lane][e] = a;
+                red[wave][lane][4 + e] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * K) {
+            const int which = tid / K, col = tid % K;
+            double t = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) t += red[wv][col >> 2][which * 4 + (col & 3)];
+            stat[((long)blockIdx.x * 2 + which) * K + col] = t;
+        }
+    }
+}
+
+inline bool first_direct_ok(int C, int K) {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("EGZ_FIRST_DIRECT");          // A/B knob: 0 = the im2col + fp32 MFMA kernel for every shape
+        on = (e && e[0] == '0') ? 0 : 1;
+    }
+    return on && K == 32 && C >= 1 && C <= 3;
+}
+inline int first_direct_ppb(long M, int W) {
+    const int step = (W % 4 == 0) ? 128 : 32;                  // pixels per block iteration (4 / 1 per thread)
+    long ppb = (M + FD_BLOCKS - 1) / FD_BLOCKS;
+    return (int)((ppb + step - 1) / step * step);
+}
+
 // partial[split * NPG + pixel group][k][kkp] with kkp = c*9 + tap padded to KP (multiple of 32):
 //   sum over the group's pixels of dy[m][k] * x[b][c][y+dy][x+dx]
 // Cin = 20: the four waves tile (k half) x (kkp half).  Cin <= 3 has ONE kkp tile (and one or two k tiles), so the spare
@@ -243,6 +365,12 @@ int first_kp(int C) { return (9 * C + 31) / 32 * 32; }
 }  // namespace
 
 EGZ_API int egz_conv_first_stat_rows(int B, int H, int W) { return egz_cdiv((long)B * H * W, FM); }
+// rows of stat_partial for a given channel configuration (the direct kernel for C <= 3 -> 32 writes one row per block)
+EGZ_API int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K) {
+    const long M = (long)B * H * W;
+    if (first_direct_ok(C, K) && M * 32 < (1l << 31)) return egz_cdiv(M, first_direct_ppb(M, W));
+    return egz_cdiv(M, FM);
+}
 
 // x: [B][C][H][W] (NCHW, as the reference DataLoader yields it), w: (64, C, 3, 3), y: [B][H][W][64].
 EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, double* stat_partial,
@@ -250,6 +378,27 @@ EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias
     EGZ_CHECK_ARG(x && w && y, "egz_conv_first_fwd: null pointer");
     EGZ_CHECK_ARG(K == 64 || K == 32, "egz_conv_first_fwd: Cout must be 64 or 32 (got %d)", K);
     EGZ_CHECK_ARG(C > 0 && C <= 64 && B > 0 && H > 0 && W > 0, "egz_conv_first_fwd: bad shape");
+    const long M = (long)B * H * W;
+    if (first_direct_ok(C, K) && M * 32 < (1l << 31)) {
+        const int ppb = first_direct_ppb(M, W), nb = egz_cdiv(M, ppb);
+#define EGZ_FD2(CC, PP)                                                                                                        \
+    do {                                                                                                                       \
+        if (stat_partial) hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, true>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb); \
+        else              hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, false>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb); \
+    } while (0)
+#define EGZ_FD(CC)                                                                                                             \
+    do {                                                                                                                       \
+        if (W % 4 == 0) EGZ_FD2(CC, 4);                                                                                        \
+        else EGZ_FD2(CC, 1);                                                                                                   \
+    } while (0)
+        if (C == 1) EGZ_FD(1);
+        else if (C == 2) EGZ_FD(2);
+        else EGZ_FD(3);
+#undef EGZ_FD
+#undef EGZ_FD2
+        EGZ_CHECK_LAUNCH("egz_conv_first_fwd(direct)");
+        return 0;
+    }
     const int grid = egz_cdiv((long)B * H * W, FM);
     if (K == 64) {
         if (stat_partial) hipLaunchKernelGGL((conv_first_fwd_kernel<true, 2>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, C);

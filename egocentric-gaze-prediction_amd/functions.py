@@ -118,6 +118,7 @@ class ConvBNReLUPool(torch.autograd.Function):
         halves of ONE buffer so that the fusion conv reads the depth-2 stack without a concatenation copy)."""
         K, C = weight.shape[0], weight.shape[1]
         padded = first and _first_conv_on_split(C, K)
+        bn_src = None       # (pre-BN conv output, batch coefficients) of the [BN -> ReLU] block that produced x (narrow layers)
         if padded:
             # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
             # for this one layer); the packed weight is padded the same way by the pack kernel
@@ -129,12 +130,21 @@ class ConvBNReLUPool(torch.autograd.Function):
             xin = H._req(x.detach(), "network input (NCHW)")
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training)
         else:
+            bn_src = getattr(x, "_egz_bn_src", None) if training else None
             xin = to_nhwc(x)
             dt = H.conv_dtype("fwd", K, C, xin)
             wp, st = H.conv_weight(weight, "fwd", dt, xin, K)
             y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
                                     epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt, streamed=st)
         B, Hh, Ww, _ = y.shape
+        if training and not first and C <= 32 and K <= 32 and ctx.needs_input_grad[0]:
+            # narrow (late-fusion) layer: build the data-gradient packing now -- in the backward pass the 5 us pack launch sits
+            # on the critical path behind an already running weight-gradient kernel (58 us there, profiles/r03_lf_timeline)
+            dtb = H.conv_dtype("dgrad", C, K, y)
+            if dtb:
+                H.conv_weight(weight, "dgrad", dtb, y, C)
+        if bn_src is not None and not H.bnsums_ok(B, Hh, Ww, C, K, H.conv_dtype("dgrad", C, K, y)):
+            bn_src = None
         if training:
             coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
                                  running_var, momentum, eps, nbt)
@@ -142,13 +152,18 @@ class ConvBNReLUPool(torch.autograd.Function):
             coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
         out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
         # max |xin| (left on xin by its producer, or by the conv launch above): the weight gradient scales x with it
-        ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta, getattr(xin, "_egz_absmax", None))
+        ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta, getattr(xin, "_egz_absmax", None),
+                              *(bn_src if bn_src is not None else (None, None)))
         ctx.cfg = (training, pool, first, C, K, padded)
-        return from_nhwc(out)
+        res = from_nhwc(out)
+        if training and not pool and H.BNSUMS_FUSE:
+            # the block above (if it is a narrow conv) folds this BatchNorm's backward sums into its data-gradient kernel
+            res._egz_bn_src = (y, coef)
+        return res
 
     @staticmethod
     def backward(ctx, dout):
-        xin, y, coef, weight, bias, gamma, beta, xam = ctx.saved_tensors
+        xin, y, coef, weight, bias, gamma, beta, xam, bn_y, bn_coef = ctx.saved_tensors
         H.carry_absmax(xin, xam)
         training, pool, first, C, K, padded = ctx.cfg
         if not training:
@@ -156,12 +171,23 @@ class ConvBNReLUPool(torch.autograd.Function):
                                       "(SP.py:119 trains in model.train(); eval runs under torch.no_grad())")
         ng = ctx.needs_input_grad
         sg, sb = H.grad_sink(gamma, ng[3]), H.grad_sink(beta, ng[4])
-        dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, to_nhwc(dout), coef, pool, out_dgamma=sg, out_dbeta=sb)
+        sums = getattr(dout, "_egz_bnsums", None)       # produced with dout by the narrow dgrad kernel of the block above
+        if sums is not None and (pool or sums[1] != dout._version or sums[0].shape[1:] != (2, K)):
+            sums = None                                 # (an accumulated / modified gradient: the sums no longer describe it)
+        sums = None if sums is None else sums[0]
         dx = dw = db = None
         sbias = H.grad_sink(bias, ng[2])           # analytically zero: the sink keeps zero_grad()'s zeros
         if ng[2] and sbias is None:
-            db = _zero_bias_grad(dy, K)
+            db = _zero_bias_grad(y, K)
         sw = H.grad_sink(weight, ng[1] and not padded)
+        if first and not padded and ng[1] and not ng[0] and H.bn_bwd_first_wgrad_ok(C, K, pool):
+            # first block of the late-fusion stack: BatchNorm backward and the conv's weight gradient in ONE pass over
+            # (y, dout) -- the gradient w.r.t. the conv output is consumed in registers and never stored
+            dw, dgamma, dbeta = H.bn_bwd_first_wgrad(y, to_nhwc(dout), coef, xin, out_dgamma=sg, out_dbeta=sb, out_dw=sw,
+                                                     sums=sums)
+            return (None, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
+                    _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None)
+        dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, to_nhwc(dout), coef, pool, out_dgamma=sg, out_dbeta=sb, sums=sums)
 
         def data_grad():
             if not ng[0]:
@@ -170,6 +196,12 @@ class ConvBNReLUPool(torch.autograd.Function):
                 raise NotImplementedError("gradient w.r.t. the network input is not needed by the reference path")
             dt = H.conv_dtype("dgrad", C, K, dy)
             wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
+            if bn_y is not None and st and dt:
+                # narrow layer on top of a [BN -> ReLU] block: the same launch accumulates that BatchNorm's backward sums
+                dxn, bsum = H.conv3x3_dgrad_bnsums(dy, wp, C, dt, bn_y, bn_coef)
+                res = from_nhwc(dxn)
+                res._egz_bnsums = (bsum, res._version)
+                return res
             return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
 
         if WGRAD_AFTER_DGRAD:

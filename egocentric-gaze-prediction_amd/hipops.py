@@ -468,7 +468,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         y._egz_absmax = amo
     uflag = 0 if not ups else (1 if ups == "fold" else 3)
     flags = uflag | (epi << 4) | (0x200 if dtype else (tile_flag or _TILE_FLAG))      # split kernels: 128-row tiles
-    if epi == EPI_BIAS_STATS:
+    if epi == EPI_BIAS_STATS and not (dtype and streamed):
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
     if dtype and streamed:       # wp = fragment-ordered packing (conv_weight): weights L2 -> registers, halo through LDS
@@ -477,7 +477,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         ns = LIB.egz_conv3x3_streamed_splits(B, H, W, C, K) if (SPLITK and epi <= EPI_BIAS_STATS) else 1
         if ns > 1:      # few pixel tiles (batch-1 inference, 14 x 14 layers at small batches): split the channel blocks
-            if stat is not None:        # the fix-up pass emits one partial row per 32 pixels
+            if epi == EPI_BIAS_STATS:   # the fix-up pass emits one partial row per 32 pixels
                 stat = torch.empty((LIB.egz_conv3x3_fwd_streamed_splitk_stat_rows(B, H, W), 2, K), dtype=torch.float64,
                                    device=x.device)
             nb = LIB.egz_conv3x3_fwd_streamed_splitk_ws_bytes(B, H, W, K, ns)
@@ -489,12 +489,14 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
                                                       C, K, epi, dtype, _p(absmax), ws.data_ptr(), nb, ns, _p(amo), _stream()),
                   "egz_conv3x3_fwd_streamed_splitk")
             return y, stat
+        if epi == EPI_BIAS_STATS:
+            stat = torch.empty((LIB.egz_conv3x3_streamed_stat_rows(B, H, W, C, K), 2, K), dtype=torch.float64, device=x.device)
         t8 = _tile8(B, H, W, C, K, 0)
         if amo is not None and (t8 or _streamed_tiles(B, H, W, K) > 16384):
             amo = None                      # no epilogue slot for this launch: the consumer runs a standalone abs-max pass
             del y._egz_absmax
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, t8, _p(absmax), None, _p(amo), _stream()),
+                                           epi, dtype, t8, _p(absmax), None, _p(amo), None, _stream()),
               "egz_conv3x3_fwd_split")
         return y, stat
     if dtype:
@@ -529,7 +531,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                           0, dtype, 1 | _tile8(B, H // 2, W // 2, K, C, 1), _p(am), None, None, _stream()),
+                                           0, dtype, 1 | _tile8(B, H // 2, W // 2, K, C, 1), _p(am), None, None, None, _stream()),
               "egz_conv3x3_fwd_streamed(ups_dgrad)")
         return dx
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
@@ -574,12 +576,46 @@ def conv3x3_dgrad_masked(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
     am = absmax_of(dy) if dtype == F16X3 else None
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
                                        EPI_MASK_SUMS, dtype, 1 if ups else 0, _p(am), mask_src.data_ptr(), amo.data_ptr(),
-                                       _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
+                                       None, _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
     tile_rows = 128 if C % 128 == 0 else 256
     tile_cols = 128 if C % 128 == 0 else 64
     ntiles = ((B * Ho * Wo + tile_rows - 1) // tile_rows) * (C // tile_cols)
     check(LIB.egz_absmax_fold(amo.data_ptr(), ntiles, _stream()), "egz_absmax_fold")
     return dx, stat, amo
+
+
+EPI_BNSUMS = 5
+# BatchNorm-backward sums of the layer below folded into the narrow data-gradient kernel (late_fusion.py:10-12 chain at
+# 32 channels): removes that layer's reduce pass (two reads of its 205 MB tensors at B = 32, 224 x 224).  EGAZE_BNSUMS_FUSE=0
+# keeps the separate pass (A/B runs, and the parity test compares the two).
+BNSUMS_FUSE = _os.environ.get("EGAZE_BNSUMS_FUSE", "1") != "0"
+BNSUMS_STATS = {"produced": 0, "consumed": 0}
+
+
+def bnsums_ok(B: int, H: int, W: int, C: int, K: int, dtype: int) -> bool:
+    """Geometry of the persistent narrow kernel (data gradient of a K -> C channel conv seen as a C -> K one)."""
+    return bool(BNSUMS_FUSE and dtype and C <= 32 and K <= 32 and C % 4 == 0 and K % 4 == 0 and H % 16 == 0 and W % 16 == 0
+                and 4 * B * H * W * C < 2 ** 32 and LIB.egz_conv3x3_streamed_ok(B, H, W, K, C, 0))
+
+
+def conv3x3_dgrad_bnsums(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int, bn_y: torch.Tensor, coef: torch.Tensor):
+    """Data gradient of a plain 3x3 conv (dy (B,H,W,K) -> dx (B,H,W,C)) whose input is the output of a train-mode
+    [BatchNorm -> ReLU]: ``bn_y`` (B,H,W,C) is that layer's pre-BN conv output and ``coef`` its (4, C) batch coefficients
+    (mean, 1/std, scale, shift).  Returns (dx, sums) with sums (rows, 2, C) fp64 = partial rows of (sum dz, sum dz * xhat),
+    the ``sums`` argument of bn_relu_pool_bwd for that layer."""
+    _req(dy, "dy"); _req(bn_y, "bn_y"); _req(coef, "coef")
+    B, H, W, K = dy.shape
+    if tuple(bn_y.shape) != (B, H, W, C) or tuple(coef.shape) != (4, C):
+        raise RuntimeError(f"bn_y {tuple(bn_y.shape)} / coef {tuple(coef.shape)} do not match the gradient {(B, H, W, C)}")
+    dx = torch.empty((B, H, W, C), dtype=torch.float32, device=dy.device)
+    stat = torch.empty((LIB.egz_conv3x3_streamed_stat_rows(B, H, W, K, C), 2, C), dtype=torch.float64, device=dy.device)
+    BNSUMS_STATS["produced"] += 1
+    PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+    am = absmax_of(dy) if dtype == F16X3 else None
+    check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
+                                       EPI_BNSUMS, dtype, 0, _p(am), bn_y.data_ptr(), None, coef.data_ptr(), _stream()),
+          "egz_conv3x3_fwd_streamed(dgrad + BN sums)")
+    return dx, stat
 
 
 def colsum_f64(stat: torch.Tensor, ncols_out: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -627,7 +663,7 @@ def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.T
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x_nchw.device)
     stat = None
     if stats:
-        stat = torch.empty((LIB.egz_conv_first_stat_rows(B, H, W), 2, K), dtype=torch.float64, device=y.device)
+        stat = torch.empty((LIB.egz_conv_first_stat_rows_for(B, H, W, C, K), 2, K), dtype=torch.float64, device=y.device)
     PROF.note_flops("egz_conv_first_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv_first_fwd(x_nchw.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
                                  _stream()), "egz_conv_first_fwd")
@@ -707,8 +743,10 @@ def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool, out: Optio
 
 
 def bn_relu_pool_bwd(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, pool: bool,
-                     out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None):
-    """Returns (dy, dgamma, dbeta); ``out_dgamma`` / ``out_dbeta``: K-float destinations (gradient sinks)."""
+                     out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None,
+                     sums: Optional[torch.Tensor] = None):
+    """Returns (dy, dgamma, dbeta); ``out_dgamma`` / ``out_dbeta``: K-float destinations (gradient sinks).
+    ``sums``: (rows, 2, K) fp64 partial rows from conv3x3_dgrad_bnsums (the producer of ``dout``): no reduce pass."""
     _req(y, "y"); _req(dout, "dout")
     B, H, W, K = y.shape
     dy = torch.empty_like(y)
@@ -718,10 +756,42 @@ def bn_relu_pool_bwd(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, po
     check(LIB.egz_bn_relu_pool_bwd(y.data_ptr(), dout.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
                                    coef[0].data_ptr(), coef[1].data_ptr(), dy.data_ptr(), dg.data_ptr(),
                                    db.data_ptr(), B, H, W, K, int(pool), ws.data_ptr(), ws.numel(), _p(am),
-                                   _stream()), "egz_bn_relu_pool_bwd")
+                                   _p(sums), 0 if sums is None else sums.shape[0], _stream()), "egz_bn_relu_pool_bwd")
+    if sums is not None:
+        BNSUMS_STATS["consumed"] += 1
     if am is not None:
         dy._egz_absmax = am      # max |dy|, folded into the same pass: scales the f16 split of the conv backward
     return dy, dg, db
+
+
+FIRST_FUSE = _os.environ.get("EGAZE_FIRST_FUSE", "1") != "0"        # A/B knob of bn_bwd_first_wgrad
+
+
+def bn_bwd_first_wgrad_ok(C: int, K: int, pool: bool) -> bool:
+    return bool(FIRST_FUSE and K == 32 and 1 <= C <= 3 and not pool)
+
+
+def bn_bwd_first_wgrad(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, x_nchw: torch.Tensor,
+                       out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None,
+                       out_dw: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None):
+    """Backward of the first [Conv2d(C <= 3 -> 32) -> BN(train) -> ReLU] block of the late-fusion stack in one pass over
+    (y, dout): returns (dw (32, C, 3, 3), dgamma, dbeta); the gradient w.r.t. the conv output is never materialised."""
+    _req(y, "y"); _req(dout, "dout"); _req(x_nchw, "x")
+    B, H, W, K = y.shape
+    C = x_nchw.shape[1]
+    if tuple(x_nchw.shape) != (B, C, H, W) or tuple(dout.shape) != tuple(y.shape):
+        raise RuntimeError(f"x {tuple(x_nchw.shape)} / dout {tuple(dout.shape)} do not match y {tuple(y.shape)}")
+    dg, db = _out(out_dgamma, (K,), y.device), _out(out_dbeta, (K,), y.device)
+    dw = _out(out_dw, (K, C, 3, 3), y.device)
+    nb = LIB.egz_bn_bwd_first_wgrad_ws_bytes(C, K)
+    ws = workspace(nb, y.device)
+    check(LIB.egz_bn_bwd_first_wgrad(y.data_ptr(), dout.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[0].data_ptr(),
+                                     coef[1].data_ptr(), x_nchw.data_ptr(), dw.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                     B, H, W, C, K, ws.data_ptr(), ws.numel(), _p(sums), 0 if sums is None else sums.shape[0],
+                                     _stream()), "egz_bn_bwd_first_wgrad")
+    if sums is not None:
+        BNSUMS_STATS["consumed"] += 1
+    return dw, dg, db
 
 
 def pairmax_fwd(y2: torch.Tensor) -> torch.Tensor:

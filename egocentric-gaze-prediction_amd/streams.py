@@ -21,13 +21,26 @@ _SIDE = {}
 _SHARED = set(filter(None, os.environ.get("EGAZE_SHARED_STREAMS", "wgrad,adam").split(",")))
 
 
+# Helper-stream kinds created with LOW priority (comma separated; A/B knob).  A weight-gradient kernel holds the whole
+# register file of the CUs it runs on, so a small kernel of the layer chain that becomes ready meanwhile waits for one of
+# its blocks to retire -- and then competes with the weight gradient's own pending blocks for the slot.
+_LOW_PRIO = set(filter(None, os.environ.get("EGAZE_LOW_PRIO_STREAMS", "").split(",")))
+
+
 def side_stream(kind: str) -> torch.cuda.Stream:
     """A persistent helper stream per (current stream, kind)."""
     cur = torch.cuda.current_stream()
     key = (cur.device.index, 0 if kind in _SHARED else cur.cuda_stream, kind)
     st = _SIDE.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=cur.device)
+        st = None
+        if kind in _LOW_PRIO:
+            try:
+                st = torch.cuda.Stream(device=cur.device, priority=1)
+            except Exception:           # this build has no priority below "normal"
+                st = None
+        if st is None:
+            st = torch.cuda.Stream(device=cur.device)
         _SIDE[key] = st
     return st
 

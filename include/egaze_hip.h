@@ -79,14 +79,21 @@ int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, flo
  * L2 -> registers, the activation halo goes through LDS.  egz_conv3x3_streamed_ok: 1 when a geometry is covered
  * (C = reduction channels % 32 == 0, K = GEMM columns % 64 == 0).  mode 0 = plain conv; mode 1 = data gradient of
  * [nn.Upsample(x2) -> nn.Conv2d] (models/model_SP.py:17-18,22-23,25-26,28-29) w.r.t. the low-res input, x = hi-res dy,
- * kind-6 packing.  epi: 0 bias, 1 bias + ReLU, 2 bias + BN partials (one row per 128 output pixels), 3 = data gradient
+ * kind-6 packing.  epi: 0 bias, 1 bias + ReLU, 2 bias + BN partials (egz_conv3x3_streamed_stat_rows rows), 3 = data gradient
  * masked by mask_src > 0 with per-channel sums and per-tile abs-max (see below). */
 int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode);
+/* rows of stat_partial ([rows][2][K] doubles) of an epi 2 / epi 5 launch of egz_conv3x3_fwd_streamed (mode 0) */
+int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K);
 int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t stream);
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
-                             const float* mask_src, unsigned int* absmax_out, hipStream_t stream);
-/* epi 1 (bias + ReLU) with absmax_out != NULL (K % 64 == 0, at most 16384 tiles): absmax_out receives max |y|, folded.
+                             const float* mask_src, unsigned int* absmax_out, const float* bn_coef, hipStream_t stream);
+/* epi 5 (narrow geometry only: C, K <= 32, H and W multiples of 16, mode 0, no bias): data gradient w.r.t. the output of a
+ * train-mode [BatchNorm2d -> ReLU] (late_fusion.py:10-12) that ALSO accumulates that BatchNorm's backward sums: mask_src =
+ * the layer's pre-BN conv output (layout of y), bn_coef = 4 rows of K floats (batch mean, 1/std, scale, shift);
+ * stat_partial receives egz_conv3x3_streamed_stat_rows rows of (sum dz, sum dz * xhat) with dz = (mask_src * scale + shift > 0) ? y : 0,
+ * the `sums` argument of egz_bn_relu_pool_bwd.
+ * epi 1 (bias + ReLU) with absmax_out != NULL (K % 64 == 0, at most 16384 tiles): absmax_out receives max |y|, folded.
  * Split-K form of a plain egz_conv3x3_fwd_streamed launch for small pixel counts (batch-1 inference as in
  * run_spatialstream.py:85-138 / AT.py:216, the 14 x 14 layers at the reference's default --batch_size_sp 8): the channel
  * blocks of a tile are divided over nsplit blocks (raw partial sums in the workspace, nsplit x B x H x W x K floats) and a
@@ -113,6 +120,7 @@ int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, 
 /* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
  *      per data/STdatas.py:50-73) and Conv2d(2,32) (models/late_fusion.py:10).  K in {64, 32}. */
 int egz_conv_first_stat_rows(int B, int H, int W);
+int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K);   /* rows of stat_partial egz_conv_first_fwd writes for C -> K */
 int egz_conv_first_fwd(const float* x_nchw, const float* w, const float* bias, float* y_nhwc, double* stat_partial,
                        int B, int H, int W, int C, int K, hipStream_t stream);
 size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C);
@@ -134,8 +142,20 @@ int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift,
 size_t egz_bn_relu_pool_bwd_ws_bytes(int K);
 int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift, const float* mean,
                          const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int K,
-                         int pool, void* workspace, size_t ws_bytes, unsigned int* absmax, hipStream_t stream);
-/* `absmax` of the three gradient producers (egz_bn_relu_pool_bwd, egz_pairmax_bwd, egz_relu_bwd_bias; optional): a buffer of
+                         int pool, void* workspace, size_t ws_bytes, unsigned int* absmax, const double* sums,
+                         int sums_rows, hipStream_t stream);
+/* Backward of the FIRST block [Conv2d(C -> 32, 3x3) -> BatchNorm2d(train) -> ReLU] of the late-fusion stack
+ * (late_fusion.py:10-12, C <= 3; the network input needs no data gradient): dgamma / dbeta and dw (32, C, 3, 3) in one pass
+ * over y (pre-BN conv output, NHWC) and dout, x = the block input [B][C][H][W]; the gradient w.r.t. the conv output is never
+ * stored.  sums / sums_rows as for egz_bn_relu_pool_bwd. */
+size_t egz_bn_bwd_first_wgrad_ws_bytes(int C, int K);
+int egz_bn_bwd_first_wgrad(const float* y, const float* dout, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, const float* x, float* dw, float* dgamma, float* dbeta, int B, int H, int W,
+                           int C, int K, void* workspace, size_t ws_bytes, const double* sums, int sums_rows,
+                           hipStream_t stream);
+/* sums (optional, pool = 0): [sums_rows][2][K] partial rows of (sum dz, sum dz * xhat) produced together with dout by
+ * egz_conv3x3_fwd_streamed epi 5 -- the reduce pass over y and dout is skipped.
+ * `absmax` of the three gradient producers (egz_bn_relu_pool_bwd, egz_pairmax_bwd, egz_relu_bwd_bias; optional): a buffer of
  * egz_absmax_elems() uints, no initialisation needed.  Slot 0 receives max |dy| as the bit pattern of a float, computed in
  * the same pass (per-block partials in the other slots + a one-block epilogue: no atomics, deterministic).  It is the scale
  * source of the f16 x3 split-half data / weight gradients (egz_conv3x3_fwd_split x_absmax, egz_conv3x3_wgrad dy_absmax read

@@ -115,6 +115,79 @@ def test_late_fusion_grads_vs_fp64():
     assert np.median(eh) < max(20 * np.median(ec), 2e-4) and max(eh) < 5e-2
 
 
+def test_bn_sums_folded_into_narrow_dgrad():
+    """The narrow data-gradient kernel accumulates the BatchNorm-backward sums of the layer below (conv3x3_dgrad_bnsums):
+    per-channel sums against an fp64 torch evaluation, and the whole LF backward against the path with the separate
+    reduce pass (same kernels otherwise; only the summation order of those two sums differs)."""
+    from egaze_amd import hipops as H
+    from egaze_amd.floss import floss
+    torch.manual_seed(5)
+    B, S, C, K = 2, 32, 32, 32
+    dy = torch.randn(B, S, S, K, device=DEV) * 1e-3
+    w = torch.randn(K, C, 3, 3, device=DEV) * 0.1
+    bn_y = torch.randn(B, S, S, C, device=DEV)
+    coef = torch.stack([bn_y.mean((0, 1, 2)), 1.0 / bn_y.std((0, 1, 2)), torch.rand(C, device=DEV) + 0.5,
+                        torch.randn(C, device=DEV) * 0.3]).contiguous()
+    wp, st = H.conv_weight(w, "dgrad", H.F16X3, dy, C)
+    assert st
+    dx, sums = H.conv3x3_dgrad_bnsums(dy, wp, C, H.F16X3, bn_y, coef)
+    ref = H.conv3x3_dgrad(dy, wp, C, dtype=H.F16X3, streamed=st)
+    assert torch.equal(dx, ref)
+    d64, y64, c64 = dx.double(), bn_y.double(), coef.double()
+    dz = torch.where(y64 * c64[2] + c64[3] > 0, d64, torch.zeros_like(d64))
+    s = sums.sum(0)
+    assert rel(s[0].cpu().numpy(), dz.sum((0, 1, 2)).cpu().numpy()) < 1e-6
+    assert rel(s[1].cpu().numpy(), (dz * (y64 - c64[0]) * c64[1]).sum((0, 1, 2)).cpu().numpy()) < 1e-5
+
+    im, feat, gt = synth.synth_lf_batch(3, 48, seed=11)
+    grads = {}
+    for fuse in (True, False):
+        H.BNSUMS_FUSE = fuse
+        try:
+            net = build()
+            net.train()
+            before = dict(H.BNSUMS_STATS)
+            floss()(net(feat.to(DEV), im.to(DEV)), gt.to(DEV)).backward()
+            torch.cuda.synchronize()
+            made = H.BNSUMS_STATS["produced"] - before["produced"], H.BNSUMS_STATS["consumed"] - before["consumed"]
+            assert made == ((2, 2) if fuse else (0, 0)), made      # the 32 -> 32 and 32 -> 8 blocks feed the two below them
+            grads[fuse] = {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()}
+        finally:
+            H.BNSUMS_FUSE = True
+    worst = max(rel(grads[True][k], grads[False][k]) for k in grads[True] if np.abs(grads[False][k]).max() > 1e-9)
+    print("LF grads, fused BN sums vs separate reduce pass: max rel %.2e" % worst)
+    assert worst < 2e-5
+
+
+@pytest.mark.parametrize("B,C,Hh,Ww", [(2, 2, 48, 48), (3, 2, 13, 20), (1, 3, 40, 72), (2, 1, 16, 16), (2, 2, 9, 13), (1, 2, 224, 224)])
+def test_first_block_backward_in_one_pass(B, C, Hh, Ww):
+    """bn_bwd_first_wgrad (BatchNorm backward + weight gradient of the first late-fusion conv without storing the gradient
+    w.r.t. the conv output) against fp64 autograd of Conv2d(C -> 32) -> BatchNorm2d(train) -> ReLU; ragged sizes (rows shorter
+    than the 32-pixel step, a partial last block)."""
+    from egaze_amd import hipops as H
+    g = torch.Generator().manual_seed(B * 1000 + Hh)
+    x = torch.randn(B, C, Hh, Ww, generator=g)
+    w = (torch.randn(32, C, 3, 3, generator=g) * 0.3).double().requires_grad_(True)
+    gamma = (torch.rand(32, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(32, generator=g) * 0.2).double().requires_grad_(True)
+    dout = torch.randn(B, 32, Hh, Ww, generator=g)
+    y = F.conv2d(x.double(), w, None, padding=1)
+    out = F.relu(F.batch_norm(y, None, None, gamma, beta, training=True, eps=1e-5))
+    out.backward(dout.double())
+    yd = y.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    mean = y.detach().mean((0, 2, 3))
+    invstd = 1.0 / torch.sqrt(y.detach().var((0, 2, 3), unbiased=False) + 1e-5)
+    coef = torch.stack([mean, invstd, gamma.detach() * invstd, beta.detach() - mean * gamma.detach() * invstd]).float().to(DEV)
+    dd = dout.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw, dg, db = H.bn_bwd_first_wgrad(yd, dd, coef, x.to(DEV))
+    assert rel(dw.cpu().numpy(), w.grad.numpy()) < 2e-5
+    assert rel(dg.cpu().numpy(), gamma.grad.numpy()) < 2e-5 and rel(db.cpu().numpy(), beta.grad.numpy()) < 2e-5
+    # same numbers as the two-pass route (apply pass, then the generic first-layer weight gradient) up to fp32 summation order
+    dy, dg2, db2 = H.bn_relu_pool_bwd(yd, dd, coef, False)
+    dw2 = H.conv_first_wgrad(x.to(DEV), dy)
+    assert rel(dw.cpu().numpy(), dw2.cpu().numpy()) < 1e-5 and torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
 def test_config1_run_spatialstream_on_hip():
     """BASELINE config 1 through the HIP path: VGG (3-conv-at-14 decoder) + plumbing + late_fusion(out, weighted)."""
     from egaze_amd.run_spatialstream import VGG, predict

@@ -162,6 +162,25 @@ def test_conv_first(C, B, Hh, Ww):
     assert rel(dw.cpu(), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("C", [1, 2, 3])
+@pytest.mark.parametrize("B,Hh,Ww", [(2, 16, 16), (1, 13, 21), (3, 48, 80), (1, 224, 224)])
+def test_conv_first_direct_32_filters(C, B, Hh, Ww):
+    """The direct kernel of the first late-fusion conv (C <= 3 -> 32 filters, models/late_fusion.py:10) against fp64: output,
+    BN partial sums (one row per block), with and without the statistics epilogue; ragged widths shorter than the 32-pixel step."""
+    h = H()
+    x = rnd(B, C, Hh, Ww, seed=21)
+    w = rnd(32, C, 3, 3, seed=22, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(32, seed=23, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    y, stat = h.conv_first_fwd(x.to(DEV), w.to(DEV), b.to(DEV), True)
+    assert stat.shape[0] == h.LIB.egz_conv_first_stat_rows_for(B, Hh, Ww, C, 32) <= 2048
+    assert rel(nchw(y), ref) < 2e-6
+    s = stat.sum(0).cpu()
+    assert rel(s[0], ref.sum(dim=(0, 2, 3))) < 1e-6 and rel(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-6
+    y2, none = h.conv_first_fwd(x.to(DEV), w.to(DEV), None, False)
+    assert none is None and rel(nchw(y2), ref - b.double().view(1, -1, 1, 1)) < 2e-6
+
+
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("B,Hh,Ww,K", [(2, 8, 8, 64), (3, 6, 10, 512), (2, 4, 4, 8)])
 def test_bn_relu_pool(pool, B, Hh, Ww, K):
@@ -616,9 +635,13 @@ def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
         want = F.relu(ref) if epi == 1 else ref
         y, stat = h.conv3x3_fwd(xd, wp, b.to(DEV), K, epi=epi, dtype=dtype, streamed=True)
         assert rel(nchw(y), want) < tol, epi
-        if epi == 2:      # one partial row per 128 pixels, or per 32 when the launch ran split-K (few pixel tiles)
+        if epi == 2:      # one partial row per 128 pixels (per 32 when the launch ran split-K: few pixel tiles), or one per
+            # block of the persistent narrow kernel (one block per CU at most, a multiple of 8)
             per = 32 if h.LIB.egz_conv3x3_streamed_splits(B, Hh, Ww, C, K) > 1 else 128
-            assert stat.shape[0] == (B * Hh * Ww + per - 1) // per
+            if C <= 32 and K <= 32 and Hh % 16 == 0 and Ww % 16 == 0:
+                assert stat.shape[0] == h.LIB.egz_conv3x3_streamed_stat_rows(B, Hh, Ww, C, K) <= 256 and stat.shape[0] % 8 == 0
+            else:
+                assert stat.shape[0] == (B * Hh * Ww + per - 1) // per
             assert rel(stat.sum(0)[0].cpu(), ref.sum(dim=(0, 2, 3))) < 1e-5
             assert rel(stat.sum(0)[1].cpu(), (ref * ref).sum(dim=(0, 2, 3))) < 1e-5
     if C % 32 == 0 and K % 64 == 0:      # same values as the LDS-DMA halo kernel up to fp32 summation order
@@ -809,9 +832,14 @@ def test_cabi_argument_errors_are_loud():
     assert h.LIB.egz_conv3x3_streamed_ok(2, 16, 16, 30, 64, 0) == 0
     y = torch.empty((2, 16, 16, 64), device=DEV)
     rc = h.LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, 2, 16, 16, 30, 64, 0, 1, 0,
-                                        None, None, None, h._stream())
+                                        None, None, None, None, h._stream())
     assert rc != 0
     with pytest.raises(RuntimeError, match="egz_conv3x3_fwd_streamed"):
+        h.check(rc, "egz_conv3x3_fwd_streamed")
+    # the BatchNorm-sums epilogue exists for the narrow geometry only
+    rc = h.LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), y.data_ptr(), 2, 16, 16, 64, 64, 5, 1,
+                                        0, None, y.data_ptr(), None, y.data_ptr(), h._stream())
+    with pytest.raises(RuntimeError, match="narrow geometry"):
         h.check(rc, "egz_conv3x3_fwd_streamed")
     # split-K needs its workspace
     xs = nhwc(rnd(1, 256, 14, 14, seed=3))

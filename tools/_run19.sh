@@ -1,6 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r19
-python -m pytest tests -m gpu -q --maxfail=20 > gpurun_out/r19/pytest.log 2>&1; tail -4 gpurun_out/r19/pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r19/smoke.log 2>&1; tail -2 gpurun_out/r19/smoke.log
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/r19/bench.json 2>/dev/null; cat gpurun_out/r19/bench.json | cut -c1-200
+timeout 900 python -m pytest tests/test_hip_lf.py tests/test_hip_config5.py tests/test_hip_drivers.py -m gpu -q -x > gpurun_out/r19/pytest.log 2>&1; tail -5 gpurun_out/r19/pytest.log
+echo "=== LF default"; timeout 300 python tools/bench_lf.py --steps 40 2>&1 | grep -v amdgpu | tail -8
+echo "=== LF first-fuse off"; EGAZE_FIRST_FUSE=0 timeout 300 python tools/bench_lf.py --steps 40 2>&1 | grep -v amdgpu | tail -8
+echo "=== LF first-fuse on, bnsums off"; EGAZE_BNSUMS_FUSE=0 timeout 300 python tools/bench_lf.py --steps 40 2>&1 | grep -v amdgpu | tail -8
+echo "=== timeline"
+rm -rf /tmp/lfprof
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/lfprof -o lf -- python $GRAFT_REPO_ROOT/tools/bench_lf.py --steps 10 > /dev/null 2>&1)
+python tools/lf_timeline.py /tmp/lfprof > gpurun_out/r19/timeline.txt 2>&1; tail -30 gpurun_out/r19/timeline.txt

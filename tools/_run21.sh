@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r21
-python -m pytest tests -m gpu -q --maxfail=20 > gpurun_out/r21/pytest.log 2>&1; tail -3 gpurun_out/r21/pytest.log
-EGAZE_PRECISION=f32 python -m pytest tests/test_hip_model_sp.py tests/test_hip_lf.py tests/test_hip_drivers.py -m gpu -q --maxfail=20 -k "not trajectory" > gpurun_out/r21/pytest_f32.log 2>&1; tail -3 gpurun_out/r21/pytest_f32.log
-EGAZE_STREAMS=0 python -m pytest tests/test_hip_model_sp.py tests/test_hip_drivers.py -m gpu -q --maxfail=20 -k "not trajectory" > gpurun_out/r21/pytest_streams0.log 2>&1; tail -3 gpurun_out/r21/pytest_streams0.log
-EGAZE_GRAD_SPLIT=bf16 python -m pytest tests/test_hip_model_sp.py -m gpu -q --maxfail=20 -k "not trajectory" > gpurun_out/r21/pytest_bf16.log 2>&1; tail -3 gpurun_out/r21/pytest_bf16.log
-EGAZE_FWD_SCALE=0 python -m pytest tests/test_hip_model_sp.py tests/test_hip_lf.py -m gpu -q --maxfail=20 -k "not trajectory" > gpurun_out/r21/pytest_noscale.log 2>&1; tail -3 gpurun_out/r21/pytest_noscale.log
+timeout 900 python -m pytest tests/test_hip_lf.py -m gpu -q -x > gpurun_out/r21/pytest.log 2>&1; tail -3 gpurun_out/r21/pytest.log
+for k in "A=0" "EGAZE_WGRAD_AFTER_DGRAD=1" "EGAZE_WGRAD_AFTER_DGRAD=1 EGAZE_BNSUMS_FUSE=0" "EGAZE_STREAMS=0" "EGAZE_STREAMS=0 EGAZE_BNSUMS_FUSE=0" "EGAZE_DETACH_WGRAD=0" ; do
+echo "=== $k"; env $k timeout 300 python tools/bench_lf.py --steps 40 2>&1 | grep "metric=off"
+done

@@ -1,6 +1,11 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r22
-python -m pytest tests/test_hip_ops.py tests/test_hip_lf.py tests/test_hip_model_sp.py -m gpu -q -k "bn_relu or lf or LF or train_step or narrow or determin" > gpurun_out/r22/pytest.log 2>&1; tail -3 gpurun_out/r22/pytest.log
-python tools/bench_lf.py 2>&1 | grep -v amdgpu
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-180
+timeout 900 python -m pytest tests/test_hip_lf.py tests/test_hip_ops.py -m gpu -q -x > gpurun_out/r22/pytest.log 2>&1; tail -3 gpurun_out/r22/pytest.log
+for k in "A=0" "EGAZE_BNSUMS_FUSE=0" "EGAZE_STREAMS=0" "EGAZE_STREAMS=0 EGAZE_BNSUMS_FUSE=0"; do
+echo "=== $k"; env $k timeout 300 python tools/bench_lf.py --steps 40 2>&1 | grep "metric=off"
+done
+echo "=== timeline"
+rm -rf /tmp/lfprof
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/lfprof -o lf -- python $GRAFT_REPO_ROOT/tools/bench_lf.py --steps 10 > /dev/null 2>&1)
+python tools/lf_timeline.py /tmp/lfprof > gpurun_out/r22/timeline.txt 2>&1; tail -52 gpurun_out/r22/timeline.txt

@@ -23,6 +23,11 @@ if b is None:
     im, feat, gt = (torch.rand(a.batch, 1, 224, 224, device=dev) for _ in range(3))
 else:
     im, feat, gt = b["im"], b["feat"], b["gt"]
+if os.environ.get("EGAZE_MAIN_PRIO"):       # experiment: the layer chain on a high-priority stream (helper streams stay normal)
+    _hp = torch.cuda.Stream(priority=int(os.environ["EGAZE_MAIN_PRIO"]))
+    _hp.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(_hp)
+    print("main stream priority", _hp.priority, "range", torch.cuda.Stream.priority_range())
 def step(metric):
     out = model(feat, im)
     loss = crit(out, gt)
