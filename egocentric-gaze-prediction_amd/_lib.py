@@ -45,21 +45,24 @@ SIGNATURES = {
     "egz_conv3x3_fwd_streamed_splitk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd_streamed_splitk": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, c_int, P, S]),
     "egz_conv3x3_streamed_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, S]),
+    "egz_conv3x3_fwd_streamed": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, S]),
     "egz_absmax_fold": (c_int, [P, c_int, S]),
     "egz_colsum_f64": (c_int, [P, c_int, c_int, c_int, P, P, c_size_t, S]),
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, S]),
+    "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, P, S]),
+    "egz_conv3x3_wgrad_narrow_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)
     "egz_conv_first_stat_rows": (c_int, [c_int, c_int, c_int]),
     "egz_conv_first_stat_rows_for": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, S]),
+    "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_conv_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "egz_conv_first_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
     # --- BatchNorm / ReLU / pool / fusion max / misc streaming passes
     "egz_bn_ws_bytes": (c_size_t, [c_int]),
     "egz_bn_finalize": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P, P,
                                 c_size_t, S]),
+    "egz_bn_finalize_deferred": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P, P,
+                                         c_int, P, S]),
     "egz_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P, S]),
     "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_bn_relu_pool_bwd_ws_bytes": (c_size_t, [c_int]),

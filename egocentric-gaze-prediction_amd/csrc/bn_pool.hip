@@ -77,6 +77,80 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part2, int nparts,
     }
 }
 
+// Finalize of a DEFERRED BatchNorm (K <= 64; late_fusion.py:11-12): the same coefficients, computed by one 256-thread block that
+// also sums the partial rows itself (no column-sum launch) and bounds the block output it never materialises:
+//   max over channels of relu(y * scale + shift) = max_k max(0, fma(ymax_k, scale_k, shift_k), fma(ymin_k, scale_k, shift_k))
+// exactly (the map is monotonic in y per channel), from the per-channel max / min rows the conv epilogue wrote.  That value
+// is the f16 split scale source (egz_absmax layout, slot 0) of the convolution that applies the BatchNorm while staging y.
+__global__ __launch_bounds__(1024) void bn_finalize_deferred_kernel(
+    const double* __restrict__ part, int nparts, int K, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+    float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift,
+    long long* __restrict__ num_batches_tracked, const float* __restrict__ mm, int mm_rows, unsigned int* __restrict__ absmax_out) {
+    __shared__ double fsum[32][128];
+    __shared__ float fmm[32][128];
+    __shared__ float bound[64];
+    const int cols = 2 * K, ngrp = 1024 / cols;                // K = 32: 16 row groups of 64 columns
+    const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
+    {
+        // four independent chains per thread (rows g, g + ngrp, ...: a one-chain loop ran at one L2 latency per row, 35 us for
+        // 256 rows), combined in a fixed order
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = grp;
+        for (; r + 3 * ngrp < nparts; r += 4 * ngrp) {
+            s0 += part[(long)r * cols + col];
+            s1 += part[(long)(r + ngrp) * cols + col];
+            s2 += part[(long)(r + 2 * ngrp) * cols + col];
+            s3 += part[(long)(r + 3 * ngrp) * cols + col];
+        }
+        for (; r < nparts; r += ngrp) s0 += part[(long)r * cols + col];
+        fsum[grp][col] = (s0 + s1) + (s2 + s3);
+        const bool ismax = col < K;
+        float m = ismax ? -INFINITY : INFINITY;
+#pragma unroll 4
+        for (int q = grp; q < mm_rows; q += ngrp) {
+            const float v = mm[(long)q * cols + col];
+            m = ismax ? fmaxf(m, v) : fminf(m, v);
+        }
+        fmm[grp][col] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        const int k = threadIdx.x;
+        if (k == 0 && num_batches_tracked) *num_batches_tracked += 1;
+        double s1 = 0.0, s2 = 0.0;
+        float mx = -INFINITY, mn = INFINITY;
+        for (int g = 0; g < ngrp; ++g) {
+            s1 += fsum[g][k];
+            s2 += fsum[g][K + k];
+            mx = fmaxf(mx, fmm[g][k]);
+            mn = fminf(mn, fmm[g][K + k]);
+        }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[k] : 1.f, bt = beta ? beta[k] : 0.f;
+        const float sc = g * invstd, sh = bt - (float)mean * sc;
+        mean_out[k] = (float)mean;
+        invstd_out[k] = invstd;
+        scale[k] = sc;
+        shift[k] = sh;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mean;
+            running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unbiased;
+        }
+        bound[k] = fmaxf(fmaxf(__builtin_fmaf(mx, sc, sh), __builtin_fmaf(mn, sc, sh)), 0.f);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, bound[k]);
+        absmax_out[0] = __float_as_uint(m);
+    }
+}
+
 __global__ void bn_eval_coeffs_kernel(int K, const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
                                       float* __restrict__ scale, float* __restrict__ shift) {
@@ -619,6 +693,26 @@ EGZ_API int egz_bn_finalize(const double* stat_partial, int rows, int K, double 
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, src, nparts, K, count, gamma, beta,
                        running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift, num_batches_tracked);
     EGZ_CHECK_LAUNCH("egz_bn_finalize");
+    return 0;
+}
+
+// egz_bn_finalize for a BatchNorm whose output is never materialised (the consuming convolution applies it while staging y):
+// minmax = [mm_rows][2][K] per-channel max / min rows of y (egz_conv_first_fwd / egz_conv3x3_fwd_streamed minmax_out),
+// absmax_out (egz_absmax layout) receives the exact max of relu(y * scale + shift).  K in {16, 32, 64}; one launch.
+EGZ_API int egz_bn_finalize_deferred(const double* stat_partial, int rows, int K, double count, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                     float* mean_out, float* invstd_out, float* scale, float* shift,
+                                     long long* num_batches_tracked, const float* minmax, int mm_rows,
+                                     unsigned int* absmax_out, hipStream_t st) {
+    EGZ_CHECK_ARG(stat_partial && mean_out && invstd_out && scale && shift && minmax && absmax_out,
+                  "egz_bn_finalize_deferred: null pointer");
+    EGZ_CHECK_ARG((K == 16 || K == 32 || K == 64) && rows > 0 && mm_rows > 0,
+                  "egz_bn_finalize_deferred: K=%d must be 16, 32 or 64", K);
+    EGZ_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "egz_bn_finalize_deferred: running stats must come in pairs");
+    hipLaunchKernelGGL(bn_finalize_deferred_kernel, dim3(1), dim3(1024), 0, st, stat_partial, rows, K, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift, num_batches_tracked,
+                       minmax, mm_rows, absmax_out);
+    EGZ_CHECK_LAUNCH("egz_bn_finalize_deferred");
     return 0;
 }
 

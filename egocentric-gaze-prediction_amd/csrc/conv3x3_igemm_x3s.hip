@@ -649,11 +649,17 @@ __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __res
 //     before the MFMAs of tile i, split and written to the OTHER LDS image after them: one barrier per tile.
 // Same LDS image, fragment addressing, arithmetic and epilogues (bias / bias + ReLU / bias + BN statistics) as the 32-column
 // configuration (WM = 4) of the kernel above, which stays the path for images that are not multiples of 16.
-template <typename T, int EPI>
+// BNIN: x is the PRE-BatchNorm output of the block below and bn_coef that BatchNorm's (mean, 1/std, scale, shift) rows: the
+// halo staging applies relu(x * scale + shift) per channel on the way into LDS (zero padding stays zero), so the normalised
+// activation tensor is never written or read (late_fusion.py:10-12; a_absmax = max of the normalised values,
+// egz_bn_finalize_deferred).  mm_out (EPI_BIAS_STATS): per-block rows [2][K] of the per-channel max / min of y -- what the
+// next layer's deferred BatchNorm needs to bound its output.
+template <typename T, int EPI, bool BNIN>
 __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, float out_scale, int total,
-    const unsigned int* __restrict__ a_absmax, const float* __restrict__ bn_y, const float* __restrict__ bn_coef) {
+    const unsigned int* __restrict__ a_absmax, const float* __restrict__ bn_y, const float* __restrict__ bn_coef,
+    float* __restrict__ mm_out) {
     using G = Geo<4>;
     constexpr int BM = G::BM, HSLOTS = G::HSLOTS, NJ = G::NJ, SPP = G::SPP, MR = G::MR, RPW = G::RPW;
     constexpr int APL = HSLOTS * XLD, ABUF = 2 * APL;
@@ -672,6 +678,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     int tile = xcd * per + (int)(blockIdx.x >> 3);
     if (tile >= t_end) {                                        // (a block without tiles still owns its row of partial sums)
         if ((EPI == EPI_BIAS_STATS || EPI == EPI_BNSUMS) && tid < 2 * K) stat[(long)blockIdx.x * 2 * K + tid] = 0.0;
+        if (EPI == EPI_BIAS_STATS && mm_out && tid < 2 * K) mm_out[(long)blockIdx.x * 2 * K + tid] = (tid < K) ? -INFINITY : INFINITY;
         return;
     }
 
@@ -691,11 +698,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     const int a_c4 = tid & 7;
     unsigned a_vo[NJ], a_rc[NJ];
     int a_lds[NJ];
+    unsigned a_in = 0, ra_ok = 0;                               // BNIN: bit j = slot j holds a real element / was inside the image
+    f32x4 in_sc = {0.f, 0.f, 0.f, 0.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
+    if (BNIN && a_c4 * 4 < C) {
+        in_sc = *reinterpret_cast<const f32x4*>(bn_coef + 2 * C + a_c4 * 4);
+        in_sh = *reinterpret_cast<const f32x4*>(bn_coef + 3 * C + a_c4 * 4);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int q = (tid >> 3) + SPP * j;
         const int hy = q / HPITCH, hx = q - hy * HPITCH;
         const bool in = hy < 18 && hx < 18 && a_c4 * 4 < C;
+        if (in) a_in |= 1u << j;
         a_vo[j] = in ? (unsigned)(((hy * W + hx) * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
         a_rc[j] = (unsigned)(hy << 8 | hx);
         a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((hx >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
@@ -708,17 +722,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
         const unsigned rlo = (y0 == 0) ? 1u : 0u, rn = (unsigned)((H - y0 < 17) ? (H - y0) : 17) - rlo;
         const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((W - x0 < 17) ? (W - x0) : 17) - clo;
         const unsigned so = (unsigned)((((long)b0 * H + y0) * W + x0) * C * 4);          // + x_bias - x_bias
+        unsigned okm = 0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bool ok = ((a_rc[j] >> 8) - rlo <= rn) && ((a_rc[j] & 255u) - clo <= cn);
+            if (BNIN && ok) okm |= 1u << j;
             ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, ok ? a_vo[j] : 0xFFFFFFFFu, so, 0));
         }
+        ra_ok = okm & a_in;
     };
     auto lstore_a = [&](const int abuf) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4(ra[j] * a_scale, hi, lo);
+            if (BNIN) {                                         // BatchNorm + ReLU of the block below, on the way into LDS;
+                const float ms = ((ra_ok >> j) & 1u) ? a_scale : 0.f;      // the zero-padding mask rides on the scale factor
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf(__builtin_fmaf(ra[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
+                Half<T>::split4(ra[j], hi, lo);
+            } else {
+                Half<T>::split4(ra[j] * a_scale, hi, lo);
+            }
             unsigned short* d = Ah + abuf * ABUF + a_lds[j];
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -745,6 +769,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     const float bn_sc = (EPI == EPI_BNSUMS && nok) ? bn_coef[2 * K + l31] : 0.f, bn_sh = (EPI == EPI_BNSUMS && nok) ? bn_coef[3 * K + l31] : 0.f;
 
     double s1 = 0.0, s2 = 0.0;                                  // partial sums of the block's tiles: ONE stat row per block
+    float vmx = -INFINITY, vmn = INFINITY;                      // EPI_BIAS_STATS + mm_out: this lane's channel max / min of y
     // output (and EPI_BNSUMS: bn_y) addressing: buffer stores / loads with a fixed per-thread byte offset inside the 16 x 16
     // patch + one scalar patch origin; lanes beyond K get an out-of-range offset (dropped / zero).  No per-lane branches: the
     // tile body stays ONE basic block, so the bn_y requests issued in front of the MFMAs are not sunk to their use and the
@@ -823,6 +848,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
                         if (EPI == EPI_BIAS_STATS) {
                             s1 += (double)v;
                             s2 += (double)v * (double)v;
+                            vmx = fmaxf(vmx, v);
+                            vmn = fminf(vmn, v);
                         }
                         if (EPI == EPI_BNSUMS) {
                             const float yp = byp[mr][r];
@@ -859,6 +886,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             stat[((long)blockIdx.x * 2 + 0) * K + l31] = t1;
             stat[((long)blockIdx.x * 2 + 1) * K + l31] = t2;
         }
+        if (EPI == EPI_BIAS_STATS && mm_out) {                   // (max / min are order-independent: no fixed order needed)
+            vmx = fmaxf(vmx, __shfl_xor(vmx, 32));
+            vmn = fminf(vmn, __shfl_xor(vmn, 32));
+            float* smm = reinterpret_cast<float*>(Ah);         // the LDS images are dead by now
+            lds_barrier();
+            if (hl == 0) {
+                smm[(wave * 2 + 0) * 32 + l31] = vmx;
+                smm[(wave * 2 + 1) * 32 + l31] = vmn;
+            }
+            lds_barrier();
+            if (wave == 0 && hl == 0 && nok) {
+                float a = smm[l31], b = smm[32 + l31];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) {
+                    a = fmaxf(a, smm[(w * 2 + 0) * 32 + l31]);
+                    b = fminf(b, smm[(w * 2 + 1) * 32 + l31]);
+                }
+                mm_out[((long)blockIdx.x * 2 + 0) * K + l31] = a;
+                mm_out[((long)blockIdx.x * 2 + 1) * K + l31] = b;
+            }
+        }
     }
 }
 
@@ -884,14 +932,15 @@ int x3p_narrow_blocks(int B, int H, int W) {
 template <typename T>
 int launch_x3p_narrow(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
                       int W, int C, int K, float out_scale, const unsigned int* a_absmax, const float* bn_y, const float* bn_coef,
-                      hipStream_t st) {
+                      float* mm_out, hipStream_t st) {
     const int total = (int)((long)B * H * W / 256);
     const int blocks = x3p_narrow_blocks(B, H, W);
-#define EGZ_X3P(E) hipLaunchKernelGGL((conv3x3_x3p_narrow_kernel<T, E>), dim3(blocks), dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, out_scale, total, a_absmax, bn_y, bn_coef)
-    if (epi == EPI_BIAS) EGZ_X3P(EPI_BIAS);
-    else if (epi == EPI_BIAS_RELU) EGZ_X3P(EPI_BIAS_RELU);
-    else if (epi == EPI_BNSUMS) EGZ_X3P(EPI_BNSUMS);
-    else EGZ_X3P(EPI_BIAS_STATS);
+#define EGZ_X3P(E, BN) hipLaunchKernelGGL((conv3x3_x3p_narrow_kernel<T, E, BN>), dim3(blocks), dim3(256), 0, st, x, wq, bias, y, stat, B, H, W, C, K, out_scale, total, a_absmax, bn_y, bn_coef, mm_out)
+    const bool bnin = bn_coef && epi != EPI_BNSUMS;             // forward epilogues: bn_coef = the INPUT's deferred BatchNorm
+    if (epi == EPI_BNSUMS) EGZ_X3P(EPI_BNSUMS, false);
+    else if (epi == EPI_BIAS) { if (bnin) EGZ_X3P(EPI_BIAS, true); else EGZ_X3P(EPI_BIAS, false); }
+    else if (epi == EPI_BIAS_RELU) { if (bnin) EGZ_X3P(EPI_BIAS_RELU, true); else EGZ_X3P(EPI_BIAS_RELU, false); }
+    else { if (bnin) EGZ_X3P(EPI_BIAS_STATS, true); else EGZ_X3P(EPI_BIAS_STATS, false); }
 #undef EGZ_X3P
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed(narrow)");
     return 0;
@@ -1108,8 +1157,14 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
 EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
                                      int B, int H, int W, int C, int K, int epi, int dtype, int mode,
                                      const unsigned int* x_absmax, const float* mask_src, unsigned int* absmax_out,
-                                     const float* bn_coef, hipStream_t st) {
+                                     const float* bn_coef, float* minmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
+    // epi 0 / 1 / 2 with bn_coef: x is a pre-BatchNorm tensor, normalised + ReLU'd while it is staged (narrow geometry only);
+    // minmax_out (epi 2, narrow geometry): [egz_conv3x3_streamed_stat_rows][2][K] per-channel max / min of y
+    EGZ_CHECK_ARG(!((bn_coef && epi != EPI_BNSUMS) || minmax_out) || (mode == 0 && x3p_narrow_ok(B, H, W, C, K) && (dtype == 1 || dtype == 2) &&
+                  epi != EPI_MASK_SUMS && (!minmax_out || epi == EPI_BIAS_STATS)),
+                  "egz_conv3x3_fwd_streamed: a deferred-BatchNorm input (bn_coef) / minmax_out exist on the narrow persistent kernel "
+                  "only (C, K <= 32, H and W multiples of 16; minmax_out with epi 2)");
     if (epi == EPI_BNSUMS) {       // data gradient + the BatchNorm-backward sums of the layer below (persistent narrow kernel only)
         EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && mode == 0 && mask_src && bn_coef && stat_partial && !bias &&
                       x3p_narrow_ok(B, H, W, C, K) && egz_conv3x3_streamed_ok(B, H, W, C, K, 0),
@@ -1117,8 +1172,8 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                       "mask_src = the pre-BN conv output of the layer below, bn_coef, stat_partial and no bias");
         const unsigned short* w16b = static_cast<const unsigned short*>(wq);
         const float osb = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
-        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, st);
-        return launch_x3p_narrow<__bf16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, st);
+        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
+        return launch_x3p_narrow<__bf16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
     }
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, mode), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d "
                   "mode=%d is not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K, mode);
@@ -1161,8 +1216,8 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
     EGZ_CHECK_ARG(!(absmax_out && epi == EPI_BIAS_RELU), "egz_conv3x3_fwd_streamed: the abs-max epilogue exists for 64- and "
                   "128-column tiles only (K %% 64 == 0)");
     if (x3p_narrow_ok(B, H, W, C, K) && epi != EPI_MASK_SUMS) {   // persistent narrow form
-        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, nullptr, st);
-        return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, nullptr, st);
+        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, bn_coef, minmax_out, st);
+        return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, bn_coef, minmax_out, st);
     }
     if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);

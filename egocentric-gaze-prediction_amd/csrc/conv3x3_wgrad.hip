@@ -624,11 +624,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
 // 16-pixel run (one MFMA k-step, 27 MFMAs for the nine taps) and keeps its own nine accumulators; the four partial sums are
 // added through LDS in a fixed order at the end.  Only 32 channels are staged (8 float4 per pixel), half of the wide
 // kernel's fetch / split work per pixel.  Same LDS image per plane and the same ds_read_b64_tr_b16 addressing.
-template <typename T, int R, int WD>
+// BNIN: x is the PRE-BatchNorm output of the block below (its normalised form is never materialised, see
+// conv3x3_x3p_narrow_kernel) and x_bn its BatchNorm's 4 x C coefficient rows: relu(x * scale + shift) is applied per channel
+// while the halo is staged (out-of-image positions stay zero); x_absmax = the max of the normalised values.
+template <typename T, int R, int WD, bool BNIN>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
     int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax,
-    const unsigned int* __restrict__ x_absmax) {
+    const unsigned int* __restrict__ x_absmax, const float* __restrict__ x_bn) {
     static_assert(R * WD == 64 && (WD == 32 || WD == 16), "patch = 64 pixels in rows of 16-pixel runs");
     const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
     const float x_scale = W16<T>::scale(x_absmax), x_inv = 1.f / x_scale;      // the activation operand, scaled the same way
@@ -670,6 +673,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
         d_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
     }
     f32x4 rx[NX], rd[ND];
+    unsigned rx_ok = 0;                                         // BNIN: bit j = rx[j] came from inside the image
+    f32x4 in_sc = {0.f, 0.f, 0.f, 0.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
+    if (BNIN && (tid & 7) * 4 < C) {                           // the thread's channel quad is fixed (c4 = tid & 7)
+        in_sc = *reinterpret_cast<const f32x4*>(x_bn + 2 * C + (tid & 7) * 4);
+        in_sh = *reinterpret_cast<const f32x4*>(x_bn + 3 * C + (tid & 7) * 4);
+    }
     // patch cursor of the NEXT fetch, advanced by one patch per call (stages are consecutive patches): three scalar adds and
     // compares per stage instead of four 64-bit divisions on the vector ALU (which also made the scalar offsets of the buffer
     // loads look divergent, wrapping every load in a waterfall loop)
@@ -690,11 +699,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
         const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((W - x0 < WD + 1) ? (W - x0) : (WD + 1)) - clo;
         const unsigned so_x = (unsigned)((((b * H + y0) * W + x0) * C) * 4);
         const unsigned so_d = (unsigned)((((b * H + y0) * W + x0) * K) * 4);
+        unsigned okm = 0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const bool ok = ((x_rc[j] >> 8) - rlo <= rn) && ((x_rc[j] & 255u) - clo <= cn);
+            if (BNIN && ok && x_vo[j] != 0xFFFFFFFFu) okm |= 1u << j;
             rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? x_vo[j] : 0xFFFFFFFFu, so_x, 0));
         }
+        rx_ok = okm;
         const unsigned rmax = (unsigned)(H - y0), cmax = (unsigned)(W - x0);
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
@@ -708,7 +720,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
             const int i = tid + 256 * j, pos = i >> 3, c4 = i & 7;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4(rx[j] * x_scale, hi, lo);
+                if (BNIN) {                                     // BatchNorm + ReLU of the block below, on the way into LDS;
+                    const float ms = ((rx_ok >> j) & 1u) ? x_scale : 0.f;  // the zero-padding mask rides on the scale factor
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rx[j][e] = fmaxf(__builtin_fmaf(rx[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
+                    W16<T>::split4(rx[j], hi, lo);
+                } else {
+                    W16<T>::split4(rx[j] * x_scale, hi, lo);
+                }
                 unsigned short* d = Xs + buf * XB + pos * 32 + c4 * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + XH) = lo;
@@ -1379,10 +1398,24 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 //        x_absmax (optional, f16 x3 only): max |x| -- x is scaled the same way (activations outside [2^-3, 6e4] otherwise
 //        leave the f16 pair's 22-bit domain).
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
+// 1 when a plain split-half weight gradient of this geometry runs on the narrow kernel (C, K <= 32, W % 16 == 0, 32-bit
+// buffer offsets) -- the only one that takes a deferred-BatchNorm activation operand (x_bn)
+EGZ_API int egz_conv3x3_wgrad_narrow_ok(int B, int H, int W, int C, int K) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || C % 4 || K % 4) return 0;
+    const unsigned long long xb = 4ull * B * H * W * C + 4ull * (W + 1) * C, db = 4ull * B * H * W * K;
+    if (xb >= (1ull << 32) || db >= (1ull << 32)) return 0;
+    return pick_narrow_x3(W, C, K, 0x2000) ? 1 : 0;
+}
+
+// x_bn (optional, narrow geometry only): x is the PRE-BatchNorm output of the block below and x_bn that BatchNorm's 4 x C
+// coefficient rows (mean, 1/std, scale, shift); relu(x * scale + shift) is applied while x is staged, x_absmax = its max.
 EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K,
                               int flags, void* workspace, size_t ws_bytes, const unsigned int* dy_absmax,
-                              const unsigned int* x_absmax, hipStream_t st) {
+                              const unsigned int* x_absmax, const float* x_bn, hipStream_t st) {
     EGZ_CHECK_ARG(x && dy && dw && workspace, "egz_conv3x3_wgrad: null pointer");
+    EGZ_CHECK_ARG(!x_bn || ((flags & 0x2000) && egz_conv3x3_wgrad_narrow_ok(B, H, W, C, K) && pick_narrow_x3(W, C, K, flags)),
+                  "egz_conv3x3_wgrad: a deferred-BatchNorm operand (x_bn) exists on the narrow split-half kernel only "
+                  "(C, K <= 32, W %% 16 == 0, plain conv)");
     EGZ_CHECK_ARG(C % 4 == 0 && K % 4 == 0 && C > 0 && K > 0, "egz_conv3x3_wgrad: C=%d K=%d must be multiples of 4", C, K);
     const bool ups = flags & 1;
     EGZ_CHECK_ARG(!ups || (H % 2 == 0 && W % 2 == 0), "egz_conv3x3_wgrad: upsampled output must be even");
@@ -1428,7 +1461,11 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         EGZ_CHECK_ARG(ws_bytes >= wgrad_ws_floats(S, nred) * sizeof(float), "egz_conv3x3_wgrad: workspace too small");
         const int pps = (int)((np + S - 1) / S);
         dim3 grid(1, S);
-#define EGZ_W9N(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
+#define EGZ_W9N(TT, RR, WW)                                                                                                   \
+        do {                                                                                                                  \
+            if (x_bn) hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
+            else      hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
+        } while (0)
         if (dy_absmax) { if (WD == 32) EGZ_W9N(_Float16, 2, 32); else EGZ_W9N(_Float16, 4, 16); }
         else           { if (WD == 32) EGZ_W9N(__bf16, 2, 32); else EGZ_W9N(__bf16, 4, 16); }
 #undef EGZ_W9N

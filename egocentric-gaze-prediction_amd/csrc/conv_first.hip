@@ -125,16 +125,18 @@ __global__ __launch_bounds__(256, 2) void conv_first_fwd_kernel(
 // (the eight quads of a pixel share the address), and the eight 16-byte stores of a pixel form one 128-byte line of the NHWC
 // output.  A block walks a contiguous pixel range 32 pixels at a time and writes ONE row of fp64 BN partial sums at the end
 // (pixel lanes reduced with wave shuffles, the four waves through LDS, fixed order).
-constexpr int FD_BLOCKS = 2048;
+constexpr int FD_BLOCKS = 512;          // one round at two resident blocks per CU; also the rows the BatchNorm finalize sums
 // PX = horizontally adjacent pixels per thread (4 when W % 4 == 0: the 3 x (PX + 2) input window of a channel is read once for
 // the four of them -- 9 instead of 18 tap loads, bounds checks and address computations per pixel; the one-pixel form spent
 // more issue slots on those than on the 72 FMAs and ran at 1.9 TB/s).
 template <int CIN, int PX, bool STATS>
 __global__ __launch_bounds__(256) void conv_first_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    double* __restrict__ stat, int B, int H, int W, int ppb) {
+    double* __restrict__ stat, int B, int H, int W, int ppb, float* __restrict__ mm_out) {
     constexpr int K = 32, NT = CIN * 9;
     __shared__ double red[4][8][8];
+    __shared__ float rmm[4][8][8];
+    float vmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, vmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
     const int tid = threadIdx.x, k4 = tid & 7, pl = tid >> 3, lane = tid & 63, wave = tid >> 6;
     const int HW = H * W, M = B * HW;
     const int m0 = blockIdx.x * ppb, m1 = (m0 + ppb < M) ? m0 + ppb : M;
@@ -177,6 +179,8 @@ __global__ __launch_bounds__(256) void conv_first_direct_kernel(
             if (STATS) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+                    vmx[e] = fmaxf(vmx[e], acc[e]);            // per-channel max / min of y (mm_out: a deferred BatchNorm
+                    vmn[e] = fminf(vmn[e], acc[e]);            // bounds its output with them, egz_bn_finalize_deferred)
                     if (PX == 1) {
                         s1[e] += (double)acc[e];
                         s2[e] += (double)acc[e] * (double)acc[e];
@@ -214,6 +218,14 @@ __global__ __launch_bounds__(256) void conv_first_direct_kernel(
                 red[wave][lane][e] = a;
                 red[wave][lane][4 + e] = q;
             }
+            float hi = vmx[e], lo = vmn[e];
+            hi = fmaxf(hi, __shfl_xor(hi, 8));  lo = fminf(lo, __shfl_xor(lo, 8));
+            hi = fmaxf(hi, __shfl_xor(hi, 16)); lo = fminf(lo, __shfl_xor(lo, 16));
+            hi = fmaxf(hi, __shfl_xor(hi, 32)); lo = fminf(lo, __shfl_xor(lo, 32));
+            if (lane < 8) {
+                rmm[wave][lane][e] = hi;
+                rmm[wave][lane][4 + e] = lo;
+            }
         }
         __syncthreads();
         if (tid < 2 * K) {
@@ -222,6 +234,15 @@ __global__ __launch_bounds__(256) void conv_first_direct_kernel(
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) t += red[wv][col >> 2][which * 4 + (col & 3)];
             stat[((long)blockIdx.x * 2 + which) * K + col] = t;
+            if (mm_out) {
+                float r = rmm[0][col >> 2][which * 4 + (col & 3)];
+#pragma unroll
+                for (int wv = 1; wv < 4; ++wv) {
+                    const float o = rmm[wv][col >> 2][which * 4 + (col & 3)];
+                    r = which ? fminf(r, o) : fmaxf(r, o);
+                }
+                mm_out[((long)blockIdx.x * 2 + which) * K + col] = r;
+            }
         }
     }
 }
@@ -373,9 +394,12 @@ EGZ_API int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K) {
 }
 
 // x: [B][C][H][W] (NCHW, as the reference DataLoader yields it), w: (64, C, 3, 3), y: [B][H][W][64].
+// minmax_out (optional; C <= 3 -> 32 with stat_partial only): [rows][2][32] per-channel max / min of y, rows as stat_partial.
 EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, double* stat_partial,
-                               int B, int H, int W, int C, int K, hipStream_t st) {
+                               int B, int H, int W, int C, int K, float* minmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && w && y, "egz_conv_first_fwd: null pointer");
+    EGZ_CHECK_ARG(!minmax_out || (stat_partial && first_direct_ok(C, K) && (long)B * H * W * 32 < (1l << 31)),
+                  "egz_conv_first_fwd: minmax_out exists on the direct kernel only (C <= 3 -> 32 filters, with stat_partial)");
     EGZ_CHECK_ARG(K == 64 || K == 32, "egz_conv_first_fwd: Cout must be 64 or 32 (got %d)", K);
     EGZ_CHECK_ARG(C > 0 && C <= 64 && B > 0 && H > 0 && W > 0, "egz_conv_first_fwd: bad shape");
     const long M = (long)B * H * W;
@@ -383,8 +407,8 @@ EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias
         const int ppb = first_direct_ppb(M, W), nb = egz_cdiv(M, ppb);
 #define EGZ_FD2(CC, PP)                                                                                                        \
     do {                                                                                                                       \
-        if (stat_partial) hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, true>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb); \
-        else              hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, false>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb); \
+        if (stat_partial) hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, true>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, minmax_out); \
+        else              hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, false>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, (float*)nullptr); \
     } while (0)
 #define EGZ_FD(CC)                                                                                                             \
     do {                                                                                                                       \

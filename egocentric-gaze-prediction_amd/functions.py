@@ -113,12 +113,23 @@ def _first_conv_on_split(C: int, K: int) -> bool:
 class ConvBNReLUPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, pool,
-                first, out_buf=None, nbt=None):
+                first, out_buf=None, nbt=None, next_k=0):
         """``out_buf``: optional (B, H', W', K) NHWC destination of the block output (model_SP hands the two encoders the
-        halves of ONE buffer so that the fusion conv reads the depth-2 stack without a concatenation copy)."""
+        halves of ONE buffer so that the fusion conv reads the depth-2 stack without a concatenation copy).
+        ``next_k``: filters of the conv-BN-ReLU block that consumes this block's output inside the same FusedSequential (0 =
+        something else does).  In training, when the geometry allows (hipops.bn_defer_ok: the late-fusion widths), this
+        block then leaves its [BN -> ReLU] to that block: it returns its PRE-BN conv output tagged with the batch
+        coefficients, and the next block's conv / weight-gradient kernels normalise while staging it."""
         K, C = weight.shape[0], weight.shape[1]
         padded = first and _first_conv_on_split(C, K)
         bn_src = None       # (pre-BN conv output, batch coefficients) of the [BN -> ReLU] block that produced x (narrow layers)
+        bn_in = getattr(x, "_egz_bn_defer", None)      # x is a deferred (pre-BN) tensor: the coefficients to apply on load
+        if bn_in is not None and (first or not training):
+            raise RuntimeError("a deferred-BatchNorm tensor reached a block that cannot normalise it")
+        Bx, Hx, Wx = x.shape[0], x.shape[2], x.shape[3]
+        defer = bool(training and not pool and next_k and out_buf is None and not padded and (C <= 32 or first)
+                     and (not first or (C <= 3 and K == 32 and __import__("os").environ.get("EGZ_FIRST_DIRECT", "1") != "0"))
+                     and H.bn_defer_ok(Bx, Hx, Wx, K, next_k, first))
         if padded:
             # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
             # for this one layer); the packed weight is padded the same way by the pack kernel
@@ -128,14 +139,18 @@ class ConvBNReLUPool(torch.autograd.Function):
                                     epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3, streamed=st)
         elif first:
             xin = H._req(x.detach(), "network input (NCHW)")
-            y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training)
+            y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training,
+                                       want_minmax=defer)
         else:
             bn_src = getattr(x, "_egz_bn_src", None) if training else None
             xin = to_nhwc(x)
             dt = H.conv_dtype("fwd", K, C, xin)
             wp, st = H.conv_weight(weight, "fwd", dt, xin, K)
+            if (bn_in is not None or defer) and not (dt and st):
+                raise RuntimeError("deferred BatchNorm: the convolution did not land on the streamed split-half kernel")
             y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
-                                    epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt, streamed=st)
+                                    epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt, streamed=st,
+                                    bn_in=bn_in, want_minmax=defer)
         B, Hh, Ww, _ = y.shape
         if training and not first and C <= 32 and K <= 32 and ctx.needs_input_grad[0]:
             # narrow (late-fusion) layer: build the data-gradient packing now -- in the backward pass the 5 us pack launch sits
@@ -145,20 +160,32 @@ class ConvBNReLUPool(torch.autograd.Function):
                 H.conv_weight(weight, "dgrad", dtb, y, C)
         if bn_src is not None and not H.bnsums_ok(B, Hh, Ww, C, K, H.conv_dtype("dgrad", C, K, y)):
             bn_src = None
-        if training:
-            coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
-                                 running_var, momentum, eps, nbt)
+        if defer:
+            # [BN -> ReLU] left to the next block: finalize the statistics and bound the output this block never writes
+            coef, am = H.bn_finalize_deferred(stat, y._egz_minmax, float(B * Hh * Ww), gamma.detach(), beta.detach(),
+                                              running_mean, running_var, momentum, eps, nbt)
+            out = y
+            out._egz_absmax = am
         else:
-            coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
-        out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
+            if training:
+                coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
+                                     running_var, momentum, eps, nbt)
+            else:
+                coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
+            out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
         # max |xin| (left on xin by its producer, or by the conv launch above): the weight gradient scales x with it
         ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta, getattr(xin, "_egz_absmax", None),
                               *(bn_src if bn_src is not None else (None, None)))
         ctx.cfg = (training, pool, first, C, K, padded)
+        ctx.deferred_in = bn_in is not None
+        if bn_in is not None and bn_src is None:
+            ctx.deferred_coef = bn_in                  # (no fused BN sums: the weight gradient still needs the coefficients)
         res = from_nhwc(out)
         if training and not pool and H.BNSUMS_FUSE:
             # the block above (if it is a narrow conv) folds this BatchNorm's backward sums into its data-gradient kernel
             res._egz_bn_src = (y, coef)
+        if defer:
+            res._egz_bn_defer = coef
         return res
 
     @staticmethod
@@ -186,7 +213,7 @@ class ConvBNReLUPool(torch.autograd.Function):
             dw, dgamma, dbeta = H.bn_bwd_first_wgrad(y, to_nhwc(dout), coef, xin, out_dgamma=sg, out_dbeta=sb, out_dw=sw,
                                                      sums=sums)
             return (None, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
-                    _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None)
+                    _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None, None)
         dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, to_nhwc(dout), coef, pool, out_dgamma=sg, out_dbeta=sb, sums=sums)
 
         def data_grad():
@@ -211,12 +238,18 @@ class ConvBNReLUPool(torch.autograd.Function):
                 if padded:
                     dw = H.conv3x3_wgrad(xin, dy)[:, :C].contiguous()      # gradient of the zero-padded channels dropped
                 else:
-                    dw = H.conv_first_wgrad(xin, dy, out=sw) if first else H.conv3x3_wgrad(xin, dy, out=sw)
+                    if first:
+                        dw = H.conv_first_wgrad(xin, dy, out=sw)
+                    else:       # deferred input: xin is the pre-BN tensor of the block below, normalised while it is staged
+                        x_bn = None
+                        if ctx.deferred_in:
+                            x_bn = bn_coef if bn_coef is not None else ctx.deferred_coef
+                        dw = H.conv3x3_wgrad(xin, dy, out=sw, x_bn=x_bn)
         if not WGRAD_AFTER_DGRAD:
             dx = data_grad()
         _close_fork(f, sw, dw, xin, dy)
         return (dx, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
-                _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None)
+                _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None, None)
 
 
 class ConvReLU(torch.autograd.Function):

@@ -451,11 +451,17 @@ def _streamed_tiles(B, H, W, K) -> int:
 # ----------------------------------------------------------------------------- convolutions
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
                 epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None,
-                streamed: bool = False):
+                streamed: bool = False, bn_in: Optional[torch.Tensor] = None, want_minmax: bool = False):
     """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups.
     ups: False | 'fold' (3x3 taps on the virtual upsampled image, wp = 'fwd' packing) | 'phase' or True (four 2x2
-    phase convolutions on the low-res input, 4/9 of the MACs, wp = 'ups_fwd' packing)."""
+    phase convolutions on the low-res input, 4/9 of the MACs, wp = 'ups_fwd' packing).
+    ``bn_in``: x is the PRE-BatchNorm output of the block below and bn_in its (4, C) coefficients -- the kernel normalises +
+    ReLUs while staging x (deferred BatchNorm; narrow streamed geometry only, x must carry the abs-max of the normalised
+    values).  ``want_minmax``: with EPI_BIAS_STATS on the narrow kernel, also return y's per-channel max / min rows as
+    ``y._egz_minmax`` (what the deferred BatchNorm of THIS layer needs)."""
     _req(x, "x")
+    if (bn_in is not None or want_minmax) and not (dtype and streamed and not ups):
+        raise RuntimeError("deferred BatchNorm operands exist on the streamed narrow kernel only")
     B, Hin, Win, C = x.shape
     H, W = (2 * Hin, 2 * Win) if ups else (Hin, Win)
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
@@ -489,14 +495,19 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
                                                       C, K, epi, dtype, _p(absmax), ws.data_ptr(), nb, ns, _p(amo), _stream()),
                   "egz_conv3x3_fwd_streamed_splitk")
             return y, stat
+        mm = None
         if epi == EPI_BIAS_STATS:
-            stat = torch.empty((LIB.egz_conv3x3_streamed_stat_rows(B, H, W, C, K), 2, K), dtype=torch.float64, device=x.device)
+            rows = LIB.egz_conv3x3_streamed_stat_rows(B, H, W, C, K)
+            stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
+            if want_minmax:
+                mm = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
+                y._egz_minmax = mm
         t8 = _tile8(B, H, W, C, K, 0)
         if amo is not None and (t8 or _streamed_tiles(B, H, W, K) > 16384):
             amo = None                      # no epilogue slot for this launch: the consumer runs a standalone abs-max pass
             del y._egz_absmax
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, t8, _p(absmax), None, _p(amo), None, _stream()),
+                                           epi, dtype, t8, _p(absmax), None, _p(amo), _p(bn_in), _p(mm), _stream()),
               "egz_conv3x3_fwd_split")
         return y, stat
     if dtype:
@@ -531,7 +542,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                           0, dtype, 1 | _tile8(B, H // 2, W // 2, K, C, 1), _p(am), None, None, None, _stream()),
+                                           0, dtype, 1 | _tile8(B, H // 2, W // 2, K, C, 1), _p(am), None, None, None, None, _stream()),
               "egz_conv3x3_fwd_streamed(ups_dgrad)")
         return dx
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
@@ -576,7 +587,7 @@ def conv3x3_dgrad_masked(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
     am = absmax_of(dy) if dtype == F16X3 else None
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
                                        EPI_MASK_SUMS, dtype, 1 if ups else 0, _p(am), mask_src.data_ptr(), amo.data_ptr(),
-                                       None, _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
+                                       None, None, _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
     tile_rows = 128 if C % 128 == 0 else 256
     tile_cols = 128 if C % 128 == 0 else 64
     ntiles = ((B * Ho * Wo + tile_rows - 1) // tile_rows) * (C // tile_cols)
@@ -613,7 +624,7 @@ def conv3x3_dgrad_bnsums(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
     PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
     am = absmax_of(dy) if dtype == F16X3 else None
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
-                                       EPI_BNSUMS, dtype, 0, _p(am), bn_y.data_ptr(), None, coef.data_ptr(), _stream()),
+                                       EPI_BNSUMS, dtype, 0, _p(am), bn_y.data_ptr(), None, coef.data_ptr(), None, _stream()),
           "egz_conv3x3_fwd_streamed(dgrad + BN sums)")
     return dx, stat
 
@@ -633,8 +644,10 @@ WGRAD_SPLIT = 0x2000       # egz_conv3x3_wgrad flag: split-half arithmetic (bf16
 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0,
-                  precision: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """-> dw (K, C, 3, 3); ``out`` = a contiguous K*C*9 destination (a gradient sink) written instead of a fresh tensor."""
+                  precision: Optional[str] = None, out: Optional[torch.Tensor] = None,
+                  x_bn: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> dw (K, C, 3, 3); ``out`` = a contiguous K*C*9 destination (a gradient sink) written instead of a fresh tensor.
+    ``x_bn``: x is a pre-BatchNorm tensor, normalised + ReLU'd while it is staged (deferred BatchNorm, narrow kernel only)."""
     _req(x, "x"); _req(dy, "dy")
     B, H, W, K = dy.shape
     C = x.shape[3]
@@ -652,21 +665,27 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
     ws = workspace(nb, x.device)
     PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, C, K, flags, ws.data_ptr(),
-                                ws.numel(), _p(am), _p(xam), _stream()), "egz_conv3x3_wgrad")
+                                ws.numel(), _p(am), _p(xam), _p(x_bn), _stream()), "egz_conv3x3_wgrad")
     return dw
 
 
-def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stats: bool):
+def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stats: bool,
+                   want_minmax: bool = False):
+    """``want_minmax`` (direct kernel, C <= 3 -> 32 filters, with stats): y's per-channel max / min rows as y._egz_minmax."""
     _req(x_nchw, "x"); _req(w, "weight")
     B, C, H, W = x_nchw.shape
     K = w.shape[0]
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x_nchw.device)
-    stat = None
+    stat = mm = None
     if stats:
-        stat = torch.empty((LIB.egz_conv_first_stat_rows_for(B, H, W, C, K), 2, K), dtype=torch.float64, device=y.device)
+        rows = LIB.egz_conv_first_stat_rows_for(B, H, W, C, K)
+        stat = torch.empty((rows, 2, K), dtype=torch.float64, device=y.device)
+        if want_minmax:
+            mm = torch.empty((rows, 2, K), dtype=torch.float32, device=y.device)
+            y._egz_minmax = mm
     PROF.note_flops("egz_conv_first_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv_first_fwd(x_nchw.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                 _stream()), "egz_conv_first_fwd")
+                                 _p(mm), _stream()), "egz_conv_first_fwd")
     return y, stat
 
 
@@ -699,6 +718,47 @@ def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, run
                               coef[2].data_ptr(), coef[3].data_ptr(), _p(num_batches_tracked), ws.data_ptr(), ws.numel(),
                               _stream()), "egz_bn_finalize")
     return coef
+
+
+# Deferred BatchNorm (late-fusion stack, training): the [BN -> ReLU] of a narrow block is applied by the NEXT block's conv and
+# weight-gradient kernels while they stage its pre-BN output, so the normalised tensor (205 MB at B = 32, 224 x 224 x 32) is
+# neither written nor read.  EGAZE_BN_DEFER=0 materialises it as before (A/B runs; the parity test compares the two).
+BN_DEFER = _os.environ.get("EGAZE_BN_DEFER", "1") != "0"
+BN_DEFER_STATS = {"deferred": 0}
+
+
+def bn_defer_ok(B: int, H: int, W: int, K: int, K_next: int, first_direct: bool) -> bool:
+    """Can the [BN -> ReLU] of a block with K output channels at (B, H, W) be left to a next 3x3 conv with K_next filters?
+    Needs the split-half policy, the persistent narrow conv kernel and the narrow weight-gradient kernel for K -> K_next, and
+    a producer that emits per-channel max / min rows (the narrow conv kernel itself, or the direct first-layer kernel)."""
+    if not (BN_DEFER and BNSUMS_FUSE and PRECISION == "split" and GRAD_SPLIT == "f16" and FWD_SCALE and STREAMED):
+        return False
+    if not (K in (16, 32) and K_next <= 32 and K_next % 4 == 0 and H % 16 == 0 and W % 16 == 0):
+        return False
+    if 4 * B * H * W * max(K, K_next) >= 2 ** 32:
+        return False
+    return bool(LIB.egz_conv3x3_streamed_ok(B, H, W, K, K_next, 0) and LIB.egz_conv3x3_streamed_ok(B, H, W, K_next, K, 0)
+                and LIB.egz_conv3x3_wgrad_narrow_ok(B, H, W, K, K_next))
+
+
+def bn_finalize_deferred(stat: torch.Tensor, minmax: torch.Tensor, count: float, gamma, beta, running_mean, running_var,
+                         momentum: float, eps: float, num_batches_tracked: Optional[torch.Tensor] = None):
+    """bn_finalize for a BatchNorm whose output is never materialised -> (coef (4, K), abs-max buffer holding the exact max of
+    relu(y * scale + shift), derived from y's per-channel max / min rows)."""
+    rows, _, K = stat.shape
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
+        raise RuntimeError("num_batches_tracked: expected an int64 HIP tensor")
+    dev = stat.device
+    coef = torch.empty((4, K), dtype=torch.float32, device=dev)
+    am = _new_absmax(dev)
+    if running_mean is not None:
+        running_mean._egz_epoch = getattr(running_mean, "_egz_epoch", 0) + 1
+    check(LIB.egz_bn_finalize_deferred(stat.data_ptr(), rows, K, float(count), _p(gamma), _p(beta), _p(running_mean),
+                                       _p(running_var), momentum, eps, coef[0].data_ptr(), coef[1].data_ptr(),
+                                       coef[2].data_ptr(), coef[3].data_ptr(), _p(num_batches_tracked), minmax.data_ptr(),
+                                       minmax.shape[0], am.data_ptr(), _stream()), "egz_bn_finalize_deferred")
+    BN_DEFER_STATS["deferred"] += 1
+    return coef, am
 
 
 def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps: float):

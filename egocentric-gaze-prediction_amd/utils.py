@@ -37,14 +37,17 @@ def _bn_args(bn: nn.BatchNorm2d):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps)
 
 
-def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first: bool, out_buf=None):
-    """One fused encoder block on the HIP path; keeps BatchNorm's num_batches_tracked bookkeeping."""
+def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first: bool, out_buf=None, next_k: int = 0):
+    """One fused encoder block on the HIP path; keeps BatchNorm's num_batches_tracked bookkeeping.
+    ``next_k``: filters of the conv-BN-ReLU block that consumes the output (0 = none): lets a narrow block leave its
+    [BN -> ReLU] to that block (functions.ConvBNReLUPool)."""
     if conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.stride != (1, 1):
         raise NotImplementedError("only 3x3 / pad 1 / stride 1 convolutions are on the reference path")
     g, b, rm, rv, training, mom, eps = _bn_args(bn)
     # num_batches_tracked += 1 happens inside the statistics kernel (egz_bn_finalize), not as a separate launch
     nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
-    return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first, out_buf, nbt)
+    return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first, out_buf, nbt,
+                                next_k)
 
 
 class FusedSequential(nn.Sequential):
@@ -83,8 +86,14 @@ class FusedSequential(nn.Sequential):
                     raise NotImplementedError("upsample in front of a BatchNorm block is not on the reference path")
                 pool = i + 3 < n and isinstance(mods[i + 3], nn.MaxPool2d)
                 step = 4 if pool else 3
+                # the consumer of this block's output, when it is another conv-BN-ReLU block of this stack
+                nm = mods[i + step] if i + step + 2 < n else None
+                next_k = nm.out_channels if (isinstance(nm, nn.Conv2d) and nm.kernel_size == (3, 3) and nm.padding == (1, 1)
+                                             and nm.stride == (1, 1) and nm.in_channels == m.out_channels
+                                             and isinstance(mods[i + step + 1], nn.BatchNorm2d)
+                                             and isinstance(mods[i + step + 2], nn.ReLU)) else 0
                 x = conv_bn_relu_pool(x, m, nxt, pool, first and m.in_channels < 32,
-                                      out_buf if i + step >= n else None)
+                                      out_buf if i + step >= n else None, next_k)
                 relu_below = False
                 i += step
             elif isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and isinstance(nxt, nn.ReLU):

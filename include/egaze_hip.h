@@ -87,7 +87,12 @@ int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K);
 int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t stream);
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
-                             const float* mask_src, unsigned int* absmax_out, const float* bn_coef, hipStream_t stream);
+                             const float* mask_src, unsigned int* absmax_out, const float* bn_coef, float* minmax_out,
+                             hipStream_t stream);
+/* Deferred BatchNorm (narrow geometry, epi 0 / 1 / 2): with bn_coef != NULL, x is the PRE-BatchNorm conv output of the block
+ * below and bn_coef that BatchNorm's 4 x C coefficient rows; relu(x * scale + shift) is applied while the halo is staged, so
+ * the normalised tensor of late_fusion.py:11-12 is never materialised (x_absmax = its max, from egz_bn_finalize_deferred).
+ * minmax_out (epi 2, narrow geometry): [egz_conv3x3_streamed_stat_rows][2][K] per-channel max / min of y. */
 /* epi 5 (narrow geometry only: C, K <= 32, H and W multiples of 16, mode 0, no bias): data gradient w.r.t. the output of a
  * train-mode [BatchNorm2d -> ReLU] (late_fusion.py:10-12) that ALSO accumulates that BatchNorm's backward sums: mask_src =
  * the layer's pre-BN conv output (layout of y), bn_coef = 4 rows of K floats (batch mean, 1/std, scale, shift);
@@ -115,14 +120,20 @@ int egz_colsum_f64(const double* part, int rows, int cols, int ncols_out, float*
 size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int flags);
 int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, int W, int C, int K, int flags,
                       void* workspace, size_t ws_bytes, const unsigned int* dy_absmax, const unsigned int* x_absmax,
-                      hipStream_t stream);
+                      const float* x_bn, hipStream_t stream);
+/* x_bn (optional): x is the PRE-BatchNorm conv output of the block below and x_bn that BatchNorm's 4 x C coefficient rows;
+ * relu(x * scale + shift) is applied while x is staged (deferred BatchNorm, late_fusion.py:11-12), x_absmax = the max of the
+ * normalised values.  Only where egz_conv3x3_wgrad_narrow_ok(B, H, W, C, K) (C, K <= 32, W % 16 == 0, flags 0x2000). */
+int egz_conv3x3_wgrad_narrow_ok(int B, int H, int W, int C, int K);
 
 /* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
  *      per data/STdatas.py:50-73) and Conv2d(2,32) (models/late_fusion.py:10).  K in {64, 32}. */
 int egz_conv_first_stat_rows(int B, int H, int W);
 int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K);   /* rows of stat_partial egz_conv_first_fwd writes for C -> K */
 int egz_conv_first_fwd(const float* x_nchw, const float* w, const float* bias, float* y_nhwc, double* stat_partial,
-                       int B, int H, int W, int C, int K, hipStream_t stream);
+                       int B, int H, int W, int C, int K, float* minmax_out, hipStream_t stream);
+/* minmax_out (optional; C <= 3 -> 32 filters with stat_partial): [rows][2][32] per-channel max / min of y, rows as
+ * stat_partial -- input of egz_bn_finalize_deferred. */
 size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C);
 int egz_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw, int B, int H, int W, int C, int K,
                          void* workspace, size_t ws_bytes, hipStream_t stream);
@@ -135,6 +146,14 @@ int egz_bn_finalize(const double* stat_partial, int rows, int K, double count, c
                     float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
                     float* invstd_out, float* scale, float* shift, long long* num_batches_tracked, void* workspace,
                     size_t ws_bytes, hipStream_t stream);
+/* The same for a BatchNorm whose output is never materialised -- the convolution above it applies relu(y * scale + shift) while
+ * staging y (egz_conv3x3_fwd_streamed bn_coef; late_fusion.py:11-12).  minmax: [mm_rows][2][K] per-channel max / min rows of y
+ * from the producing conv; absmax_out (egz_absmax layout) receives the exact max of the normalised + ReLU'd values, the f16
+ * split scale of that convolution.  K in {16, 32, 64}; one launch, no workspace. */
+int egz_bn_finalize_deferred(const double* stat_partial, int rows, int K, double count, const float* gamma, const float* beta,
+                             float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
+                             float* invstd_out, float* scale, float* shift, long long* num_batches_tracked,
+                             const float* minmax, int mm_rows, unsigned int* absmax_out, hipStream_t stream);
 int egz_bn_eval_coeffs(int K, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
 int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W,

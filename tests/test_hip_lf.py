@@ -159,6 +159,41 @@ def test_bn_sums_folded_into_narrow_dgrad():
     assert worst < 2e-5
 
 
+def test_deferred_batchnorm_matches_materialised():
+    """Training step of the late-fusion stack with the [BN -> ReLU] of the two 32-channel blocks applied by the NEXT block's
+    conv / weight-gradient kernels while they stage the pre-BN tensor (hipops.BN_DEFER) against the same step with the
+    normalised tensors materialised: identical arithmetic per element (same fma, same exact abs-max, hence the same f16 split),
+    so outputs, running statistics and gradients must agree to fp32 round-off of the reductions."""
+    from egaze_amd import hipops as H
+    from egaze_amd.floss import floss
+    im, feat, gt = synth.synth_lf_batch(3, 48, seed=11)
+    res = {}
+    for defer in (True, False):
+        H.BN_DEFER = defer
+        try:
+            net = build()
+            net.train()
+            before = H.BN_DEFER_STATS["deferred"]
+            out = net(feat.to(DEV), im.to(DEV))
+            floss()(out, gt.to(DEV)).backward()
+            torch.cuda.synchronize()
+            assert H.BN_DEFER_STATS["deferred"] - before == (2 if defer else 0)      # blocks 1 and 2; block 3 feeds the 1x1 head
+            res[defer] = (out.detach().cpu().numpy().copy(),
+                          {k: p.grad.detach().cpu().numpy().copy() for k, p in net.named_parameters()},
+                          {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items() if "running" in k})
+        finally:
+            H.BN_DEFER = True
+    o1, g1, r1 = res[True]
+    o0, g0, r0 = res[False]
+    print("deferred BN: out max abs diff %.2e" % np.abs(o1 - o0).max())
+    assert rel(o1, o0) < 1e-6
+    for k in r0:
+        assert rel(r1[k], r0[k]) < 1e-6, k
+    worst = max(rel(g1[k], g0[k]) for k in g0 if np.abs(g0[k]).max() > 1e-9)
+    print("deferred BN: grads max rel %.2e" % worst)
+    assert worst < 2e-5
+
+
 @pytest.mark.parametrize("B,C,Hh,Ww", [(2, 2, 48, 48), (3, 2, 13, 20), (1, 3, 40, 72), (2, 1, 16, 16), (2, 2, 9, 13), (1, 2, 224, 224)])
 def test_first_block_backward_in_one_pass(B, C, Hh, Ww):
     """bn_bwd_first_wgrad (BatchNorm backward + weight gradient of the first late-fusion conv without storing the gradient

@@ -173,7 +173,7 @@ def test_conv_first_direct_32_filters(C, B, Hh, Ww):
     b = rnd(32, seed=23, scale=0.1)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     y, stat = h.conv_first_fwd(x.to(DEV), w.to(DEV), b.to(DEV), True)
-    assert stat.shape[0] == h.LIB.egz_conv_first_stat_rows_for(B, Hh, Ww, C, 32) <= 2048
+    assert stat.shape[0] == h.LIB.egz_conv_first_stat_rows_for(B, Hh, Ww, C, 32) <= 512
     assert rel(nchw(y), ref) < 2e-6
     s = stat.sum(0).cpu()
     assert rel(s[0], ref.sum(dim=(0, 2, 3))) < 1e-6 and rel(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-6
@@ -832,13 +832,13 @@ def test_cabi_argument_errors_are_loud():
     assert h.LIB.egz_conv3x3_streamed_ok(2, 16, 16, 30, 64, 0) == 0
     y = torch.empty((2, 16, 16, 64), device=DEV)
     rc = h.LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, 2, 16, 16, 30, 64, 0, 1, 0,
-                                        None, None, None, None, h._stream())
+                                        None, None, None, None, None, h._stream())
     assert rc != 0
     with pytest.raises(RuntimeError, match="egz_conv3x3_fwd_streamed"):
         h.check(rc, "egz_conv3x3_fwd_streamed")
     # the BatchNorm-sums epilogue exists for the narrow geometry only
     rc = h.LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), y.data_ptr(), 2, 16, 16, 64, 64, 5, 1,
-                                        0, None, y.data_ptr(), None, y.data_ptr(), h._stream())
+                                        0, None, y.data_ptr(), None, y.data_ptr(), None, h._stream())
     with pytest.raises(RuntimeError, match="narrow geometry"):
         h.check(rc, "egz_conv3x3_fwd_streamed")
     # split-K needs its workspace
