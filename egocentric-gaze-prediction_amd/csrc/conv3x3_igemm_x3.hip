@@ -664,10 +664,14 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
         }
     }
 
-    // ---- epilogue (as conv3x3_igemm_x3_kernel)
+    // ---- epilogue (as conv3x3_igemm_x3_kernel).  Outputs below 4 GiB leave through BUFFER stores with an out-of-range offset
+    // for rows / columns that do not exist instead of a per-lane branch around each store: with the branch every store sat in
+    // its own basic block behind an s_waitcnt vmcnt(0), i.e. waited for the previous one to be acknowledged.
     double* red = reinterpret_cast<double*>(Ah);
     __shared__ float samax[4];
     float amx = 0.f;
+    const bool bufst = (unsigned long long)B * H * W * K * 4ull < (1ull << 32);        // block-uniform (H, W: the output image)
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, bufst ? (int)((unsigned)B * H * W * K * 4u) : 0, 0x00020000);
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int col = wn * WN + nr * 32 + l31;
@@ -679,6 +683,20 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long off = Ro[wm * 64 + mr * 32 + egz_acc_row(r, lane)];
+                if (bufst) {
+                    const bool ok = off >= 0 && nok;
+                    float v = acc[mr][nr][r] * out_scale + bz;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs,
+                                                          ok ? (unsigned)(off + n0 + col) * 4u : 0xFFFFFFFFu, 0, 0);
+                    const float vs = ok ? v : 0.f;
+                    if (EPI == EPI_BIAS_RELU) amx = fmaxf(amx, vs);
+                    if (EPI == EPI_BIAS_STATS) {
+                        s1 += (double)vs;
+                        s2 += (double)vs * (double)vs;
+                    }
+                    continue;
+                }
                 if (off >= 0 && nok) {
                     float v = acc[mr][nr][r] * out_scale + bz;
                     if (EPI == EPI_BIAS_RELU) {

@@ -511,6 +511,15 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     constexpr int SR = (RPW > 128) ? RPW / 128 : 1;            // 128-row stat rows a wave owns (2 on the 256-row waves)
     double s1 = 0.0, s2 = 0.0, s1b[SR], s2b[SR];
     float amx = 0.f;
+#ifndef EGZ_X3S_BUFSTORE
+#define EGZ_X3S_BUFSTORE 1
+#endif
+    // The result goes out through BUFFER stores whose per-lane byte offset is out of range for rows / columns that do not exist
+    // (dropped by the hardware): no per-lane branch around a store.  With `if (valid) y[...] = v` every store sat in its own
+    // basic block and the wait-count pass put s_waitcnt vmcnt(0) in front of each one -- 32-64 stores per wave, each waiting
+    // for the previous one to be acknowledged.  (The output is < 4 GiB: egz_conv3x3_streamed_ok.)
+    constexpr bool BUFST = EGZ_X3S_BUFSTORE && EPI != EPI_PARTIAL && EPI != EPI_MASK_SUMS;
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         if (SR > 1 && (mr & 3) == 0 && mr) {                    // a 128-row group is complete: park its sums
@@ -524,6 +533,20 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             const long off = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)];
             if (EPI == EPI_PARTIAL) {                          // raw partial sums of this split; epilogue in the fix-up pass
                 if (off >= 0 && nok) y[(long)split * M * K + off + col] = acc[mr][r] * out_scale;
+                continue;
+            }
+            if (BUFST) {
+                const bool ok = off >= 0 && nok;
+                float v = acc[mr][r] * out_scale + bz;
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs,
+                                                      ok ? (unsigned)(off + col) * 4u : 0xFFFFFFFFu, 0, 0);
+                const float vs = ok ? v : 0.f;
+                if (EPI == EPI_BIAS_RELU) amx = fmaxf(amx, vs);                  // (post-ReLU: vs >= 0)
+                if (EPI == EPI_BIAS_STATS) {
+                    s1 += (double)vs;
+                    s2 += (double)vs * (double)vs;
+                }
                 continue;
             }
             if (off >= 0 && nok) {
@@ -1112,6 +1135,7 @@ EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode)
         H >>= 1;
         W >>= 1;
     }
+    if (4ull * B * H * W * K >= (1ull << 32)) return 0;                // the result leaves through 32-bit buffer offsets
     // column tile: 128 (K % 128 == 0), 64 (K % 64 == 0), else 32-column tiles padded up to K (narrow layers)
     const bool small = (K % 128 == 0) && !tile8;                        // 128 x 128 tile: 8 x 16 patches, 256 slots
     const int prow = small ? 8 : 16, bm = small ? 128 : 256, hzero = small ? 255 : 383;
