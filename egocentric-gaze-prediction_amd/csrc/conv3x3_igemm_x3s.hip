@@ -518,8 +518,10 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // (dropped by the hardware): no per-lane branch around a store.  With `if (valid) y[...] = v` every store sat in its own
     // basic block and the wait-count pass put s_waitcnt vmcnt(0) in front of each one -- 32-64 stores per wave, each waiting
     // for the previous one to be acknowledged.  (The output is < 4 GiB: egz_conv3x3_streamed_ok.)
-    constexpr bool BUFST = EGZ_X3S_BUFSTORE && EPI != EPI_PARTIAL && EPI != EPI_MASK_SUMS;
+    constexpr bool BUFST = EGZ_X3S_BUFSTORE && EPI != EPI_PARTIAL;
     const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mk_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(EPI == EPI_MASK_SUMS ? mask_src : y), 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         if (SR > 1 && (mr & 3) == 0 && mr) {                    // a 128-row group is complete: park its sums
@@ -528,9 +530,26 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             s1 = 0.0;
             s2 = 0.0;
         }
+        unsigned mko[16];                                       // EPI_MASK_SUMS: the 16 mask values of this row group, requested
+        float mkv[16];                                          // together (branch-free buffer loads), consumed below
+        if (BUFST && EPI == EPI_MASK_SUMS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long off = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)];
+                mko[r] = (off >= 0 && nok) ? (unsigned)(off + col) * 4u : 0xFFFFFFFFu;
+                mkv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mk_rs, mko[r], 0, 0));
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long off = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)];
+            if (BUFST && EPI == EPI_MASK_SUMS) {                // (out-of-range lanes read 0: masked, not stored, not summed)
+                const float v = (mkv[r] > 0.f) ? acc[mr][r] * out_scale : 0.f;
+                amx = fmaxf(amx, fabsf(v));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, mko[r], 0, 0);
+                s1 += (double)v;
+                continue;
+            }
             if (EPI == EPI_PARTIAL) {                          // raw partial sums of this split; epilogue in the fix-up pass
                 if (off >= 0 && nok) y[(long)split * M * K + off + col] = acc[mr][r] * out_scale;
                 continue;

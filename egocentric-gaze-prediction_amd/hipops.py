@@ -560,11 +560,12 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
 
 
 EPI_MASK_SUMS = 3
-# ReLU backward of a decoder block folded into the epilogue of the dgrad kernel above it (functions.ConvReLU).  Opt-in:
-# it removes 11 passes over the decoder gradients (relu_bwd_bias 1.06 -> 0.1 ms per step) but lengthens the MFMA-bound dgrad
-# launches by the same amount -- measured 35.56 vs 35.39 ms per step (profiles/r02_bench_ab_knobs.txt), so the default keeps
-# the separate HBM-bound pass, which overlaps with the weight-gradient stream.
-MASK_FUSE = _os.environ.get("EGAZE_MASK_FUSE", "0") != "0"
+# ReLU backward of a decoder block folded into the epilogue of the dgrad kernel above it (functions.ConvReLU): it removes 11
+# passes over the decoder gradients (relu_bwd_bias, 1.0 ms per step).  Round 2 measured it slower (35.56 vs 35.39 ms,
+# profiles/r02_bench_ab_knobs.txt) -- with the mask load inside a per-lane branch every epilogue element waited for its own
+# load.  With the branch-free epilogue (buffer loads / stores with out-of-range offsets for invalid rows, round 3) the step
+# is 0.55 ms faster with it (32.6 vs 33.15 ms, profiles/r03_ab_notes.txt), so it is the default; EGAZE_MASK_FUSE=0 = A/B.
+MASK_FUSE = _os.environ.get("EGAZE_MASK_FUSE", "1") != "0"
 MASK_FUSE_STATS = {"produced": 0, "consumed": 0}                 # how often the fused form ran / was picked up (tests)
 
 
