@@ -318,10 +318,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
                     for (int r = 0; r < 16; ++r) acc[mr][nr][r] += wt[((mr * NR + nr) * 16 + r) * 256 + tid];
     }
 
-    // ---- epilogue (same as the fp32 kernel; out_scale undoes the weight pre-scaling of the f16 path exactly)
+    // ---- epilogue (same as the fp32 kernel; out_scale undoes the weight pre-scaling of the f16 path exactly).  Outputs below
+    // 4 GiB leave through buffer stores with an out-of-range offset for invalid rows / columns instead of a per-lane branch
+    // around each store (see conv3x3_igemm_x3h_kernel).
     double* red = reinterpret_cast<double*>(As);   // [2 (wm)][2 (sum, sumsq)][128] doubles = 4 KB
     __shared__ float samax[4];
     float amx = 0.f;                               // EPI_BIAS_RELU: max of the activation this thread wrote
+    const bool bufst = (unsigned long long)B * H * W * K * 4ull < (1ull << 32);        // block-uniform (H, W: the output image)
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, bufst ? (int)((unsigned)B * H * W * K * 4u) : 0, 0x00020000);
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
         const int col = wn * WN + nr * 32 + l31;
@@ -333,6 +337,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long off = Ro[wm * 64 + mr * 32 + egz_acc_row(r, lane)];
+                if (bufst) {
+                    const bool ok = off >= 0 && nok;
+                    float v = acc[mr][nr][r] * out_scale + bz;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs,
+                                                          ok ? (unsigned)(off + n0 + col) * 4u : 0xFFFFFFFFu, 0, 0);
+                    const float vs = ok ? v : 0.f;
+                    if (EPI == EPI_BIAS_RELU) amx = fmaxf(amx, vs);
+                    if (EPI == EPI_BIAS_STATS) {
+                        s1 += (double)vs;
+                        s2 += (double)vs * (double)vs;
+                    }
+                    continue;
+                }
                 if (off >= 0 && nok) {
                     float v = acc[mr][nr][r] * out_scale + bz;
                     if (EPI == EPI_BIAS_RELU) {

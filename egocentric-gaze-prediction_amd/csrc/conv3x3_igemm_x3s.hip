@@ -507,7 +507,12 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // ---- epilogue: every wave owns RPW rows x 32 columns; out_scale undoes the f16 weight pre-scaling exactly
     const int col = n0 + wn * 32 + l31;
     const bool nok = col < K;
-    const float bz = (bias && nok) ? bias[col] : 0.f;
+    const float bz = (EPI != EPI_BNSUMS && bias && nok) ? bias[col] : 0.f;
+    // EPI_BNSUMS (data gradient w.r.t. the output of a train-mode [BatchNorm -> ReLU]): `bias` carries that BatchNorm's 4 x K
+    // coefficient rows (mean, 1/std, scale, shift) and mask_src its pre-BN conv output; the epilogue also accumulates the two
+    // per-channel sums of the BatchNorm backward (see the enum) -- the reduce pass of that layer disappears.
+    const float cmu = (EPI == EPI_BNSUMS && nok) ? bias[col] : 0.f, cis = (EPI == EPI_BNSUMS && nok) ? bias[K + col] : 0.f;
+    const float csc = (EPI == EPI_BNSUMS && nok) ? bias[2 * K + col] : 0.f, csh = (EPI == EPI_BNSUMS && nok) ? bias[3 * K + col] : 0.f;
     constexpr int SR = (RPW > 128) ? RPW / 128 : 1;            // 128-row stat rows a wave owns (2 on the 256-row waves)
     double s1 = 0.0, s2 = 0.0, s1b[SR], s2b[SR];
     float amx = 0.f;
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     constexpr bool BUFST = EGZ_X3S_BUFSTORE && EPI != EPI_PARTIAL;
     const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mk_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(EPI == EPI_MASK_SUMS ? mask_src : y), 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
+        const_cast<float*>((EPI == EPI_MASK_SUMS || EPI == EPI_BNSUMS) ? mask_src : y), 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         if (SR > 1 && (mr & 3) == 0 && mr) {                    // a 128-row group is complete: park its sums
@@ -532,13 +537,28 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         }
         unsigned mko[16];                                       // EPI_MASK_SUMS: the 16 mask values of this row group, requested
         float mkv[16];                                          // together (branch-free buffer loads), consumed below
-        if (BUFST && EPI == EPI_MASK_SUMS) {
+        if (BUFST && (EPI == EPI_MASK_SUMS || EPI == EPI_BNSUMS)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long off = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)];
                 mko[r] = (off >= 0 && nok) ? (unsigned)(off + col) * 4u : 0xFFFFFFFFu;
                 mkv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(mk_rs, mko[r], 0, 0));
             }
+        }
+        if (BUFST && EPI == EPI_BNSUMS) {                      // 16 rows in fp32, then one fp64 add per row group
+            float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[mr][r] * out_scale;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, mko[r], 0, 0);
+                const float yp = mkv[r];
+                const float dz = (mko[r] != 0xFFFFFFFFu && yp * csc + csh > 0.f) ? v : 0.f;
+                q1 += dz;
+                q2 += dz * ((yp - cmu) * cis);
+            }
+            s1 += (double)q1;
+            s2 += (double)q2;
+            continue;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -593,7 +613,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             absmax_out[1 + gt] = __float_as_uint(m);
         }
     }
-    if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS) {
+    if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS || EPI == EPI_BNSUMS) {
         // one partial row per 128 pixel rows (the granularity egz_conv3x3_stat_rows promises)
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
@@ -1112,7 +1132,14 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 #define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1)
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS) absmax_out = nullptr;
     if (absmax_out) EGZ_CHECK_ARG(total <= 16384, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
-    if (epi == EPI_MASK_SUMS) {
+    if (epi == EPI_BNSUMS) {
+        if constexpr ((WM == 1 || WM == 2) && MODE == PLAIN) {      // data gradients of the encoders: 128- / 64-column 4-wave tiles
+            if (patch) EGZ_X3S(EPI_BNSUMS, true); else EGZ_X3S(EPI_BNSUMS, false);
+        } else {
+            egz_set_error("egz_conv3x3_fwd_streamed: the BatchNorm-sums epilogue is built for the 128- / 64-column tiles of plain convs");
+            return (int)hipErrorInvalidValue;
+        }
+    } else if (epi == EPI_MASK_SUMS) {
         if constexpr (WM == 1 || WM == 2) {      // data gradients of the SP decoder: 128- and 64-column 4-wave tiles
             if (patch) EGZ_X3S(EPI_MASK_SUMS, true); else EGZ_X3S(EPI_MASK_SUMS, false);
         } else {
@@ -1208,15 +1235,25 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                   epi != EPI_MASK_SUMS && (!minmax_out || epi == EPI_BIAS_STATS)),
                   "egz_conv3x3_fwd_streamed: a deferred-BatchNorm input (bn_coef) / minmax_out exist on the narrow persistent kernel "
                   "only (C, K <= 32, H and W multiples of 16; minmax_out with epi 2)");
-    if (epi == EPI_BNSUMS) {       // data gradient + the BatchNorm-backward sums of the layer below (persistent narrow kernel only)
+    if (epi == EPI_BNSUMS) {       // data gradient + the BatchNorm-backward sums of the layer below
         EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && mode == 0 && mask_src && bn_coef && stat_partial && !bias &&
-                      x3p_narrow_ok(B, H, W, C, K) && egz_conv3x3_streamed_ok(B, H, W, C, K, 0),
-                      "egz_conv3x3_fwd_streamed: epi 5 (BatchNorm sums) needs the narrow geometry (C, K <= 32, H and W multiples of 16), "
-                      "mask_src = the pre-BN conv output of the layer below, bn_coef, stat_partial and no bias");
+                      egz_conv3x3_streamed_ok(B, H, W, C, K, 0) && (x3p_narrow_ok(B, H, W, C, K) || K % 64 == 0),
+                      "egz_conv3x3_fwd_streamed: epi 5 (BatchNorm sums) needs mode 0, the narrow geometry (C, K <= 32, H and W "
+                      "multiples of 16) or K %% 64 == 0, mask_src = the pre-BN conv output of the layer below, bn_coef, "
+                      "stat_partial and no bias");
         const unsigned short* w16b = static_cast<const unsigned short*>(wq);
         const float osb = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
-        if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
-        return launch_x3p_narrow<__bf16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
+        if (x3p_narrow_ok(B, H, W, C, K)) {
+            if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
+            return launch_x3p_narrow<__bf16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
+        }
+        // wide tiles: the coefficient rows travel in the kernel's (otherwise unused) bias argument
+        if (K % 128 == 0) {
+            if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
+            return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
+        }
+        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
+        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
     }
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, mode), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d "
                   "mode=%d is not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K, mode);

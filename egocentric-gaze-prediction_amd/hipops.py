@@ -604,10 +604,21 @@ BNSUMS_FUSE = _os.environ.get("EGAZE_BNSUMS_FUSE", "1") != "0"
 BNSUMS_STATS = {"produced": 0, "consumed": 0}
 
 
+# ... and for the wide layers (the VGG encoders: conv -> BN -> ReLU -> conv without a pool in between, utils.py:64-76): the same
+# epilogue on the 128- / 64-column tiles of the streamed kernel.  EGAZE_BNSUMS_WIDE=0 keeps the reduce pass there (A/B).
+BNSUMS_WIDE = _os.environ.get("EGAZE_BNSUMS_WIDE", "1") != "0"
+
+
 def bnsums_ok(B: int, H: int, W: int, C: int, K: int, dtype: int) -> bool:
-    """Geometry of the persistent narrow kernel (data gradient of a K -> C channel conv seen as a C -> K one)."""
-    return bool(BNSUMS_FUSE and dtype and C <= 32 and K <= 32 and C % 4 == 0 and K % 4 == 0 and H % 16 == 0 and W % 16 == 0
-                and 4 * B * H * W * C < 2 ** 32 and LIB.egz_conv3x3_streamed_ok(B, H, W, K, C, 0))
+    """Can the data gradient of a K <- C channel conv (dy (B,H,W,K) -> dx (B,H,W,C)) also produce the BatchNorm-backward sums
+    of the C-channel block below?  The persistent narrow kernel (C, K <= 32), or the streamed kernel's 64- / 128-column
+    tiles (C % 64 == 0)."""
+    if not (BNSUMS_FUSE and dtype and 4 * B * H * W * C < 2 ** 32 and LIB.egz_conv3x3_streamed_ok(B, H, W, K, C, 0)):
+        return False
+    if C <= 32 and K <= 32:
+        return C % 4 == 0 and K % 4 == 0 and H % 16 == 0 and W % 16 == 0
+    return bool(BNSUMS_WIDE and STREAMED and C % 64 == 0 and K % 32 == 0
+                and (not SPLITK or LIB.egz_conv3x3_streamed_splits(B, H, W, K, C) <= 1))      # (few-tile launches stay split-K)
 
 
 def conv3x3_dgrad_bnsums(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int, bn_y: torch.Tensor, coef: torch.Tensor):

@@ -93,8 +93,9 @@ int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, 
  * below and bn_coef that BatchNorm's 4 x C coefficient rows; relu(x * scale + shift) is applied while the halo is staged, so
  * the normalised tensor of late_fusion.py:11-12 is never materialised (x_absmax = its max, from egz_bn_finalize_deferred).
  * minmax_out (epi 2, narrow geometry): [egz_conv3x3_streamed_stat_rows][2][K] per-channel max / min of y. */
-/* epi 5 (narrow geometry only: C, K <= 32, H and W multiples of 16, mode 0, no bias): data gradient w.r.t. the output of a
- * train-mode [BatchNorm2d -> ReLU] (late_fusion.py:10-12) that ALSO accumulates that BatchNorm's backward sums: mask_src =
+/* epi 5 (mode 0, no bias; the narrow geometry C, K <= 32 with H and W multiples of 16, or K % 64 == 0): data gradient w.r.t. the
+ * output of a train-mode [BatchNorm2d -> ReLU] (late_fusion.py:10-12; the conv -> BN -> ReLU -> conv pairs of the VGG
+ * encoders, utils.py:64-76) that ALSO accumulates that BatchNorm's backward sums: mask_src =
  * the layer's pre-BN conv output (layout of y), bn_coef = 4 rows of K floats (batch mean, 1/std, scale, shift);
  * stat_partial receives egz_conv3x3_streamed_stat_rows rows of (sum dz, sum dz * xhat) with dz = (mask_src * scale + shift > 0) ? y : 0,
  * the `sums` argument of egz_bn_relu_pool_bwd.

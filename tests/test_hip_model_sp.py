@@ -493,6 +493,35 @@ def test_relu_backward_folded_into_dgrad_above(monkeypatch):
             assert torch.equal(a, b), k
 
 
+def test_bn_backward_sums_folded_into_encoder_dgrad(monkeypatch):
+    """Encoder chains conv -> BN -> ReLU -> conv (no pool in between: 8 of the 13 VGG convs per stream): the BatchNorm-backward
+    sums of the lower block come out of the data-gradient epilogue of the upper one (hipops.BNSUMS_WIDE) instead of a reduce
+    pass.  The folded form must run and be picked up 16 times, and give the same gradients as the separate pass up to the
+    summation order of those two sums."""
+    import egaze_amd.hipops as H
+    from egaze_amd.floss import floss
+    if H.PRECISION != "split" or not H.BNSUMS_FUSE:
+        pytest.skip("the folded BatchNorm sums live in the split-half streamed kernel (default mode)")
+    grads = {}
+    monkeypatch.setattr(H, "SPLITK", False)      # (at this small size the 14 x 14 layers would otherwise stay on split-K launches)
+    for fuse in (True, False):
+        monkeypatch.setattr(H, "BNSUMS_WIDE", fuse)
+        before = dict(H.BNSUMS_STATS)
+        model, _ = build_model()
+        x_s, x_t, gt, _ = synth.synth_sp_batch(2, 64, seed=9)
+        model.train()
+        out = model(x_s.to(DEV), x_t.to(DEV))
+        floss()(out, gt.to(DEV).view(out.size())).backward()
+        torch.cuda.synchronize()
+        grads[fuse] = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+        made = (H.BNSUMS_STATS["produced"] - before["produced"], H.BNSUMS_STATS["consumed"] - before["consumed"])
+        assert made == ((16, 16) if fuse else (0, 0)), made
+    worst = max(rel(grads[True][k].numpy(), grads[False][k].numpy()) for k in grads[True]
+                if grads[False][k].abs().max() > 1e-9)
+    print("SP grads, BN sums in the dgrad epilogue vs reduce pass: max rel %.2e" % worst)
+    assert worst < 1e-4
+
+
 def test_graphed_eval_forward_matches_eager_and_follows_weight_updates():
     """egaze_amd.graphs.GraphedModule: the eval-mode SP forward captured into one hipGraph (both encoder streams, the
     split-K launches of the small layers, lazy weight packings built before the capture) replays bit-identically to the

@@ -181,6 +181,38 @@ def test_conv_first_direct_32_filters(C, B, Hh, Ww):
     assert none is None and rel(nchw(y2), ref - b.double().view(1, -1, 1, 1)) < 2e-6
 
 
+@pytest.mark.parametrize("B,Hh,Ww,C,K", [(2, 16, 16, 64, 64), (1, 28, 28, 128, 64), (3, 9, 7, 64, 128), (2, 32, 48, 128, 256),
+                                         (1, 20, 56, 64, 96)])
+def test_dgrad_with_bn_sums_wide(B, Hh, Ww, C, K, monkeypatch):
+    """EPI_BNSUMS on the 64- / 128-column tiles of the streamed kernel (the encoders' conv -> BN -> ReLU -> conv pairs): the data
+    gradient is bit-identical to the plain launch and the two per-channel sums match an fp64 evaluation; patch and raster
+    geometries, a partial last tile."""
+    h = H()
+    monkeypatch.setattr(h, "SPLITK", False)      # (launches with few pixel tiles stay on the split-K form, which has no such epilogue)
+    g = torch.Generator().manual_seed(B * 100 + C)
+    dy = (torch.randn(B, Hh, Ww, K, generator=g) * 1e-3).to(DEV)
+    w = (torch.randn(K, C, 3, 3, generator=g) * 0.05).to(DEV)
+    bn_y = torch.randn(B, Hh, Ww, C, generator=g).to(DEV)
+    coef = torch.stack([bn_y.mean((0, 1, 2)), 1.0 / bn_y.std((0, 1, 2)), torch.rand(C, generator=g).to(DEV) + 0.5,
+                        torch.randn(C, generator=g).to(DEV) * 0.3]).contiguous()
+    assert h.bnsums_ok(B, Hh, Ww, C, K, h.F16X3)
+    wp, st = h.conv_weight(w, "dgrad", h.F16X3, dy, C)
+    assert st
+    dx, sums = h.conv3x3_dgrad_bnsums(dy, wp, C, h.F16X3, bn_y, coef)
+    ref = h.conv3x3_dgrad(dy, wp, C, dtype=h.F16X3, streamed=st)
+    assert torch.equal(dx, ref)
+    assert sums.shape == ((B * Hh * Ww + 127) // 128, 2, C)
+    d64, y64, c64 = dx.double(), bn_y.double(), coef.double()
+    dz = torch.where(y64 * c64[2] + c64[3] > 0, d64, torch.zeros_like(d64))
+    s = sums.sum(0)
+    assert rel(s[0].cpu(), dz.sum((0, 1, 2)).cpu()) < 2e-6
+    assert rel(s[1].cpu(), (dz * (y64 - c64[0]) * c64[1]).sum((0, 1, 2)).cpu()) < 2e-5
+    # ... and they drive the BatchNorm backward of the layer below to the same result as its own reduce pass
+    dyb, dg, db = h.bn_relu_pool_bwd(bn_y, dx, coef, False, sums=sums)
+    dyb0, dg0, db0 = h.bn_relu_pool_bwd(bn_y, dx, coef, False)
+    assert rel(dg.cpu(), dg0.cpu()) < 2e-5 and rel(db.cpu(), db0.cpu()) < 2e-5 and rel(dyb.cpu(), dyb0.cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("B,Hh,Ww,K", [(2, 8, 8, 64), (3, 6, 10, 512), (2, 4, 4, 8)])
 def test_bn_relu_pool(pool, B, Hh, Ww, K):
@@ -836,8 +868,8 @@ def test_cabi_argument_errors_are_loud():
     assert rc != 0
     with pytest.raises(RuntimeError, match="egz_conv3x3_fwd_streamed"):
         h.check(rc, "egz_conv3x3_fwd_streamed")
-    # the BatchNorm-sums epilogue exists for the narrow geometry only
-    rc = h.LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), y.data_ptr(), 2, 16, 16, 64, 64, 5, 1,
+    # the BatchNorm-sums epilogue exists for the narrow geometry and for 64- / 128-column tiles: not for 96 columns
+    rc = h.LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), y.data_ptr(), 2, 16, 16, 64, 96, 5, 1,
                                         0, None, y.data_ptr(), None, y.data_ptr(), None, h._stream())
     with pytest.raises(RuntimeError, match="narrow geometry"):
         h.check(rc, "egz_conv3x3_fwd_streamed")
