@@ -1339,6 +1339,16 @@ int pick_patch_x3(int W, int C, int K, int flags) {
     if (!(flags & 0x2000) || (flags & 0x800) || C % 32 != 0) return 0;
     if (K % 64 != 0 && ((flags & 1) || K > 64 || K % 4 != 0)) return 0;   // K < 64 (late-fusion widths): plain form, masked k-tile
     if (C % 64 != 0 && ((flags & 1) || C != 32)) return 0;       // C = 32 (padded first conv): plain 9-tap form, half c-tile
+    // Large images: the 4 x 8 patch.  A stage stages the patch's halo, (R + 2) x (WD + 2) pixels for 32 outputs: 3.2x for 1 x 32,
+    // 2.25x for 2 x 16, 1.9x for 4 x 8 -- and every staged element costs a fetch from L2 and an f16 split.  On the 224- and
+    // 112-wide layers the squarer patch is 5-10 % faster (64 -> 64 @ 224: 474 -> 441 us, @ 224 decoder: 397 -> 358, 128 -> 128
+    // @ 112: 368 -> 351; profiles/r03_ab_notes.txt); at 56 and below it makes no difference.  EGZ_WGRAD_WD=0: the old rule.
+    static int wide8 = -1;
+    if (wide8 < 0) {
+        const char* e = getenv("EGZ_WGRAD_WD");
+        wide8 = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    if (wide8 && W >= 112 && W % 8 == 0) return 8;
     if (W % 32 == 0 || (W > 16 && W < 32)) return 32;
     if (W % 16 == 0 || (W > 8 && W < 16)) return 16;
     if (W % 8 == 0) return 8;
