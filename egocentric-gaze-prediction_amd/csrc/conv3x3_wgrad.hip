@@ -1357,6 +1357,7 @@ int pick_patch_x3(int W, int C, int K, int flags) {
 // narrow split-half kernel (C, K <= 32, plain conv): run width of its 64-pixel patch (0 = not applicable)
 int pick_narrow_x3(int W, int C, int K, int flags) {
     if (!(flags & 0x2000) || (flags & 0x801) || C > 32 || K > 32) return 0;
+    // (a 4 x 16 patch where a 2 x 32 one fits measured the same on the late-fusion step: 1.30 vs 1.31 ms)
     return (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : 0;
 }
 long npatch_x3n(int B, int H, int W, int WD) { return (long)B * ((H + 64 / WD - 1) / (64 / WD)) * (W / WD); }
