@@ -818,14 +818,15 @@ namespace {
 // contiguous pixel range 32 pixels at a time; its partial sums are reduced over the pixel lanes with wave shuffles and over the
 // four waves through LDS, in a fixed order, and written as one partial row; first_wgrad_rows_kernel sums the rows in fp64.
 constexpr int FWG_BLOCKS = 1024;
-template <int CIN, int PX, bool FIN>      // PX = horizontally adjacent pixels per thread (4 when W % 4 == 0, see conv_first_direct_kernel)
+// KQ = filter quads = K / 4: 8 (late fusion, 32 filters) or 16 (Conv2d(3, 64), the RGB encoder's first layer).
+template <int CIN, int PX, bool FIN, int KQ>      // PX = horizontally adjacent pixels per thread (4 when W % 4 == 0, see conv_first_direct_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_first_wgrad_kernel(
     const float* __restrict__ y, const float* __restrict__ dout, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* mdz, const float* mdzx,
     const float* __restrict__ x, float* __restrict__ part, int B, int H, int W, int ppb, const double* __restrict__ rows,
     int nrows, double count, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    constexpr int K = 32, NT = CIN * 9;
-    __shared__ float red[4][8][NT * 4];
+    constexpr int K = 4 * KQ, NT = CIN * 9, PL = 256 / KQ;
+    __shared__ float red[4][KQ][NT * 4];
     __shared__ double fsum[FIN ? 4 : 1][128];
     __shared__ float fm[2][64];
     if (FIN) {                                                  // the BatchNorm finalize step, redone by every block (see above)
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(256) void bn_bwd_first_wgrad_kernel(
         mdz = fm[0];
         mdzx = fm[1];
     }
-    const int tid = threadIdx.x, k4 = tid & 7, pl = tid >> 3, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, k4 = tid % KQ, pl = tid / KQ, lane = tid & 63, wave = tid >> 6;
     const int HW = H * W, M = B * HW;
     const int m0 = blockIdx.x * ppb, m1 = (m0 + ppb < M) ? m0 + ppb : M;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + k4 * 4), sh = *reinterpret_cast<const f32x4*>(shift + k4 * 4);
@@ -846,7 +847,7 @@ __global__ __launch_bounds__(256) void bn_bwd_first_wgrad_kernel(
         for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
     int m = m0 + pl * PX;                                      // first of the thread's PX pixels (same image row: W % PX == 0)
     int b = m / HW, py = (m - b * HW) / W, px = m - b * HW - py * W;          // advanced by 32 PX pixels per iteration below
-    for (; m < m1; m += 32 * PX) {
+    for (; m < m1; m += PL * PX) {
         f32x4 g[PX], v[PX];
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(256) void bn_bwd_first_wgrad_kernel(
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[c * 9 + t][e] += r[e] * xw[c][t / 3][p + t % 3];
         }
-        px += 32 * PX;
+        px += PL * PX;
         while (px >= W) {
             px -= W;
             if (++py == H) {
@@ -891,16 +892,15 @@ __global__ __launch_bounds__(256) void bn_bwd_first_wgrad_kernel(
             }
         }
     }
-    // pixel lanes of a wave: lane = (pl & 7) * 8 + k4
+    // pixel lanes of a wave: lane = (pl % (64 / KQ)) * KQ + k4
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = acc[t][e];
-            a += __shfl_xor(a, 8);
-            a += __shfl_xor(a, 16);
-            a += __shfl_xor(a, 32);
-            if (lane < 8) red[wave][lane][t * 4 + e] = a;
+#pragma unroll
+            for (int o = KQ; o < 64; o <<= 1) a += __shfl_xor(a, o);
+            if (lane < KQ) red[wave][lane][t * 4 + e] = a;
         }
     __syncthreads();
     // part[block][k][c * 9 + tap]
@@ -953,8 +953,8 @@ EGZ_API int egz_bn_bwd_first_wgrad(const float* y, const float* dout, const floa
                                    int W, int C, int K, void* workspace, size_t ws_bytes, const double* sums, int sums_rows,
                                    hipStream_t st) {
     EGZ_CHECK_ARG(y && dout && scale && shift && mean && invstd && x && dw && workspace, "egz_bn_bwd_first_wgrad: null pointer");
-    EGZ_CHECK_ARG(K == 32 && C >= 1 && C <= 3, "egz_bn_bwd_first_wgrad: covers C <= 3 input channels and 32 filters (got %d -> %d)", C, K);
-    EGZ_CHECK_ARG(B > 0 && H > 0 && W > 0 && (long)B * H * W * 32 < (1l << 31), "egz_bn_bwd_first_wgrad: bad shape");
+    EGZ_CHECK_ARG((K == 32 || K == 64) && C >= 1 && C <= 3, "egz_bn_bwd_first_wgrad: covers C <= 3 input channels and 32 / 64 filters (got %d -> %d)", C, K);
+    EGZ_CHECK_ARG(B > 0 && H > 0 && W > 0 && (long)B * H * W * K < (1l << 31), "egz_bn_bwd_first_wgrad: bad shape");
     EGZ_CHECK_ARG(!sums || sums_rows > 0, "egz_bn_bwd_first_wgrad: sums need sums_rows > 0");
     const size_t need = egz_bn_bwd_first_wgrad_ws_bytes(C, K);
     EGZ_CHECK_ARG(ws_bytes >= need, "egz_bn_bwd_first_wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -968,7 +968,7 @@ EGZ_API int egz_bn_bwd_first_wgrad(const float* y, const float* dout, const floa
     float* mdz = reinterpret_cast<float*>(part2 + (size_t)RED_ROWS * 2 * K);
     float* mdzx = mdz + K;
     float* wpart = reinterpret_cast<float*>(static_cast<char*>(workspace) + egz_bn_relu_pool_bwd_ws_bytes(K));
-    const bool fin_fused = sums && sums_rows <= FIN_MAX_ROWS && fin_in_kernel();
+    const bool fin_fused = sums && sums_rows <= FIN_MAX_ROWS && K <= 64 && fin_in_kernel();
     if (sums) {
         part = const_cast<double*>(sums);
         blocks = sums_rows;
@@ -989,29 +989,38 @@ EGZ_API int egz_bn_bwd_first_wgrad(const float* y, const float* dout, const floa
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K, (double)npix, dgamma, dbeta, mdz, mdzx);
         EGZ_CHECK_LAUNCH("egz_bn_bwd_first_wgrad(finalize)");
     }
-    const int step = (W % 4 == 0) ? 128 : 32;                  // pixels per block iteration (4 / 1 per thread)
+    // pixels per thread: 4 (W % 4 == 0; C = 3: 2 -- with 108 accumulators the 4-pixel form is left with one wave per SIMD) or 1
+    const int pxt = (C == 3) ? ((W % 2 == 0) ? 2 : 1) : ((W % 4 == 0) ? 4 : 1);
+    const int step = (256 / (K / 4)) * pxt;                    // pixels per block iteration
     int ppb = (int)((npix + FWG_BLOCKS - 1) / FWG_BLOCKS);
     ppb = (ppb + step - 1) / step * step;
     const int nb = (int)((npix + ppb - 1) / ppb);
-#define EGZ_FWG2(CC, PP)                                                                                                         \
+#define EGZ_FWG3(CC, PP, QQ)                                                                                                     \
     do {                                                                                                                         \
         if (fin_fused)                                                                                                           \
-            hipLaunchKernelGGL((bn_bwd_first_wgrad_kernel<CC, PP, true>), dim3(nb), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, \
+            hipLaunchKernelGGL((bn_bwd_first_wgrad_kernel<CC, PP, true, QQ>), dim3(nb), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, \
                                (const float*)nullptr, (const float*)nullptr, x, wpart, B, H, W, ppb, sums, sums_rows, (double)npix, dgamma, dbeta); \
         else                                                                                                                     \
-            hipLaunchKernelGGL((bn_bwd_first_wgrad_kernel<CC, PP, false>), dim3(nb), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, \
+            hipLaunchKernelGGL((bn_bwd_first_wgrad_kernel<CC, PP, false, QQ>), dim3(nb), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, \
                                mdz, mdzx, x, wpart, B, H, W, ppb, (const double*)nullptr, 0, 1.0, (float*)nullptr, (float*)nullptr); \
+    } while (0)
+#define EGZ_FWG2(CC, PP)                                                                                                         \
+    do {                                                                                                                         \
+        if (K == 32) EGZ_FWG3(CC, PP, 8);                                                                                        \
+        else EGZ_FWG3(CC, PP, 16);                                                                                               \
     } while (0)
 #define EGZ_FWG(CC)                                                                                                              \
     do {                                                                                                                         \
-        if (W % 4 == 0) EGZ_FWG2(CC, 4);                                                                                         \
+        if (pxt == 4) EGZ_FWG2(CC, 4);                                                                                           \
         else EGZ_FWG2(CC, 1);                                                                                                    \
     } while (0)
     if (C == 1) EGZ_FWG(1);
     else if (C == 2) EGZ_FWG(2);
-    else EGZ_FWG(3);
+    else if (pxt == 2) EGZ_FWG2(3, 2);
+    else EGZ_FWG2(3, 1);
 #undef EGZ_FWG
 #undef EGZ_FWG2
+#undef EGZ_FWG3
     EGZ_CHECK_LAUNCH("egz_bn_bwd_first_wgrad(apply + wgrad)");
     const int n = K * C * 9;
     hipLaunchKernelGGL(first_wgrad_rows_kernel, dim3(egz_cdiv(n, 16)), dim3(256), 0, st, wpart, dw, nb, n);

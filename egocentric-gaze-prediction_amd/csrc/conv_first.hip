@@ -129,28 +129,30 @@ constexpr int FD_BLOCKS = 512;          // one round at two resident blocks per 
 // PX = horizontally adjacent pixels per thread (4 when W % 4 == 0: the 3 x (PX + 2) input window of a channel is read once for
 // the four of them -- 9 instead of 18 tap loads, bounds checks and address computations per pixel; the one-pixel form spent
 // more issue slots on those than on the 72 FMAs and ran at 1.9 TB/s).
-template <int CIN, int PX, bool STATS>
+// KQ = filter quads = K / 4: 8 (the late-fusion conv, 32 filters) or 16 (Conv2d(3, 64), the RGB encoder's first layer,
+// utils.py:70 at SP.py:53): thread = (pixel lane tid / KQ, quad tid % KQ), 256 / KQ pixel lanes per block.
+template <int CIN, int PX, bool STATS, int KQ>
 __global__ __launch_bounds__(256) void conv_first_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
     double* __restrict__ stat, int B, int H, int W, int ppb, float* __restrict__ mm_out) {
-    constexpr int K = 32, NT = CIN * 9;
-    __shared__ double red[4][8][8];
-    __shared__ float rmm[4][8][8];
+    constexpr int K = 4 * KQ, NT = CIN * 9, PL = 256 / KQ;
+    __shared__ double red[4][KQ][8];
+    __shared__ float rmm[4][KQ][8];
     float vmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, vmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-    const int tid = threadIdx.x, k4 = tid & 7, pl = tid >> 3, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, k4 = tid % KQ, pl = tid / KQ, lane = tid & 63, wave = tid >> 6;
     const int HW = H * W, M = B * HW;
     const int m0 = blockIdx.x * ppb, m1 = (m0 + ppb < M) ? m0 + ppb : M;
     float wr[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) wr[t][e] = w[(long)(k4 * 4 + e) * NT + t];          // w: (32, CIN, 3, 3)
+        for (int e = 0; e < 4; ++e) wr[t][e] = w[(long)(k4 * 4 + e) * NT + t];          // w: (K, CIN, 3, 3)
     f32x4 bz = {0.f, 0.f, 0.f, 0.f};
     if (bias) bz = *reinterpret_cast<const f32x4*>(bias + k4 * 4);
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     int m = m0 + pl * PX;                                      // first of the thread's PX pixels (same image row: W % PX == 0)
     int b = m / HW, py = (m - b * HW) / W, px = m - b * HW - py * W;
-    for (; m < m1; m += 32 * PX) {
+    for (; m < m1; m += PL * PX) {
         float xw[CIN][3][PX + 2];
         const float* xb = x + (long)b * CIN * HW + (long)py * W + px;
 #pragma unroll
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_first_direct_kernel(
                 s2[e] += (double)q2[e];
             }
         }
-        px += 32 * PX;
+        px += PL * PX;
         while (px >= W) {
             px -= W;
             if (++py == H) {
@@ -207,28 +209,27 @@ __global__ __launch_bounds__(256) void conv_first_direct_kernel(
             }
         }
     }
-    if (STATS) {
+    if (STATS) {                                                // lane = (pixel lane % (64 / KQ)) * KQ + quad
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             double a = s1[e], q = s2[e];
-            a += __shfl_xor(a, 8);  q += __shfl_xor(q, 8);
-            a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
-            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
-            if (lane < 8) {
+            float hi = vmx[e], lo = vmn[e];
+#pragma unroll
+            for (int o = KQ; o < 64; o <<= 1) {
+                a += __shfl_xor(a, o);
+                q += __shfl_xor(q, o);
+                hi = fmaxf(hi, __shfl_xor(hi, o));
+                lo = fminf(lo, __shfl_xor(lo, o));
+            }
+            if (lane < KQ) {
                 red[wave][lane][e] = a;
                 red[wave][lane][4 + e] = q;
-            }
-            float hi = vmx[e], lo = vmn[e];
-            hi = fmaxf(hi, __shfl_xor(hi, 8));  lo = fminf(lo, __shfl_xor(lo, 8));
-            hi = fmaxf(hi, __shfl_xor(hi, 16)); lo = fminf(lo, __shfl_xor(lo, 16));
-            hi = fmaxf(hi, __shfl_xor(hi, 32)); lo = fminf(lo, __shfl_xor(lo, 32));
-            if (lane < 8) {
                 rmm[wave][lane][e] = hi;
                 rmm[wave][lane][4 + e] = lo;
             }
         }
         __syncthreads();
-        if (tid < 2 * K) {
+        if (tid < 2 * K) {                                      // (K <= 64: at most 128 of the 256 threads)
             const int which = tid / K, col = tid % K;
             double t = 0.0;
 #pragma unroll
@@ -253,10 +254,10 @@ inline bool first_direct_ok(int C, int K) {
         const char* e = getenv("EGZ_FIRST_DIRECT");          // A/B knob: 0 = the im2col + fp32 MFMA kernel for every shape
         on = (e && e[0] == '0') ? 0 : 1;
     }
-    return on && K == 32 && C >= 1 && C <= 3;
+    return on && (K == 32 || K == 64) && C >= 1 && C <= 3;
 }
-inline int first_direct_ppb(long M, int W) {
-    const int step = (W % 4 == 0) ? 128 : 32;                  // pixels per block iteration (4 / 1 per thread)
+inline int first_direct_ppb(long M, int W, int K) {
+    const int step = (256 / (K / 4)) * ((W % 4 == 0) ? 4 : 1);  // pixels per block iteration (4 / 1 per thread)
     long ppb = (M + FD_BLOCKS - 1) / FD_BLOCKS;
     return (int)((ppb + step - 1) / step * step);
 }
@@ -389,7 +390,7 @@ EGZ_API int egz_conv_first_stat_rows(int B, int H, int W) { return egz_cdiv((lon
 // rows of stat_partial for a given channel configuration (the direct kernel for C <= 3 -> 32 writes one row per block)
 EGZ_API int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K) {
     const long M = (long)B * H * W;
-    if (first_direct_ok(C, K) && M * 32 < (1l << 31)) return egz_cdiv(M, first_direct_ppb(M, W));
+    if (first_direct_ok(C, K) && M * K < (1l << 31)) return egz_cdiv(M, first_direct_ppb(M, W, K));
     return egz_cdiv(M, FM);
 }
 
@@ -398,17 +399,22 @@ EGZ_API int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K) {
 EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, double* stat_partial,
                                int B, int H, int W, int C, int K, float* minmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && w && y, "egz_conv_first_fwd: null pointer");
-    EGZ_CHECK_ARG(!minmax_out || (stat_partial && first_direct_ok(C, K) && (long)B * H * W * 32 < (1l << 31)),
-                  "egz_conv_first_fwd: minmax_out exists on the direct kernel only (C <= 3 -> 32 filters, with stat_partial)");
+    EGZ_CHECK_ARG(!minmax_out || (stat_partial && first_direct_ok(C, K) && (long)B * H * W * K < (1l << 31)),
+                  "egz_conv_first_fwd: minmax_out exists on the direct kernel only (C <= 3 -> 32 / 64 filters, with stat_partial)");
     EGZ_CHECK_ARG(K == 64 || K == 32, "egz_conv_first_fwd: Cout must be 64 or 32 (got %d)", K);
     EGZ_CHECK_ARG(C > 0 && C <= 64 && B > 0 && H > 0 && W > 0, "egz_conv_first_fwd: bad shape");
     const long M = (long)B * H * W;
-    if (first_direct_ok(C, K) && M * 32 < (1l << 31)) {
-        const int ppb = first_direct_ppb(M, W), nb = egz_cdiv(M, ppb);
+    if (first_direct_ok(C, K) && M * K < (1l << 31)) {
+        const int ppb = first_direct_ppb(M, W, K), nb = egz_cdiv(M, ppb);
+#define EGZ_FD3(CC, PP, QQ)                                                                                                    \
+    do {                                                                                                                       \
+        if (stat_partial) hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, true, QQ>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, minmax_out); \
+        else              hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, false, QQ>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, (float*)nullptr); \
+    } while (0)
 #define EGZ_FD2(CC, PP)                                                                                                        \
     do {                                                                                                                       \
-        if (stat_partial) hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, true>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, minmax_out); \
-        else              hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, false>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, (float*)nullptr); \
+        if (K == 32) EGZ_FD3(CC, PP, 8);                                                                                       \
+        else EGZ_FD3(CC, PP, 16);                                                                                              \
     } while (0)
 #define EGZ_FD(CC)                                                                                                             \
     do {                                                                                                                       \
@@ -420,6 +426,7 @@ EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias
         else EGZ_FD(3);
 #undef EGZ_FD
 #undef EGZ_FD2
+#undef EGZ_FD3
         EGZ_CHECK_LAUNCH("egz_conv_first_fwd(direct)");
         return 0;
     }

@@ -840,14 +840,14 @@ FIRST_FUSE = _os.environ.get("EGAZE_FIRST_FUSE", "1") != "0"        # A/B knob o
 
 
 def bn_bwd_first_wgrad_ok(C: int, K: int, pool: bool) -> bool:
-    return bool(FIRST_FUSE and K == 32 and 1 <= C <= 3 and not pool)
+    return bool(FIRST_FUSE and K in (32, 64) and 1 <= C <= 3 and not pool)
 
 
 def bn_bwd_first_wgrad(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, x_nchw: torch.Tensor,
                        out_dgamma: Optional[torch.Tensor] = None, out_dbeta: Optional[torch.Tensor] = None,
                        out_dw: Optional[torch.Tensor] = None, sums: Optional[torch.Tensor] = None):
-    """Backward of the first [Conv2d(C <= 3 -> 32) -> BN(train) -> ReLU] block of the late-fusion stack in one pass over
-    (y, dout): returns (dw (32, C, 3, 3), dgamma, dbeta); the gradient w.r.t. the conv output is never materialised."""
+    """Backward of a first [Conv2d(C <= 3 -> 32 | 64) -> BN(train) -> ReLU] block (the late-fusion stack; the RGB encoder) in one
+    pass over (y, dout): returns (dw (K, C, 3, 3), dgamma, dbeta); the gradient w.r.t. the conv output is never materialised."""
     _req(y, "y"); _req(dout, "dout"); _req(x_nchw, "x")
     B, H, W, K = y.shape
     C = x_nchw.shape[1]

@@ -130,10 +130,11 @@ int egz_conv3x3_wgrad_narrow_ok(int B, int H, int W, int C, int K);
 /* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
  *      per data/STdatas.py:50-73) and Conv2d(2,32) (models/late_fusion.py:10).  K in {64, 32}. */
 int egz_conv_first_stat_rows(int B, int H, int W);
-int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K);   /* rows of stat_partial egz_conv_first_fwd writes for C -> K */
+int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K);   /* rows of stat_partial egz_conv_first_fwd writes for C -> K
+                                                                        * (C <= 3: the direct kernel, one row per block) */
 int egz_conv_first_fwd(const float* x_nchw, const float* w, const float* bias, float* y_nhwc, double* stat_partial,
                        int B, int H, int W, int C, int K, float* minmax_out, hipStream_t stream);
-/* minmax_out (optional; C <= 3 -> 32 filters with stat_partial): [rows][2][32] per-channel max / min of y, rows as
+/* minmax_out (optional; C <= 3 with stat_partial): [rows][2][K] per-channel max / min of y, rows as
  * stat_partial -- input of egz_bn_finalize_deferred. */
 size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C);
 int egz_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw, int B, int H, int W, int C, int K,
@@ -164,8 +165,8 @@ int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, 
                          const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int K,
                          int pool, void* workspace, size_t ws_bytes, unsigned int* absmax, const double* sums,
                          int sums_rows, hipStream_t stream);
-/* Backward of the FIRST block [Conv2d(C -> 32, 3x3) -> BatchNorm2d(train) -> ReLU] of the late-fusion stack
- * (late_fusion.py:10-12, C <= 3; the network input needs no data gradient): dgamma / dbeta and dw (32, C, 3, 3) in one pass
+/* Backward of a FIRST block [Conv2d(C -> K, 3x3) -> BatchNorm2d(train) -> ReLU] with C <= 3 and K = 32 (late_fusion.py:10-12)
+ * or 64 (the RGB encoder, utils.py:70 at SP.py:53; the network input needs no data gradient): dgamma / dbeta and dw (K, C, 3, 3) in one pass
  * over y (pre-BN conv output, NHWC) and dout, x = the block input [B][C][H][W]; the gradient w.r.t. the conv output is never
  * stored.  sums / sums_rows as for egz_bn_relu_pool_bwd. */
 size_t egz_bn_bwd_first_wgrad_ws_bytes(int C, int K);

@@ -194,18 +194,19 @@ def test_deferred_batchnorm_matches_materialised():
     assert worst < 2e-5
 
 
-@pytest.mark.parametrize("B,C,Hh,Ww", [(2, 2, 48, 48), (3, 2, 13, 20), (1, 3, 40, 72), (2, 1, 16, 16), (2, 2, 9, 13), (1, 2, 224, 224)])
-def test_first_block_backward_in_one_pass(B, C, Hh, Ww):
+@pytest.mark.parametrize("B,C,Hh,Ww,K", [(2, 2, 48, 48, 32), (3, 2, 13, 20, 32), (1, 3, 40, 72, 32), (2, 1, 16, 16, 32), (2, 2, 9, 13, 32),
+                                         (1, 2, 224, 224, 32), (2, 3, 48, 48, 64), (1, 3, 13, 21, 64), (1, 3, 224, 224, 64), (2, 2, 16, 20, 64)])
+def test_first_block_backward_in_one_pass(B, C, Hh, Ww, K):
     """bn_bwd_first_wgrad (BatchNorm backward + weight gradient of the first late-fusion conv without storing the gradient
     w.r.t. the conv output) against fp64 autograd of Conv2d(C -> 32) -> BatchNorm2d(train) -> ReLU; ragged sizes (rows shorter
     than the 32-pixel step, a partial last block)."""
     from egaze_amd import hipops as H
     g = torch.Generator().manual_seed(B * 1000 + Hh)
     x = torch.randn(B, C, Hh, Ww, generator=g)
-    w = (torch.randn(32, C, 3, 3, generator=g) * 0.3).double().requires_grad_(True)
-    gamma = (torch.rand(32, generator=g) + 0.5).double().requires_grad_(True)
-    beta = (torch.randn(32, generator=g) * 0.2).double().requires_grad_(True)
-    dout = torch.randn(B, 32, Hh, Ww, generator=g)
+    w = (torch.randn(K, C, 3, 3, generator=g) * 0.3).double().requires_grad_(True)
+    gamma = (torch.rand(K, generator=g) + 0.5).double().requires_grad_(True)
+    beta = (torch.randn(K, generator=g) * 0.2).double().requires_grad_(True)
+    dout = torch.randn(B, K, Hh, Ww, generator=g)
     y = F.conv2d(x.double(), w, None, padding=1)
     out = F.relu(F.batch_norm(y, None, None, gamma, beta, training=True, eps=1e-5))
     out.backward(dout.double())

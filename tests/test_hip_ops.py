@@ -162,18 +162,19 @@ def test_conv_first(C, B, Hh, Ww):
     assert rel(dw.cpu(), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("K", [32, 64])
 @pytest.mark.parametrize("C", [1, 2, 3])
 @pytest.mark.parametrize("B,Hh,Ww", [(2, 16, 16), (1, 13, 21), (3, 48, 80), (1, 224, 224)])
-def test_conv_first_direct_32_filters(C, B, Hh, Ww):
+def test_conv_first_direct_32_filters(C, B, Hh, Ww, K):
     """The direct kernel of the first late-fusion conv (C <= 3 -> 32 filters, models/late_fusion.py:10) against fp64: output,
     BN partial sums (one row per block), with and without the statistics epilogue; ragged widths shorter than the 32-pixel step."""
     h = H()
     x = rnd(B, C, Hh, Ww, seed=21)
-    w = rnd(32, C, 3, 3, seed=22, scale=(2.0 / (9 * C)) ** 0.5)
-    b = rnd(32, seed=23, scale=0.1)
+    w = rnd(K, C, 3, 3, seed=22, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=23, scale=0.1)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     y, stat = h.conv_first_fwd(x.to(DEV), w.to(DEV), b.to(DEV), True)
-    assert stat.shape[0] == h.LIB.egz_conv_first_stat_rows_for(B, Hh, Ww, C, 32) <= 512
+    assert stat.shape[0] == h.LIB.egz_conv_first_stat_rows_for(B, Hh, Ww, C, K) <= 512
     assert rel(nchw(y), ref) < 2e-6
     s = stat.sum(0).cpu()
     assert rel(s[0], ref.sum(dim=(0, 2, 3))) < 1e-6 and rel(s[1], (ref ** 2).sum(dim=(0, 2, 3))) < 1e-6
