@@ -848,6 +848,169 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             o_vo[mr][r] = nok ? (unsigned)((((i >> 4) * W + (i & 15)) * K + l31) * 4) : 0xFFFFFFFFu;
         }
 
+#ifndef EGZ_X3P_PIPE
+#define EGZ_X3P_PIPE 1
+#endif
+#if EGZ_X3P_PIPE
+    // ---- software-pipelined tile loop.  The block is alone on its CU with one wave per SIMD, so nothing overlaps a wave's own
+    // phases: fetch -> MFMAs -> epilogue (32 stores, statistics) -> split + LDS stores of the next halo -> barrier ran back to
+    // back.  Here the 108 MFMAs of tile i are issued in 18 groups of six, and behind each group goes a piece of the OTHER work:
+    // two epilogue elements of tile i - 1 (its accumulators were copied aside) and, in the second half, one piece of the halo
+    // of tile i + 1 (requested at the top of the iteration).  The first iteration has no previous tile: its side stores / loads
+    // go through a zero-length buffer resource (dropped / zero) and its statistics terms are zero.  Measured: -10 % on the
+    // 32 -> 8 layer, -3..5 % on the data gradients, nothing on the 32 -> 32 forward (profiles/r03_ab_notes.txt) -- the launches
+    // sit at 3.3-3.7 TB/s with one tile's loads in flight per CU; a second halo register set (two tiles in flight) spilled and
+    // was slower.
+    auto lstore_piece = [&](const int abuf, const int j) {
+        u32x2 hi, lo;
+        if (BNIN) {
+            const float ms = ((ra_ok >> j) & 1u) ? a_scale : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf(__builtin_fmaf(ra[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
+            Half<T>::split4(ra[j], hi, lo);
+        } else {
+            Half<T>::split4(ra[j] * a_scale, hi, lo);
+        }
+        unsigned short* d = Ah + abuf * ABUF + a_lds[j];
+        *reinterpret_cast<u32x2*>(d) = hi;
+        *reinterpret_cast<u32x2*>(d + APL) = lo;
+    };
+    static_assert(NJ <= 12, "one halo piece per MFMA group of the second half");
+    f32x16 pacc[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pacc[i][r] = 0.f;
+    unsigned pso = 0;
+    bool have_prev = false;                                     // block-uniform
+    gload_a(tile);
+    lstore_a(0);
+    lds_barrier();
+    int buf = 0;
+    for (;;) {
+        const int nxt = tile + nbx;
+        const bool more = nxt < t_end;                          // block-uniform
+        if (more) gload_a(nxt);
+        const int pbytes = have_prev ? obytes : 0;
+        const __amdgpu_buffer_rsrc_t py_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, pbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t pbn_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(EPI == EPI_BNSUMS ? bn_y : y), 0, pbytes, 0x00020000);
+        const float pbz = have_prev ? bz : 0.f;
+        float byp[MR][16];
+        if (EPI == EPI_BNSUMS) {                                // the previous tile's values of the pre-BN tensor below
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    byp[mr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pbn_rs, o_vo[mr][r], pso, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the 32 elements of a tile are summed in fp32 and added to the fp64 block sums once per tile: 4 double-precision
+        // instructions per tile instead of 128 (the kernel is issue-bound: ~980 vector instructions per 108 MFMAs, SQ counters)
+        float q1 = 0.f, q2 = 0.f;
+        auto epi_elem = [&](const int mr, const int r) {
+            float v = pacc[mr][r] * out_scale + pbz;
+            if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), py_rs, o_vo[mr][r], pso, 0);
+            if (EPI == EPI_BIAS_STATS) {
+                q1 += v;
+                q2 += v * v;
+                vmx = fmaxf(vmx, have_prev ? v : -INFINITY);
+                vmn = fminf(vmn, have_prev ? v : INFINITY);
+            }
+            if (EPI == EPI_BNSUMS) {
+                const float yp = byp[mr][r];
+                const float dz = (yp * bn_sc + bn_sh > 0.f) ? v : 0.f;
+                q1 += dz;
+                q2 += dz * ((yp - bn_mu) * bn_is);
+            }
+        };
+        f32x16 acc[MR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // the activation fragments of group g + 1 are read from LDS before the MFMAs of group g (two register sets): a lone wave
+        // has nobody to hide its own LDS latency behind
+        u32x4 fh[2][MR], fl[2][MR];
+        auto frag_read = [&](const int g, u32x4 (&h)[MR], u32x4 (&l)[MR]) {
+            const int t = g >> 1, ks = g & 1;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                const int a = (fa9[t] + buf * (ABUF * 2) + mr * MRSTEP) ^ (ks * 32);
+                h[mr] = *reinterpret_cast<const u32x4*>(Ab + a);
+                l[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + a);
+            }
+        };
+        frag_read(0, fh[0], fl[0]);
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            const int t = g >> 1, ks = g & 1;
+            if (g + 1 < 18) frag_read(g + 1, fh[(g + 1) & 1], fl[(g + 1) & 1]);
+            u32x4 (&ah)[MR] = fh[g & 1];
+            u32x4 (&al)[MR] = fl[g & 1];
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+                    acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bq[t][ks * 2 + 1] : bq[t][ks * 2], acc[mr]);
+            if (g < 16) {                                       // two epilogue elements of the previous tile
+                epi_elem((2 * g) >> 4, (2 * g) & 15);
+                epi_elem((2 * g + 1) >> 4, (2 * g + 1) & 15);
+            }
+            if (g >= 18 - NJ) lstore_piece(buf ^ 1, g - (18 - NJ));      // (stale registers when there is no next tile: harmless)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (EPI == EPI_BIAS_STATS || EPI == EPI_BNSUMS) {
+            s1 += (double)q1;
+            s2 += (double)q2;
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i) pacc[i] = acc[i];
+        {
+            const int b0 = tile / ppi, rem = tile - b0 * ppi;
+            const int y0 = (rem / pw) * 16, x0 = (rem % pw) * 16;
+            pso = (unsigned)((((long)b0 * H + y0) * W + x0) * K * 4);
+        }
+        have_prev = true;
+        if (!more) break;
+        lds_barrier();                                          // everyone has staged its share and is done reading `buf`
+        buf ^= 1;
+        tile = nxt;
+    }
+    {   // ---- epilogue of the last tile
+        float byp[MR][16];
+        if (EPI == EPI_BNSUMS) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    byp[mr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bn_rs, o_vo[mr][r], pso, 0));
+        }
+        float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = pacc[mr][r] * out_scale + bz;
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, o_vo[mr][r], pso, 0);
+                if (EPI == EPI_BIAS_STATS) {
+                    q1 += v;
+                    q2 += v * v;
+                    vmx = fmaxf(vmx, v);
+                    vmn = fminf(vmn, v);
+                }
+                if (EPI == EPI_BNSUMS) {
+                    const float yp = byp[mr][r];
+                    const float dz = (yp * bn_sc + bn_sh > 0.f) ? v : 0.f;
+                    q1 += dz;
+                    q2 += dz * ((yp - bn_mu) * bn_is);
+                }
+            }
+        s1 += (double)q1;
+        s2 += (double)q2;
+    }
+#else
     gload_a(tile);
     lstore_a(0);
     lds_barrier();
@@ -930,6 +1093,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
         buf ^= 1;
         tile = nxt;
     }
+#endif
     if (EPI == EPI_BIAS_STATS || EPI == EPI_BNSUMS) {            // row blockIdx.x: the four waves' sums in wave order
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
