@@ -957,6 +957,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
                 epi_elem((2 * g) >> 4, (2 * g) & 15);
                 epi_elem((2 * g + 1) >> 4, (2 * g + 1) & 15);
             }
+            // (all pieces in the last NJ / 2 groups, two per group, measured the same: the halo fetch is not what the wave waits for)
             if (g >= 18 - NJ) lstore_piece(buf ^ 1, g - (18 - NJ));      // (stale registers when there is no next tile: harmless)
             __builtin_amdgcn_sched_barrier(0);
         }
