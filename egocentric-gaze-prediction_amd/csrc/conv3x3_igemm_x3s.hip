@@ -582,9 +582,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                                                       ok ? (unsigned)(off + col) * 4u : 0xFFFFFFFFu, 0, 0);
                 const float vs = ok ? v : 0.f;
                 if (EPI == EPI_BIAS_RELU) amx = fmaxf(amx, vs);                  // (post-ReLU: vs >= 0)
-                if (EPI == EPI_BIAS_STATS) {
-                    s1 += (double)vs;
-                    s2 += (double)vs * (double)vs;
+                if (EPI == EPI_BIAS_STATS) {                   // (fp64 per element: the variance is a difference of these two
+                    s1 += (double)vs;                          //  sums, and fp32 partial sums over 16 rows already cost the
+                    s2 += (double)vs * (double)vs;             //  gradients their fp32-class accuracy -- test_model_sp_grads_vs_fp64)
                 }
                 continue;
             }
@@ -904,16 +904,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
                     byp[mr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pbn_rs, o_vo[mr][r], pso, 0));
         }
         __builtin_amdgcn_sched_barrier(0);
-        // the 32 elements of a tile are summed in fp32 and added to the fp64 block sums once per tile: 4 double-precision
-        // instructions per tile instead of 128 (the kernel is issue-bound: ~980 vector instructions per 108 MFMAs, SQ counters)
+        // EPI_BNSUMS: the 32 elements of a tile are summed in fp32 and added to the fp64 block sums once per tile -- 4
+        // double-precision instructions per tile instead of 128 (the kernel is issue-bound: ~980 vector instructions per 108
+        // MFMAs, SQ counters).  The forward statistics stay fp64 per element (their difference is the variance).
         float q1 = 0.f, q2 = 0.f;
         auto epi_elem = [&](const int mr, const int r) {
             float v = pacc[mr][r] * out_scale + pbz;
             if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), py_rs, o_vo[mr][r], pso, 0);
-            if (EPI == EPI_BIAS_STATS) {
-                q1 += v;
-                q2 += v * v;
+            if (EPI == EPI_BIAS_STATS) {                       // (fp64 per element: the variance is a difference of the two sums)
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
                 vmx = fmaxf(vmx, have_prev ? v : -INFINITY);
                 vmn = fminf(vmn, have_prev ? v : INFINITY);
             }
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             if (g >= 18 - NJ) lstore_piece(buf ^ 1, g - (18 - NJ));      // (stale registers when there is no next tile: harmless)
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (EPI == EPI_BIAS_STATS || EPI == EPI_BNSUMS) {
+        if (EPI == EPI_BNSUMS) {
             s1 += (double)q1;
             s2 += (double)q2;
         }
@@ -996,8 +997,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, o_vo[mr][r], pso, 0);
                 if (EPI == EPI_BIAS_STATS) {
-                    q1 += v;
-                    q2 += v * v;
+                    s1 += (double)v;
+                    s2 += (double)v * (double)v;
                     vmx = fmaxf(vmx, v);
                     vmn = fminf(vmn, v);
                 }
@@ -1008,8 +1009,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
                     q2 += dz * ((yp - bn_mu) * bn_is);
                 }
             }
-        s1 += (double)q1;
-        s2 += (double)q2;
+        if (EPI == EPI_BNSUMS) {
+            s1 += (double)q1;
+            s2 += (double)q2;
+        }
     }
 #else
     gload_a(tile);
