@@ -247,7 +247,9 @@ class ConvBNReLUPool(torch.autograd.Function):
                         dw = H.conv3x3_wgrad(xin, dy, out=sw, x_bn=x_bn)
         if not WGRAD_AFTER_DGRAD:
             dx = data_grad()
-        _close_fork(f, sw, dw, xin, dy)
+        # (the coefficient rows of a deferred input are read by the detached weight-gradient kernel too: keep them alive for it)
+        _close_fork(f, sw, dw, xin, dy, (bn_coef if bn_coef is not None else getattr(ctx, "deferred_coef", None))
+                    if ctx.deferred_in else None)
         return (dx, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
                 _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None, None)
 
