@@ -77,6 +77,7 @@ class GradReducer:
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self.handle_of = {}                          # bucket -> async handle of its collective (optim._OverlappedTail waits on it)
         if getattr(self, "events", None):
             self.last_events, self.events = self.events, []      # the finished step's bucket events (record_events)
 
@@ -96,6 +97,7 @@ class GradReducer:
             with torch.cuda.stream(comm):
                 self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
+                self.handle_of[b] = self._handles[-1]
                 if self.record_events:
                     # the library runs the collective on its own stream, ordered after `comm`; the handle's wait() orders a
                     # stream after the collective -- make `comm` wait and mark that point
@@ -106,6 +108,14 @@ class GradReducer:
             return
         self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True))
+        self.handle_of[b] = self._handles[-1]
+
+    def ensure_launched(self, b: int):
+        """Issue bucket b's collective now if its hook has not done so yet (the optimizer's overlapped tail steps a bucket as
+        soon as its gradients are final and needs the reduced values; hooks of one parameter run in registration order)."""
+        if self.active and not self._launched[b]:
+            self._launch(b)
+        return self.handle_of.get(b)
 
     def _make_hook(self, i: int):
         b = self.bucket_of[i]
@@ -155,6 +165,10 @@ class GradReducer:
         if optimizer is not None and self.wait in optimizer.pre_step_hooks:
             optimizer.pre_step_hooks.remove(self.wait)
             optimizer.grad_scale = 1.0
+        if optimizer is not None and getattr(optimizer, "_reducer", None) is self:
+            optimizer._reducer = None
+            if getattr(optimizer, "_tail", None) is not None:
+                optimizer._tail.adopt(None)
         self.active = False
 
 
@@ -168,6 +182,9 @@ def attach(optimizer, bucket_bytes: int = 25 * 1024 * 1024, group=None, force: O
     if red.active:
         from . import hipops
         hipops.bump_weight_epoch()          # parameters were overwritten by the broadcast
+        optimizer._reducer = red            # the overlapped optimizer tail steps a bucket right behind its all-reduce
+        if getattr(optimizer, "_tail", None) is not None:
+            optimizer._tail.adopt(red)
     return red
 
 

@@ -27,6 +27,11 @@ from . import streams
 # are final (gradient-sink hooks, as dp.GradReducer does for the all-reduce) instead of as one 0.22 ms HBM-bound kernel plus
 # ~70 pack launches between the backward pass and the next forward.  Element-wise identical to the single launch.
 _OVERLAP = os.environ.get("EGAZE_OVERLAP_ADAM", "1") != "0"
+# The overlapped tail under data parallelism (each bucket stepped on the side stream right behind its own all-reduce,
+# _OverlappedTail.adopt).  Bit-identical to reduce-then-step (tests/test_hip_dp.py) but measured slightly SLOWER at world size 1
+# over RCCL (33.33 vs 32.94 ms per step, no reducer: 31.26 -- the cost of the data-parallel path there is the collectives'
+# own kernels and stream joins, not the optimizer tail), and not measurable here at N > 1: opt-in, EGAZE_DP_TAIL=1.
+_DP_TAIL = os.environ.get("EGAZE_DP_TAIL", "0") != "0"
 
 
 class _OverlappedTail:
@@ -34,6 +39,18 @@ class _OverlappedTail:
 
     def __init__(self, opt):
         self.opt = opt
+        self.stream = None
+        self.enabled = False
+        self.reducer = None
+        self.stats = {"in_backward": 0, "in_finish": 0}       # buckets stepped under the backward pass / in step()
+        self._own_buckets()
+        for i, p in enumerate(opt.params):
+            p._egz_sink.hooks.append(self._make_hook(i))
+        if getattr(opt, "_reducer", None) is not None:
+            self.adopt(opt._reducer)
+
+    def _own_buckets(self):
+        opt = self.opt
         order = sorted(range(len(opt.params)), key=lambda i: opt.offsets[i], reverse=True)      # backward order
         self.buckets, self.bucket_of = [], {}
         cur, cur_end, cur_start = [], None, None
@@ -49,11 +66,24 @@ class _OverlappedTail:
                 cur, cur_end = [], None
         if cur:
             self.buckets.append((cur_start, cur_end, cur))
-        self.stream = None
-        self.enabled = False
         self._reset()
-        for i, p in enumerate(opt.params):
-            p._egz_sink.hooks.append(self._make_hook(i))
+
+    def adopt(self, reducer):
+        """Data parallel: take over the gradient reducer's buckets (dp.GradReducer cuts them the same way, in backward order),
+        so that a bucket is stepped right behind ITS all-reduce: the tail makes the reducer issue the bucket's collective as
+        soon as the bucket's gradients are final, lets the side stream wait for that collective's handle, and runs the Adam
+        slice (1 / world folded in) and the repacking there -- under the rest of the backward pass, as at world size 1.
+        ``None``: back to the tail's own buckets."""
+        self.reducer = reducer
+        if reducer is None:
+            self._own_buckets()
+            return
+        idx = [[] for _ in reducer.buckets]
+        for i, b in reducer.bucket_of.items():
+            idx[b].append(i)
+        self.buckets = [(reducer.buckets[b][0], reducer.buckets[b][1], idx[b]) for b in range(len(reducer.buckets))]
+        self.bucket_of = dict(reducer.bucket_of)
+        self._reset()
 
     def _reset(self):
         self.fired = [False] * len(self.opt.params)
@@ -62,29 +92,39 @@ class _OverlappedTail:
 
     def usable(self) -> bool:
         o = self.opt
-        return (self.enabled and not o.pre_step_hooks and not o.capturable and streams.ENABLED and o.flat_p.is_cuda
+        red = self.reducer
+        # the only pre-step hook the tail can live with is the wait() of the reducer whose buckets it has adopted
+        hooks_ok = ((_DP_TAIL and all(getattr(h, "__self__", None) is red for h in o.pre_step_hooks)) if red is not None
+                    else not o.pre_step_hooks)
+        return (self.enabled and hooks_ok and not o.capturable and streams.ENABLED and o.flat_p.is_cuda
                 and not torch.cuda.is_current_stream_capturing())
 
     def _make_hook(self, i):
-        b = self.bucket_of[i]
-
         def hook(_param):
             if self.fired[i] or not self.usable():
                 return
+            b = self.bucket_of[i]
             self.fired[i] = True
             self.pending[b] -= 1
             if self.pending[b] == 0 and not self.done[b]:
-                self._launch(b, self.opt.step_count + 1)
+                self._launch(b, self.opt.step_count + 1, in_backward=True)
         return hook
 
-    def _launch(self, b, step):
+    def _launch(self, b, step, in_backward=False):
         o = self.opt
         start, end, idx = self.buckets[b]
         self.done[b] = True
+        self.stats["in_backward" if in_backward else "in_finish"] += 1
         if self.stream is None:
             self.stream = streams.side_stream("adam")
+        handle = None
+        if self.reducer is not None and in_backward:
+            # (from finish() the reducer's wait() has already run: every collective is joined into the stepping stream)
+            handle = self.reducer.ensure_launched(b)
         streams.join_all_into(self.stream, include_comm=False)      # every producer of the bucket's gradients, every reader of its weights
         with torch.cuda.stream(self.stream):
+            if handle is not None:
+                handle.wait()                                       # the side stream continues behind the bucket's all-reduce
             H.adam_step(o.flat_p, o.flat_g, o.flat_m, o.flat_v, o.lr, o.betas[0], o.betas[1], o.eps, step, o.grad_scale,
                         lo=start, hi=end)
             ps = [o.params[i] for i in idx]
@@ -165,7 +205,9 @@ class FusedAdam:
         issued on a side stream as soon as the bucket's gradients are final, i.e. DURING the backward pass (_OverlappedTail).
         Element-wise the same update, but parameters start changing before ``backward()`` returns -- so code that inspects
         parameters between ``backward()`` and ``step()``, or accumulates gradients over several backward passes, must not
-        enable it.  Ignored with a gradient reducer attached (the all-reduce has to come first) and while capturable."""
+        enable it.  With a gradient reducer attached (dp.attach) it is ignored unless EGAZE_DP_TAIL=1, in which case the tail
+        adopts the reducer's buckets and steps each bucket behind its own all-reduce (_OverlappedTail.adopt); ignored while
+        capturable."""
         if on and _OVERLAP:
             if self._tail is None:
                 self._tail = _OverlappedTail(self)
