@@ -39,16 +39,28 @@ def kernel_src_sha():
 
 
 class stdout_to_stderr:
-    """RCCL prints a version banner straight to file descriptor 1 when its first communicator comes up; the contract of this
-    script is ONE JSON line on stdout, so descriptor 1 points at stderr while a process group is initialised / first used."""
+    """RCCL prints a version banner to C stdout when its first communicator comes up; the contract of this script is ONE JSON
+    line on stdout, so descriptor 1 points at stderr while a process group is initialised / first used.  The banner goes through
+    C stdio, which is block-buffered when stdout is a pipe or a file: it has to be flushed BEFORE descriptor 1 is restored, or it
+    surfaces at process exit, after the JSON line."""
+
+    @staticmethod
+    def _flush_c():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
 
     def __enter__(self):
         sys.stdout.flush()
+        self._flush_c()
         self.saved = os.dup(1)
         os.dup2(2, 1)
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c()
         os.dup2(self.saved, 1)
         os.close(self.saved)
         return False
