@@ -90,6 +90,8 @@ SIGNATURES = {
     "egz_conv1x1_sigmoid_fwd": (c_int, [P, P, P, P, P, c_long, c_int, S]),
     "egz_conv1x1_sigmoid_bwd_ws_bytes": (c_size_t, [c_int]),
     "egz_conv1x1_sigmoid_bwd": (c_int, [P, P, P, P, P, P, P, c_long, c_int, P, c_size_t, S]),
+    "egz_conv1x1_sigmoid_bwd_rows": (c_int, [c_long, c_int]),
+    "egz_conv1x1_sigmoid_bwd_masked": (c_int, [P, P, P, P, P, P, P, P, P, c_long, c_int, P, c_size_t, S]),
     "egz_loss_ws_bytes": (c_size_t, [c_int]),
     "egz_floss_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, S]),
     "egz_floss_bwd": (c_int, [P, P, P, P, P, c_long, S]),

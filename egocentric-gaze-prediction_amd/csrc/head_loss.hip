@@ -6,6 +6,8 @@
 //     (SP.py:103-106 `--loss_function` switch).
 #include "egz_common.h"
 
+EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st);      // bn_pool.hip
+
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
@@ -34,16 +36,23 @@ __global__ __launch_bounds__(256) void conv1x1_sigmoid_fwd_kernel(const float* _
 }
 
 // dlogit = dout*out*(1-out); dx[m][c] = dlogit*w[c]; partial dw[c] = sum_m dlogit*x[m][c]; partial db = sum dlogit
-template <int LPP>
+// MASK: x is the post-ReLU output of the conv block below (models/model_SP.py:28-30: Conv2d 3x3 -> ReLU -> Conv2d 1x1).  The
+// ReLU backward of that block, the column sums of the masked gradient (= its bias gradient) and max |dx| for the f16 scaling
+// of its conv backward are taken here, where x is in registers anyway -- the standalone pass (egz_relu_bwd_bias: 1.2 GB per
+// step at batch 32, nothing to overlap with at the head of the backward pass) goes away.  mstat: [gridDim.x][C] fp64 partial
+// rows, absmax: partial slots 1 + blockIdx.x (folded by egz_absmax_fold).
+template <int LPP, bool MASK>
 __global__ __launch_bounds__(256) void conv1x1_sigmoid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ out, const float* __restrict__ dout,
-                                                                  float* __restrict__ dx, double* __restrict__ part, long M) {
+                                                                  float* __restrict__ dx, double* __restrict__ part, long M,
+                                                                  double* __restrict__ mstat, unsigned int* __restrict__ absmax) {
     constexpr int C = LPP * 4;
     __shared__ double red[256 / LPP][C + 1];
     const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + sub * 4);
     const long ppb = blockDim.x / LPP;
     double aw[4] = {0, 0, 0, 0}, ab = 0.0;
+    float ms[4] = {0.f, 0.f, 0.f, 0.f}, amx = 0.f;
     for (long m = blockIdx.x * ppb + grp; m < M; m += (long)gridDim.x * ppb) {
         const float o = out[m];
         const float dl = dout[m] * o * (1.f - o);
@@ -51,7 +60,14 @@ __global__ __launch_bounds__(256) void conv1x1_sigmoid_bwd_kernel(const float* _
         if (dx) {
             f32x4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = dl * wv[e];
+            for (int e = 0; e < 4; ++e) {
+                r[e] = dl * wv[e];
+                if (MASK) {
+                    r[e] = v[e] > 0.f ? r[e] : 0.f;
+                    ms[e] += r[e];
+                    amx = fmaxf(amx, fabsf(r[e]));
+                }
+            }
             *reinterpret_cast<f32x4*>(dx + m * C + sub * 4) = r;
         }
 #pragma unroll
@@ -66,6 +82,22 @@ __global__ __launch_bounds__(256) void conv1x1_sigmoid_bwd_kernel(const float* _
         double t = 0.0;
         for (int g = 0; g < 256 / LPP; ++g) t += red[g][i];
         part[(long)blockIdx.x * (C + 1) + i] = t;
+    }
+    if (MASK) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[grp][sub * 4 + e] = (double)ms[e];
+        __shared__ float s_am[4];
+        for (int off = 32; off > 0; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off));
+        if ((threadIdx.x & 63) == 0) s_am[threadIdx.x >> 6] = amx;
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += blockDim.x) {
+            double t = 0.0;
+            for (int g = 0; g < 256 / LPP; ++g) t += red[g][i];
+            mstat[(long)blockIdx.x * C + i] = t;
+        }
+        if (threadIdx.x == 0)
+            absmax[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(s_am[0], s_am[1]), fmaxf(s_am[2], s_am[3])));
     }
 }
 
@@ -290,18 +322,36 @@ EGZ_API int egz_conv1x1_sigmoid_fwd(const float* x, const float* w, const float*
     return 0;
 }
 
+// blocks of the backward launch = rows of its partial-sum workspaces
+EGZ_API int egz_conv1x1_sigmoid_bwd_rows(long M, int C) {
+    const long g = (M * (C / 4) + 255) / 256;
+    return (int)(g > HEAD_BLOCKS ? HEAD_BLOCKS : (g < 1 ? 1 : g));
+}
 EGZ_API size_t egz_conv1x1_sigmoid_bwd_ws_bytes(int C) { return (size_t)HEAD_BLOCKS * (C + 1) * sizeof(double); }
 
-// dout: gradient w.r.t. the sigmoid output [M]; dx may be null.  dw: (1,C,1,1), db: (1,).
-EGZ_API int egz_conv1x1_sigmoid_bwd(const float* x, const float* w, const float* out, const float* dout, float* dx,
-                                    float* dw, float* db, long M, int C, void* workspace, size_t ws_bytes,
-                                    hipStream_t st) {
-    EGZ_CHECK_ARG(x && w && out && dout && dw && workspace, "egz_conv1x1_sigmoid_bwd: null pointer");
-    EGZ_CHECK_ARG(ws_bytes >= egz_conv1x1_sigmoid_bwd_ws_bytes(C), "egz_conv1x1_sigmoid_bwd: workspace too small");
+static int head_bwd_launch(const float* x, const float* w, const float* out, const float* dout, float* dx, float* dw, float* db,
+                           long M, int C, void* workspace, size_t ws_bytes, double* mstat, unsigned int* absmax,
+                           hipStream_t st, const char* what) {
+    if (!(x && w && out && dout && dw && workspace)) {
+        egz_set_error("%s: null pointer", what);
+        return (int)hipErrorInvalidValue;
+    }
+    if (ws_bytes < egz_conv1x1_sigmoid_bwd_ws_bytes(C)) {
+        egz_set_error("%s: workspace too small", what);
+        return (int)hipErrorInvalidValue;
+    }
     double* part = static_cast<double*>(workspace);
-    long g = (M * (C / 4) + 255) / 256;
-    const int grid = (int)(g > HEAD_BLOCKS ? HEAD_BLOCKS : g);
-#define EGZ_HEAD_BWD(L) hipLaunchKernelGGL(conv1x1_sigmoid_bwd_kernel<L>, dim3(grid), dim3(256), 0, st, x, w, out, dout, dx, part, M)
+    const int grid = egz_conv1x1_sigmoid_bwd_rows(M, C);
+    const bool mask = mstat != nullptr;
+#define EGZ_HEAD_BWD(L)                                                                                                   \
+    do {                                                                                                                  \
+        if (mask)                                                                                                         \
+            hipLaunchKernelGGL((conv1x1_sigmoid_bwd_kernel<L, true>), dim3(grid), dim3(256), 0, st, x, w, out, dout, dx,  \
+                               part, M, mstat, absmax);                                                                   \
+        else                                                                                                              \
+            hipLaunchKernelGGL((conv1x1_sigmoid_bwd_kernel<L, false>), dim3(grid), dim3(256), 0, st, x, w, out, dout, dx, \
+                               part, M, mstat, absmax);                                                                   \
+    } while (0)
     switch (C) {
         case 8: EGZ_HEAD_BWD(2); break;
         case 16: EGZ_HEAD_BWD(4); break;
@@ -309,13 +359,34 @@ EGZ_API int egz_conv1x1_sigmoid_bwd(const float* x, const float* w, const float*
         case 64: EGZ_HEAD_BWD(16); break;
         case 128: EGZ_HEAD_BWD(32); break;
         case 256: EGZ_HEAD_BWD(64); break;
-        default: egz_set_error("egz_conv1x1_sigmoid_bwd: unsupported C=%d", C); return (int)hipErrorInvalidValue;
+        default: egz_set_error("%s: unsupported C=%d", what, C); return (int)hipErrorInvalidValue;
     }
 #undef EGZ_HEAD_BWD
-    EGZ_CHECK_LAUNCH("egz_conv1x1_sigmoid_bwd");
+    EGZ_CHECK_LAUNCH(what);
     hipLaunchKernelGGL(head_bwd_final_kernel, dim3(egz_cdiv(C + 1, 8)), dim3(256), 0, st, part, grid, C, dw, db);
-    EGZ_CHECK_LAUNCH("egz_conv1x1_sigmoid_bwd(final)");
+    EGZ_CHECK_LAUNCH(what);
     return 0;
+}
+
+// dout: gradient w.r.t. the sigmoid output [M]; dx may be null.  dw: (1,C,1,1), db: (1,).
+EGZ_API int egz_conv1x1_sigmoid_bwd(const float* x, const float* w, const float* out, const float* dout, float* dx,
+                                    float* dw, float* db, long M, int C, void* workspace, size_t ws_bytes,
+                                    hipStream_t st) {
+    return head_bwd_launch(x, w, out, dout, dx, dw, db, M, C, workspace, ws_bytes, nullptr, nullptr, st,
+                           "egz_conv1x1_sigmoid_bwd");
+}
+
+// The same with the ReLU backward of the block that produced x (x = its post-ReLU output) applied to dx:
+// dx = (x > 0) ? dlogit * w : 0;  mstat: [egz_conv1x1_sigmoid_bwd_rows(M, C)][C] fp64 partial rows whose column sums are that
+// block's bias gradient (egz_colsum_f64);  absmax: an egz_absmax_elems() buffer, slot 0 = max |dx| on return.
+EGZ_API int egz_conv1x1_sigmoid_bwd_masked(const float* x, const float* w, const float* out, const float* dout, float* dx,
+                                           float* dw, float* db, double* mstat, unsigned int* absmax, long M, int C,
+                                           void* workspace, size_t ws_bytes, hipStream_t st) {
+    EGZ_CHECK_ARG(dx && mstat && absmax, "egz_conv1x1_sigmoid_bwd_masked: null pointer");
+    int rc = head_bwd_launch(x, w, out, dout, dx, dw, db, M, C, workspace, ws_bytes, mstat, absmax, st,
+                             "egz_conv1x1_sigmoid_bwd_masked");
+    if (rc) return rc;
+    return egz_absmax_fold(absmax, egz_conv1x1_sigmoid_bwd_rows(M, C), st);
 }
 
 EGZ_API size_t egz_loss_ws_bytes(int B) { return (size_t)LOSS_BLOCKS * sizeof(double) + (size_t)2 * B * sizeof(double); }

@@ -392,11 +392,16 @@ class FusionBlock(torch.autograd.Function):
 
 
 class HeadSigmoid(torch.autograd.Function):
+    """Conv2d 1x1 (C -> 1) -> Sigmoid.  ``relu_below``: the input is the output of a ConvReLU block (the decoder's last
+    3x3 conv, models/model_SP.py:28-32); its ReLU backward, bias-gradient sums and abs-max are then taken in this node's
+    backward kernel and handed down as ``_egz_premasked`` (see ConvReLU) instead of a 1.2 GB pass of their own."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu_below=False):
         xin = to_nhwc(x)
         out, _ = H.conv1x1_sigmoid_fwd(xin, H._req(weight.detach(), "weight"), bias.detach() if bias is not None else None)
         ctx.save_for_backward(xin, out, weight, bias)
+        ctx.relu_below = bool(relu_below)
         B, Hh, Ww = out.shape
         return out.view(B, 1, Hh, Ww)
 
@@ -405,10 +410,16 @@ class HeadSigmoid(torch.autograd.Function):
         xin, out, weight, bias = ctx.saved_tensors
         ng = ctx.needs_input_grad
         sw, sb = H.grad_sink(weight, ng[1]), H.grad_sink(bias, ng[2] and bias is not None)
+        if ctx.relu_below and ng[0] and H.MASK_FUSE and H.HEAD_MASK_FUSE:
+            dx, dw, db, stat, am = H.conv1x1_sigmoid_bwd_masked(xin, weight.detach(), out, dout.contiguous(), out_dw=sw,
+                                                                out_db=sb)
+            d = from_nhwc(dx)
+            d._egz_premasked = (stat, am if H._want_absmax() else None)
+            return d, _finish(weight, sw, dw if ng[1] else None), _finish(bias, sb, db if ng[2] else None), None
         dx, dw, db = H.conv1x1_sigmoid_bwd(xin, weight.detach(), out, dout.contiguous(), need_dx=ng[0], out_dw=sw,
                                            out_db=sb)
         return (from_nhwc(dx) if dx is not None else None, _finish(weight, sw, dw if ng[1] else None),
-                _finish(bias, sb, db if ng[2] else None))
+                _finish(bias, sb, db if ng[2] else None), None)
 
 
 class FlossLoss(torch.autograd.Function):

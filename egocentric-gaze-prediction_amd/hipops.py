@@ -566,6 +566,7 @@ EPI_MASK_SUMS = 3
 # load.  With the branch-free epilogue (buffer loads / stores with out-of-range offsets for invalid rows, round 3) the step
 # is 0.55 ms faster with it (32.6 vs 33.15 ms, profiles/r03_ab_notes.txt), so it is the default; EGAZE_MASK_FUSE=0 = A/B.
 MASK_FUSE = _os.environ.get("EGAZE_MASK_FUSE", "1") != "0"
+HEAD_MASK_FUSE = _os.environ.get("EGAZE_HEAD_MASK_FUSE", "1") != "0"   # the same for the block under the 1x1 head (A/B knob)
 MASK_FUSE_STATS = {"produced": 0, "consumed": 0}                 # how often the fused form ran / was picked up (tests)
 
 
@@ -1003,6 +1004,26 @@ def conv1x1_sigmoid_bwd(x, w, out, dout, need_dx: bool = True, out_dw=None, out_
                                       dw.data_ptr(), db.data_ptr(), M, C, ws.data_ptr(), ws.numel(), _stream()),
           "egz_conv1x1_sigmoid_bwd")
     return dx, dw, db
+
+
+def conv1x1_sigmoid_bwd_masked(x, w, out, dout, out_dw=None, out_db=None):
+    """Head backward with the ReLU backward of the conv block below folded in (x = that block's post-ReLU output):
+    -> (dx masked, dw, db, stat rows (rows, C) fp64 whose column sums are the block's bias gradient, abs-max buffer of dx) --
+    the ``_egz_premasked`` hand-over of conv3x3_dgrad_masked (functions.ConvReLU.backward)."""
+    _req(x, "x"); _req(out, "out"); _req(dout, "dout")
+    C = x.shape[-1]
+    M = x.numel() // C
+    dx = torch.empty_like(x)
+    dw = _out(out_dw, (1, C, 1, 1), x.device)
+    db = _out(out_db, (1,), x.device)
+    ws = workspace(LIB.egz_conv1x1_sigmoid_bwd_ws_bytes(C), x.device)
+    stat = torch.empty((int(LIB.egz_conv1x1_sigmoid_bwd_rows(M, C)), C), dtype=torch.float64, device=x.device)
+    amo = _new_absmax(x.device)
+    check(LIB.egz_conv1x1_sigmoid_bwd_masked(x.data_ptr(), w.data_ptr(), out.data_ptr(), dout.data_ptr(), dx.data_ptr(),
+                                             dw.data_ptr(), db.data_ptr(), stat.data_ptr(), amo.data_ptr(), M, C,
+                                             ws.data_ptr(), ws.numel(), _stream()), "egz_conv1x1_sigmoid_bwd_masked")
+    MASK_FUSE_STATS["produced"] += 1
+    return dx, dw, db, stat, amo
 
 
 def floss_fwd(inp: torch.Tensor, target: torch.Tensor, weighted: bool = True):

@@ -104,7 +104,7 @@ class FusedSequential(nn.Sequential):
             elif isinstance(m, nn.Conv2d) and m.kernel_size == (1, 1) and m.out_channels == 1 and i == n - 1:
                 if not fuse_sigmoid:
                     raise NotImplementedError("the 1x1 head runs fused with the Sigmoid that follows it")
-                x = HeadSigmoid.apply(x, m.weight, m.bias)
+                x = HeadSigmoid.apply(x, m.weight, m.bias, relu_below)
                 i += 1
             else:
                 raise NotImplementedError(f"layer pattern at index {i} ({type(m).__name__}) is not on the HIP path")

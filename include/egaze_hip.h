@@ -216,6 +216,14 @@ int egz_conv1x1_sigmoid_fwd(const float* x, const float* w, const float* bias, f
 size_t egz_conv1x1_sigmoid_bwd_ws_bytes(int C);
 int egz_conv1x1_sigmoid_bwd(const float* x, const float* w, const float* out, const float* dout, float* dx, float* dw,
                             float* db, long M, int C, void* workspace, size_t ws_bytes, hipStream_t stream);
+/* The same with the ReLU backward of the block below folded in, for `Conv2d 3x3 -> ReLU -> Conv2d 1x1 -> Sigmoid`
+ * (models/model_SP.py:28-32): x is that block's post-ReLU output, dx = (x > 0) ? dlogit * w : 0.  mstat: fp64 partial rows
+ * [egz_conv1x1_sigmoid_bwd_rows(M, C)][C] whose column sums (egz_colsum_f64) are the 3x3 conv's bias gradient; absmax: an
+ * egz_absmax_elems() buffer, slot 0 = max |dx| on return.  Replaces the autograd ReLU-backward pass between the two convs. */
+int egz_conv1x1_sigmoid_bwd_rows(long M, int C);
+int egz_conv1x1_sigmoid_bwd_masked(const float* x, const float* w, const float* out, const float* dout, float* dx, float* dw,
+                                   float* db, double* mstat, unsigned int* absmax, long M, int C, void* workspace,
+                                   size_t ws_bytes, hipStream_t stream);
 
 /* ---- floss.forward / build_weight_from_target (floss.py:9-41): W = width / (||p - centroid(argmax set)|| + 1),
  *      F.binary_cross_entropy(input, target, W) with torch's -100 log clamp, mean reduction.  weighted = 0 gives

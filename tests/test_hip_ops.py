@@ -309,6 +309,37 @@ def test_head_sigmoid(C):
     assert rel(dw.cpu(), w.grad) < 1e-5 and rel(db.cpu(), b.grad) < 1e-5
 
 
+@pytest.mark.parametrize("C,B,Hh,Ww", [(64, 2, 9, 11), (64, 3, 40, 56), (8, 2, 9, 11)])
+def test_head_sigmoid_masked_backward(C, B, Hh, Ww):
+    """Head backward with the ReLU backward of the block below folded in (egz_conv1x1_sigmoid_bwd_masked) against the two-pass
+    form it replaces (egz_conv1x1_sigmoid_bwd, then egz_relu_bwd_bias) and against autograd of
+    sigmoid(conv1x1(relu(y))) w.r.t. y (models/model_SP.py:28-32): dx bit-identical to the two-pass form, the bias-gradient
+    sums and the weight gradient to fp32 round-off, max |dx| exact."""
+    h = H()
+    y = rnd(B, C, Hh, Ww, seed=31).requires_grad_(True)
+    w = rnd(1, C, 1, 1, seed=32, scale=0.2).requires_grad_(True)
+    b = torch.tensor([0.1], requires_grad=True)
+    ref = torch.sigmoid(F.conv2d(torch.relu(y), w, b))
+    dout = rnd(B, 1, Hh, Ww, seed=33)
+    ref.backward(dout)
+    a = nhwc(torch.relu(y.detach()))                 # the block's post-ReLU output (what ConvReLU saves)
+    wd, bd, dd = w.detach().to(DEV), b.detach().to(DEV), dout[:, 0].contiguous().to(DEV)
+    out, _ = h.conv1x1_sigmoid_fwd(a, wd, bd)
+    dx0, dw0, db0 = h.conv1x1_sigmoid_bwd(a, wd, out, dd)
+    dz0, dbias0 = h.relu_bwd_bias(a, dx0)
+    dx, dw, db, stat, am = h.conv1x1_sigmoid_bwd_masked(a, wd, out, dd)
+    assert torch.equal(dx, dz0)
+    assert torch.equal(dw, dw0) and torch.equal(db, db0)
+    dbias = h.colsum_f64(stat, C)
+    assert rel(dbias, dbias0) < 1e-6
+    assert rel(dbias.cpu(), nchw(dx).sum((0, 2, 3))) < 1e-5
+    assert rel(nchw(dx), y.grad) < 1e-5
+    assert rel(dw.cpu(), w.grad) < 1e-5 and rel(db.cpu(), b.grad) < 1e-5
+    torch.cuda.synchronize()
+    got = am[:1].view(torch.float32).item()
+    assert got == dx.abs().max().item()
+
+
 def test_adam_matches_oracle():
     from oracle import egaze_oracle as O
     h = H()
