@@ -93,11 +93,16 @@ template <int WM> struct Geo {
 // wait for vmcnt(0).  lgkmcnt(0) = this wave's LDS reads / writes are done; the "memory" clobber pins the compiler.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-enum { PLAIN = 0, UPSD = 1 };
+enum { PLAIN = 0, UPSD = 1, UPSF = 2 };
 
 // wq: fragment-ordered split weights (see the header); x: [B][H][W][C] fp32 (the gathered operand);
 // MODE PLAIN: y [B][H][W][K] = conv3x3(x);  MODE UPSD: y [B][H/2][W/2][K] = the data gradient of [nearest x2 upsample ->
 // conv3x3] w.r.t. the LOW-res input, x = the hi-res dy (see the UPSD notes in front of the image loop).
+// MODE UPSF: y [B][H][W][K] = conv3x3(nearest x2 upsample(x)), x [B][H/2][W/2][C], as four phase convolutions: output pixel
+// (2 yy + p, 2 xx + q) is a 2 x 2-tap convolution of the low-res image with the pre-summed weights of phase (p, q) (kind-7
+// packing) -- 4/9 of the MACs.  A tile is (phase, low-res pixel tile, column tile), the phase innermost in the tile order so that
+// the four phases of a pixel tile meet in one L2; the tap shifts ((a + p - 1, b + q - 1), a, b in {0, 1}) are block-uniform
+// run-time values, the staged image is the plain low-res halo, and the rows go out to the strided hi-res positions.
 template <typename T, int WM, int EPI, bool PATCH, int MODE>
 __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
@@ -110,9 +115,11 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     constexpr int APL = HSLOTS * XLD;                          // elements per plane of an activation image
     constexpr int ABUF = 2 * APL;                              // elements per image (hi + lo)
     constexpr int NIMG = (MODE == UPSD) ? 4 : 1;               // staged images per channel block
-    constexpr int NT = (MODE == UPSD) ? 4 : 9;                 // taps per staged image
-    constexpr int NRING = (MODE == UPSD) ? 2 : 3;              // weight-fragment register sets (NIMG * NT % NRING == 0)
-    static_assert(MODE == PLAIN || WM == 1 || WM == 8 || WM == 16, "the upsample data gradient is built for the 128-column tiles only");
+    constexpr int NT = (MODE == PLAIN) ? 9 : 4;                // taps per staged image
+    constexpr int NRING = (MODE == PLAIN) ? 3 : 2;             // weight-fragment register sets (NIMG * NT % NRING == 0)
+    static_assert(MODE != UPSD || WM == 1 || WM == 8 || WM == 16, "the upsample data gradient is built for the 128-column tiles only");
+    static_assert(MODE != UPSF || ((WM == 1 || WM == 2) && EPI != EPI_PARTIAL && EPI != EPI_BIAS_STATS && EPI != EPI_MASK_SUMS && EPI != EPI_BNSUMS),
+                  "the upsample forward is built for the 4-wave 128- / 64-column tiles, bias / bias + ReLU epilogues");
     __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
     __shared__ long Ro[BM];
     __shared__ double sred[(RPW < 128) ? 4 * 2 * 32 : 1];       // BN partial sums of the waves that share a 128-row stat row
@@ -131,9 +138,11 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     if (gts >= total) return;
     const int split = (EPI == EPI_PARTIAL) ? gts % nsplit : 0;
     const int gt = (EPI == EPI_PARTIAL) ? gts / nsplit : gts;
-    const int tile_n = gt % ntn, tile_m = gt / ntn;
+    const int phase = (MODE == UPSF) ? (gt & 3) : 0, ph_p = phase >> 1, ph_q = phase & 1;    // UPSF: block-uniform
+    const int gtl = (MODE == UPSF) ? (gt >> 2) : gt;
+    const int tile_n = gtl % ntn, tile_m = gtl / ntn;
     const int n0 = tile_n * BN;
-    const int Ho = (MODE == UPSD) ? (H >> 1) : H, Wo = (MODE == UPSD) ? (W >> 1) : W;     // output image
+    const int Ho = (MODE != PLAIN) ? (H >> 1) : H, Wo = (MODE != PLAIN) ? (W >> 1) : W;   // image the tile's pixel rows live in
     const long HW = (long)Ho * Wo, M = (long)B * HW;
     const long m0 = (long)tile_m * BM;
     const int pw = Wo >> 4, ppi = (Ho / G::PROWS) * pw;         // patches per row / per image
@@ -142,7 +151,18 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 
     for (int i = tid; i < BM; i += NTHR) {
         long off = -1;
-        if (PATCH) off = (((long)b0 * Ho + y0 + (i >> 4)) * Wo + x0 + (i & 15)) * K;
+        if (MODE == UPSF) {                                    // low-res pixel (b, yy, xx) -> hi-res (2 yy + p, 2 xx + q)
+            int ob = b0, yy = y0 + (i >> 4), xx = x0 + (i & 15);
+            bool ok = true;
+            if (!PATCH) {
+                ok = m0 + i < M;
+                ob = (int)((m0 + i) / HW);
+                const int rem = (int)((m0 + i) - (long)ob * HW);
+                yy = rem / Wo;
+                xx = rem - yy * Wo;
+            }
+            if (ok) off = (((long)ob * H + 2 * yy + ph_p) * W + 2 * xx + ph_q) * K;
+        } else if (PATCH) off = (((long)b0 * Ho + y0 + (i >> 4)) * Wo + x0 + (i & 15)) * K;
         else if (m0 + i < M) off = (m0 + i) * K;
         Ro[i] = off;
     }
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // D_pq[yy][xx] = dy[2 yy + p][2 xx + q] -- an Ho x Wo image whose pixel (yy, xx) sits at a byte offset that is affine
     // in (p, q): the map below is built for (p, q) = (0, 0) and a component is selected by ONE scalar offset.
     const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
+        const_cast<float*>(x), 0, (int)((unsigned)B * ((MODE == UPSF) ? Ho * Wo : H * W) * C * 4u), 0x00020000);
     const int a_c4 = tid & 7;
     // The single-image configurations (64- and 32-column tiles) run at the register limit: their LDS staging addresses are
     // recomputed at each use from an opaque copy of the slot base (12 registers less; ~10 integer ops per staged slot, twelve
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             }
         }
         if ((unsigned)iy < (unsigned)Ho && (unsigned)ix < (unsigned)Wo)
-            pix = (MODE == UPSD) ? ((long)ib * H + 2 * iy) * W + 2 * ix : ((long)ib * H + iy) * W + ix;
+            pix = (MODE == UPSD) ? ((long)ib * H + 2 * iy) * W + 2 * ix : ((long)ib * Ho + iy) * Wo + ix;
         if (a_c4 * 4 >= C) pix = -1;                           // C < 32 (one zero-padded channel block): channels past C read zeros
         a_vo[j] = (pix >= 0) ? (unsigned)((pix * C + a_c4 * 4) * 4) : 0xFFFFFFFFu;
         if constexpr (!LDS_RECOMP) a_lds[j] = q * XLD + (((a_c4 >> 1) ^ ((col >> 2) & 3)) << 3) + (a_c4 & 1) * 4;
@@ -206,8 +226,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     const int c_lo = (EPI == EPI_PARTIAL) ? (split * ncb) / nsplit : 0;
     const int c_hi = (EPI == EPI_PARTIAL) ? ((split + 1) * ncb) / nsplit : ncb;
     const int S_lo = c_lo * NIMG * NT, S_hi = c_hi * NIMG * NT;
+    // (UPSF: the four phases' packings follow each other, S slices each)
     const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(wq), 0, (int)((unsigned)S * nt32 * 4096u), 0x00020000);
+        const_cast<unsigned short*>(wq) + (long)phase * S * nt32 * 2048, 0, (int)((unsigned)S * nt32 * 4096u), 0x00020000);
     const unsigned b_vo = (unsigned)lane * 16u;
     const unsigned b_tile = (unsigned)(tile_n * NWN + wn) * 4096u;
     u32x4 bq[NRING][4];                                         // [ring][ks * 2 + plane]
@@ -224,6 +245,10 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // and a row whose shifted pixel falls outside the image (per-group validity mask) reads the all-zero slot instead.
     // The per-tap value is recomputed from an opaque base every slice: hoisting all 36 of them costs more registers than
     // the kernel has.
+    // (dy + 1, dx + 1) of table entry t: the nine shifts of a 3 x 3 window, or -- UPSF -- the four taps of this block's phase
+    auto tap_dy1 = [&](const int t) -> int { return (MODE == UPSF) ? (t >> 1) + ph_p : t / 3; };
+    auto tap_dx1 = [&](const int t) -> int { return (MODE == UPSF) ? (t & 1) + ph_q : t % 3; };
+    constexpr int NTAB = (MODE == UPSF) ? 4 : 9;
     int fa9[9];
     int sl0 = wm * RPW + l31 + Wo + 1;
     unsigned vmask[MR];
@@ -232,8 +257,8 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     if (PATCH) {
         const int i = wm * RPW + l31;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int dy = t / 3 - 1, dx = t % 3 - 1;
+        for (int t = 0; t < NTAB; ++t) {
+            const int dy = tap_dy1(t) - 1, dx = tap_dx1(t) - 1;
             const int slot = ((i >> 4) + 1 + dy) * HPITCH + (i & 15) + 1 + dx, col = (i & 15) + 1 + dx;
             fa9[t] = (slot * XLD + ((hl ^ ((col >> 2) & 3)) << 3)) * 2;
         }
@@ -244,8 +269,8 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             const int rem = (int)(m % HW), py = rem / Wo, px = rem - py * Wo;
             unsigned mk = 0;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
+            for (int t = 0; t < NTAB; ++t) {
+                const int dy = tap_dy1(t) - 1, dx = tap_dx1(t) - 1;
                 mk |= (m < M && (unsigned)(py + dy) < (unsigned)Ho && (unsigned)(px + dx) < (unsigned)Wo) ? (1u << t) : 0u;
             }
             vmask[mr] = mk;
@@ -259,7 +284,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             if constexpr (LDS_RECOMP) {                        // (register-limited configurations: the table entry is recomputed)
                 int i = wm * RPW + l31;
                 asm volatile("" : "+v"(i));
-                const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+                const int dy = tap_dy1(t9) - 1, dx = tap_dx1(t9) - 1;
                 const int col = (i & 15) + 1 + dx, slot = ((i >> 4) + 1 + dy) * HPITCH + col;
                 f = (slot * XLD + ((hl ^ ((col >> 2) & 3)) << 3)) * 2 + abuf * (ABUF * 2);
             } else {
@@ -271,7 +296,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         } else {
             int base = sl0;
             asm volatile("" : "+v"(base));
-            const int dy = t9 / 3 - 1, dx = t9 % 3 - 1;
+            const int dy = tap_dy1(t9) - 1, dx = tap_dx1(t9) - 1;
             const int slot = base + dy * Wo + dx;
             const int a = slot * (XLD * 2) + ((hl ^ ((slot >> 2) & 3)) << 4) + abuf * (ABUF * 2);
             const int z = HZERO * (XLD * 2) + (hl << 4) + abuf * (ABUF * 2);          // the all-zero slot
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // four upsample data gradients ran at half the rate of the plain convolutions (profiles/r02_conv_microbench.txt)
     constexpr bool FINE = (G::NABUF == 2) && (WM == 16 || EGZ_X3S_FINE_ALL);   // instruction-level interleave of a slice (main loop)
     // (the interleaved loop fetches half 1 of an upsample-dgrad image in the same tap that splits half 0: two register sets)
-    constexpr int RAOFF = (MODE == UPSD && (EGZ_UPSD_PIPE || FINE)) ? NJ / 2 : 0;
+    constexpr int RAOFF = (NT == 4 && (EGZ_UPSD_PIPE || FINE)) ? NJ / 2 : 0;
     f32x4 ra[NJ / 2 + RAOFF];
     auto gload_a = [&](int cblk, const int img, const int half) {
         const unsigned so = (unsigned)(cblk * XBK * 4) +
@@ -483,7 +508,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                         read_a0(shift_of(nimg, 0), abuf ^ 1);
                     }
                 } else {
-                    if (more && t == 6) gload_a(ncblk, nimg, 0);
+                    if (more && t == NT - 3) gload_a(ncblk, nimg, 0);
                     if (t < NT - 1) read_a0(shift_of(img, t + 1), 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -524,7 +549,8 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // basic block and the wait-count pass put s_waitcnt vmcnt(0) in front of each one -- 32-64 stores per wave, each waiting
     // for the previous one to be acknowledged.  (The output is < 4 GiB: egz_conv3x3_streamed_ok.)
     constexpr bool BUFST = EGZ_X3S_BUFSTORE && EPI != EPI_PARTIAL;
-    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
+    constexpr unsigned OUTMUL = (MODE == UPSF) ? 4u : 1u;       // UPSF: y is the hi-res image, four output pixels per tile-image pixel
+    const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, BUFST ? (int)(OUTMUL * (unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mk_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>((EPI == EPI_MASK_SUMS || EPI == EPI_BNSUMS) ? mask_src : y), 0, BUFST ? (int)((unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
 #pragma unroll
@@ -671,6 +697,8 @@ __device__ __forceinline__ float weff9s(const float* __restrict__ w9, int py, in
 __device__ __forceinline__ float frag_value(const float* __restrict__ w, int C, int K, int kind, int si, int n, int k) {
     if (kind == 4) return (n < K && k < C) ? w[((long)n * C + k) * 9 + si] : 0.f;
     if (kind == 5) return (n < C && k < K) ? w[((long)k * C + n) * 9 + (8 - si)] : 0.f;
+    if (kind == 7)       // forward of [upsample x2 -> conv]: si = phase (p, q) * 4 + tap (a, b), the 'ups_fwd' pre-summed taps
+        return (n < K && k < C) ? weff9s(w + ((long)n * C + k) * 9, (si >> 2) >> 1, (si & 3) >> 1, (si >> 2) & 1, si & 1) : 0.f;
     if (!(n < C && k < K)) return 0.f;
     const int img = si >> 2, tap = si & 3;
     const int oy = 2 * (tap >> 1) - (img >> 1), ox = 2 * (tap & 1) - (img & 1);        // ty - 1, tx - 1
@@ -682,14 +710,18 @@ __device__ __forceinline__ float frag_value(const float* __restrict__ w, int C, 
 template <typename T>
 __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wq,
                                                              int C, int K, int kind, int Np, int Rp, float scale) {
-    const int nt32 = Np >> 5, spb = (kind == 6) ? 16 : 9;      // slices per channel block
-    const long n = (long)(Rp / XBK) * spb * nt32 * 1024;      // values (each has a hi and a lo half)
+    const int nt32 = Np >> 5, spb = (kind == 6) ? 16 : (kind == 7) ? 4 : 9;      // slices per channel block
+    const int ncb = Rp / XBK;
+    const long n = (long)ncb * ((kind == 7) ? 16 : spb) * nt32 * 1024;      // values (each has a hi and a lo half)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
         const long r = i >> 10;
         const int ntile = (int)(r % nt32);
         const int s = (int)(r / nt32);
-        const int cblk = s / spb, tap = s - cblk * spb;
+        // kind 7: [phase][channel block][tap] -- one phase's slices are contiguous (a tile of the kernel runs one phase)
+        const int ph = (kind == 7) ? s / (ncb * 4) : 0, sl = s - ph * ncb * 4;
+        const int cblk = sl / spb;
+        const int tap = (kind == 7) ? ph * 4 + (sl - cblk * spb) : sl - cblk * spb;
         const int col = ntile * 32 + (lane & 31), k = cblk * XBK + ks * 16 + (lane >> 5) * 8 + e;
         unsigned short h, l;
         Half<T>::split(frag_value(w, C, K, kind, tap, col, k) * scale, h, l);
@@ -1290,17 +1322,24 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
                int W, int C, int K, float out_scale, const unsigned int* a_absmax, const float* mask_src,
                unsigned int* absmax_out, hipStream_t st) {
     using G = Geo<WM>;
-    const int Ho = (MODE == UPSD) ? H / 2 : H, Wo = (MODE == UPSD) ? W / 2 : W;
+    const int Ho = (MODE != PLAIN) ? H / 2 : H, Wo = (MODE != PLAIN) ? W / 2 : W;
     const long M = (long)B * Ho * Wo;
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
     const bool patch = (Wo % 16 == 0) && (Ho % G::PROWS == 0);
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
-    const int total = mt * (Kp / G::BN);
+    const int total = mt * (Kp / G::BN) * ((MODE == UPSF) ? 4 : 1);
     const dim3 grid(((total + 7) / 8) * 8);
 #define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1)
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS) absmax_out = nullptr;
     if (absmax_out) EGZ_CHECK_ARG(total <= 16384, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
-    if (epi == EPI_BNSUMS) {
+    if constexpr (MODE == UPSF) {                                   // decoder blocks: bias + ReLU (or plain bias)
+        if (epi != EPI_BIAS && epi != EPI_BIAS_RELU) {
+            egz_set_error("egz_conv3x3_fwd_streamed: the upsample forward has the bias and bias + ReLU epilogues only");
+            return (int)hipErrorInvalidValue;
+        }
+        if (patch) { if (epi == EPI_BIAS) EGZ_X3S(EPI_BIAS, true); else EGZ_X3S(EPI_BIAS_RELU, true); }
+        else       { if (epi == EPI_BIAS) EGZ_X3S(EPI_BIAS, false); else EGZ_X3S(EPI_BIAS_RELU, false); }
+    } else if (epi == EPI_BNSUMS) {
         if constexpr ((WM == 1 || WM == 2) && MODE == PLAIN) {      // data gradients of the encoders: 128- / 64-column 4-wave tiles
             if (patch) EGZ_X3S(EPI_BNSUMS, true); else EGZ_X3S(EPI_BNSUMS, false);
         } else {
@@ -1308,7 +1347,7 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
             return (int)hipErrorInvalidValue;
         }
     } else if (epi == EPI_MASK_SUMS) {
-        if constexpr (WM == 1 || WM == 2) {      // data gradients of the SP decoder: 128- and 64-column 4-wave tiles
+        if constexpr ((WM == 1 || WM == 2) && MODE != UPSF) {      // data gradients of the SP decoder: 128- and 64-column 4-wave tiles
             if (patch) EGZ_X3S(EPI_MASK_SUMS, true); else EGZ_X3S(EPI_MASK_SUMS, false);
         } else {
             egz_set_error("egz_conv3x3_fwd_streamed: the mask epilogue is not built for 32-column tiles");
@@ -1337,10 +1376,24 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 // input, H x W = the hi-res gradient image (both even), 128-column tiles only; mode | 0x10: on the 8-wave 256 x 128 tile; mode | 0x20: on the 4-wave 256 x 128 tile with one wave
 // per SIMD (8 accumulator tiles per wave).  Needs the split-half channel constraints
 // and either the patch geometry or a raster run whose halo fits the LDS image (on the OUTPUT image: H/2 x W/2 in mode 1).
+// mode 2: forward of [nearest x2 upsample -> conv3x3] as four phase convolutions, H x W = the hi-res output image (both even),
+// K % 64 == 0, C % 32 == 0, 4-wave tiles on the low-res image.
 EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode) {
     const bool tile8 = (mode & 0x30) != 0;                              // a 256 x 128 tile: 0x10 = 8 waves, 0x20 = 4 waves x 8 accumulators (K % 128 == 0 only)
     mode &= 0xF;
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || mode < 0 || mode > 1) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || mode < 0 || mode > 2) return 0;
+    if (mode == 2) {     // forward of [upsample x2 -> conv]: H x W = the hi-res OUTPUT image; tiles live on the low-res image
+        if (tile8 || K % 64 != 0 || C % 32 != 0 || (H & 1) || (W & 1)) return 0;
+        if (4ull * B * H * W * K >= (1ull << 32)) return 0;
+        H >>= 1;
+        W >>= 1;
+        if (4ull * B * H * W * C >= (1ull << 32)) return 0;
+        if ((long)egz_cdiv((long)B * H * W, K % 128 == 0 ? 128 : 256) * (K % 128 == 0 ? K / 128 : K / 64) * 4 > 16384) return 0;   // abs-max slots
+        const bool small2 = (K % 128 == 0);
+        const int prow2 = small2 ? 8 : 16, bm2 = small2 ? 128 : 256, hzero2 = small2 ? 255 : 383;
+        if (W % 16 == 0 && H % prow2 == 0) return 1;
+        return (bm2 + 2 * W + 2 <= hzero2) ? 1 : 0;
+    }
     if (tile8 && K % 128 != 0) return 0;
     if (!(C % 32 == 0 || (C < 32 && C % 4 == 0))) return 0;            // whole channel blocks, or one zero-padded block
     if (4ull * B * H * W * C >= (1ull << 32)) return 0;
@@ -1368,13 +1421,15 @@ EGZ_API int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K) {
 // Fragment-ordered split packing for the streamed kernel.  kind 4: forward of a (K, C, 3, 3) weight (GEMM columns = K,
 // reduction = C); kind 5: its data gradient (columns = C, reduction = K, taps flipped); kind 6: the data gradient of
 // [upsample x2 -> conv] w.r.t. the low-res input (columns = C, reduction = K, 16 polyphase taps).  dtype 1 = f16 (values
-// pre-scaled by 2^10), 2 = bf16.  wq needs egz_pack_w3x3_elems(C, K, kind == 6) * 4 bytes, like the plane-ordered packings.
+// pre-scaled by 2^10), 2 = bf16.  kind 7: the forward of [upsample x2 -> conv] as four phase convolutions (columns = K,
+// reduction = C, [phase][channel block][2 x 2 pre-summed taps]).  wq needs egz_pack_w3x3_elems(C, K, kind >= 6) * 4 bytes, like
+// the plane-ordered packings.
 EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t st) {
-    EGZ_CHECK_ARG(w && wq && C > 0 && K > 0 && kind >= 4 && kind <= 6 && (dtype == 1 || dtype == 2),
+    EGZ_CHECK_ARG(w && wq && C > 0 && K > 0 && kind >= 4 && kind <= 7 && (dtype == 1 || dtype == 2),
                   "egz_pack_w3x3_split_frag: bad arguments");
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
-    const int Np = (kind == 4) ? Kp : Cp, Rp = (kind == 4) ? Cp : Kp;
-    const long n = (long)(kind == 6 ? 16 : 9) * Np * Rp;
+    const int Np = (kind == 4 || kind == 7) ? Kp : Cp, Rp = (kind == 4 || kind == 7) ? Cp : Kp;
+    const long n = (long)(kind >= 6 ? 16 : 9) * Np * Rp;
     const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
     unsigned short* o = static_cast<unsigned short*>(wq);
     if (dtype == 1) hipLaunchKernelGGL(pack_split_frag_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, F16_WSCALE);
@@ -1448,6 +1503,11 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         }
         if (dtype == 1) return launch_x3s<_Float16, 8, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
         return launch_x3s<__bf16, 8, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+    }
+    if (mode == 2) {     // forward of [upsample x2 -> conv] (kind-7 packing): f16 x3 only (the forward arithmetic)
+        EGZ_CHECK_ARG(dtype == 1, "egz_conv3x3_fwd_streamed: the upsample forward runs in f16 x3 (dtype 1)");
+        if (K % 128 == 0) return launch_x3s<_Float16, 1, UPSF>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        return launch_x3s<_Float16, 2, UPSF>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
     if (mode == 1) {
         if (dtype == 1) return launch_x3s<_Float16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);

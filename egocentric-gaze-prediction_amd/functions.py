@@ -266,7 +266,7 @@ class ConvReLU(torch.autograd.Function):
         K, C = weight.shape[0], weight.shape[1]
         xin = to_nhwc(x)
         dt = H.conv_dtype("fwd", K, C, xin)
-        wp, st = (H.packed_weight(weight, "ups_fwd", dt), False) if ups else H.conv_weight(weight, "fwd", dt, xin, K)
+        wp, st = H.conv_weight(weight, "ups_fwd" if ups else "fwd", dt, xin, K)
         y, _ = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups="phase" if ups else False,
                              epi=H.EPI_BIAS_RELU, dtype=dt, streamed=st)
         ctx.save_for_backward(xin, y, weight, bias, getattr(xin, "_egz_absmax", None))

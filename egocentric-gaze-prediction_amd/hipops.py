@@ -166,7 +166,8 @@ def _uid(w: torch.Tensor) -> int:
 _PACK_FN = {"fwd": ("egz_pack_w3x3_fwd", 0, 0), "dgrad": ("egz_pack_w3x3_dgrad", 0, 1),
             "ups_fwd": ("egz_pack_w3x3_ups_fwd", 1, 2), "ups_dgrad": ("egz_pack_w3x3_ups_dgrad", 1, 3),
             # MFMA-fragment-ordered split packings of the streamed-weight kernel (split dtypes only)
-            "fwd_frag": (None, 0, 4), "dgrad_frag": (None, 0, 5), "ups_dgrad_frag": (None, 1, 6)}
+            "fwd_frag": (None, 0, 4), "dgrad_frag": (None, 0, 5), "ups_dgrad_frag": (None, 1, 6),
+            "ups_fwd_frag": (None, 1, 7)}
 
 # Arithmetic of the wide convolutions (GEMM output channels % 128 == 0):
 #   "split" (default) error-compensated split-half operands on the 16-bit MFMA path: f16 x3 (22 significant bits;
@@ -212,6 +213,9 @@ def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.T
 
 
 STREAMED = _os.environ.get("EGAZE_STREAMED", "1") != "0"      # A/B knob: 0 = halo kernel with LDS-DMA weights for plain convs
+# Forward of the four upsample-fused decoder convs on the streamed-weight halo kernel (MODE UPSF: the low-res halo staged once
+# per channel block for the 2 x 2 taps of a phase) instead of the per-tap gather kernel.  A/B knob: EGAZE_UPSF=0.
+UPSF_STREAMED = _os.environ.get("EGAZE_UPSF", "1") != "0"
 # 8-wave 256 x 128 tile of the streamed kernel (the two waves of a column share their weight fragments through the vector
 # L1).  Measured per layer shape (profiles/r02_x3s_tile8.txt): -5 ... -7 % where the weight matrix is largest (512 GEMM
 # columns at 28 x 28), +5 ... +10 % on the 128- / 256-column layers (one 512-thread block per CU interleaves worse than two
@@ -247,10 +251,14 @@ def _tile8(B, Ho, Wo, C, gemm_out, mode) -> int:
 def conv_weight(w: torch.Tensor, role: str, dtype: int, x: torch.Tensor, gemm_out: int):
     """The packed weight a plain 3x3 conv launch over the NHWC operand ``x`` needs -> (packed buffer, streamed flag).
     Split-half launches whose geometry the streamed-weight kernel covers (egz_conv3x3_streamed_ok) use the MFMA-fragment-
-    ordered packing; everything else the plane-ordered one.  role: 'fwd' | 'dgrad' | 'ups_dgrad' (x = the hi-res dy)."""
+    ordered packing; everything else the plane-ordered one.  role: 'fwd' | 'dgrad' | 'ups_dgrad' (x = the hi-res dy) |
+    'ups_fwd' (x = the low-res input of [upsample x2 -> conv]; four phase convolutions, f16 x3 only)."""
     if dtype and STREAMED:
         B, H, W, C = x.shape
-        if LIB.egz_conv3x3_streamed_ok(B, H, W, C, gemm_out, 1 if role == "ups_dgrad" else 0):
+        if role == "ups_fwd":
+            if UPSF_STREAMED and dtype == F16X3 and LIB.egz_conv3x3_streamed_ok(B, 2 * H, 2 * W, C, gemm_out, 2):
+                return packed_weight(w, "ups_fwd_frag", dtype), True
+        elif LIB.egz_conv3x3_streamed_ok(B, H, W, C, gemm_out, 1 if role == "ups_dgrad" else 0):
             return packed_weight(w, role + "_frag", dtype), True
     return packed_weight(w, role, dtype), False
 
@@ -477,9 +485,15 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     if epi == EPI_BIAS_STATS and not (dtype and streamed):
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
+    if dtype and streamed and ups:      # wp = the 'ups_fwd_frag' packing: four phase convolutions on the streamed-weight kernel
+        if ups == "fold" or epi not in (EPI_BIAS, EPI_BIAS_RELU) or bn_in is not None:
+            raise RuntimeError("the streamed upsample forward is the phase form with a bias / bias + ReLU epilogue")
+        PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), None, B, H, W, C, K,
+                                           epi, dtype, 2, _p(absmax), None, _p(amo), None, None, _stream()),
+              "egz_conv3x3_fwd_split")
+        return y, None
     if dtype and streamed:       # wp = fragment-ordered packing (conv_weight): weights L2 -> registers, halo through LDS
-        if ups:
-            raise RuntimeError("the streamed-weight kernel covers plain convolutions only")
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         ns = LIB.egz_conv3x3_streamed_splits(B, H, W, C, K) if (SPLITK and epi <= EPI_BIAS_STATS) else 1
         if ns > 1:      # few pixel tiles (batch-1 inference, 14 x 14 layers at small batches): split the channel blocks

@@ -876,6 +876,38 @@ def test_conv3x3_streamed_ups_dgrad(B, Hl, Wl, C, K, dtype, tol):
     assert rel(dx, dg) < (2e-6 if dtype == 1 else 3e-5)
 
 
+@pytest.mark.parametrize("epi_relu", [True, False])
+@pytest.mark.parametrize("B,Hl,Wl,C,K", [
+    (2, 16, 32, 128, 64),      # 64-column tile, low-res patch geometry (the 128 -> 64 @ 224 layer's form)
+    (2, 16, 16, 64, 128),      # 128-column tile, patch geometry
+    (3, 14, 14, 128, 128),     # raster runs, several channel blocks (the 28 x 28 / 56 x 56 layers' form)
+    (2, 28, 28, 64, 256),      # two column tiles
+    (1, 5, 3, 64, 64), (2, 9, 7, 96, 192), (1, 12, 12, 32, 64)])
+def test_conv3x3_streamed_ups_fwd(B, Hl, Wl, C, K, epi_relu):
+    """Forward of [nearest x2 upsample -> conv3x3 (-> ReLU)] (models/model_SP.py:16-18 etc.) as four phase convolutions on the
+    streamed-weight kernel (MODE UPSF, kind-7 packing) against fp64 torch and against the per-tap gather kernel it replaces;
+    the max |y| the bias + ReLU epilogue emits for the next layer's f16 split must be exact."""
+    h = H()
+    x = rnd(B, C, Hl, Wl, seed=81)
+    w = rnd(K, C, 3, 3, seed=82, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=83, scale=0.1)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    if epi_relu:
+        ref = torch.relu(ref)
+    xd, wd, bd = nhwc(x), w.to(DEV), b.to(DEV)
+    epi = h.EPI_BIAS_RELU if epi_relu else h.EPI_BIAS
+    wq, st = h.conv_weight(wd, "ups_fwd", h.F16X3, xd, K)
+    assert st, "geometry expected on the streamed kernel"
+    y, _ = h.conv3x3_fwd(xd, wq, bd, K, ups="phase", epi=epi, dtype=h.F16X3, streamed=True)
+    assert tuple(y.shape) == (B, 2 * Hl, 2 * Wl, K)
+    assert rel(nchw(y), ref) < 2e-6
+    y0, _ = h.conv3x3_fwd(xd, h.packed_weight(wd, "ups_fwd", h.F16X3), bd, K, ups="phase", epi=epi, dtype=h.F16X3)
+    assert rel(y, y0) < 2e-6
+    if epi_relu and h._want_fwd_absmax():
+        torch.cuda.synchronize()
+        assert y._egz_absmax[:1].view(torch.float32).item() == y.max().item()
+
+
 def test_cabi_argument_errors_are_loud():
     """Error behaviour of the boundary: bad arguments never launch -- the C-ABI returns a non-zero code with a message
     (egz_last_error) and the Python layer raises RuntimeError, as the reference's torch ops would (empty batch, wrong

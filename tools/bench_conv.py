@@ -75,7 +75,7 @@ def main():
         fdt = a.dtype if (a.dtype and K % 64 == 0) else 0
         ddt = a.dtype if (a.dtype and C % 64 == 0) else 0
         # plain convs: the packing / kernel hipops picks for this geometry (streamed-weight kernel unless EGAZE_STREAMED=0)
-        wp, fst = (H.packed_weight(w, "ups_fwd", fdt), False) if ups else H.conv_weight(w, "fwd", fdt, x, K)
+        wp, fst = H.conv_weight(w, "ups_fwd" if ups else "fwd", fdt, x, K)
         wd, dst = H.conv_weight(w, "dgrad", ddt, dy, C)
         res = []
         if "fwd" in a.what:
