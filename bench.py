@@ -330,10 +330,10 @@ def main():
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
             roofline = {"bound": "mfma",
-                        "kernel": ("conv3x3_igemm_x3s_kernel + conv3x3_igemm_x3h_kernel (egz_conv3x3_fwd_streamed + "
-                                   "egz_conv3x3_fwd_split: all conv fwd + dgrad launches -- the streamed-weight halo kernel "
-                                   "for plain convs and the polyphase upsample dgrad, the LDS-DMA halo kernel for the "
-                                   "upsample forward; split-half f16x3 / bf16x3 operands on "
+                        "kernel": ("conv3x3_igemm_x3s_kernel (egz_conv3x3_fwd_streamed, + egz_conv3x3_fwd_split for "
+                                   "geometries it does not cover: all conv fwd + dgrad launches -- the streamed-weight halo "
+                                   "kernel for plain convs, the four-phase upsample forward and the polyphase upsample "
+                                   "dgrad; split-half f16x3 / bf16x3 operands on "
                                    "v_mfma_f32_32x32x16_{f16,bf16}; each algorithmic MAC costs 3 MFMA MACs, priced against "
                                    "the dense 16-bit MFMA peak)" if split else
                                    "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
