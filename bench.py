@@ -306,8 +306,9 @@ def main():
         streams.ENABLED = was
         split = H.PRECISION == "split"
         ig = {"calls": 0, "ms": 0.0, "flops": 0.0}
-        # split mode: plain convs run on the streamed-weight kernel (egz_conv3x3_fwd_streamed), the upsample forms on the
-        # per-tap gather kernel (egz_conv3x3_fwd_split); their algorithmic FLOPs are noted under one name by hipops
+        # split mode: every conv fwd / dgrad launch runs on the streamed-weight kernel (egz_conv3x3_fwd_streamed; the per-tap
+        # gather kernel egz_conv3x3_fwd_split only for geometries it does not cover); hipops notes the algorithmic FLOPs of the
+        # whole family under ONE name (egz_conv3x3_fwd_split), whether or not that entry point itself ran in the step
         entries = ("egz_conv3x3_fwd_split", "egz_conv3x3_fwd_streamed", "egz_conv3x3_fwd_streamed_splitk") if split else ("egz_conv3x3_fwd", "egz_conv3x3_ups_dgrad")
         for entry in entries:
             for k2 in ig:
@@ -499,7 +500,7 @@ def main():
             finally:
                 redirect.__exit__()
         tot = sum(v["ms"] for v in prof.values())
-        breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v["calls"]}
         breakdown["_sum_kernel_ms"] = round(tot, 3)
     if dist is not None:
         dist.barrier()

@@ -41,6 +41,8 @@ class _Profiler:
         for name, evs in self.events.items():
             out[name] = {"calls": len(evs), "ms": sum(a.elapsed_time(b) for a, b in evs),
                          "flops": self.flops.get(name, 0.0)}
+        for name, v in self.flops.items():      # FLOPs noted under a family name none of whose own launches ran in this step
+            out.setdefault(name, {"calls": 0, "ms": 0.0, "flops": v})
         return out
 
     def note_flops(self, name, v):
