@@ -706,28 +706,60 @@ __device__ __forceinline__ float frag_value(const float* __restrict__ w, int C, 
                   (ox <= 0) ? 1 : 0);
 }
 
-// one thread per (slice, ntile32, ks, lane, e): both planes of one value
+// one value (both planes) of a fragment-ordered packing: i = ((((slice * nt32 + ntile) * 2 + ks) * 64 + lane) * 8 + e)
+template <typename T>
+__device__ __forceinline__ void frag_pack_one(const float* __restrict__ w, unsigned short* __restrict__ wq, int C, int K,
+                                              int kind, int Np, int Rp, float scale, long i) {
+    const int nt32 = Np >> 5, spb = (kind == 6) ? 16 : (kind == 7) ? 4 : 9;      // slices per channel block
+    const int ncb = Rp / XBK;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
+    const long r = i >> 10;
+    const int ntile = (int)(r % nt32);
+    const int s = (int)(r / nt32);
+    // kind 7: [phase][channel block][tap] -- one phase's slices are contiguous (a tile of the kernel runs one phase)
+    const int ph = (kind == 7) ? s / (ncb * 4) : 0, sl = s - ph * ncb * 4;
+    const int cblk = sl / spb;
+    const int tap = (kind == 7) ? ph * 4 + (sl - cblk * spb) : sl - cblk * spb;
+    const int col = ntile * 32 + (lane & 31), k = cblk * XBK + ks * 16 + (lane >> 5) * 8 + e;
+    unsigned short h, l;
+    Half<T>::split(frag_value(w, C, K, kind, tap, col, k) * scale, h, l);
+    const long base = ((r * 2 + ks) * 2) * 512 + lane * 8 + e;     // plane 0; plane 1 is 512 elements on
+    wq[base] = h;
+    wq[base + 512] = l;
+}
+
+// one thread per (slice, ntile32, ks, lane, e)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wq,
                                                              int C, int K, int kind, int Np, int Rp, float scale) {
-    const int nt32 = Np >> 5, spb = (kind == 6) ? 16 : (kind == 7) ? 4 : 9;      // slices per channel block
-    const int ncb = Rp / XBK;
-    const long n = (long)ncb * ((kind == 7) ? 16 : spb) * nt32 * 1024;      // values (each has a hi and a lo half)
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
-        const long r = i >> 10;
-        const int ntile = (int)(r % nt32);
-        const int s = (int)(r / nt32);
-        // kind 7: [phase][channel block][tap] -- one phase's slices are contiguous (a tile of the kernel runs one phase)
-        const int ph = (kind == 7) ? s / (ncb * 4) : 0, sl = s - ph * ncb * 4;
-        const int cblk = sl / spb;
-        const int tap = (kind == 7) ? ph * 4 + (sl - cblk * spb) : sl - cblk * spb;
-        const int col = ntile * 32 + (lane & 31), k = cblk * XBK + ks * 16 + (lane >> 5) * 8 + e;
-        unsigned short h, l;
-        Half<T>::split(frag_value(w, C, K, kind, tap, col, k) * scale, h, l);
-        const long base = ((r * 2 + ks) * 2) * 512 + lane * 8 + e;     // plane 0; plane 1 is 512 elements on
-        wq[base] = h;
-        wq[base + 512] = l;
+    const long n = (long)((kind >= 6) ? 16 : 9) * Np * Rp;      // values (each has a hi and a lo half)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        frag_pack_one<T>(w, wq, C, K, kind, Np, Rp, scale, i);
+}
+
+// Several packings in ONE launch (the optimizer's bucketed tail refreshes ~10 packings per bucket: one launch instead of ten
+// 5-8 us ones that each wait for a CU slot behind the convolution blocks).  table: nrows x 8 int64
+// [w, wq, C, K, kind, dtype, values, first block]; block b works on the row whose block range holds it, 2048 values per block.
+constexpr int FRAG_PER_BLOCK = 2048;
+__global__ __launch_bounds__(256) void pack_split_frag_multi_kernel(const long* __restrict__ table, int nrows) {
+    int lo = 0, hi = nrows - 1;
+    while (lo < hi) {                       // last row whose first block <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[8 * mid + 7] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const long* r = table + 8 * lo;
+    const float* w = reinterpret_cast<const float*>(r[0]);
+    unsigned short* wq = reinterpret_cast<unsigned short*>(r[1]);
+    const int C = (int)r[2], K = (int)r[3], kind = (int)r[4], dtype = (int)r[5];
+    const long n = r[6];
+    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
+    const int Np = (kind == 4 || kind == 7) ? Kp : Cp, Rp = (kind == 4 || kind == 7) ? Cp : Kp;
+    const long base = ((long)blockIdx.x - r[7]) * FRAG_PER_BLOCK;
+    for (int e = threadIdx.x; e < FRAG_PER_BLOCK; e += 256) {
+        const long i = base + e;
+        if (i >= n) break;
+        if (dtype == 1) frag_pack_one<_Float16>(w, wq, C, K, kind, Np, Rp, F16_WSCALE, i);
+        else            frag_pack_one<__bf16>(w, wq, C, K, kind, Np, Rp, 1.f, i);
     }
 }
 
@@ -1435,6 +1467,17 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
     if (dtype == 1) hipLaunchKernelGGL(pack_split_frag_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, F16_WSCALE);
     else            hipLaunchKernelGGL(pack_split_frag_kernel<__bf16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, 1.f);
     EGZ_CHECK_LAUNCH("egz_pack_w3x3_split_frag");
+    return 0;
+}
+
+// Several fragment-ordered packings in one launch.  table (device): nrows x 8 int64 [w, wq, C, K, kind (4..7), dtype (1 | 2),
+// values = (kind >= 6 ? 16 : 9) * Np * Rp, first block]; a row owns ceil(values / egz_pack_w3x3_split_frag_multi_per_block())
+// consecutive blocks starting at its first block; total_blocks = the sum.  Same results as egz_pack_w3x3_split_frag per row.
+EGZ_API int egz_pack_w3x3_split_frag_multi_per_block(void) { return FRAG_PER_BLOCK; }
+EGZ_API int egz_pack_w3x3_split_frag_multi(const void* table, int nrows, int total_blocks, hipStream_t st) {
+    EGZ_CHECK_ARG(table && nrows > 0 && total_blocks > 0, "egz_pack_w3x3_split_frag_multi: bad arguments");
+    hipLaunchKernelGGL(pack_split_frag_multi_kernel, dim3(total_blocks), dim3(256), 0, st, static_cast<const long*>(table), nrows);
+    EGZ_CHECK_LAUNCH("egz_pack_w3x3_split_frag_multi");
     return 0;
 }
 

@@ -318,6 +318,57 @@ def refresh_packings(params) -> int:
     return n
 
 
+_FRAG_TABLES = {}
+
+
+def refresh_packings_multi(params) -> int:
+    """refresh_packings with ONE launch for all fragment-ordered packings of these parameters
+    (egz_pack_w3x3_split_frag_multi; plane-ordered ones, if any, are rebuilt one by one): the optimizer's bucketed tail refreshes
+    ~10 packings per bucket, and each small launch waits for a CU slot behind the convolution blocks of the backward pass.
+    Tables are cached per set of (weight, buffer) pointers -- stable, the parameters live in the optimizer's flat buffer.
+    Not for use inside a hipGraph capture (the first call of a set uploads its table)."""
+    uids = {getattr(p, "_egz_uid", None): p for p in params}
+    uids.pop(None, None)
+    rows, entries, n = [], [], 0
+    for key, ent in list(_PACKED.items()):
+        uid, kind, dtype = key
+        w = uids.get(uid)
+        if w is None or ent[2]() is not w or key not in _USED:      # only packings a launch asked for since their last rebuild
+            continue
+        if ent[0] == _tag(w):
+            continue
+        kidx = _PACK_FN[kind][2]
+        if kidx < 4 or not dtype:
+            packed_weight(w, kind, dtype)
+            _USED.discard(key)
+            n += 1
+            continue
+        K, C = w.shape[0], w.shape[1]
+        Cp, Kp = (C + 31) // 32 * 32, (K + 31) // 32 * 32
+        rows.append((w.data_ptr(), ent[1].data_ptr(), C, K, kidx, dtype, (16 if kidx >= 6 else 9) * Cp * Kp))
+        entries.append((key, w))
+    if not rows:
+        return n
+    sig = tuple(rows)
+    hit = _FRAG_TABLES.get(sig)
+    if hit is None:
+        per = int(LIB.egz_pack_w3x3_split_frag_multi_per_block())
+        first, table = 0, []
+        for r in rows:
+            table.append(list(r) + [first])
+            first += (r[6] + per - 1) // per
+        if len(_FRAG_TABLES) > 64:
+            _FRAG_TABLES.clear()
+        hit = (torch.tensor(table, dtype=torch.int64, device=entries[0][1].device), first)
+        _FRAG_TABLES[sig] = hit
+    check(LIB.egz_pack_w3x3_split_frag_multi(hit[0].data_ptr(), len(rows), hit[1], _stream()), "egz_pack_w3x3_split_frag_multi")
+    for key, w in entries:
+        ent = _PACKED[key]
+        _PACKED[key] = (_tag(w), ent[1], ent[2])
+        _USED.discard(key)
+    return n + len(rows)
+
+
 _PACK_PER_BLOCK = 2048
 _MULTI_TABLES = {}
 

@@ -129,7 +129,10 @@ class _OverlappedTail:
                         lo=start, hi=end)
             ps = [o.params[i] for i in idx]
             H.touch_params(ps)
-            H.refresh_packings(ps)
+            if _TAIL_MULTIPACK and not torch.cuda.is_current_stream_capturing():
+                H.refresh_packings_multi(ps)         # one launch for the bucket's fragment-ordered packings
+            else:
+                H.refresh_packings(ps)
 
     def finish(self, step):
         for b in range(len(self.buckets)):
@@ -143,6 +146,10 @@ class _OverlappedTail:
 # per-layer packs (41.2 vs 40.3 ms/step): the single kernel sits alone at the end of the step, the 74 small lazy
 # launches hide behind the other streams' kernels.  Opt-in for A/B runs.
 _MULTIPACK = os.environ.get("EGAZE_MULTIPACK", "0") != "0"
+# The bucketed tail's packings in one launch per bucket (hipops.refresh_packings_multi: 8 launches instead of ~80 per step).
+# Bit-identical, and no faster (31.80 vs 31.80 ms per step, profiles/r03_ab_notes.txt): the tail stream's small launches
+# already hide under the backward pass.  Opt-in: EGAZE_TAIL_MULTIPACK=1.
+_TAIL_MULTIPACK = os.environ.get("EGAZE_TAIL_MULTIPACK", "0") != "0"
 
 
 class FusedAdam:

@@ -79,12 +79,19 @@ int egz_conv3x3_fwd_split(const float* x, const void* wp, const float* bias, flo
  * L2 -> registers, the activation halo goes through LDS.  egz_conv3x3_streamed_ok: 1 when a geometry is covered
  * (C = reduction channels % 32 == 0, K = GEMM columns % 64 == 0).  mode 0 = plain conv; mode 1 = data gradient of
  * [nn.Upsample(x2) -> nn.Conv2d] (models/model_SP.py:17-18,22-23,25-26,28-29) w.r.t. the low-res input, x = hi-res dy,
- * kind-6 packing.  epi: 0 bias, 1 bias + ReLU, 2 bias + BN partials (egz_conv3x3_streamed_stat_rows rows), 3 = data gradient
+ * kind-6 packing; mode 2 = the FORWARD of [nn.Upsample(x2) -> nn.Conv2d] as four 2 x 2-tap phase convolutions over the
+ * low-res input (x = [B][H/2][W/2][C], y = [B][H][W][K], H x W passed = the hi-res output, kind-7 packing =
+ * [phase][channel block][pre-summed tap], f16 x3 only, epi 0 / 1, K % 64 == 0).  epi: 0 bias, 1 bias + ReLU, 2 bias + BN partials (egz_conv3x3_streamed_stat_rows rows), 3 = data gradient
  * masked by mask_src > 0 with per-channel sums and per-tile abs-max (see below). */
 int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode);
 /* rows of stat_partial ([rows][2][K] doubles) of an epi 2 / epi 5 launch of egz_conv3x3_fwd_streamed (mode 0) */
 int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K);
 int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t stream);
+/* Several fragment-ordered packings in one launch (the bucketed optimizer tail).  table (device): nrows x 8 int64
+ * [w, wq, C, K, kind 4..7, dtype 1|2, values = (kind >= 6 ? 16 : 9) * Np * Rp, first block]; a row owns
+ * ceil(values / egz_pack_w3x3_split_frag_multi_per_block()) consecutive blocks; total_blocks = their sum. */
+int egz_pack_w3x3_split_frag_multi_per_block(void);
+int egz_pack_w3x3_split_frag_multi(const void* table, int nrows, int total_blocks, hipStream_t stream);
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
                              const float* mask_src, unsigned int* absmax_out, const float* bn_coef, float* minmax_out,

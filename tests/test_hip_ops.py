@@ -489,6 +489,30 @@ def test_repack_params_multi_launch():
             assert torch.equal(h.packed_weight(w, kind, dt), multi[(i, kind, dt)]), (i, kind, dt)
 
 
+def test_refresh_packings_multi_launch():
+    """The bucketed optimizer tail's one-launch refresh of fragment-ordered packings (egz_pack_w3x3_split_frag_multi, kinds
+    4-7) == the per-tensor egz_pack_w3x3_split_frag launches, bit for bit; plane-ordered packings in the same set go through
+    their own kernels; entries count as current afterwards."""
+    h = H()
+    ws = [torch.nn.Parameter(rnd(64, 32, 3, 3, seed=61).to(DEV)), torch.nn.Parameter(rnd(128, 64, 3, 3, seed=62).to(DEV)),
+          torch.nn.Parameter(rnd(96, 160, 3, 3, seed=63).to(DEV)), torch.nn.Parameter(rnd(32, 8, 3, 3, seed=64).to(DEV))]
+    kinds = [("fwd_frag", 1), ("dgrad_frag", 1), ("dgrad_frag", 2), ("ups_dgrad_frag", 1), ("ups_fwd_frag", 1), ("fwd", 1)]
+    for w in ws:
+        for kind, dt in kinds:
+            h.packed_weight(w, kind, dt)
+    with torch.no_grad():
+        for i, w in enumerate(ws):
+            w.data.copy_(rnd(*w.shape, seed=80 + i).to(DEV))         # in place, like the fused optimizer
+    h.touch_params(ws)
+    assert h.refresh_packings_multi(ws) == len(ws) * len(kinds)
+    assert h.refresh_packings_multi(ws) == 0                          # nothing is stale (and nothing was asked for since)
+    multi = {(i, kind, dt): h.packed_weight(w, kind, dt).clone() for i, w in enumerate(ws) for kind, dt in kinds}
+    h.bump_weight_epoch()                                             # force the per-tensor path
+    for i, w in enumerate(ws):
+        for kind, dt in kinds:
+            assert torch.equal(h.packed_weight(w, kind, dt), multi[(i, kind, dt)]), (i, kind, dt)
+
+
 def test_split_kernels_shape_fuzz():
     """Geometry dispatch fuzz: random (B, H, W, C, K) through every split-half kernel family (halo patch / halo raster run /
     per-tap gather forward and data gradient, 9-tap and phase-form weight gradients, upsample forms) against the exact-f32
