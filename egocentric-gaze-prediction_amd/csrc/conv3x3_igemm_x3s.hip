@@ -690,57 +690,75 @@ __device__ __forceinline__ float weff9s(const float* __restrict__ w9, int py, in
     return s;
 }
 
-// value of GEMM-view weight element (slice-in-block si, n, k): kind 4 = forward (n = output channel, k = input channel,
-// si = tap), kind 5 = data gradient (n = input channel, k = output channel, taps flipped), kind 6 = data gradient of
-// [upsample x2 -> conv] w.r.t. the low-res input: si = component (p, q) * 4 + tap (a, b)  <->  the 4x4 / stride-2 gather
-// tap (ty, tx) = (2a + 1 - p, 2b + 1 - q) of the 'ups_dgrad' packing (egz_pack_w3x3_split kind 3).
-__device__ __forceinline__ float frag_value(const float* __restrict__ w, int C, int K, int kind, int si, int n, int k) {
-    if (kind == 4) return (n < K && k < C) ? w[((long)n * C + k) * 9 + si] : 0.f;
-    if (kind == 5) return (n < C && k < K) ? w[((long)k * C + n) * 9 + (8 - si)] : 0.f;
-    if (kind == 7)       // forward of [upsample x2 -> conv]: si = phase (p, q) * 4 + tap (a, b), the 'ups_fwd' pre-summed taps
-        return (n < K && k < C) ? weff9s(w + ((long)n * C + k) * 9, (si >> 2) >> 1, (si & 3) >> 1, (si >> 2) & 1, si & 1) : 0.f;
-    if (!(n < C && k < K)) return 0.f;
+// value of GEMM-view weight element (slice-in-block si) from the nine taps w9 of its (output channel, input channel) pair:
+// kind 4 = forward (si = tap), kind 5 = data gradient (taps flipped), kind 6 = data gradient of [upsample x2 -> conv] w.r.t.
+// the low-res input: si = component (p, q) * 4 + tap (a, b)  <->  the 4x4 / stride-2 gather tap (ty, tx) = (2a + 1 - p,
+// 2b + 1 - q) of the 'ups_dgrad' packing (egz_pack_w3x3_split kind 3); kind 7 = forward of [upsample x2 -> conv]: si = phase
+// (p, q) * 4 + tap (a, b), the 'ups_fwd' pre-summed taps.
+__device__ __forceinline__ float frag_value9(const float* w9, int kind, int si) {
+    if (kind == 4) return w9[si];
+    if (kind == 5) return w9[8 - si];
+    if (kind == 7) return weff9s(w9, (si >> 2) >> 1, (si & 3) >> 1, (si >> 2) & 1, si & 1);
     const int img = si >> 2, tap = si & 3;
     const int oy = 2 * (tap >> 1) - (img >> 1), ox = 2 * (tap & 1) - (img & 1);        // ty - 1, tx - 1
-    return weff9s(w + ((long)k * C + n) * 9, (oy == -1 || oy == 1) ? 1 : 0, (oy <= 0) ? 1 : 0, (ox == -1 || ox == 1) ? 1 : 0,
-                  (ox <= 0) ? 1 : 0);
+    return weff9s(w9, (oy == -1 || oy == 1) ? 1 : 0, (oy <= 0) ? 1 : 0, (ox == -1 || ox == 1) ? 1 : 0, (ox <= 0) ? 1 : 0);
 }
 
-// one value (both planes) of a fragment-ordered packing: i = ((((slice * nt32 + ntile) * 2 + ks) * 64 + lane) * 8 + e)
-template <typename T>
-__device__ __forceinline__ void frag_pack_one(const float* __restrict__ w, unsigned short* __restrict__ wq, int C, int K,
-                                              int kind, int Np, int Rp, float scale, long i) {
-    const int nt32 = Np >> 5, spb = (kind == 6) ? 16 : (kind == 7) ? 4 : 9;      // slices per channel block
-    const int ncb = Rp / XBK;
-    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), ks = (int)((i >> 9) & 1);
-    const long r = i >> 10;
-    const int ntile = (int)(r % nt32);
-    const int s = (int)(r / nt32);
-    // kind 7: [phase][channel block][tap] -- one phase's slices are contiguous (a tile of the kernel runs one phase)
-    const int ph = (kind == 7) ? s / (ncb * 4) : 0, sl = s - ph * ncb * 4;
-    const int cblk = sl / spb;
-    const int tap = (kind == 7) ? ph * 4 + (sl - cblk * spb) : sl - cblk * spb;
+// All slices of one (GEMM column, reduction element) pair: j = (((channel block * nt32 + ntile) * 2 + ks) * 64 + lane) * 8 + e.
+// The nine taps of the pair are read ONCE (36 contiguous bytes; one thread per packed VALUE read each weight nine times from
+// nine launches' worth of distance -- 9x the weight bytes out of L2 per packing, 0.6 ms per step over the ~80 packings) and
+// every slice's hi / lo halves are derived from them.  Fragment order: value (slice s, ntile, ks, lane, e) sits at
+// (((s * nt32 + ntile) * 2 + ks) * 2 + plane) * 512 + lane * 8 + e.
+template <typename T, int KIND>
+__device__ __forceinline__ void frag_pack_pair(const float* __restrict__ w, unsigned short* __restrict__ wq, int C, int K,
+                                               int Np, int Rp, float scale, long j) {
+    constexpr int NS = (KIND >= 6) ? 16 : 9;                   // slices per channel block
+    const int nt32 = Np >> 5, ncb = Rp / XBK;
+    const int e = (int)(j & 7), lane = (int)((j >> 3) & 63), ks = (int)((j >> 9) & 1);
+    const long r2 = j >> 10;
+    const int ntile = (int)(r2 % nt32), cblk = (int)(r2 / nt32);
     const int col = ntile * 32 + (lane & 31), k = cblk * XBK + ks * 16 + (lane >> 5) * 8 + e;
-    unsigned short h, l;
-    Half<T>::split(frag_value(w, C, K, kind, tap, col, k) * scale, h, l);
-    const long base = ((r * 2 + ks) * 2) * 512 + lane * 8 + e;     // plane 0; plane 1 is 512 elements on
-    wq[base] = h;
-    wq[base + 512] = l;
+    float w9[9];
+    const bool fwd = (KIND == 4 || KIND == 7);                 // columns = output channels, reduction = input channels
+    const bool ok = fwd ? (col < K && k < C) : (col < C && k < K);
+    const float* src = w + (fwd ? ((long)col * C + k) : ((long)k * C + col)) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w9[t] = ok ? src[t] : 0.f;
+#pragma unroll
+    for (int si = 0; si < NS; ++si) {
+        // kind 7: [phase][channel block][tap] -- one phase's slices are contiguous (a tile of the kernel runs one phase)
+        const long s = (KIND == 7) ? (long)(si >> 2) * (ncb * 4) + cblk * 4 + (si & 3) : (long)cblk * NS + si;
+        const long r = s * nt32 + ntile;
+        unsigned short h, l;
+        Half<T>::split(frag_value9(w9, KIND, si) * scale, h, l);
+        const long base = ((r * 2 + ks) * 2) * 512 + lane * 8 + e;     // plane 0; plane 1 is 512 elements on
+        wq[base] = h;
+        wq[base + 512] = l;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void frag_pack_pair_k(const float* __restrict__ w, unsigned short* __restrict__ wq, int C, int K,
+                                                 int kind, int Np, int Rp, float scale, long j) {
+    if (kind == 4) frag_pack_pair<T, 4>(w, wq, C, K, Np, Rp, scale, j);
+    else if (kind == 5) frag_pack_pair<T, 5>(w, wq, C, K, Np, Rp, scale, j);
+    else if (kind == 6) frag_pack_pair<T, 6>(w, wq, C, K, Np, Rp, scale, j);
+    else frag_pack_pair<T, 7>(w, wq, C, K, Np, Rp, scale, j);
 }
 
-// one thread per (slice, ntile32, ks, lane, e)
+// one thread per (channel block, ntile32, ks, lane, e)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ wq,
                                                              int C, int K, int kind, int Np, int Rp, float scale) {
-    const long n = (long)((kind >= 6) ? 16 : 9) * Np * Rp;      // values (each has a hi and a lo half)
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        frag_pack_one<T>(w, wq, C, K, kind, Np, Rp, scale, i);
+    const long n = (long)Np * Rp;                              // (column, reduction element) pairs
+    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < n; j += (long)gridDim.x * blockDim.x)
+        frag_pack_pair_k<T>(w, wq, C, K, kind, Np, Rp, scale, j);
 }
 
 // Several packings in ONE launch (the optimizer's bucketed tail refreshes ~10 packings per bucket: one launch instead of ten
 // 5-8 us ones that each wait for a CU slot behind the convolution blocks).  table: nrows x 8 int64
-// [w, wq, C, K, kind, dtype, values, first block]; block b works on the row whose block range holds it, 2048 values per block.
-constexpr int FRAG_PER_BLOCK = 2048;
+// [w, wq, C, K, kind, dtype, pairs = Np * Rp, first block]; block b works on the row whose block range holds it, 1024 (column,
+// reduction element) pairs per block.
+constexpr int FRAG_PER_BLOCK = 1024;
 __global__ __launch_bounds__(256) void pack_split_frag_multi_kernel(const long* __restrict__ table, int nrows) {
     int lo = 0, hi = nrows - 1;
     while (lo < hi) {                       // last row whose first block <= blockIdx.x
@@ -758,8 +776,8 @@ __global__ __launch_bounds__(256) void pack_split_frag_multi_kernel(const long* 
     for (int e = threadIdx.x; e < FRAG_PER_BLOCK; e += 256) {
         const long i = base + e;
         if (i >= n) break;
-        if (dtype == 1) frag_pack_one<_Float16>(w, wq, C, K, kind, Np, Rp, F16_WSCALE, i);
-        else            frag_pack_one<__bf16>(w, wq, C, K, kind, Np, Rp, 1.f, i);
+        if (dtype == 1) frag_pack_pair_k<_Float16>(w, wq, C, K, kind, Np, Rp, F16_WSCALE, i);
+        else            frag_pack_pair_k<__bf16>(w, wq, C, K, kind, Np, Rp, 1.f, i);
     }
 }
 
@@ -1461,7 +1479,7 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
                   "egz_pack_w3x3_split_frag: bad arguments");
     const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
     const int Np = (kind == 4 || kind == 7) ? Kp : Cp, Rp = (kind == 4 || kind == 7) ? Cp : Kp;
-    const long n = (long)(kind >= 6 ? 16 : 9) * Np * Rp;
+    const long n = (long)Np * Rp;
     const int g = egz_cdiv(n, 256) > 4096 ? 4096 : egz_cdiv(n, 256);
     unsigned short* o = static_cast<unsigned short*>(wq);
     if (dtype == 1) hipLaunchKernelGGL(pack_split_frag_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, F16_WSCALE);
@@ -1471,7 +1489,7 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
 }
 
 // Several fragment-ordered packings in one launch.  table (device): nrows x 8 int64 [w, wq, C, K, kind (4..7), dtype (1 | 2),
-// values = (kind >= 6 ? 16 : 9) * Np * Rp, first block]; a row owns ceil(values / egz_pack_w3x3_split_frag_multi_per_block())
+// pairs = Np * Rp, first block]; a row owns ceil(pairs / egz_pack_w3x3_split_frag_multi_per_block())
 // consecutive blocks starting at its first block; total_blocks = the sum.  Same results as egz_pack_w3x3_split_frag per row.
 EGZ_API int egz_pack_w3x3_split_frag_multi_per_block(void) { return FRAG_PER_BLOCK; }
 EGZ_API int egz_pack_w3x3_split_frag_multi(const void* table, int nrows, int total_blocks, hipStream_t st) {

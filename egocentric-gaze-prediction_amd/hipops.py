@@ -345,7 +345,7 @@ def refresh_packings_multi(params) -> int:
             continue
         K, C = w.shape[0], w.shape[1]
         Cp, Kp = (C + 31) // 32 * 32, (K + 31) // 32 * 32
-        rows.append((w.data_ptr(), ent[1].data_ptr(), C, K, kidx, dtype, (16 if kidx >= 6 else 9) * Cp * Kp))
+        rows.append((w.data_ptr(), ent[1].data_ptr(), C, K, kidx, dtype, Cp * Kp))
         entries.append((key, w))
     if not rows:
         return n

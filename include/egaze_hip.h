@@ -88,8 +88,8 @@ int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode);
 int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K);
 int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t stream);
 /* Several fragment-ordered packings in one launch (the bucketed optimizer tail).  table (device): nrows x 8 int64
- * [w, wq, C, K, kind 4..7, dtype 1|2, values = (kind >= 6 ? 16 : 9) * Np * Rp, first block]; a row owns
- * ceil(values / egz_pack_w3x3_split_frag_multi_per_block()) consecutive blocks; total_blocks = their sum. */
+ * [w, wq, C, K, kind 4..7, dtype 1|2, pairs = Np * Rp (padded columns x padded reduction channels), first block]; a row owns
+ * ceil(pairs / egz_pack_w3x3_split_frag_multi_per_block()) consecutive blocks; total_blocks = their sum. */
 int egz_pack_w3x3_split_frag_multi_per_block(void);
 int egz_pack_w3x3_split_frag_multi(const void* table, int nrows, int total_blocks, hipStream_t stream);
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
