@@ -112,6 +112,7 @@ SIGNATURES = {
     "egz_tanh_bwd": (c_int, [P, P, P, c_long, S]),
     "egz_add": (c_int, [P, P, P, c_long, S]),
     # --- optimizer
+    "egz_cat2_planes": (c_int, [P, P, P, c_int, c_long, S]),
     "egz_u8_normalize": (c_int, [P, P, c_long, c_long, c_int, P, P, S]),
     "egz_crop_mean": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, S]),
     "egz_window_mean": (c_int, [P, P, P, c_int, c_int, c_int, c_int, S]),

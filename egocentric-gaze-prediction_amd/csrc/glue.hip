@@ -158,7 +158,28 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restric
     }
 }
 
+// torch.cat((f, g), dim=1) of two one-channel maps (models/late_fusion.py:19): out[b][0] = f[b], out[b][1] = g[b]
+__global__ __launch_bounds__(256) void cat2_planes_kernel(const f32x4* __restrict__ f, const f32x4* __restrict__ g,
+                                                          f32x4* __restrict__ out, long hw4, long n4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / hw4, r = i - b * hw4;
+        out[2 * b * hw4 + r] = f[i];
+        out[(2 * b + 1) * hw4 + r] = g[i];
+    }
+}
 }  // namespace
+
+// f, g: [B][1][H][W] (HW % 4 == 0, 16-byte aligned) -> out [B][2][H][W]: the late-fusion stack's input (late_fusion.py:19)
+EGZ_API int egz_cat2_planes(const float* f, const float* g, float* out, int B, long HW, hipStream_t st) {
+    EGZ_CHECK_ARG(f && g && out && B > 0 && HW > 0 && HW % 4 == 0, "egz_cat2_planes: bad arguments (HW must be a multiple of 4)");
+    EGZ_CHECK_ARG(((uintptr_t)f | (uintptr_t)g | (uintptr_t)out) % 16 == 0, "egz_cat2_planes: pointers must be 16-byte aligned");
+    const long n4 = (long)B * HW / 4;
+    const int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(cat2_planes_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(f),
+                       reinterpret_cast<const f32x4*>(g), reinterpret_cast<f32x4*>(out), HW / 4, n4);
+    EGZ_CHECK_LAUNCH("egz_cat2_planes");
+    return 0;
+}
 
 // src: n bytes laid out [...][C][plane]; dst: n floats, same order.  mean / std: C floats on the device.
 EGZ_API int egz_u8_normalize(const unsigned char* src, float* dst, long n, long plane, int C, const float* mean,

@@ -965,6 +965,15 @@ def stack2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def cat2_planes(f: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """torch.cat((f, g), dim=1) of two (B, 1, H, W) maps in one kernel (models/late_fusion.py:19)."""
+    _req(f, "f"); _req(g, "g")
+    B, _, Hh, Ww = f.shape
+    out = torch.empty((B, 2, Hh, Ww), dtype=torch.float32, device=f.device)
+    check(LIB.egz_cat2_planes(f.data_ptr(), g.data_ptr(), out.data_ptr(), B, Hh * Ww, _stream()), "egz_cat2_planes")
+    return out
+
+
 def fill_zero(t: torch.Tensor):
     """hipMemsetAsync on the current stream (zero_grad of the flat gradient buffer)."""
     check(LIB.egz_fill_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()), "egz_fill_zero")

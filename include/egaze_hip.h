@@ -296,6 +296,9 @@ int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long n, doub
 int egz_aae_auc(const float* out, const float* gt, int B, int H, int W, const double* gw, int R, double dist,
                 double* res, hipStream_t stream);
 
+/* torch.cat((f, g), dim=1) of two one-channel maps, the late-fusion stack's input (models/late_fusion.py:19):
+ * f, g [B][1][H][W] -> out [B][2][H][W]; HW % 4 == 0, 16-byte aligned pointers. */
+int egz_cat2_planes(const float* f, const float* g, float* out, int B, long HW, hipStream_t stream);
 /* Input pipeline on the device (data/STdatas.py:50-68, data/lateDataset.py:22-33): uint8 planes [...][C][plane] ->
  * (u8 / 255 - mean[c]) / std[c] in fp32, the reference's three correctly-rounded operations (bit-exact). */
 int egz_u8_normalize(const unsigned char* src, float* dst, long n, long plane, int C, const float* mean,

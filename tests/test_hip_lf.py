@@ -351,3 +351,13 @@ def test_lf_train_step_graphed_matches_eager():
     assert torch.equal(o0, o1) and torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
+
+
+def test_cat2_planes_matches_torch_cat():
+    """late_fusion's input concatenation (models/late_fusion.py:19) as one kernel: bit-identical to torch.cat, and the model
+    takes that route for contiguous device maps."""
+    import egaze_amd.hipops as H
+    g = torch.Generator().manual_seed(5)
+    f = torch.rand(3, 1, 20, 12, generator=g).to(DEV)
+    w = torch.rand(3, 1, 20, 12, generator=g).to(DEV)
+    assert torch.equal(H.cat2_planes(f, w), torch.cat((f, w), dim=1))
