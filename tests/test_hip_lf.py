@@ -121,6 +121,8 @@ def test_bn_sums_folded_into_narrow_dgrad():
     reduce pass (same kernels otherwise; only the summation order of those two sums differs)."""
     from egaze_amd import hipops as H
     from egaze_amd.floss import floss
+    if H.PRECISION != "split":
+        pytest.skip("the folded BatchNorm sums live in the split-half narrow kernel (default mode)")
     torch.manual_seed(5)
     B, S, C, K = 2, 32, 32, 32
     dy = torch.randn(B, S, S, K, device=DEV) * 1e-3
@@ -166,6 +168,8 @@ def test_deferred_batchnorm_matches_materialised():
     so outputs, running statistics and gradients must agree to fp32 round-off of the reductions."""
     from egaze_amd import hipops as H
     from egaze_amd.floss import floss
+    if H.PRECISION != "split":
+        pytest.skip("deferred BatchNorm lives in the split-half narrow kernels (default mode)")
     im, feat, gt = synth.synth_lf_batch(3, 48, seed=11)
     res = {}
     for defer in (True, False):
