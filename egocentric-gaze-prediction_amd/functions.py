@@ -147,6 +147,20 @@ class ConvBNReLUPool(torch.autograd.Function):
             bn_src = getattr(x, "_egz_bn_src", None) if training else None
             xin = to_nhwc(x)
             dt = H.conv_dtype("fwd", K, C, xin)
+            fold = (H.EVAL_FOLD and not training and not pool and out_buf is None and bn_in is None and dt == H.F16X3
+                    and K % 64 == 0 and H.INFER_CALL)       # (grad mode is always off inside forward(): the caller's mode)
+            if fold and torch.cuda.is_current_stream_capturing() and getattr(weight, "_egz_fold", None) is None:
+                fold = False                 # (a capture without a warm-up forward: the unfolded path is capturable)
+            if fold:
+                # inference: BatchNorm folded into the convolution, bias + ReLU epilogue -- no normalise pass (hipops.bn_folded_conv)
+                wf, bf = H.bn_folded_conv(weight, bias, gamma, beta, running_mean, running_var, eps)
+                wpf, stf = H.conv_weight(wf, "fwd", dt, xin, K)
+                if stf:
+                    out, _ = H.conv3x3_fwd(xin, wpf, bf, K, ups=False, epi=H.EPI_BIAS_RELU, dtype=dt, streamed=True)
+                    H.EVAL_FOLD_STATS["folded"] += 1
+                    ctx.cfg = (training, pool, first, C, K, padded)
+                    ctx.folded = True
+                    return from_nhwc(out)
             wp, st = H.conv_weight(weight, "fwd", dt, xin, K)
             if (bn_in is not None or defer) and not (dt and st):
                 raise RuntimeError("deferred BatchNorm: the convolution did not land on the streamed split-half kernel")

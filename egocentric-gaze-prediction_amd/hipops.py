@@ -870,6 +870,43 @@ def _stream_device(t):
     return t.device.index or 0
 
 
+# Inference: a [Conv2d 3x3 -> BatchNorm2d (eval) -> ReLU] block without a pool runs as ONE launch -- the BatchNorm's eval-mode
+# affine map is folded into the convolution (w' = w * scale[k], b' = b * scale[k] + shift[k], the bias + ReLU epilogue), so the
+# normalise pass (one read + one write of the layer's output, 8 of the 13 blocks of a VGG16-BN encoder) disappears.  The folded
+# tensors are cached on the weight and rebuilt when the weight, the bias or the BatchNorm's coefficients change.  Rounding: the
+# product w * scale is rounded once per weight (relative 6e-8) -- eval outputs move by ~1e-7 relative.  A/B knob: EGAZE_EVAL_FOLD=0.
+EVAL_FOLD = _os.environ.get("EGAZE_EVAL_FOLD", "1") != "0"
+EVAL_FOLD_STATS = {"folded": 0}
+INFER_CALL = False      # set by utils.conv_bn_relu_pool right before ConvBNReLUPool.apply: the block runs under torch.no_grad()
+
+
+def bn_folded_conv(weight, bias, gamma, beta, running_mean, running_var, eps: float):
+    """-> (w', b') of the folded block, cached on ``weight`` (pass the module's own parameter / buffer objects).  Not to be
+    called inside a hipGraph capture before the cache is warm (the fold itself is a few stock elementwise kernels, once per
+    weight change)."""
+    coef = bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
+    key = (_tag(weight), None if bias is None else _tag(bias), _tag(running_mean), _tag(running_var),
+           None if gamma is None else _tag(gamma), None if beta is None else _tag(beta), float(eps))
+    hit = getattr(weight, "_egz_fold", None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("bn_folded_conv: cold cache inside a hipGraph capture (run one eager forward first)")
+    with torch.no_grad():
+        K = weight.shape[0]
+        wf = hit[1] if hit is not None else torch.empty_like(weight.detach())
+        bf = hit[2] if hit is not None else torch.empty((K,), dtype=torch.float32, device=weight.device)
+        torch.mul(weight.detach(), coef[2].view(K, 1, 1, 1), out=wf)
+        if bias is not None:
+            torch.addcmul(coef[3], bias.detach(), coef[2], out=bf)
+        else:
+            bf.copy_(coef[3])
+    touch_params([wf])                       # its packings are stale
+    torch.cuda.current_stream().synchronize()
+    weight._egz_fold = (key, wf, bf)
+    return wf, bf
+
+
 def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _req(y, "y")
     B, H, W, K = y.shape

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from . import hipops as H
 from .functions import ConvBNReLUPool, ConvReLU, HeadSigmoid
 
 # utils.py:57-62 -- last max pooling removed
@@ -46,6 +47,7 @@ def conv_bn_relu_pool(x, conv: nn.Conv2d, bn: nn.BatchNorm2d, pool: bool, first:
     g, b, rm, rv, training, mom, eps = _bn_args(bn)
     # num_batches_tracked += 1 happens inside the statistics kernel (egz_bn_finalize), not as a separate launch
     nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+    H.INFER_CALL = not torch.is_grad_enabled()     # no graph will be built: inference (eval blocks may fold their BatchNorm)
     return ConvBNReLUPool.apply(x, conv.weight, conv.bias, g, b, rm, rv, training, mom, eps, pool, first, out_buf, nbt,
                                 next_k)
 

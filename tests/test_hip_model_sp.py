@@ -609,3 +609,39 @@ def test_overlapped_optimizer_tail_matches_plain_step():
     assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
     for k in b0:
         assert torch.equal(b0[k], b1[k]), k
+
+
+def test_eval_batchnorm_folded_into_conv(monkeypatch):
+    """Inference: the [Conv -> BatchNorm (eval) -> ReLU] blocks without a pool run as one launch with the BatchNorm folded into
+    the weights (hipops.bn_folded_conv).  Same gaze map as the unfolded path to fp32 round-off, the folded form actually runs
+    (8 of 13 blocks per encoder), and the cached folded weights follow a change of the weights and of the running statistics."""
+    import egaze_amd.hipops as H
+    if H.PRECISION != "split":
+        pytest.skip("the fold uses the split-half streamed kernel's bias + ReLU epilogue (default mode)")
+    model, _ = build_model()
+    model.eval()
+    x_s, x_t, _, _ = synth.synth_sp_batch(2, 64, seed=3)
+    x_s, x_t = x_s.to(DEV), x_t.to(DEV)
+
+    def run(fold):
+        monkeypatch.setattr(H, "EVAL_FOLD", fold)
+        before = H.EVAL_FOLD_STATS["folded"]
+        with torch.no_grad():
+            out = model(x_s, x_t)
+        torch.cuda.synchronize()
+        return out.clone(), H.EVAL_FOLD_STATS["folded"] - before
+
+    o1, n1 = run(True)
+    o0, n0 = run(False)
+    assert n0 == 0 and n1 >= 14, (n0, n1)
+    assert rel(o1.cpu().numpy(), o0.cpu().numpy()) < 1e-5         # (measured 1e-6 ... 3e-6: one more rounding per weight)
+    # the weights and the running statistics move (an optimizer step / a training epoch): the cached fold must follow
+    conv = [m for m in model.features_s.children() if isinstance(m, torch.nn.Conv2d)][2]
+    bn = [m for m in model.features_s.children() if isinstance(m, torch.nn.BatchNorm2d)][2]
+    with torch.no_grad():
+        conv.weight.mul_(1.25)
+        bn.running_mean.add_(0.05)
+    o1b, _ = run(True)
+    o0b, _ = run(False)
+    assert rel(o1b.cpu().numpy(), o0b.cpu().numpy()) < 1e-5
+    assert rel(o0b.cpu().numpy(), o0.cpu().numpy()) > 1e-4       # (the change is visible at all)
