@@ -14,6 +14,7 @@ from torch.utils.data import DataLoader
 
 from .data._io import imwrite, resize
 from .data.STdatas import stage_batch
+from . import hipops as H
 from .functions import MSELoss
 from .models.LSTMnet import lstmnet
 from .models.model_SP import model_SP
@@ -167,6 +168,7 @@ class _GraphedSampleStep:
             g = torch.cuda.CUDAGraph()
             count = self.opt.step_count
             with torch.cuda.graph(g):
+                H.ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()))
                 self._unit()
             self.opt.step_count = count        # the capture ran the host side of step() without executing anything
             self.graph = g

@@ -162,11 +162,7 @@ __global__ void bn_eval_coeffs_kernel(int K, const float* __restrict__ gamma, co
     shift[k] = (beta ? beta[k] : 0.f) - rm[k] * sc;
 }
 
-// max |v| of everything the launch wrote, without atomics (tens of thousands of device-scope atomics on one address cost
-// milliseconds): every block stores the bit pattern of its own maximum into absmax[1 + blockIdx.x] and a one-block
-// epilogue kernel folds the <= EGZ_ABSMAX_PARTIALS partials into absmax[0].  Bit patterns of non-negative floats order like
-// unsigned ints and max is exact and order independent: the result is deterministic.  No zero-initialisation is needed.
-constexpr int ABSMAX_PARTIALS = 16384;
+// max |v| of everything the launch wrote: the block's maximum goes into the abs-max buffer (layout and rationale: egz_common.h)
 __device__ __forceinline__ void block_absmax_commit(float m, unsigned int* __restrict__ absmax) {
     if (!absmax) return;                                  // uniform
     __shared__ float s_am[16];
@@ -176,26 +172,8 @@ __device__ __forceinline__ void block_absmax_commit(float m, unsigned int* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < nw; ++w) m = fmaxf(m, s_am[w]);
-        absmax[1 + blockIdx.x] = __float_as_uint(m);
+        absmax_commit(absmax, blockIdx.x, m);
     }
-}
-__global__ __launch_bounds__(256) void absmax_final_kernel(unsigned int* __restrict__ absmax, int nblocks) {
-    __shared__ unsigned int s[256];
-    unsigned int m = 0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) m = max(m, absmax[1 + i]);
-    s[threadIdx.x] = m;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) s[threadIdx.x] = max(s[threadIdx.x], s[threadIdx.x + st]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) absmax[0] = s[0];
-}
-int absmax_finish(unsigned int* absmax, int nblocks, hipStream_t st, const char* what) {
-    if (!absmax) return 0;
-    hipLaunchKernelGGL(absmax_final_kernel, dim3(1), dim3(256), 0, st, absmax, nblocks);
-    EGZ_CHECK_LAUNCH(what);
-    return 0;
 }
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n4, unsigned int* __restrict__ absmax) {
     float m = 0.f;
@@ -736,7 +714,7 @@ EGZ_API int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float
     if (pool) hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, absmax);
     else      hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, absmax);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_fwd");
-    return absmax_finish(absmax, ew_grid(n), st, "egz_bn_relu_pool_fwd(absmax)");
+    return 0;
 }
 
 EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {
@@ -776,7 +754,7 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
         hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), dim3(grid), dim3(256), 0, st, y, dout, scale, shift, mean, invstd,
                            (const float*)nullptr, (const float*)nullptr, dy, B, H, W, K, absmax, sums, sums_rows, (double)B * H * W, dgamma, dbeta);
         EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(finalize + apply)");
-        return absmax_finish(absmax, grid, st, "egz_bn_relu_pool_bwd(absmax)");
+        return 0;
     }
     if (sums) {
         part = const_cast<double*>(sums);
@@ -801,7 +779,7 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
     if (pool) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
     else      hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(apply)");
-    return absmax_finish(absmax, ew_grid(n), st, "egz_bn_relu_pool_bwd(absmax)");
+    return 0;
 }
 
 
@@ -1039,18 +1017,20 @@ EGZ_API int egz_pairmax_bwd(const float* y2, const float* dz, float* dy2, long n
     EGZ_CHECK_ARG(y2 && dz && dy2 && n % 4 == 0, "egz_pairmax_bwd: bad arguments");
     hipLaunchKernelGGL(pairmax_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, y2, dz, dy2, n / 4, absmax);
     EGZ_CHECK_LAUNCH("egz_pairmax_bwd");
-    return absmax_finish(absmax, ew_grid(n / 4), st, "egz_pairmax_bwd(absmax)");
+    return 0;
 }
 
-// absmax[0] = max |x| as the bit pattern of a float; absmax must hold egz_absmax_elems() uints (slot 0 + per-block
-// partials, no initialisation needed); n must be a multiple of 4.  The gradient producers above fold the same reduction
-// into their own pass; this entry point serves callers that hold a bare tensor.
-EGZ_API int egz_absmax_elems(void) { return 1 + ABSMAX_PARTIALS; }
+// max |x| into an abs-max buffer of egz_absmax_elems() uints (layout: egz_common.h).  Every OTHER entry point that takes an
+// `absmax` / `absmax_out` buffer folds this reduction into its own pass and expects the buffer ZERO-FILLED by the caller; this one
+// serves callers that hold a bare tensor and zero-fills the buffer itself (stream-ordered).  n must be a multiple of 4.
+EGZ_API int egz_absmax_elems(void) { return EGZ_AM_SLOTS * EGZ_AM_STRIDE; }
 EGZ_API int egz_absmax(const float* x, long n, unsigned int* absmax, hipStream_t st) {
     EGZ_CHECK_ARG(x && absmax && n > 0 && n % 4 == 0, "egz_absmax: bad arguments");
+    hipError_t e = hipMemsetAsync(absmax, 0, sizeof(unsigned int) * EGZ_AM_SLOTS * EGZ_AM_STRIDE, st);
+    if (e != hipSuccess) { egz_set_error("egz_absmax: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(absmax_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, st, x, n / 4, absmax);
     EGZ_CHECK_LAUNCH("egz_absmax");
-    return absmax_finish(absmax, ew_grid(n / 4), st, "egz_absmax(final)");
+    return 0;
 }
 
 // per-channel sum / sum-of-squares partials of an NHWC tensor [rows][K] in the conv-epilogue format, so that
@@ -1128,7 +1108,7 @@ EGZ_API int egz_relu_bwd_bias(const float* out, const float* dout, float* dy, fl
     }
     hipLaunchKernelGGL(colsum_final_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K, db);
     EGZ_CHECK_LAUNCH("egz_relu_bwd_bias(final)");
-    return absmax_finish(absmax, blocks, st, "egz_relu_bwd_bias(absmax)");
+    return 0;
 }
 
 // dxu: [B][2H][2W][C] -> dx: [B][H][W][C]
@@ -1230,12 +1210,6 @@ __global__ void colsum_final_n_kernel(const double* __restrict__ part, int npart
     out[k] = (float)s;
 }
 }  // namespace
-
-// absmax[0] = max over the partial slots absmax[1 .. nparts] a producer kernel filled (bit patterns of non-negative floats)
-EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st) {
-    EGZ_CHECK_ARG(absmax && nparts > 0 && nparts <= ABSMAX_PARTIALS, "egz_absmax_fold: bad arguments");
-    return absmax_finish(absmax, nparts, st, "egz_absmax_fold");
-}
 
 // out[c] = sum over rows of part[row][c] for c < ncols_out; part: [rows][cols] fp64 (e.g. the stat rows of a conv epilogue,
 // cols = 2 K, ncols_out = K = the sum plane).  workspace: RED_ROWS * cols doubles.  Fixed summation order.

@@ -20,7 +20,6 @@
 #include "x3_split.h"
 #include <type_traits>
 
-EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st);      // bn_pool.hip
 EGZ_API int egz_absmax(const float* x, long n, unsigned int* absmax, hipStream_t st);
 
 namespace {
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
         if (lane == 0) samax[wave] = amx;
         __syncthreads();
-        if (tid == 0) absmax_out[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
+        if (tid == 0) absmax_commit(absmax_out, blockIdx.x, fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
     }
     if (EPI == EPI_BIAS_STATS) {
         __syncthreads();
@@ -743,7 +742,7 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
         if (lane == 0) samax[wave] = amx;
         __syncthreads();
-        if (tid == 0) absmax_out[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
+        if (tid == 0) absmax_commit(absmax_out, blockIdx.x, fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
     }
     if (EPI == EPI_BIAS_STATS) {
         __syncthreads();
@@ -907,7 +906,6 @@ int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bi
             else EGZ_X3H(EPI_BIAS_STATS);
 #undef EGZ_X3H
             EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_split(halo)");
-            if (amo) return egz_absmax_fold(amo, (int)grid.x, st);
             return absmax_pass();
         }
     }
@@ -930,7 +928,6 @@ int launch_x3(int epi, const float* x, const unsigned short* wp, const float* bi
 #undef EGZ_X3
 #undef EGZ_X3L
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_split");
-    if (amo) return egz_absmax_fold(amo, p.main, st);
     return absmax_pass();
 }
 

@@ -38,7 +38,6 @@
 #define EGZ_X3S_DIAG 0        // fragment reads, 4 no halo restaging, 8 no barrier between images
 #endif
 
-EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st);      // bn_pool.hip
 
 namespace {
 using namespace x3;
@@ -626,7 +625,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         }
     }
     if ((EPI == EPI_MASK_SUMS || EPI == EPI_BIAS_RELU) && absmax_out) {           // block-uniform
-        // per-tile max |value| -> absmax_out[1 + tile] (bit pattern; folded by egz_absmax_fold, no atomics).  EPI_BIAS_RELU:
+        // per-tile max |value| -> the abs-max buffer (egz_common.h: one atomic max per tile at most).  EPI_BIAS_RELU:
         // the result is a post-ReLU activation that the next convolution splits into f16 halves -- its abs-max scales that split
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o));
@@ -636,7 +635,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             float m = samax[0];
 #pragma unroll
             for (int w = 1; w < NTHR / 64; ++w) m = fmaxf(m, samax[w]);
-            absmax_out[1 + gt] = __float_as_uint(m);
+            absmax_commit(absmax_out, (unsigned)gt, m);
         }
     }
     if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS || EPI == EPI_BNSUMS) {
@@ -1302,8 +1301,7 @@ __global__ __launch_bounds__(256) void splitk_fixup_kernel(const float* __restri
         if ((threadIdx.x & 63) == 0) samax[threadIdx.x >> 6] = amx;
         __syncthreads();
         if (threadIdx.x == 0)
-            absmax_out[1 + blockIdx.y * gridDim.x + blockIdx.x] =
-                __float_as_uint(fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
+            absmax_commit(absmax_out, blockIdx.y * gridDim.x + blockIdx.x, fmaxf(fmaxf(samax[0], samax[1]), fmaxf(samax[2], samax[3])));
     }
     if (EPI == EPI_BIAS_STATS) {
 #pragma unroll
@@ -1357,13 +1355,10 @@ int launch_x3s_splitk(int epi, const float* x, const unsigned short* wq, const f
     else       hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, false, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit);
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed_splitk");
     const dim3 fg(egz_cdiv(M, FIX_ROWS), egz_cdiv(K, 64));
-    if (epi == EPI_BIAS_RELU && absmax_out)
-        EGZ_CHECK_ARG((long)fg.x * fg.y <= 16384, "egz_conv3x3_fwd_streamed_splitk: %ld fix-up blocks exceed the abs-max partial slots", (long)fg.x * fg.y);
     if (epi == EPI_BIAS) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit, nullptr);
     else if (epi == EPI_BIAS_RELU) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_RELU>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit, absmax_out);
     else hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS_STATS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit, nullptr);
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed_splitk(fixup)");
-    if (epi == EPI_BIAS_RELU && absmax_out) return egz_absmax_fold(absmax_out, (int)(fg.x * fg.y), st);
     return 0;
 }
 
@@ -1381,7 +1376,6 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const dim3 grid(((total + 7) / 8) * 8);
 #define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1)
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS) absmax_out = nullptr;
-    if (absmax_out) EGZ_CHECK_ARG(total <= 16384, "egz_conv3x3_fwd_streamed: %d tiles exceed the abs-max partial slots", total);
     if constexpr (MODE == UPSF) {                                   // decoder blocks: bias + ReLU (or plain bias)
         if (epi != EPI_BIAS && epi != EPI_BIAS_RELU) {
             egz_set_error("egz_conv3x3_fwd_streamed: the upsample forward has the bias and bias + ReLU epilogues only");
@@ -1414,7 +1408,6 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     }
 #undef EGZ_X3S
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed");
-    if (epi == EPI_BIAS_RELU && absmax_out) return egz_absmax_fold(absmax_out, total, st);     // (epi 3: the caller folds)
     return 0;
 }
 
@@ -1506,8 +1499,7 @@ EGZ_API int egz_pack_w3x3_split_frag_multi(const void* table, int nrows, int tot
 // epi: 0 bias, 1 bias + ReLU, 2 bias + per-channel (sum, sumsq) partials in egz_conv3x3_streamed_stat_rows(B, H, W, C, K)
 // rows (one per 128 output pixels; one per block on the persistent narrow kernel); 3 (data gradients, 128- / 64-column tiles): y = result where
 // mask_src > 0 else 0 (mask_src: [B][H'][W'][K], the post-ReLU activation whose gradient this is), stat rows = per-channel
-// sums of the masked result (plane 0; the bias gradient of the layer below), absmax_out[1 + tile] = per-tile max |y| (fold
-// with egz_absmax_fold(absmax_out, tiles)).  Only for geometries egz_conv3x3_streamed_ok accepts.
+// sums of the masked result (plane 0; the bias gradient of the layer below), absmax_out (zero-filled by the caller) = max |y|.  Only for geometries egz_conv3x3_streamed_ok accepts.
 EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial,
                                      int B, int H, int W, int C, int K, int epi, int dtype, int mode,
                                      const unsigned int* x_absmax, const float* mask_src, unsigned int* absmax_out,

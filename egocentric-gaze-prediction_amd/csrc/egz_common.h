@@ -35,12 +35,36 @@ static inline int egz_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // 32x32 accumulator element `reg` of lane `lane` sits at row (reg&3)+8*(reg>>2)+4*(lane>>5),
 // column lane&31 (cdna_hip_programming.md section 3; dtype-independent on gfx950).
-__device__ __forceinline__ int egz_acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }// Power-of-two scale that brings a tensor whose max |value| is *absmax (float bit pattern, egz_absmax / the gradient
-// producers of bn_pool.hip) into [2^12, 2^13): gradients of 1e-3 .. 1e-9 become f16-representable with 22 significant
+__device__ __forceinline__ int egz_acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }// Abs-max buffer of a tensor (egz_absmax_elems() uints, ZERO-FILLED by the caller before the producing launch): EGZ_AM_SLOTS slots,
+// one per 128-byte line (index slot * EGZ_AM_STRIDE), each holding the bit pattern of a non-negative float.  A producing
+// block folds its own maximum into slot (block index % EGZ_AM_SLOTS) with ONE device-scope atomic max -- skipped when the slot
+// already holds a larger value, so a launch of thousands of blocks issues a few dozen atomics, spread over 32 lines; bit patterns
+// of non-negative floats order like unsigned ints and max is exact and order independent: the result is deterministic.  A
+// consumer takes the maximum of the slots (one load per lane + five shuffles) at the top of its kernel -- no fold launch sits
+// between producer and consumer (round 3: 84 one-block fold launches per SP step, each waiting ~17 us for a CU slot).
+constexpr int EGZ_AM_SLOTS = 32, EGZ_AM_STRIDE = 32;
+__device__ __forceinline__ void absmax_commit(unsigned int* __restrict__ absmax, unsigned int idx, float m) {
+    unsigned int* p = absmax + (idx & (EGZ_AM_SLOTS - 1)) * EGZ_AM_STRIDE;
+    const unsigned int bits = __float_as_uint(m);
+    if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        __hip_atomic_fetch_max(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// max over the slots; every lane of the calling wave must be active (call it at the top of a kernel)
+__device__ __forceinline__ unsigned int absmax_bits(const unsigned int* __restrict__ absmax) {
+    unsigned int v = absmax[(threadIdx.x & (EGZ_AM_SLOTS - 1)) * EGZ_AM_STRIDE];
+#pragma unroll
+    for (int off = EGZ_AM_SLOTS / 2; off > 0; off >>= 1) {
+        const unsigned int o = (unsigned int)__shfl_xor((int)v, off);
+        v = v > o ? v : o;
+    }
+    return v;
+}
+// Power-of-two scale that brings a tensor whose max |value| is in `absmax` (layout above; egz_absmax / the producers of
+// bn_pool.hip and the conv epilogues) into [2^12, 2^13): gradients of 1e-3 .. 1e-9 become f16-representable with 22 significant
 // bits in the hi + lo pair.  Multiplying by it and dividing the accumulators by it afterwards is exact.
 __device__ __forceinline__ float absmax_scale(const unsigned int* __restrict__ absmax) {
     if (!absmax) return 1.f;
-    const float am = __uint_as_float(*absmax);
+    const float am = __uint_as_float(absmax_bits(absmax));
     if (!(am > 0.f) || !(am < INFINITY)) return 1.f;
     int e;
     frexpf(am, &e);
@@ -48,6 +72,3 @@ __device__ __forceinline__ float absmax_scale(const unsigned int* __restrict__ a
     se = se > 100 ? 100 : (se < -100 ? -100 : se);
     return ldexpf(1.f, se);
 }
-
-
-

@@ -6,7 +6,6 @@
 //     (SP.py:103-106 `--loss_function` switch).
 #include "egz_common.h"
 
-EGZ_API int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t st);      // bn_pool.hip
 
 namespace {
 
@@ -40,7 +39,7 @@ __global__ __launch_bounds__(256) void conv1x1_sigmoid_fwd_kernel(const float* _
 // ReLU backward of that block, the column sums of the masked gradient (= its bias gradient) and max |dx| for the f16 scaling
 // of its conv backward are taken here, where x is in registers anyway -- the standalone pass (egz_relu_bwd_bias: 1.2 GB per
 // step at batch 32, nothing to overlap with at the head of the backward pass) goes away.  mstat: [gridDim.x][C] fp64 partial
-// rows, absmax: partial slots 1 + blockIdx.x (folded by egz_absmax_fold).
+// rows, absmax: the abs-max buffer (zero-filled by the caller; egz_common.h).
 template <int LPP, bool MASK>
 __global__ __launch_bounds__(256) void conv1x1_sigmoid_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ out, const float* __restrict__ dout,
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void conv1x1_sigmoid_bwd_kernel(const float* _
             mstat[(long)blockIdx.x * C + i] = t;
         }
         if (threadIdx.x == 0)
-            absmax[1 + blockIdx.x] = __float_as_uint(fmaxf(fmaxf(s_am[0], s_am[1]), fmaxf(s_am[2], s_am[3])));
+            absmax_commit(absmax, blockIdx.x, fmaxf(fmaxf(s_am[0], s_am[1]), fmaxf(s_am[2], s_am[3])));
     }
 }
 
@@ -386,7 +385,7 @@ EGZ_API int egz_conv1x1_sigmoid_bwd_masked(const float* x, const float* w, const
     int rc = head_bwd_launch(x, w, out, dout, dx, dw, db, M, C, workspace, ws_bytes, mstat, absmax, st,
                              "egz_conv1x1_sigmoid_bwd_masked");
     if (rc) return rc;
-    return egz_absmax_fold(absmax, egz_conv1x1_sigmoid_bwd_rows(M, C), st);
+    return 0;
 }
 
 EGZ_API size_t egz_loss_ws_bytes(int B) { return (size_t)LOSS_BLOCKS * sizeof(double) + (size_t)2 * B * sizeof(double); }

@@ -23,6 +23,14 @@ import torch
 import torch.distributed as dist
 
 
+_DIAG_NO_COLLECTIVE = os.environ.get("EGAZE_DP_DIAG", "") == "nocoll"
+
+
+class _NoHandle:
+    def wait(self):
+        pass
+
+
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, params: Sequence[torch.nn.Parameter], offsets: Sequence[int],
                  bucket_bytes: int = 25 * 1024 * 1024, group=None, flat_param: Optional[torch.Tensor] = None,
@@ -94,6 +102,10 @@ class GradReducer:
             from . import streams
             comm = streams.comm_stream(self.flat_grad.device)
             streams.join_all_into(comm)
+            if _DIAG_NO_COLLECTIVE:              # diagnostic (EGAZE_DP_DIAG=nocoll): the joins without the collective itself
+                self._handles.append(_NoHandle())
+                self.handle_of[b] = self._handles[-1]
+                return
             with torch.cuda.stream(comm):
                 self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
@@ -172,7 +184,7 @@ class GradReducer:
         self.active = False
 
 
-def attach(optimizer, bucket_bytes: int = 25 * 1024 * 1024, group=None, force: Optional[bool] = None,
+def attach(optimizer, bucket_bytes: int = int(os.environ.get("EGAZE_DP_BUCKET_MB", "25")) * 1024 * 1024, group=None, force: Optional[bool] = None,
            record_events: bool = False) -> GradReducer:
     """Wire a GradReducer to a FusedAdam: reduce before the step, average inside the Adam kernel."""
     red = GradReducer(optimizer.flat_g, optimizer.params, optimizer.offsets, bucket_bytes, group, optimizer.flat_p,

@@ -44,6 +44,7 @@ class GraphedModule:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
+            H.ABSMAX_ARENA.capture_begin(self.static_in[0].device)
             self.static_out = self.module(*self.static_in)
         self.epoch = self._signature()
 
@@ -99,6 +100,7 @@ class GraphedTrainStep:
             g = torch.cuda.CUDAGraph()
             count = self.opt.step_count
             with torch.cuda.graph(g):
+                H.ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()))
                 self._unit()
             self.opt.step_count = count          # the capture ran the host side of step() without executing anything
             self.graph = g

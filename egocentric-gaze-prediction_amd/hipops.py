@@ -454,15 +454,67 @@ DIRECT_GRADS = _os.environ.get("EGAZE_DIRECT_GRADS", "1") != "0"      # A/B knob
 
 
 # ----------------------------------------------------------------------------- abs-max of gradient tensors
-_ABSMAX_ELEMS = [0]
+
+
+class _AbsmaxArena:
+    """Zero-filled abs-max buffers (egz_common.h: the producers fold their maxima in with atomic max, so a buffer must start at
+    zero).  Buffers are cut from chunks that ONE fill zeroes (a chunk serves ~250 buffers = about one SP step); a chunk is
+    filled on the stream that was current when it was created and every other stream that takes a buffer from it waits for
+    that fill once.  A hipGraph capture gets chunks of its own: the captured fill re-zeroes them on every replay, and buffers
+    handed out before / after the capture are never touched by it."""
+    CHUNK = 256
+
+    def __init__(self):
+        self.elems = 0
+        self.chunk = None
+        self.used = 0
+        self.tag = None
+        self.event = None
+        self.waited = set()
+        self.capture_seq = 0
+
+    def capture_begin(self, device):
+        """First statement inside a hipGraph capture (graphs.py, AT.py): the capture's buffers come from a chunk of its own whose
+        fill is captured HERE, on the capture's origin stream, before any side stream forks."""
+        self.capture_seq += 1
+        self.chunk = None
+        self.take(device)
+
+    def take(self, device) -> torch.Tensor:
+        if not self.elems:
+            self.elems = int(LIB.egz_absmax_elems())
+        capturing = torch.cuda.is_current_stream_capturing()
+        tag = (capturing, self.capture_seq if capturing else 0, str(device))
+        if self.chunk is None or self.used == self.CHUNK or tag != self.tag:
+            self.chunk = torch.zeros(self.CHUNK * self.elems, dtype=torch.int32, device=device)
+            self.used, self.tag = 0, tag
+            if capturing:
+                self.event = None                    # inside a capture the forked streams are ordered by the capture graph itself
+            else:
+                self.event = torch.cuda.Event()
+                self.event.record()
+            self.waited = {torch.cuda.current_stream().cuda_stream}
+        elif self.event is not None:
+            st = torch.cuda.current_stream()
+            if st.cuda_stream not in self.waited:
+                st.wait_event(self.event)
+                self.waited.add(st.cuda_stream)
+        buf = self.chunk[self.used * self.elems:(self.used + 1) * self.elems]
+        self.used += 1
+        return buf
+
+
+ABSMAX_ARENA = _AbsmaxArena()
 
 
 def _new_absmax(device) -> torch.Tensor:
-    """Abs-max buffer of a gradient tensor: slot 0 = max |x| as the bit pattern of a non-negative float, the other slots
-    are the per-block partials of the producing kernel (no initialisation needed, no atomics)."""
-    if not _ABSMAX_ELEMS[0]:
-        _ABSMAX_ELEMS[0] = int(LIB.egz_absmax_elems())
-    return torch.empty(_ABSMAX_ELEMS[0], dtype=torch.int32, device=device)
+    """A zero-filled abs-max buffer (32 slots, one per 128-byte line; see egz_common.h and _AbsmaxArena)."""
+    return ABSMAX_ARENA.take(device)
+
+
+def absmax_value(am: torch.Tensor) -> torch.Tensor:
+    """max |x| held by an abs-max buffer, as a 1-element float32 tensor (the maximum over its slots)."""
+    return am.view(32, -1)[:, 0].max().reshape(1).view(torch.float32)
 
 
 def _want_absmax() -> bool:
@@ -657,10 +709,6 @@ def conv3x3_dgrad_masked(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
                                        EPI_MASK_SUMS, dtype, 1 if ups else 0, _p(am), mask_src.data_ptr(), amo.data_ptr(),
                                        None, None, _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
-    tile_rows = 128 if C % 128 == 0 else 256
-    tile_cols = 128 if C % 128 == 0 else 64
-    ntiles = ((B * Ho * Wo + tile_rows - 1) // tile_rows) * (C // tile_cols)
-    check(LIB.egz_absmax_fold(amo.data_ptr(), ntiles, _stream()), "egz_absmax_fold")
     return dx, stat, amo
 
 

@@ -121,7 +121,6 @@ int egz_conv3x3_fwd_streamed_splitk(const float* x, const void* wq, const float*
                                     hipStream_t stream);
 /* helpers of the epi = 3 (ReLU mask + bias-gradient sums + abs-max) form of egz_conv3x3_fwd_streamed, which folds the
  * nn.ReLU backward of a decoder layer (models/model_SP.py:13-29) into the data gradient of the layer above it */
-int egz_absmax_fold(unsigned int* absmax, int nparts, hipStream_t stream);
 int egz_colsum_f64(const double* part, int rows, int cols, int ncols_out, float* out, void* workspace, size_t ws_bytes,
                    hipStream_t stream);
 /* dw (K,C,3,3) = sum_pixels dy (x) x   (autograd of the same conv; loss.backward() at SP.py:136, LF.py:99) */
@@ -184,10 +183,12 @@ int egz_bn_bwd_first_wgrad(const float* y, const float* dout, const float* scale
 /* sums (optional, pool = 0): [sums_rows][2][K] partial rows of (sum dz, sum dz * xhat) produced together with dout by
  * egz_conv3x3_fwd_streamed epi 5 -- the reduce pass over y and dout is skipped.
  * `absmax` of the three gradient producers (egz_bn_relu_pool_bwd, egz_pairmax_bwd, egz_relu_bwd_bias; optional): a buffer of
- * egz_absmax_elems() uints, no initialisation needed.  Slot 0 receives max |dy| as the bit pattern of a float, computed in
- * the same pass (per-block partials in the other slots + a one-block epilogue: no atomics, deterministic).  It is the scale
- * source of the f16 x3 split-half data / weight gradients (egz_conv3x3_fwd_split x_absmax, egz_conv3x3_wgrad dy_absmax read
- * slot 0); egz_absmax computes it for a bare tensor (n % 4 == 0). */
+ * egz_absmax_elems() uints that the CALLER ZERO-FILLS before the producing call (true for every `absmax` / `absmax_out`
+ * argument of this header except egz_absmax's, which zero-fills its own).  Layout: 32 slots, one per 128-byte line, each the
+ * bit pattern of a non-negative float; a producing block folds its maximum into one slot with at most one device-scope atomic
+ * max (max is exact and order independent: deterministic), a consumer (`x_absmax`, `dy_absmax`, `a_absmax` arguments) takes
+ * the maximum of the slots at the top of its kernel -- no fold launch between producer and consumer.  It is the scale source
+ * of the f16 x3 split-half forward / data / weight gradients; egz_absmax computes it for a bare tensor (n % 4 == 0). */
 int egz_absmax_elems(void);
 int egz_absmax(const float* x, long n, unsigned int* absmax, hipStream_t stream);
 

@@ -336,7 +336,7 @@ def test_head_sigmoid_masked_backward(C, B, Hh, Ww):
     assert rel(nchw(dx), y.grad) < 1e-5
     assert rel(dw.cpu(), w.grad) < 1e-5 and rel(db.cpu(), b.grad) < 1e-5
     torch.cuda.synchronize()
-    got = am[:1].view(torch.float32).item()
+    got = h.absmax_value(am).item()
     assert got == dx.abs().max().item()
 
 
@@ -569,7 +569,7 @@ def test_gradient_absmax_scaling(mag):
     wref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1)
     dyd, wd = nhwc(dy), w.to(DEV)
     am = h.absmax_of(dyd)
-    assert torch.equal(am[:1].view(torch.float32).cpu(), dy.abs().max().reshape(1))     # bit pattern of the exact max
+    assert torch.equal(h.absmax_value(am).cpu(), dy.abs().max().reshape(1))     # bit pattern of the exact max
     dx = h.conv3x3_dgrad(dyd, h.packed_weight(wd, "dgrad", 1), C, dtype=1)
     assert rel(nchw(dx), dref) < 2e-6
     dw = h.conv3x3_wgrad(nhwc(x), dyd, precision="split_f16")
@@ -584,7 +584,7 @@ def test_gradient_absmax_scaling(mag):
     finally:
         h.PRECISION, h.GRAD_SPLIT = keep
     want = (dy2.abs().max()).reshape(1).cpu()
-    assert torch.equal(dy2._egz_absmax[:1].view(torch.float32).cpu(), want)
+    assert torch.equal(h.absmax_value(dy2._egz_absmax).cpu(), want)
 
 
 @pytest.mark.parametrize("mag", [1e-5, 1e-2, 1.0, 1e3, 2e5])
@@ -608,7 +608,7 @@ def test_forward_activation_scaling(mag):
         coef[3] = 0.1 * mag
         a = h.bn_relu_pool_fwd(ypre, coef, True)
         am = a._egz_absmax
-        assert torch.equal(am[:1].view(torch.float32).cpu(), a.max().reshape(1).cpu())          # exact max, as a bit pattern
+        assert torch.equal(h.absmax_value(am).cpu(), a.max().reshape(1).cpu())          # exact max, as a bit pattern
         a_ref = a.permute(0, 3, 1, 2).double().cpu()
         w = rnd(K, C, 3, 3, seed=72, scale=(2.0 / (9 * C)) ** 0.5)
         b = rnd(K, seed=73, scale=0.1 * mag)
@@ -621,7 +621,7 @@ def test_forward_activation_scaling(mag):
         assert h.ABSMAX_STATS["standalone"] == before          # the producer's scalar was used, no extra pass
         assert rel(nchw(y), ref) < 2e-6
         # ---- producer 2: the conv's own bias + ReLU epilogue emitted max |y| for the next layer
-        assert torch.equal(y._egz_absmax[:1].view(torch.float32).cpu(), y.max().reshape(1).cpu())
+        assert torch.equal(h.absmax_value(y._egz_absmax).cpu(), y.max().reshape(1).cpu())
         # ---- the gather-kernel family (phase-upsample forward) scales the same way and emits its abs-max too
         w2 = rnd(64, K, 3, 3, seed=74, scale=(2.0 / (9 * K)) ** 0.5)
         w2d = torch.nn.Parameter(w2.to(DEV))
@@ -631,7 +631,7 @@ def test_forward_activation_scaling(mag):
                               dtype=h.F16X3)
         assert h.ABSMAX_STATS["standalone"] == before
         assert rel(nchw(y2), ref2) < 2e-6
-        assert torch.equal(y2._egz_absmax[:1].view(torch.float32).cpu(), y2.max().reshape(1).cpu())
+        assert torch.equal(h.absmax_value(y2._egz_absmax).cpu(), y2.max().reshape(1).cpu())
         # ---- weight gradient: the x operand is scaled by its abs-max, dy by its own
         dy = rnd(B, K, Hh, Ww, seed=75)
         wref = torch.nn.grad.conv2d_weight(a_ref, w.shape, dy.double(), padding=1)
@@ -929,7 +929,7 @@ def test_conv3x3_streamed_ups_fwd(B, Hl, Wl, C, K, epi_relu):
     assert rel(y, y0) < 2e-6
     if epi_relu and h._want_fwd_absmax():
         torch.cuda.synchronize()
-        assert y._egz_absmax[:1].view(torch.float32).item() == y.max().item()
+        assert h.absmax_value(y._egz_absmax).item() == y.max().item()
 
 
 def test_cabi_argument_errors_are_loud():
