@@ -168,6 +168,13 @@ def main():
     # EGAZE_DP_FORCE=1 at N = 1: a process group of ONE rank over RCCL -- the timed step then runs the data-parallel code
     # path (bucket hooks, async all-reduce from the comm stream, the joins in front of Adam) on the one GPU of the box
     dp_forced = world == 1 and os.environ.get("EGAZE_DP_FORCE") == "1"
+    if os.environ.get("EGAZE_PRESTREAMS", "0") != "0":        # diagnostic: helper streams created BEFORE the process group
+        import egaze_amd.streams as _st
+        for _k in ("encoder_t", "wgrad", "adam", "at"):
+            _st.side_stream(_k)
+        _st.comm_stream(dev)
+    if os.environ.get("EGAZE_DUMMY_STREAMS"):                  # diagnostic: N unrelated streams created first
+        _dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ["EGAZE_DUMMY_STREAMS"]))]
     if world > 1 or dp_forced:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -480,6 +487,9 @@ def main():
                     s_.bind(("127.0.0.1", 0))
                     port = s_.getsockname()[1]
                 tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                tdist.barrier()                  # creates the communicator
+                step()
+                group_only_ms = _timed(5)        # an RCCL communicator exists, the reducer does not: RCCL's own side effect
                 reds = [(dp.attach(optimizer, force=True), optimizer)]
                 if use_at:
                     reds.append((dp.attach(opt_at, force=True), opt_at))
@@ -491,10 +501,13 @@ def main():
                 for red, o in reds:
                     red.detach(o)
                 tdist.destroy_process_group()
-                rccl = {"ms_per_step": rccl_ms, "ms_per_step_without": plain_ms, "delta_ms": rccl_ms - plain_ms,
+                rccl = {"ms_per_step": rccl_ms, "ms_per_step_without": plain_ms, "ms_per_step_group_initialised_reducer_off": group_only_ms,
+                        "delta_ms": rccl_ms - plain_ms, "delta_ms_of_the_reducer": rccl_ms - group_only_ms,
                         "buckets": nb, "buckets_issued_inside_backward_per_step": inb,
-                        "note": "untimed leg: 5 steps with dp.GradReducer forced on over the nccl (RCCL) backend at world size 1 "
-                                "vs 5 steps without; the timed region above runs without it at N = 1"}
+                        "note": "untimed leg: 5 steps without a process group, 5 with an RCCL group of one rank initialised but no "
+                                "reducer, 5 with dp.GradReducer forced on (bucket hooks, async all-reduces from the comm stream, "
+                                "joins in front of Adam); ~1 ms per step appears with the communicator alone (not with gloo): "
+                                "profiles/r04_dp_world1.txt.  The timed region above runs without any of it at N = 1"}
             except Exception as e:       # a box without a working RCCL must not lose the bench line
                 rccl = {"error": repr(e)[:300]}
             finally:

@@ -23,7 +23,8 @@ import torch
 import torch.distributed as dist
 
 
-_DIAG_NO_COLLECTIVE = os.environ.get("EGAZE_DP_DIAG", "") == "nocoll"
+_DIAG = os.environ.get("EGAZE_DP_DIAG", "")            # timing diagnostics (profiles/r04_dp_world1.txt): nocoll / nojoin / nohooks
+_DIAG_NO_COLLECTIVE = _DIAG in ("nocoll", "nojoin")
 
 
 class _NoHandle:
@@ -70,6 +71,8 @@ class GradReducer:
             self.buckets.append([cur_start, cur_end, cur_n])
         self._reset()
         self._hooks = []
+        if self.active and _DIAG == "nohooks":
+            self.active = False
         if self.active:
             if flat_param is not None:
                 dist.broadcast(flat_param, src=0, group=group)       # identical replicas to start from
@@ -84,6 +87,7 @@ class GradReducer:
         self._fired = [False] * len(self.bucket_of)
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._producers = [dict() for _ in self.buckets]      # bucket -> {stream id: stream} that wrote gradients of the bucket
         self._handles = []
         self.handle_of = {}                          # bucket -> async handle of its collective (optim._OverlappedTail waits on it)
         if getattr(self, "events", None):
@@ -99,9 +103,18 @@ class GradReducer:
             # compute streams themselves are not held up (joining them here would serialise the weight-gradient streams
             # with the data-gradient chain once per bucket).  The library orders the collective after the stream it is
             # issued from; wait() orders the optimizer step after the collective.
+            # Only the streams that WROTE this bucket are joined (each parameter's hook runs on the stream its gradient kernels
+            # were issued on): round 3 joined every helper stream of the process, which tied an unrelated model training on
+            # its own stream (bench.py's AT step, a second optimizer) into every bucket and cost +1.1 ms per step at world 1
+            # before a single collective ran (profiles/r04_dp_world1.txt).
             from . import streams
             comm = streams.comm_stream(self.flat_grad.device)
-            streams.join_all_into(comm)
+            producers = dict(self._producers[b])
+            cur = torch.cuda.current_stream()
+            producers[cur.cuda_stream] = cur
+            for sid, st in producers.items():
+                if sid != comm.cuda_stream and _DIAG != "nojoin":
+                    comm.wait_stream(st)
             if _DIAG_NO_COLLECTIVE:              # diagnostic (EGAZE_DP_DIAG=nocoll): the joins without the collective itself
                 self._handles.append(_NoHandle())
                 self.handle_of[b] = self._handles[-1]
@@ -132,13 +145,17 @@ class GradReducer:
     def _make_hook(self, i: int):
         b = self.bucket_of[i]
 
-        def hook(_param):
+        def hook(_param, producer=None):
             # a parameter can report twice per backward: from its gradient sink (in-place write, hipops.GradSink) and
             # again from autograd, which runs the post-accumulate hook even when the node returned None for it
             # (observed on torch 2.10) -- the first report is the one that follows the gradient kernels
             if self._fired[i]:
                 return
             self._fired[i] = True
+            if self.flat_grad.is_cuda:
+                for st in (torch.cuda.current_stream(), producer):
+                    if st is not None:
+                        self._producers[b][st.cuda_stream] = st
             self._pending[b] -= 1
             if self._pending[b] == 0 and not self._launched[b]:
                 self._launch(b)

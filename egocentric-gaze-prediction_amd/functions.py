@@ -57,6 +57,7 @@ def _close_fork(f, sink, dw, *inputs):
     gradient tensor goes back to autograd and the streams are joined."""
     if sink is not None and DETACH_WGRAD and not (f.enabled and torch.cuda.is_current_stream_capturing()):
         f.detach(*inputs)
+        H.PENDING_PRODUCER[0] = f.side if f.enabled else None      # the stream the weight gradient is being written on
         _join_at_end_of_backward()
     else:
         f.join(dw)            # (inside a hipGraph capture every fork joins back: a capture must end with one open stream)

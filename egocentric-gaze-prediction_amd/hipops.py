@@ -442,12 +442,17 @@ def grad_sink(param, wanted: bool = True) -> Optional[torch.Tensor]:
     return sk.buf
 
 
+PENDING_PRODUCER = [None]       # helper stream a detached weight-gradient fork just left running (functions._close_fork)
+
+
 def grad_done(param):
-    """Run the sink hooks of ``param`` (its gradient is final on the current stream)."""
+    """Run the sink hooks of ``param``: its gradient is final on the current stream -- or on the helper stream a detached
+    weight-gradient fork left running (the hooks get that stream as their second argument)."""
+    st, PENDING_PRODUCER[0] = PENDING_PRODUCER[0], None
     sk = getattr(param, "_egz_sink", None)
     if sk is not None:
         for h in sk.hooks:
-            h(param)
+            h(param, st)
 
 
 DIRECT_GRADS = _os.environ.get("EGAZE_DIRECT_GRADS", "1") != "0"      # A/B knob

@@ -100,7 +100,7 @@ class _OverlappedTail:
                 and not torch.cuda.is_current_stream_capturing())
 
     def _make_hook(self, i):
-        def hook(_param):
+        def hook(_param, _producer=None):
             if self.fired[i] or not self.usable():
                 return
             b = self.bucket_of[i]

@@ -17,7 +17,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 enum { F_FMA = 0, F_CVT = 1, F_MIX = 2, F_LDS = 3, F_PKADD = 4, F_NONE = 5 };
 
-template <int N, int KIND, int NTHR>
+template <int N, int KIND, int NTHR, int AGPR>
 __global__ __launch_bounds__(NTHR) void probe(const u32x4* __restrict__ in, float* __restrict__ out, long long* __restrict__ cyc, int iters) {
     __shared__ __attribute__((aligned(16))) float lds[8192];
     const int tid = threadIdx.x;
@@ -33,12 +33,15 @@ __global__ __launch_bounds__(NTHR) void probe(const u32x4* __restrict__ in, floa
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(float, a[i & 3]) * 1e-20f + (float)i;
     f32x4 ld = {0.f, 0.f, 0.f, 0.f};
+    f32x4 ldn[4] = {ld, ld, ld, ld};
     const float c1 = 1.0000001f, c2 = 1e-9f;
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
-            acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc[m & 3], 0, 0, 0);
+            if (AGPR == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[m & 3]) : "v"(a), "v"(b));
+            else if (AGPR == 2) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[m & 3]) : "v"(a), "v"(b));
+            else acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc[m & 3], 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 const int j = (m * N + k) & 7;
@@ -54,8 +57,8 @@ __global__ __launch_bounds__(NTHR) void probe(const u32x4* __restrict__ in, floa
                     v[j] = r;
                 }
                 if (KIND == F_LDS) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(&lds[((tid * 4 + (m * N + k) * 256) & 8188)]);
-                    ld += t;
+                    ld += ldn[k];                 // the value read one slot ago
+                    ldn[k] = *reinterpret_cast<const f32x4*>(&lds[((tid * 4 + (m * N + k) * 256) & 8188)]);
                 }
                 if (KIND == F_PKADD) {
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -78,14 +81,14 @@ __global__ __launch_bounds__(NTHR) void probe(const u32x4* __restrict__ in, floa
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int N, int KIND, int NTHR>
+template <int N, int KIND, int NTHR, int AGPR>
 static void run(const u32x4* din, float* dout, long long* dcyc, const char* name) {
     const int iters = 2000, blocks = 256;
-    hipLaunchKernelGGL((probe<N, KIND, NTHR>), dim3(blocks), dim3(NTHR), 0, 0, din, dout, dcyc, 10);
+    hipLaunchKernelGGL((probe<N, KIND, NTHR, AGPR>), dim3(blocks), dim3(NTHR), 0, 0, din, dout, dcyc, 10);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((probe<N, KIND, NTHR>), dim3(blocks), dim3(NTHR), 0, 0, din, dout, dcyc, iters);
+    hipLaunchKernelGGL((probe<N, KIND, NTHR, AGPR>), dim3(blocks), dim3(NTHR), 0, 0, din, dout, dcyc, iters);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -97,7 +100,7 @@ static void run(const u32x4* din, float* dout, long long* dcyc, const char* name
     avg /= blocks;
     const int wps = NTHR / 256;                              // waves per SIMD
     const double mfma_per_simd = 12.0 * iters * wps;
-    printf("%-8s N=%2d  waves/SIMD %d  cycles(s_memtime) per MFMA per SIMD %7.1f   wall ns per MFMA per SIMD %6.2f\n", name, N, wps,
+    printf("%-8s acc=%s N=%2d  waves/SIMD %d  cycles(s_memtime) per MFMA per SIMD %7.1f   wall ns per MFMA per SIMD %6.2f\n", name, AGPR == 1 ? "AGPR" : AGPR == 2 ? "VGPR" : "auto", N, wps,
            avg / mfma_per_simd, ms * 1e6 / mfma_per_simd);
     fflush(stdout);
 }
@@ -109,7 +112,7 @@ int main() {
     u32x4* din; float* dout; long long* dcyc;
     CK(hipMalloc(&din, hin.size() * 4)); CK(hipMalloc(&dout, 256 * 512 * 4)); CK(hipMalloc(&dcyc, 256 * 8));
     CK(hipMemcpy(din, hin.data(), hin.size() * 4, hipMemcpyHostToDevice));
-#define ROW(N, K, NAME) run<N, K, 256>(din, dout, dcyc, NAME); run<N, K, 512>(din, dout, dcyc, NAME);
+#define ROW(N, K, NAME) run<N, K, 256, 1>(din, dout, dcyc, NAME); run<N, K, 256, 2>(din, dout, dcyc, NAME); run<N, K, 512, 1>(din, dout, dcyc, NAME); run<N, K, 512, 2>(din, dout, dcyc, NAME);
     ROW(0, F_NONE, "none")
     ROW(2, F_FMA, "v_fma") ROW(4, F_FMA, "v_fma") ROW(6, F_FMA, "v_fma") ROW(8, F_FMA, "v_fma") ROW(12, F_FMA, "v_fma")
     ROW(4, F_CVT, "cvt_pk") ROW(8, F_CVT, "cvt_pk")
