@@ -168,13 +168,6 @@ def main():
     # EGAZE_DP_FORCE=1 at N = 1: a process group of ONE rank over RCCL -- the timed step then runs the data-parallel code
     # path (bucket hooks, async all-reduce from the comm stream, the joins in front of Adam) on the one GPU of the box
     dp_forced = world == 1 and os.environ.get("EGAZE_DP_FORCE") == "1"
-    if os.environ.get("EGAZE_PRESTREAMS", "0") != "0":        # diagnostic: helper streams created BEFORE the process group
-        import egaze_amd.streams as _st
-        for _k in ("encoder_t", "wgrad", "adam", "at"):
-            _st.side_stream(_k)
-        _st.comm_stream(dev)
-    if os.environ.get("EGAZE_DUMMY_STREAMS"):                  # diagnostic: N unrelated streams created first
-        _dummies = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ["EGAZE_DUMMY_STREAMS"]))]
     if world > 1 or dp_forced:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -207,7 +200,6 @@ def main():
     model.train()
     criterion = floss().to(dev)
     optimizer = FusedAdam(model.parameters(), lr=1e-7)          # gaze_full.py --lr default
-    optimizer.overlap_with_backward(True)       # step() follows backward() directly (SP.py:136-137): bucketed Adam under the backward
     if dist is not None:
         dp.attach(optimizer)
     batch = synthetic.sp_batch(args.batch, args.size, dev, seed=100 + rank)

@@ -130,7 +130,9 @@ class _GraphedSampleStep:
         self.state = torch.zeros((2, lstm.num_layer, 1, lstm.num_channel), device=device)      # (h, c)
         self.one = torch.ones((), device=device)                          # d loss / d loss
         from .models import LSTMnet as _L
-        self.single_step = bool(_L.B1_FUSED)      # the (1, 1, C) step runs on the fused single-step path (all sinks written)
+        # the (1, 1, C) step runs on the fused single-step path AND every gradient is written in full by a sink -- with
+        # EGAZE_DIRECT_GRADS=0 gradients go through AccumulateGrad and the flat buffer must be zeroed every step
+        self.single_step = bool(_L.B1_FUSED) and bool(H.DIRECT_GRADS)
         self.loss = None                     # the loss tensor of the last step (a graph-owned tensor once captured)
         self.graph, self.calls = None, 0
         self.opt.set_capturable(True)

@@ -77,6 +77,19 @@ class LF():
         # once and replayed (graphs.GraphedTrainStep); single process only -- the gradient reducer's hooks are host code.
         graphed = None
         use_graph = train and LF_GRAPH and dp.world_size() == 1 and self.device.type == 'cuda'
+        try:
+            return self._run_loop(loader, train, every, use_graph, losses, auc, aae)
+        finally:
+            # an exception / KeyboardInterrupt inside the loop must not leave the optimizer capturable with a stale host step
+            # count: close() syncs the count back from the device and leaves capturable mode
+            g = getattr(self, "_graphed", None)
+            if g is not None:
+                g.close()
+                self._graphed = None
+
+    def _run_loop(self, loader, train, every, use_graph, losses, auc, aae):
+        from .data.STdatas import staged_batches
+        graphed = None
         for i, (sample, (im, gt, feat)) in _progress(enumerate(staged_batches(loader, self.device, _stage_late))):
             if use_graph and graphed is None:
                 from .graphs import GraphedTrainStep
@@ -84,7 +97,7 @@ class LF():
                 def fwd_loss(feat_, im_, gt_):
                     o = self.model(feat_, im_)
                     return self.criterion(o, gt_), o
-                graphed = GraphedTrainStep(fwd_loss, self.optimizer, (feat, im, gt))
+                graphed = self._graphed = GraphedTrainStep(fwd_loss, self.optimizer, (feat, im, gt))
             if graphed is not None and feat.shape == graphed.static_in[0].shape:
                 loss, out = graphed(feat, im, gt)             # one replay = one LF.trainLate iteration (LF.py:90-100)
                 aae1, auc1, _ = computeAAEAUC(out, gt)
@@ -110,8 +123,6 @@ class LF():
                 print('Epoch: [{0}][{1}/{2}]\t''AUCAAE_late {auc.avg:.3f} ({aae.avg:.3f})\t'
                       'Loss {loss.val:.4f} ({loss.avg:.4f})\t'.format(self.epochnow, i + 1, len(loader) + 1, auc=auc,
                                                                       loss=losses, aae=aae))
-        if graphed is not None:
-            graphed.close()
         if dp.world_size() > 1:                      # global averages so that every rank agrees on the best epoch
             return tuple(dp.reduce_meters((losses.sum, losses.count), (auc.sum, auc.count), (aae.sum, aae.count)))
         return losses.avg, auc.avg, aae.avg

@@ -104,7 +104,6 @@ class SP():
         else:
             params = self.model.parameters()
         self.optimizer = FusedAdam(params, lr=self.lr)
-        self.optimizer.overlap_with_backward(True)      # trainSP calls step() right after backward() (SP.py:136-137)
         if pretrained_optimizer is not None:
             self.optimizer.load_state_dict(pretrained_optimizer)
         self.reducer = dp.attach(self.optimizer) if torch.distributed.is_initialized() else None

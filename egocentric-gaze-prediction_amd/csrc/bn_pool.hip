@@ -609,19 +609,10 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
     }
 }
 
-// Grid of the element-wise passes: n float4 items over 256-thread blocks, grid-stride, capped.  The cap is the experiment knob
-// EGZ_EW_CAP (default 8192): a conv kernel's two resident blocks per CU take the whole register file, so a streaming pass from
-// another HIP stream only gets the slots conv blocks free -- a narrower grid holds fewer of those slots (for longer).
-inline int ew_cap() {
-    static int cap = 0;
-    if (!cap) {
-        const char* e = getenv("EGZ_EW_CAP");
-        cap = e ? atoi(e) : 8192;
-        if (cap < 64) cap = 64;
-        if (cap > 8192) cap = 8192;
-    }
-    return cap;
-}
+// Grid of the element-wise passes: n float4 items over 256-thread blocks, grid-stride, capped at 8192 blocks.  (Narrower grids --
+// fewer of the CU slots that conv blocks free, held for longer -- change nothing down to 1024 blocks and lose below:
+// profiles/r03_ew_cap_ab.txt.)
+inline int ew_cap() { return 8192; }
 inline int ew_grid(long n) {
     long g = (n + 255) / 256;
     const int cap = ew_cap();
@@ -630,14 +621,7 @@ inline int ew_grid(long n) {
 
 constexpr int BWD_BLOCKS = 1024;
 constexpr int FIN_MAX_ROWS = 512, FIN_GRID = 2048;     // in-kernel finalize: at most this many partial rows / blocks re-summing them
-inline bool fin_in_kernel() {                            // A/B knob EGZ_BN_FIN_FUSE=0: separate column-sum + finalize launches
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EGZ_BN_FIN_FUSE");
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on != 0;
-}
+inline bool fin_in_kernel() { return true; }          // few partial rows: the apply pass sums them itself
 
 }  // namespace
 

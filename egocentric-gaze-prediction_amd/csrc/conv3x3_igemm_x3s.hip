@@ -24,19 +24,6 @@
 #include "egz_common.h"
 #include "x3_split.h"
 
-#ifndef EGZ_UPSD_PIPE         // A/B knob: 1 = both halves of an upsample-dgrad image fetched at tap 0 into two register sets
-                              // (measured: no gain, 675 vs 678 us -- the staging latency is already covered; costs 12 VGPRs)
-#define EGZ_UPSD_PIPE 0
-#endif
-#ifndef EGZ_X3S_FINE_ALL      // A/B knob: 1 = the instruction-level interleave of the one-wave-per-SIMD tile on every
-#define EGZ_X3S_FINE_ALL 1    // double-buffered configuration (the default 128 x 128 tile too): fwd -1 %, dgrad -3 % (r03_x3s_fine.txt)
-#endif
-#ifndef EGZ_WAVE_SCALAR       // A/B knob: 0 = wave index left in a VGPR (weight-fragment loads in waterfall loops)
-#define EGZ_WAVE_SCALAR 1
-#endif
-#ifndef EGZ_X3S_DIAG          // timing diagnostics (WRONG RESULTS): 1 no weight loads in the loop, 2 half the activation
-#define EGZ_X3S_DIAG 0        // fragment reads, 4 no halo restaging, 8 no barrier between images
-#endif
 
 
 namespace {
@@ -63,29 +50,21 @@ constexpr int HPITCH = 20;              // patch geometry: halo columns per LDS 
 //   1: 4 waves 1 x 4, tile 128 x 128, activation image double buffered (2 blocks / CU)
 //   2: 4 waves 2 x 2, tile 256 x 64 (the 64-channel layers)
 //   4: 4 waves 4 x 1, tile 256 x 32, every wave 64 rows (the narrow layers of the late-fusion stack, late_fusion.py:10-12)
-//   8: 8 waves 2 x 4, tile 256 x 128, one 512-thread block per CU.  The two waves of a column share their weight fragments:
-//      they issue the same 1 KB loads at the same time and the second is served by the CU's vector L1 instead of L2 -- the
-//      weight-fragment stream is the largest non-MFMA cost of this kernel (profiles/r02_x3s_diag.txt: -21 % without it).
-//  16: 4 waves 1 x 4, tile 256 x 128, every wave 256 rows x 32 columns = EIGHT accumulator tiles, ONE wave per SIMD (the
-//      accumulators live in AGPRs; 512 registers per wave).  A 1 KB weight fragment feeds 24 MFMAs instead of 12: the
-//      weight-fragment stream L2 -> registers, the largest non-MFMA cost of this kernel (-20 % without it,
-//      profiles/r03_x3s_diag.txt), is halved per MFMA -- without the duplicate loads of the 8-wave tile.
+// (Round 2 / 3 also carried an 8-wave 256 x 128 tile and a one-wave-per-SIMD 256 x 128 tile with eight accumulator tiles per wave:
+// both measured neutral-to-slower on the step -- profiles/r02_x3s_tile8.txt, r03_x3s_tile16.txt -- and were removed in round 4.)
 template <int WM> struct Geo {
-    static constexpr int WMM = (WM == 8) ? 2 : (WM == 16) ? 1 : WM;         // waves along the pixel dimension
-    static constexpr int NWN = (WM == 8 || WM == 16) ? 4 : 4 / WM;         // waves along the columns
+    static constexpr int WMM = WM;                             // waves along the pixel dimension
+    static constexpr int NWN = 4 / WM;                         // waves along the columns
     static constexpr int NTHR = 64 * WMM * NWN;
-    static constexpr int MR = (WM == 4) ? 2 : (WM == 16) ? 8 : 4;          // 32-row groups (accumulator tiles) per wave
+    static constexpr int MR = (WM == 4) ? 2 : 4;               // 32-row groups (accumulator tiles) per wave
     static constexpr int RPW = 32 * MR;                        // pixel rows per wave
     static constexpr int BM = RPW * WMM, BN = 32 * NWN;
     static constexpr int HSLOTS = (WM == 1) ? 256 : 384, HZERO = HSLOTS - 1;
-    static constexpr int NABUF = (WM == 1 || WM == 8 || WM == 16) ? 2 : 1;
+    static constexpr int NABUF = (WM == 1) ? 2 : 1;
     static constexpr int PROWS = BM / 16;                      // patch: PROWS x 16 pixels
     static constexpr int SPP = NTHR / 8;                       // halo slots staged per pass (8 threads x 4 channels per slot)
     static constexpr int NJ = HSLOTS / SPP;                    // halo slots per thread
-#ifndef EGZ_X3S_OCC4
-#define EGZ_X3S_OCC4 3
-#endif
-    static constexpr int OCC = (WM == 4) ? EGZ_X3S_OCC4 : (WM == 16) ? 1 : 2;     // waves per SIMD the register budget is cut for
+    static constexpr int OCC = (WM == 4) ? 3 : 2;   // waves per SIMD the register budget is cut for
 };
 
 // workgroup barrier that leaves this wave's global loads (the weight prefetch ring) in flight: __syncthreads() would
@@ -116,7 +95,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     constexpr int NIMG = (MODE == UPSD) ? 4 : 1;               // staged images per channel block
     constexpr int NT = (MODE == PLAIN) ? 9 : 4;                // taps per staged image
     constexpr int NRING = (MODE == PLAIN) ? 3 : 2;             // weight-fragment register sets (NIMG * NT % NRING == 0)
-    static_assert(MODE != UPSD || WM == 1 || WM == 8 || WM == 16, "the upsample data gradient is built for the 128-column tiles only");
+    static_assert(MODE != UPSD || WM == 1, "the upsample data gradient is built for the 128-column tile only");
     static_assert(MODE != UPSF || ((WM == 1 || WM == 2) && EPI != EPI_PARTIAL && EPI != EPI_BIAS_STATS && EPI != EPI_MASK_SUMS && EPI != EPI_BNSUMS),
                   "the upsample forward is built for the 4-wave 128- / 64-column tiles, bias / bias + ReLU epilogues");
     __shared__ __attribute__((aligned(16))) unsigned short Ah[G::NABUF * ABUF];
@@ -128,7 +107,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     out_scale /= a_scale;
     // the wave index is wave-uniform: telling the compiler (readfirstlane -> SGPR) keeps everything derived from it scalar --
     // in particular the soffset of the weight-fragment loads, which otherwise is wrapped in a waterfall loop per load
-    const int tid = threadIdx.x, lane = tid & 63, wave = EGZ_WAVE_SCALAR ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN, hl = lane >> 5, l31 = lane & 31;
     const int ntn = Kp / BN;
     // XCD-aware tile id: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
@@ -314,9 +293,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     // or -- UPSD, where an image only lasts four taps -- both halves in flight at once, fetched at tap 0 and split at taps 2
     // and 3: one tap of distance (~0.4 us per wave) did not cover the HBM latency of the strided polyphase fetch, and the
     // four upsample data gradients ran at half the rate of the plain convolutions (profiles/r02_conv_microbench.txt)
-    constexpr bool FINE = (G::NABUF == 2) && (WM == 16 || EGZ_X3S_FINE_ALL);   // instruction-level interleave of a slice (main loop)
+    constexpr bool FINE = (G::NABUF == 2);   // instruction-level interleave of a slice (main loop)
     // (the interleaved loop fetches half 1 of an upsample-dgrad image in the same tap that splits half 0: two register sets)
-    constexpr int RAOFF = (NT == 4 && (EGZ_UPSD_PIPE || FINE)) ? NJ / 2 : 0;
+    constexpr int RAOFF = (NT == 4 && FINE) ? NJ / 2 : 0;
     f32x4 ra[NJ / 2 + RAOFF];
     auto gload_a = [&](int cblk, const int img, const int half) {
         const unsigned so = (unsigned)(cblk * XBK * 4) +
@@ -349,9 +328,6 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         tap_addr(t9, abuf, cur);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
-#if EGZ_X3S_DIAG & 2
-            if (mr >= MR / 2) { ah0[mr] = ah0[mr - MR / 2]; al0[mr] = al0[mr - MR / 2]; continue; }
-#endif
             ah0[mr] = *reinterpret_cast<const u32x4*>(Ab + cur[mr]);
             al0[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[mr]);
         }
@@ -392,9 +368,8 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     read_a0(shift_of(0, 0), 0);
 
     // staging schedule of the NEXT image inside the NT taps of the current one (double-buffered images)
-    constexpr bool UP2 = (NT == 4) && EGZ_UPSD_PIPE;             // both halves fetched at tap 0 (two register sets)
-    constexpr int G0 = (NT == 9) ? 1 : 0, L0 = (NT == 9) ? 3 : (UP2 ? 2 : 1), G1 = (NT == 9) ? 4 : (UP2 ? 0 : 1),
-                  L1 = (NT == 9) ? 6 : (UP2 ? 3 : 2);
+    // (fetching both halves of an upsample-gradient image at tap 0 into two register sets measured no gain: r03_upsd_pipe_ab.txt)
+    constexpr int G0 = (NT == 9) ? 1 : 0, L0 = (NT == 9) ? 3 : 1, G1 = (NT == 9) ? 4 : 1, L1 = (NT == 9) ? 6 : 2;
     for (int c = c_lo; c < c_hi; ++c) {
 #pragma unroll
         for (int img = 0; img < NIMG; ++img) {
@@ -473,15 +448,10 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                     continue;
                 }
                 // the set being refilled was last read by slice s - 1
-#if !(EGZ_X3S_DIAG & 1)
                 gload_b(s + NRING - 1 < S_hi ? s + NRING - 1 : S_hi - 1, (img * NT + t + NRING - 1) % NRING);
-#endif
                 u32x4 ah1[MR], al1[MR];
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
-#if EGZ_X3S_DIAG & 2
-                    if (mr >= MR / 2) { ah1[mr] = ah1[mr - MR / 2]; al1[mr] = al1[mr - MR / 2]; continue; }
-#endif
                     ah1[mr] = *reinterpret_cast<const u32x4*>(Ab + (cur[mr] ^ 32));
                     al1[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[mr] ^ 32));
                 }
@@ -490,20 +460,16 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                 __builtin_amdgcn_sched_barrier(0);
                 if (G::NABUF == 2) {
                     // the next image goes into the OTHER buffer while this one is being multiplied
-#if !(EGZ_X3S_DIAG & 4)
                     if (more) {
                         if (t == L0) lstore_a(abuf ^ 1, 0);
                         if (t == G0) gload_a(ncblk, nimg, 0);
                         if (t == L1) lstore_a(abuf ^ 1, 1);
                         if (t == G1) gload_a(ncblk, nimg, 1);
                     }
-#endif
                     if (t < NT - 1) {
                         read_a0(shift_of(img, t + 1), abuf);
                     } else if (more) {
-#if !(EGZ_X3S_DIAG & 8)
                         lds_barrier();                         // every wave has staged its share and is done reading
-#endif
                         read_a0(shift_of(nimg, 0), abuf ^ 1);
                     }
                 } else {
@@ -540,14 +506,11 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     constexpr int SR = (RPW > 128) ? RPW / 128 : 1;            // 128-row stat rows a wave owns (2 on the 256-row waves)
     double s1 = 0.0, s2 = 0.0, s1b[SR], s2b[SR];
     float amx = 0.f;
-#ifndef EGZ_X3S_BUFSTORE
-#define EGZ_X3S_BUFSTORE 1
-#endif
     // The result goes out through BUFFER stores whose per-lane byte offset is out of range for rows / columns that do not exist
     // (dropped by the hardware): no per-lane branch around a store.  With `if (valid) y[...] = v` every store sat in its own
     // basic block and the wait-count pass put s_waitcnt vmcnt(0) in front of each one -- 32-64 stores per wave, each waiting
     // for the previous one to be acknowledged.  (The output is < 4 GiB: egz_conv3x3_streamed_ok.)
-    constexpr bool BUFST = EGZ_X3S_BUFSTORE && EPI != EPI_PARTIAL;
+    constexpr bool BUFST = EPI != EPI_PARTIAL;
     constexpr unsigned OUTMUL = (MODE == UPSF) ? 4u : 1u;       // UPSF: y is the hi-res image, four output pixels per tile-image pixel
     const __amdgpu_buffer_rsrc_t y_rs = __builtin_amdgcn_make_buffer_rsrc(y, 0, BUFST ? (int)(OUTMUL * (unsigned)M * (unsigned)K * 4u) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mk_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -753,32 +716,6 @@ __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __res
         frag_pack_pair_k<T>(w, wq, C, K, kind, Np, Rp, scale, j);
 }
 
-// Several packings in ONE launch (the optimizer's bucketed tail refreshes ~10 packings per bucket: one launch instead of ten
-// 5-8 us ones that each wait for a CU slot behind the convolution blocks).  table: nrows x 8 int64
-// [w, wq, C, K, kind, dtype, pairs = Np * Rp, first block]; block b works on the row whose block range holds it, 1024 (column,
-// reduction element) pairs per block.
-constexpr int FRAG_PER_BLOCK = 1024;
-__global__ __launch_bounds__(256) void pack_split_frag_multi_kernel(const long* __restrict__ table, int nrows) {
-    int lo = 0, hi = nrows - 1;
-    while (lo < hi) {                       // last row whose first block <= blockIdx.x
-        const int mid = (lo + hi + 1) >> 1;
-        if (table[8 * mid + 7] <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
-    }
-    const long* r = table + 8 * lo;
-    const float* w = reinterpret_cast<const float*>(r[0]);
-    unsigned short* wq = reinterpret_cast<unsigned short*>(r[1]);
-    const int C = (int)r[2], K = (int)r[3], kind = (int)r[4], dtype = (int)r[5];
-    const long n = r[6];
-    const int Cp = (C + 31) / 32 * 32, Kp = (K + 31) / 32 * 32;
-    const int Np = (kind == 4 || kind == 7) ? Kp : Cp, Rp = (kind == 4 || kind == 7) ? Cp : Kp;
-    const long base = ((long)blockIdx.x - r[7]) * FRAG_PER_BLOCK;
-    for (int e = threadIdx.x; e < FRAG_PER_BLOCK; e += 256) {
-        const long i = base + e;
-        if (i >= n) break;
-        if (dtype == 1) frag_pack_pair_k<_Float16>(w, wq, C, K, kind, Np, Rp, F16_WSCALE, i);
-        else            frag_pack_pair_k<__bf16>(w, wq, C, K, kind, Np, Rp, 1.f, i);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Persistent form for the narrowest layers (late_fusion.py:10-12: at most 32 reduction channels AND at most 32 GEMM columns,
@@ -929,10 +866,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             o_vo[mr][r] = nok ? (unsigned)((((i >> 4) * W + (i & 15)) * K + l31) * 4) : 0xFFFFFFFFu;
         }
 
-#ifndef EGZ_X3P_PIPE
-#define EGZ_X3P_PIPE 1
-#endif
-#if EGZ_X3P_PIPE
     // ---- software-pipelined tile loop.  The block is alone on its CU with one wave per SIMD, so nothing overlaps a wave's own
     // phases: fetch -> MFMAs -> epilogue (32 stores, statistics) -> split + LDS stores of the next halo -> barrier ran back to
     // back.  Here the 108 MFMAs of tile i are issued in 18 groups of six, and behind each group goes a piece of the OTHER work:
@@ -1095,90 +1028,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             s2 += (double)q2;
         }
     }
-#else
-    gload_a(tile);
-    lstore_a(0);
-    lds_barrier();
-    int buf = 0;
-    for (;;) {
-        const int nxt = tile + nbx;
-        const bool more = nxt < t_end;                          // block-uniform
-        if (more) gload_a(nxt);
-        // EPI_BNSUMS: this tile's values of the pre-BN tensor below, requested now and consumed in the epilogue (one wave per
-        // SIMD: nothing else hides a load issued there -- fetched in the epilogue the launch took 3x as long)
-        float byp[MR][16];
-        if (EPI == EPI_BNSUMS) {
-            const int b0 = tile / ppi, rem = tile - b0 * ppi;
-            const int y0 = (rem / pw) * 16, x0 = (rem % pw) * 16;
-            const unsigned so = (unsigned)((((long)b0 * H + y0) * W + x0) * K * 4);
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    byp[mr][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bn_rs, o_vo[mr][r], so, 0));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x16 acc[MR];
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 ah[MR], al[MR];
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr) {
-                    const int a = (fa9[t] + buf * (ABUF * 2) + mr * MRSTEP) ^ (ks * 32);
-                    ah[mr] = *reinterpret_cast<const u32x4*>(Ab + a);
-                    al[mr] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + a);
-                }
-#pragma unroll
-                for (int term = 0; term < 3; ++term)
-#pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
-                        acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bq[t][ks * 2 + 1] : bq[t][ks * 2], acc[mr]);
-            }
-        }
-        // ---- epilogue of this tile: the wave owns patch rows 4 wave .. 4 wave + 3 (64 pixels) x 32 columns
-        {
-            const int b0 = tile / ppi, rem = tile - b0 * ppi;
-            const int y0 = (rem / pw) * 16, x0 = (rem % pw) * 16;
-            const unsigned so = (unsigned)((((long)b0 * H + y0) * W + x0) * K * 4);
-            {
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    {
-                        float v = acc[mr][r] * out_scale + bz;         // (lanes beyond K: zero columns, bz = 0 -> v = 0)
-                        if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, o_vo[mr][r], so, 0);
-                        if (EPI == EPI_BIAS_STATS) {
-                            s1 += (double)v;
-                            s2 += (double)v * (double)v;
-                            vmx = fmaxf(vmx, v);
-                            vmn = fminf(vmn, v);
-                        }
-                        if (EPI == EPI_BNSUMS) {
-                            const float yp = byp[mr][r];
-                            const float dz = (yp * bn_sc + bn_sh > 0.f) ? v : 0.f;
-                            s1 += (double)dz;
-                            s2 += (double)(dz * ((yp - bn_mu) * bn_is));
-                        }
-                    }
-                }
-            }
-            }
-        }
-        if (!more) break;
-        lstore_a(buf ^ 1);
-        lds_barrier();                                          // everyone has staged its share and is done reading `buf`
-        buf ^= 1;
-        tile = nxt;
-    }
-#endif
     if (EPI == EPI_BIAS_STATS || EPI == EPI_BNSUMS) {            // row blockIdx.x: the four waves' sums in wave order
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
@@ -1221,12 +1070,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
     }
 }
 
-#ifndef EGZ_X3P_NARROW
-#define EGZ_X3P_NARROW 1
-#endif
 // geometry of the persistent narrow kernel (the output is addressed through a 32-bit buffer resource)
 bool x3p_narrow_ok(int B, int H, int W, int C, int K) {
-    return EGZ_X3P_NARROW && C <= 32 && K <= 32 && H % 16 == 0 && W % 16 == 0 && 4ull * B * H * W * K < (1ull << 32);
+    return C <= 32 && K <= 32 && H % 16 == 0 && W % 16 == 0 && 4ull * B * H * W * K < (1ull << 32);
 }
 
 // blocks of a persistent narrow launch = rows of its partial-sum buffer (epi 2 / 5): one block per CU, a multiple of 8 (XCDs)
@@ -1416,28 +1262,23 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 // 1 when the streamed-weight kernel covers this geometry (C = reduction channels: a multiple of 32, or a multiple of 4
 // below 32; K = GEMM columns: any).
 // mode 0: plain conv over an H x W image; mode 1: data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res
-// input, H x W = the hi-res gradient image (both even), 128-column tiles only; mode | 0x10: on the 8-wave 256 x 128 tile; mode | 0x20: on the 4-wave 256 x 128 tile with one wave
-// per SIMD (8 accumulator tiles per wave).  Needs the split-half channel constraints
+// input, H x W = the hi-res gradient image (both even), 128-column tiles only.  Needs the split-half channel constraints
 // and either the patch geometry or a raster run whose halo fits the LDS image (on the OUTPUT image: H/2 x W/2 in mode 1).
 // mode 2: forward of [nearest x2 upsample -> conv3x3] as four phase convolutions, H x W = the hi-res output image (both even),
 // K % 64 == 0, C % 32 == 0, 4-wave tiles on the low-res image.
 EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode) {
-    const bool tile8 = (mode & 0x30) != 0;                              // a 256 x 128 tile: 0x10 = 8 waves, 0x20 = 4 waves x 8 accumulators (K % 128 == 0 only)
-    mode &= 0xF;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || mode < 0 || mode > 2) return 0;
     if (mode == 2) {     // forward of [upsample x2 -> conv]: H x W = the hi-res OUTPUT image; tiles live on the low-res image
-        if (tile8 || K % 64 != 0 || C % 32 != 0 || (H & 1) || (W & 1)) return 0;
+        if (K % 64 != 0 || C % 32 != 0 || (H & 1) || (W & 1)) return 0;
         if (4ull * B * H * W * K >= (1ull << 32)) return 0;
         H >>= 1;
         W >>= 1;
         if (4ull * B * H * W * C >= (1ull << 32)) return 0;
-        if ((long)egz_cdiv((long)B * H * W, K % 128 == 0 ? 128 : 256) * (K % 128 == 0 ? K / 128 : K / 64) * 4 > 16384) return 0;   // abs-max slots
         const bool small2 = (K % 128 == 0);
         const int prow2 = small2 ? 8 : 16, bm2 = small2 ? 128 : 256, hzero2 = small2 ? 255 : 383;
         if (W % 16 == 0 && H % prow2 == 0) return 1;
         return (bm2 + 2 * W + 2 <= hzero2) ? 1 : 0;
     }
-    if (tile8 && K % 128 != 0) return 0;
     if (!(C % 32 == 0 || (C < 32 && C % 4 == 0))) return 0;            // whole channel blocks, or one zero-padded block
     if (4ull * B * H * W * C >= (1ull << 32)) return 0;
     if (mode == 1) {
@@ -1447,7 +1288,7 @@ EGZ_API int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode)
     }
     if (4ull * B * H * W * K >= (1ull << 32)) return 0;                // the result leaves through 32-bit buffer offsets
     // column tile: 128 (K % 128 == 0), 64 (K % 64 == 0), else 32-column tiles padded up to K (narrow layers)
-    const bool small = (K % 128 == 0) && !tile8;                        // 128 x 128 tile: 8 x 16 patches, 256 slots
+    const bool small = (K % 128 == 0);                                  // 128 x 128 tile: 8 x 16 patches, 256 slots
     const int prow = small ? 8 : 16, bm = small ? 128 : 256, hzero = small ? 255 : 383;
     if (W % 16 == 0 && H % prow == 0) return 1;
     return (bm + 2 * W + 2 <= hzero) ? 1 : 0;
@@ -1478,17 +1319,6 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
     if (dtype == 1) hipLaunchKernelGGL(pack_split_frag_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, F16_WSCALE);
     else            hipLaunchKernelGGL(pack_split_frag_kernel<__bf16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, 1.f);
     EGZ_CHECK_LAUNCH("egz_pack_w3x3_split_frag");
-    return 0;
-}
-
-// Several fragment-ordered packings in one launch.  table (device): nrows x 8 int64 [w, wq, C, K, kind (4..7), dtype (1 | 2),
-// pairs = Np * Rp, first block]; a row owns ceil(pairs / egz_pack_w3x3_split_frag_multi_per_block())
-// consecutive blocks starting at its first block; total_blocks = the sum.  Same results as egz_pack_w3x3_split_frag per row.
-EGZ_API int egz_pack_w3x3_split_frag_multi_per_block(void) { return FRAG_PER_BLOCK; }
-EGZ_API int egz_pack_w3x3_split_frag_multi(const void* table, int nrows, int total_blocks, hipStream_t st) {
-    EGZ_CHECK_ARG(table && nrows > 0 && total_blocks > 0, "egz_pack_w3x3_split_frag_multi: bad arguments");
-    hipLaunchKernelGGL(pack_split_frag_multi_kernel, dim3(total_blocks), dim3(256), 0, st, static_cast<const long*>(table), nrows);
-    EGZ_CHECK_LAUNCH("egz_pack_w3x3_split_frag_multi");
     return 0;
 }
 
@@ -1539,24 +1369,6 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                   "mask_src and absmax_out and takes no bias");
     const unsigned short* w16 = static_cast<const unsigned short*>(wq);
     const float os = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
-    if (mode & 0x20) {                                                  // 4-wave 256 x 128 tile, one wave per SIMD
-        EGZ_CHECK_ARG(epi != EPI_MASK_SUMS, "egz_conv3x3_fwd_streamed: the mask epilogue runs on the two-waves-per-SIMD tiles");
-        if ((mode & 0xF) == 1) {
-            if (dtype == 1) return launch_x3s<_Float16, 16, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-            return launch_x3s<__bf16, 16, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-        }
-        if (dtype == 1) return launch_x3s<_Float16, 16, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-        return launch_x3s<__bf16, 16, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-    }
-    if (mode & 0x10) {                                                  // 8-wave 256 x 128 tile
-        EGZ_CHECK_ARG(epi != EPI_MASK_SUMS, "egz_conv3x3_fwd_streamed: the mask epilogue runs on the 4-wave tiles");
-        if ((mode & 0xF) == 1) {
-            if (dtype == 1) return launch_x3s<_Float16, 8, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-            return launch_x3s<__bf16, 8, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-        }
-        if (dtype == 1) return launch_x3s<_Float16, 8, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-        return launch_x3s<__bf16, 8, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-    }
     if (mode == 2) {     // forward of [upsample x2 -> conv] (kind-7 packing): f16 x3 only (the forward arithmetic)
         EGZ_CHECK_ARG(dtype == 1, "egz_conv3x3_fwd_streamed: the upsample forward runs in f16 x3 (dtype 1)");
         if (K % 128 == 0) return launch_x3s<_Float16, 1, UPSF>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);

@@ -313,17 +313,9 @@ template <> struct W16<_Float16> {
 // eight XCDs, so each XCD's L2 fetches that range of x and dy from HBM separately (measured 2.5 x the algorithmic bytes);
 // here XCD j runs whole splits j, j + 8, ... -- all tiles of a pixel range share one L2 and stream through it together.
 // Needs gridDim.y % 8 == 0 (otherwise the natural map is kept); the result is independent of the map.
-#ifndef EGZ_WGRAD_XCD
-#define EGZ_WGRAD_XCD 1
-#endif
-#ifndef EGZ_WGRAD_FINE        // A/B knob: 1 = the split + LDS stores of the next stage issued piecewise behind the last 18 MFMAs of
-#define EGZ_WGRAD_FINE 0      // the current one.  Measured slower (4.14 vs 3.82 ms over the 12 layer shapes): the pieces wait for their
-#endif                        // global loads earlier and the longer live ranges spill (68 B / lane) -- unlike the forward kernel, whose
-                              // staging registers are loaded two taps ahead.  The block form stays.
 __device__ __forceinline__ void wgrad_block(int& tile, int& split) {
     tile = blockIdx.x;
     split = blockIdx.y;
-#if EGZ_WGRAD_XCD
     const int nt = gridDim.x, ns = gridDim.y;
     if ((ns & 7) == 0) {
         const int flat = blockIdx.y * nt + blockIdx.x;
@@ -331,7 +323,6 @@ __device__ __forceinline__ void wgrad_block(int& tile, int& split) {
         tile = r % nt;
         split = (flat & 7) + 8 * (r / nt);
     }
-#endif
 }
 
 template <typename T, bool UPS, int R, int WD>
@@ -513,31 +504,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
         }
     };
 
-    // one staged float4 of the next stage: split + two LDS stores (piece p < NX: halo slot, else dY) -- issued one at a time
-    // in the shadow of the last MFMAs of the stage (EGZ_WGRAD_FINE) instead of as a block behind them
-    static_assert(NX + ND <= 9, "the last 18 MFMAs of a stage carry at most 9 staging pieces");
-    auto lstore_piece = [&](int buf, const int p) {
-        if (p < NX) {
-            const int i = tid + 256 * p;
-            const int pos = i >> 4, c4 = i & 15;
-            if (pos < NH) {
-                u32x2_t hi, lo;
-                W16<T>::split4(rx[p] * x_scale, hi, lo);
-                unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
-                *reinterpret_cast<u32x2_t*>(d) = hi;
-                *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
-            }
-        } else if (p < NX + ND) {
-            const int j = p - NX;
-            const int i = tid + 256 * j;
-            const int pp = i >> 4, k4 = i & 15;
-            u32x2_t hi, lo;
-            W16<T>::split4(rd[j] * d_scale, hi, lo);
-            unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
-            *reinterpret_cast<u32x2_t*>(d) = hi;
-            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
-        }
-    };
 
     // transpose-read addressing: 16-lane group g = lane >> 4 covers channels 16 * (g & 1) .. +15 of the wave's half and
     // reduction elements 8 * (g >> 1) .. +7 (two reads of 4 pixels); lane u of the group hands in pixel (u >> 2),
@@ -582,19 +548,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                     xh[ts] = W16<T>::frag(Xb + xoff(ks, 0, tap), Xb + xoff(ks, 1, tap));
                     xl[ts] = W16<T>::frag(Xb + 2 * XH + xoff(ks, 0, tap), Xb + 2 * XH + xoff(ks, 1, tap));
                 }
-                if (EGZ_WGRAD_FINE && ks == KS - 1 && tr >= 1) {
-                    // the last 18 MFMAs of the stage carry the split + LDS stores of the next stage, one piece per two MFMAs
-                    const bool nxt = g + 1 < g1;                // block-uniform
-#pragma unroll
-                    for (int m = 0; m < 9; ++m) {
-                        const int term = m / 3, ts = m % 3;
-                        acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
-                        const int mm = (tr - 1) * 9 + m;
-                        if (nxt && (mm & 1) == 0) lstore_piece(buf ^ 1, mm >> 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    continue;
-                }
+                // (issuing the next stage's split + LDS stores piecewise behind the last MFMAs, as the forward kernel does, measured
+                // slower here -- 4.14 vs 3.82 ms over the 12 layer shapes, profiles/r03_wgrad_ab.txt -- and was removed)
 #pragma unroll
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -602,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                         acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
             }
         }
-        if (!EGZ_WGRAD_FINE && g + 1 < g1) lstore(buf ^ 1);
+        if (g + 1 < g1) lstore(buf ^ 1);
         __syncthreads();
     }
 #pragma unroll
@@ -1342,17 +1297,12 @@ int pick_patch_x3(int W, int C, int K, int flags) {
     // Large images: the 4 x 8 patch.  A stage stages the patch's halo, (R + 2) x (WD + 2) pixels for 32 outputs: 3.2x for 1 x 32,
     // 2.25x for 2 x 16, 1.9x for 4 x 8 -- and every staged element costs a fetch from L2 and an f16 split.  On the 224- and
     // 112-wide layers the squarer patch is 5-10 % faster (64 -> 64 @ 224: 474 -> 441 us, @ 224 decoder: 397 -> 358, 128 -> 128
-    // @ 112: 368 -> 351; profiles/r03_ab_notes.txt); at 56 and below it makes no difference.  EGZ_WGRAD_WD=0: the old rule.
-    static int wide8 = -1;
-    if (wide8 < 0) {
-        const char* e = getenv("EGZ_WGRAD_WD");
-        wide8 = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    if (wide8 && W >= 112 && W % 8 == 0) return 8;
+    // @ 112: 368 -> 351; profiles/r03_ab_notes.txt); at 56 and below it makes no difference.
+    if (W >= 112 && W % 8 == 0) return 8;
     // ... and on rows of 17-31 pixels (the 28 x 28 layers): four 8-wide patches with the last one partly masked waste the same
     // 14 % as one masked 32-wide run, with the smaller halo (512 -> 512 @ 28: 388 -> 353 us, 256 -> 512: 210 -> 190).  At 14 x 14
     // the 2 x 16 patch stays (4 x 8: 116 -> 122 us).
-    if (wide8 && W > 16 && W < 32) return 8;
+    if (W > 16 && W < 32) return 8;
     if (W % 32 == 0 || (W > 16 && W < 32)) return 32;
     if (W % 16 == 0 || (W > 8 && W < 16)) return 16;
     if (W % 8 == 0) return 8;
@@ -1365,10 +1315,7 @@ int pick_narrow_x3(int W, int C, int K, int flags) {
     return (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : 0;
 }
 long npatch_x3n(int B, int H, int W, int WD) { return (long)B * ((H + 64 / WD - 1) / (64 / WD)) * (W / WD); }
-#ifndef EGZ_X3_BLOCKS
-#define EGZ_X3_BLOCKS 512
-#endif
-constexpr int X3_BLOCKS = EGZ_X3_BLOCKS;   // blocks per launch of the split-half kernel: one round of 2 resident blocks per CU
+constexpr int X3_BLOCKS = 512;   // blocks per launch of the split-half kernel: one round of 2 resident blocks per CU
 long npatch_x3(int B, int H, int W, int WD) { return (long)B * ((H + 32 / WD - 1) / (32 / WD)) * ((W + WD - 1) / WD); }
 
 int pick_bt(int C, int K, int flags) {

@@ -248,14 +248,7 @@ __global__ __launch_bounds__(256) void conv_first_direct_kernel(
     }
 }
 
-inline bool first_direct_ok(int C, int K) {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("EGZ_FIRST_DIRECT");          // A/B knob: 0 = the im2col + fp32 MFMA kernel for every shape
-        on = (e && e[0] == '0') ? 0 : 1;
-    }
-    return on && (K == 32 || K == 64) && C >= 1 && C <= 3;
-}
+inline bool first_direct_ok(int C, int K) { return (K == 32 || K == 64) && C >= 1 && C <= 3; }
 inline int first_direct_ppb(long M, int W, int K) {
     const int step = (256 / (K / 4)) * ((W % 4 == 0) ? 4 : 1);  // pixels per block iteration (4 / 1 per thread)
     long ppb = (M + FD_BLOCKS - 1) / FD_BLOCKS;

@@ -23,15 +23,6 @@ import torch
 import torch.distributed as dist
 
 
-_DIAG = os.environ.get("EGAZE_DP_DIAG", "")            # timing diagnostics (profiles/r04_dp_world1.txt): nocoll / nojoin / nohooks
-_DIAG_NO_COLLECTIVE = _DIAG in ("nocoll", "nojoin")
-
-
-class _NoHandle:
-    def wait(self):
-        pass
-
-
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, params: Sequence[torch.nn.Parameter], offsets: Sequence[int],
                  bucket_bytes: int = 25 * 1024 * 1024, group=None, flat_param: Optional[torch.Tensor] = None,
@@ -71,8 +62,6 @@ class GradReducer:
             self.buckets.append([cur_start, cur_end, cur_n])
         self._reset()
         self._hooks = []
-        if self.active and _DIAG == "nohooks":
-            self.active = False
         if self.active:
             if flat_param is not None:
                 dist.broadcast(flat_param, src=0, group=group)       # identical replicas to start from
@@ -89,7 +78,6 @@ class GradReducer:
         self._launched = [False] * len(self.buckets)
         self._producers = [dict() for _ in self.buckets]      # bucket -> {stream id: stream} that wrote gradients of the bucket
         self._handles = []
-        self.handle_of = {}                          # bucket -> async handle of its collective (optim._OverlappedTail waits on it)
         if getattr(self, "events", None):
             self.last_events, self.events = self.events, []      # the finished step's bucket events (record_events)
 
@@ -113,16 +101,11 @@ class GradReducer:
             cur = torch.cuda.current_stream()
             producers[cur.cuda_stream] = cur
             for sid, st in producers.items():
-                if sid != comm.cuda_stream and _DIAG != "nojoin":
+                if sid != comm.cuda_stream:
                     comm.wait_stream(st)
-            if _DIAG_NO_COLLECTIVE:              # diagnostic (EGAZE_DP_DIAG=nocoll): the joins without the collective itself
-                self._handles.append(_NoHandle())
-                self.handle_of[b] = self._handles[-1]
-                return
             with torch.cuda.stream(comm):
                 self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                                      async_op=True))
-                self.handle_of[b] = self._handles[-1]
                 if self.record_events:
                     # the library runs the collective on its own stream, ordered after `comm`; the handle's wait() orders a
                     # stream after the collective -- make `comm` wait and mark that point
@@ -133,14 +116,6 @@ class GradReducer:
             return
         self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
                                              async_op=True))
-        self.handle_of[b] = self._handles[-1]
-
-    def ensure_launched(self, b: int):
-        """Issue bucket b's collective now if its hook has not done so yet (the optimizer's overlapped tail steps a bucket as
-        soon as its gradients are final and needs the reduced values; hooks of one parameter run in registration order)."""
-        if self.active and not self._launched[b]:
-            self._launch(b)
-        return self.handle_of.get(b)
 
     def _make_hook(self, i: int):
         b = self.bucket_of[i]
@@ -196,12 +171,10 @@ class GradReducer:
             optimizer.grad_scale = 1.0
         if optimizer is not None and getattr(optimizer, "_reducer", None) is self:
             optimizer._reducer = None
-            if getattr(optimizer, "_tail", None) is not None:
-                optimizer._tail.adopt(None)
         self.active = False
 
 
-def attach(optimizer, bucket_bytes: int = int(os.environ.get("EGAZE_DP_BUCKET_MB", "25")) * 1024 * 1024, group=None, force: Optional[bool] = None,
+def attach(optimizer, bucket_bytes: int = 25 * 1024 * 1024, group=None, force: Optional[bool] = None,
            record_events: bool = False) -> GradReducer:
     """Wire a GradReducer to a FusedAdam: reduce before the step, average inside the Adam kernel."""
     red = GradReducer(optimizer.flat_g, optimizer.params, optimizer.offsets, bucket_bytes, group, optimizer.flat_p,
@@ -211,9 +184,7 @@ def attach(optimizer, bucket_bytes: int = int(os.environ.get("EGAZE_DP_BUCKET_MB
     if red.active:
         from . import hipops
         hipops.bump_weight_epoch()          # parameters were overwritten by the broadcast
-        optimizer._reducer = red            # the overlapped optimizer tail steps a bucket right behind its all-reduce
-        if getattr(optimizer, "_tail", None) is not None:
-            optimizer._tail.adopt(red)
+        optimizer._reducer = red
     return red
 
 

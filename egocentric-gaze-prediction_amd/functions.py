@@ -39,15 +39,10 @@ def from_nhwc(y: torch.Tensor) -> torch.Tensor:
     return H.carry_absmax(y.permute(0, 3, 1, 2), y)
 
 
-DETACH_WGRAD = __import__("os").environ.get("EGAZE_DETACH_WGRAD", "1") != "0"      # A/B knob
-# Issue order inside a conv backward.  The weight gradient W_L and the data gradient D_L of a layer both need dy_L; issued
-# together they share the matrix cores (whose throughput is fixed by the power budget), finish together, and the HBM-bound
-# BN / ReLU backward pass R_(L-1) of the next layer then runs with the matrix cores idle.  Issued D_L first and W_L behind it
-# (the helper stream waits for the stream position AFTER the dgrad launch), the chain becomes D_L, [W_L || R_(L-1)], D_(L-1),
-# ... -- the HBM-bound pass hides under the weight gradient.  Measured: no difference (35.58 vs 35.57 ms per step,
-# profiles/r02_bench_ab_knobs.txt) -- with detached weight-gradient streams the helper queue is never empty anyway -- so the
-# original order stays the default.
-WGRAD_AFTER_DGRAD = __import__("os").environ.get("EGAZE_WGRAD_AFTER_DGRAD", "0") != "0"
+DETACH_WGRAD = True       # weight-gradient forks that end in a gradient sink are left running (streams.fork.detach)
+# (Issuing the weight gradient W_L BEHIND the data gradient D_L instead of in front of it measured no difference -- 35.58 vs
+# 35.57 ms per step, profiles/r02_bench_ab_knobs.txt: with detached weight-gradient streams the helper queue is never empty --
+# and the switch was removed in round 4.)
 
 
 def _close_fork(f, sink, dw, *inputs):
@@ -131,7 +126,7 @@ class ConvBNReLUPool(torch.autograd.Function):
             raise RuntimeError("a deferred-BatchNorm tensor reached a block that cannot normalise it")
         Bx, Hx, Wx = x.shape[0], x.shape[2], x.shape[3]
         defer = bool(training and not pool and next_k and out_buf is None and not padded and (C <= 32 or first)
-                     and (not first or (C <= 3 and K == 32 and __import__("os").environ.get("EGZ_FIRST_DIRECT", "1") != "0"))
+                     and (not first or (C <= 3 and K == 32))
                      and H.bn_defer_ok(Bx, Hx, Wx, K, next_k, first))
         if padded:
             # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
@@ -150,8 +145,9 @@ class ConvBNReLUPool(torch.autograd.Function):
             dt = H.conv_dtype("fwd", K, C, xin)
             fold = (H.EVAL_FOLD and not training and not pool and out_buf is None and bn_in is None and dt == H.F16X3
                     and K % 64 == 0 and H.INFER_CALL)       # (grad mode is always off inside forward(): the caller's mode)
-            if fold and torch.cuda.is_current_stream_capturing() and getattr(weight, "_egz_fold", None) is None:
-                fold = False                 # (a capture without a warm-up forward: the unfolded path is capturable)
+            if fold and torch.cuda.is_current_stream_capturing() and not H.bn_fold_is_warm(
+                    weight, bias, gamma, beta, running_mean, running_var, eps):
+                fold = False                 # (a capture with a cold or STALE fold cache: the unfolded path is capturable)
             if fold:
                 # inference: BatchNorm folded into the convolution, bias + ReLU epilogue -- no normalise pass (hipops.bn_folded_conv)
                 wf, bf = H.bn_folded_conv(weight, bias, gamma, beta, running_mean, running_var, eps)
@@ -248,8 +244,6 @@ class ConvBNReLUPool(torch.autograd.Function):
                 return res
             return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
 
-        if WGRAD_AFTER_DGRAD:
-            dx = data_grad()
         with fork("wgrad") as f:                # the weight gradient runs on a helper stream (both only read dy)
             if ng[1]:
                 if padded:
@@ -262,8 +256,7 @@ class ConvBNReLUPool(torch.autograd.Function):
                         if ctx.deferred_in:
                             x_bn = bn_coef if bn_coef is not None else ctx.deferred_coef
                         dw = H.conv3x3_wgrad(xin, dy, out=sw, x_bn=x_bn)
-        if not WGRAD_AFTER_DGRAD:
-            dx = data_grad()
+        dx = data_grad()
         # (the coefficient rows of a deferred input are read by the detached weight-gradient kernel too: keep them alive for it)
         _close_fork(f, sw, dw, xin, dy, (bn_coef if bn_coef is not None else getattr(ctx, "deferred_coef", None))
                     if ctx.deferred_in else None)
@@ -329,13 +322,10 @@ class ConvReLU(torch.autograd.Function):
                 return from_nhwc(H.conv3x3_ups_dgrad(dy, wp, C, dtype=dt, streamed=st))
             return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
 
-        if WGRAD_AFTER_DGRAD:
-            dx = data_grad()
         with fork("wgrad") as f:
             if ng[1]:
                 dw = H.conv3x3_wgrad(xin, dy, ups=ups, out=sw)
-        if not WGRAD_AFTER_DGRAD:
-            dx = data_grad()
+        dx = data_grad()
         _close_fork(f, sw, dw, xin, dy)
         return dx, _finish(weight, sw, dw), _finish(bias, sbias, db), None, None
 
@@ -395,13 +385,10 @@ class FusionBlock(torch.autograd.Function):
             B = dx2.shape[0] // 2
             return from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
 
-        if WGRAD_AFTER_DGRAD:
-            dfs, dft = data_grad()
         with fork("wgrad") as f:
             if ng[2]:
                 dw = H.conv3x3_wgrad(x2, dy2, out=sw).view(weight.shape)
-        if not WGRAD_AFTER_DGRAD:
-            dfs, dft = data_grad()
+        dfs, dft = data_grad()
         _close_fork(f, sw, dw, x2, dy2)
         return (dfs, dft, _finish(weight, sw, dw), _finish(bias, sbias, db),
                 _finish(gamma, sg, dgamma if ng[4] else None), _finish(beta, sb, dbeta if ng[5] else None),

@@ -17,7 +17,6 @@ from ._lib import LIB as _RAW_LIB, check
 
 EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_STATS = 0, 1, 2
 import os as _os
-_TILE_FLAG = int(_os.environ.get("EGAZE_TILE", "0"), 0)     # A/B knob: 0x100 / 0x200 force the 128-row tiles
 
 
 class _Profiler:
@@ -214,40 +213,15 @@ def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.T
     return F16X3 if (role == "fwd" or GRAD_SPLIT == "f16") else BF16X3
 
 
-STREAMED = _os.environ.get("EGAZE_STREAMED", "1") != "0"      # A/B knob: 0 = halo kernel with LDS-DMA weights for plain convs
-# Forward of the four upsample-fused decoder convs on the streamed-weight halo kernel (MODE UPSF: the low-res halo staged once
-# per channel block for the 2 x 2 taps of a phase) instead of the per-tap gather kernel.  A/B knob: EGAZE_UPSF=0.
-UPSF_STREAMED = _os.environ.get("EGAZE_UPSF", "1") != "0"
-# 8-wave 256 x 128 tile of the streamed kernel (the two waves of a column share their weight fragments through the vector
-# L1).  Measured per layer shape (profiles/r02_x3s_tile8.txt): -5 ... -7 % where the weight matrix is largest (512 GEMM
-# columns at 28 x 28), +5 ... +10 % on the 128- / 256-column layers (one 512-thread block per CU interleaves worse than two
-# independent 256-thread blocks); restricted to >= 512 columns and at least one tile per CU it changes the SP step by less
-# than the run-to-run noise (35.63 vs 35.60 ms) -- so it is opt-in: EGAZE_TILE8=1 (>= 512 columns), EGAZE_TILE8=all (wherever
-# the geometry allows; tests).
-TILE8 = _os.environ.get("EGAZE_TILE8", "0")
+# Module-level switches of this file are plain constants unless they read the environment: the tests flip them with
+# monkeypatch (each one names the test that exercises its off position); round 4 removed the environment knobs of everything
+# that was measured and decided.
+STREAMED = True           # plain convs on the streamed-weight halo kernel (False: the round-1 LDS-DMA halo / gather kernels)
+UPSF_STREAMED = True      # forward of the four upsample-fused decoder convs on the streamed kernel (MODE UPSF)
 # Split-K form of the streamed kernel when a launch has too few pixel tiles to fill the chip (egz_conv3x3_streamed_splits):
-# batch-1 inference runs its 28 x 28 / 14 x 14 layers on 8-28 of 512 block slots otherwise.  A/B knob: EGAZE_SPLITK=0.
+# batch-1 inference runs its 28 x 28 / 14 x 14 layers on 8-28 of 512 block slots otherwise.  A/B knob: EGAZE_SPLITK=0
+# (tests: test_conv3x3_streamed_splitk, the whole-model gradient tests pin the summation order with it).
 SPLITK = _os.environ.get("EGAZE_SPLITK", "1") != "0"
-
-
-# 4-wave 256 x 128 tile with ONE wave per SIMD and eight accumulator tiles per wave (csrc Geo<16>): every weight fragment feeds
-# twice the MFMAs.  EGAZE_TILE16=1: where the launch has at least one tile per CU; =all: wherever the geometry allows (tests).
-TILE16 = _os.environ.get("EGAZE_TILE16", "0")
-
-
-def _tile8(B, Ho, Wo, C, gemm_out, mode) -> int:
-    """0x10 when the launch should run on the 8-wave tile, 0x20 for the 4-wave / 8-accumulator tile."""
-    if TILE16 != "0" and gemm_out % 128 == 0:
-        if TILE16 == "all" or ((B * Ho * Wo + 255) // 256) * (gemm_out // 128) >= 256:
-            H_, W_ = (2 * Ho, 2 * Wo) if mode else (Ho, Wo)
-            if LIB.egz_conv3x3_streamed_ok(B, H_, W_, C, gemm_out, mode | 0x20):
-                return 0x20
-    if TILE8 == "0" or gemm_out % 128 != 0:
-        return 0
-    if TILE8 != "all" and (gemm_out < 512 or ((B * Ho * Wo + 255) // 256) * (gemm_out // 128) < 256):
-        return 0
-    H_, W_ = (2 * Ho, 2 * Wo) if mode else (Ho, Wo)
-    return 0x10 if LIB.egz_conv3x3_streamed_ok(B, H_, W_, C, gemm_out, mode | 0x10) else 0
 
 
 def conv_weight(w: torch.Tensor, role: str, dtype: int, x: torch.Tensor, gemm_out: int):
@@ -300,118 +274,6 @@ def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
     return buf
 
 
-def refresh_packings(params) -> int:
-    """Rebuild every cached packing of these parameters NOW, on the current stream (the bucketed optimizer tail calls this
-    on its side stream right after the bucket's Adam kernel, so that the ~70 small pack launches of a step run under the rest
-    of the backward pass instead of in front of the next forward's convolutions).  Returns the number of packings refreshed."""
-    uids = {getattr(p, "_egz_uid", None): p for p in params}
-    uids.pop(None, None)
-    n = 0
-    for key, ent in list(_PACKED.items()):
-        uid, kind, dtype = key
-        w = uids.get(uid)
-        if w is None or ent[2]() is not w or key not in _USED:      # only packings a launch asked for since their last rebuild
-            continue
-        packed_weight(w, kind, dtype)
-        _USED.discard(key)
-        n += 1
-    return n
-
-
-_FRAG_TABLES = {}
-
-
-def refresh_packings_multi(params) -> int:
-    """refresh_packings with ONE launch for all fragment-ordered packings of these parameters
-    (egz_pack_w3x3_split_frag_multi; plane-ordered ones, if any, are rebuilt one by one): the optimizer's bucketed tail refreshes
-    ~10 packings per bucket, and each small launch waits for a CU slot behind the convolution blocks of the backward pass.
-    Tables are cached per set of (weight, buffer) pointers -- stable, the parameters live in the optimizer's flat buffer.
-    Not for use inside a hipGraph capture (the first call of a set uploads its table)."""
-    uids = {getattr(p, "_egz_uid", None): p for p in params}
-    uids.pop(None, None)
-    rows, entries, n = [], [], 0
-    for key, ent in list(_PACKED.items()):
-        uid, kind, dtype = key
-        w = uids.get(uid)
-        if w is None or ent[2]() is not w or key not in _USED:      # only packings a launch asked for since their last rebuild
-            continue
-        if ent[0] == _tag(w):
-            continue
-        kidx = _PACK_FN[kind][2]
-        if kidx < 4 or not dtype:
-            packed_weight(w, kind, dtype)
-            _USED.discard(key)
-            n += 1
-            continue
-        K, C = w.shape[0], w.shape[1]
-        Cp, Kp = (C + 31) // 32 * 32, (K + 31) // 32 * 32
-        rows.append((w.data_ptr(), ent[1].data_ptr(), C, K, kidx, dtype, Cp * Kp))
-        entries.append((key, w))
-    if not rows:
-        return n
-    sig = tuple(rows)
-    hit = _FRAG_TABLES.get(sig)
-    if hit is None:
-        per = int(LIB.egz_pack_w3x3_split_frag_multi_per_block())
-        first, table = 0, []
-        for r in rows:
-            table.append(list(r) + [first])
-            first += (r[6] + per - 1) // per
-        if len(_FRAG_TABLES) > 64:
-            _FRAG_TABLES.clear()
-        hit = (torch.tensor(table, dtype=torch.int64, device=entries[0][1].device), first)
-        _FRAG_TABLES[sig] = hit
-    check(LIB.egz_pack_w3x3_split_frag_multi(hit[0].data_ptr(), len(rows), hit[1], _stream()), "egz_pack_w3x3_split_frag_multi")
-    for key, w in entries:
-        ent = _PACKED[key]
-        _PACKED[key] = (_tag(w), ent[1], ent[2])
-        _USED.discard(key)
-    return n + len(rows)
-
-
-_PACK_PER_BLOCK = 2048
-_MULTI_TABLES = {}
-
-
-def repack_params(params) -> int:
-    """Refresh EVERY cached split packing of these parameters in one launch (egz_pack_w3x3_split_multi) -- called by the
-    fused optimizer right after it rewrote them, instead of ~74 lazy per-layer pack launches during the next step.
-    Packings are only refreshed, never created: the first forward / backward builds them lazily.  Returns the row count."""
-    rows, entries = [], []
-    uids = {getattr(p, "_egz_uid", None) for p in params}
-    uids.discard(None)
-    for key, ent in _PACKED.items():
-        uid, kind, dtype = key
-        if uid not in uids or not dtype or _PACK_FN[kind][2] >= 4:
-            continue
-        w = ent[2]()
-        if w is None or not w.is_cuda:
-            continue
-        K, C = w.shape[0], w.shape[1]
-        Cp, Kp = (C + 31) // 32 * 32, (K + 31) // 32 * 32
-        kidx = _PACK_FN[kind][2]
-        rows.append((w.data_ptr(), ent[1].data_ptr(), C, K, kidx, dtype, (16 if kidx >= 2 else 9) * Cp * Kp))
-        entries.append((key, w))
-    if not rows:
-        return 0
-    sig = tuple(rows)
-    hit = _MULTI_TABLES.get(sig)
-    if hit is None:
-        first, table = 0, []
-        for r in rows:
-            table.append(list(r) + [first])
-            first += (r[6] + _PACK_PER_BLOCK - 1) // _PACK_PER_BLOCK
-        dev = entries[0][1].device
-        hit = (torch.tensor(table, dtype=torch.int64, device=dev), first)
-        _MULTI_TABLES.clear()                     # pointers are stable (flat parameter buffer): one live table
-        _MULTI_TABLES[sig] = hit
-    check(LIB.egz_pack_w3x3_split_multi(hit[0].data_ptr(), len(rows), hit[1], _stream()), "egz_pack_w3x3_split_multi")
-    for key, w in entries:
-        ent = _PACKED[key]
-        _PACKED[key] = (_tag(w), ent[1], ent[2])
-    return len(rows)
-
-
 # ----------------------------------------------------------------------------- gradient sinks
 class GradSink:
     """Where a parameter's gradient lands when the parameter lives in a fused optimizer's flat buffers (optim.FusedAdam):
@@ -455,7 +317,7 @@ def grad_done(param):
             h(param, st)
 
 
-DIRECT_GRADS = _os.environ.get("EGAZE_DIRECT_GRADS", "1") != "0"      # A/B knob
+DIRECT_GRADS = True      # gradient sinks on (False: every gradient goes back through autograd's AccumulateGrad; AT._GraphedSampleStep honours it)
 
 
 # ----------------------------------------------------------------------------- abs-max of gradient tensors
@@ -560,13 +422,6 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
     return am
 
 
-def _streamed_tiles(B, H, W, K) -> int:
-    """Tiles of a plain streamed launch (128 x 128 when K % 128 == 0, else 256 x 64): its abs-max epilogue has 16384 slots."""
-    bm, bn = (128, 128) if K % 128 == 0 else (256, 64)
-    return ((B * H * W + bm - 1) // bm) * ((K + bn - 1) // bn)
-
-
-# ----------------------------------------------------------------------------- convolutions
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
                 epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None,
                 streamed: bool = False, bn_in: Optional[torch.Tensor] = None, want_minmax: bool = False):
@@ -591,7 +446,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         amo = _new_absmax(x.device)
         y._egz_absmax = amo
     uflag = 0 if not ups else (1 if ups == "fold" else 3)
-    flags = uflag | (epi << 4) | (0x200 if dtype else (tile_flag or _TILE_FLAG))      # split kernels: 128-row tiles
+    flags = uflag | (epi << 4) | (0x200 if dtype else tile_flag)      # split kernels: 128-row tiles
     if epi == EPI_BIAS_STATS and not (dtype and streamed):
         rows = LIB.egz_conv3x3_stat_rows(B, H, W, K, flags)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=x.device)
@@ -612,9 +467,6 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
                                    device=x.device)
             nb = LIB.egz_conv3x3_fwd_streamed_splitk_ws_bytes(B, H, W, K, ns)
             ws = workspace(nb, x.device)
-            if amo is not None and ((B * H * W + 31) // 32) * ((K + 63) // 64) > 16384:
-                amo = None
-                del y._egz_absmax
             check(LIB.egz_conv3x3_fwd_streamed_splitk(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W,
                                                       C, K, epi, dtype, _p(absmax), ws.data_ptr(), nb, ns, _p(amo), _stream()),
                   "egz_conv3x3_fwd_streamed_splitk")
@@ -626,12 +478,8 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
             if want_minmax:
                 mm = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
                 y._egz_minmax = mm
-        t8 = _tile8(B, H, W, C, K, 0)
-        if amo is not None and (t8 or _streamed_tiles(B, H, W, K) > 16384):
-            amo = None                      # no epilogue slot for this launch: the consumer runs a standalone abs-max pass
-            del y._egz_absmax
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, t8, _p(absmax), None, _p(amo), _p(bn_in), _p(mm), _stream()),
+                                           epi, dtype, 0, _p(absmax), None, _p(amo), _p(bn_in), _p(mm), _stream()),
               "egz_conv3x3_fwd_split")
         return y, stat
     if dtype:
@@ -666,7 +514,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                           0, dtype, 1 | _tile8(B, H // 2, W // 2, K, C, 1), _p(am), None, None, None, None, _stream()),
+                                           0, dtype, 1, _p(am), None, None, None, None, _stream()),
               "egz_conv3x3_fwd_streamed(ups_dgrad)")
         return dx
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
@@ -679,7 +527,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         return dx
     PROF.note_flops("egz_conv3x3_ups_dgrad", 2.0 * B * H * W * K * 9 * C)     # algorithmic (reference) FLOPs
     check(LIB.egz_conv3x3_ups_dgrad(dy.data_ptr(), wp_ups_dgrad.data_ptr(), dx.data_ptr(), B, H, W, C, K,
-                                    _TILE_FLAG, _stream()), "egz_conv3x3_ups_dgrad")
+                                    0, _stream()), "egz_conv3x3_ups_dgrad")
     return dx
 
 
@@ -688,9 +536,9 @@ EPI_MASK_SUMS = 3
 # passes over the decoder gradients (relu_bwd_bias, 1.0 ms per step).  Round 2 measured it slower (35.56 vs 35.39 ms,
 # profiles/r02_bench_ab_knobs.txt) -- with the mask load inside a per-lane branch every epilogue element waited for its own
 # load.  With the branch-free epilogue (buffer loads / stores with out-of-range offsets for invalid rows, round 3) the step
-# is 0.55 ms faster with it (32.6 vs 33.15 ms, profiles/r03_ab_notes.txt), so it is the default; EGAZE_MASK_FUSE=0 = A/B.
-MASK_FUSE = _os.environ.get("EGAZE_MASK_FUSE", "1") != "0"
-HEAD_MASK_FUSE = _os.environ.get("EGAZE_HEAD_MASK_FUSE", "1") != "0"   # the same for the block under the 1x1 head (A/B knob)
+# is 0.55 ms faster with it (32.6 vs 33.15 ms, profiles/r03_ab_notes.txt), so it is the default (off position: test_relu_backward_folded_into_dgrad_epilogue flips MASK_FUSE).
+MASK_FUSE = True
+HEAD_MASK_FUSE = True   # the same for the block under the 1x1 head (test_head_sigmoid_masked_backward covers the kernel)
 MASK_FUSE_STATS = {"produced": 0, "consumed": 0}                 # how often the fused form ran / was picked up (tests)
 
 
@@ -719,15 +567,15 @@ def conv3x3_dgrad_masked(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
 
 EPI_BNSUMS = 5
 # BatchNorm-backward sums of the layer below folded into the narrow data-gradient kernel (late_fusion.py:10-12 chain at
-# 32 channels): removes that layer's reduce pass (two reads of its 205 MB tensors at B = 32, 224 x 224).  EGAZE_BNSUMS_FUSE=0
+# 32 channels): removes that layer's reduce pass (two reads of its 205 MB tensors at B = 32, 224 x 224).  BNSUMS_FUSE = False
 # keeps the separate pass (A/B runs, and the parity test compares the two).
-BNSUMS_FUSE = _os.environ.get("EGAZE_BNSUMS_FUSE", "1") != "0"
+BNSUMS_FUSE = True
 BNSUMS_STATS = {"produced": 0, "consumed": 0}
 
 
 # ... and for the wide layers (the VGG encoders: conv -> BN -> ReLU -> conv without a pool in between, utils.py:64-76): the same
-# epilogue on the 128- / 64-column tiles of the streamed kernel.  EGAZE_BNSUMS_WIDE=0 keeps the reduce pass there (A/B).
-BNSUMS_WIDE = _os.environ.get("EGAZE_BNSUMS_WIDE", "1") != "0"
+# epilogue on the 128- / 64-column tiles of the streamed kernel.  BNSUMS_WIDE = False keeps the reduce pass there (test_bn_backward_sums_folded_into_encoder_dgrad compares the two).
+BNSUMS_WIDE = True
 
 
 def bnsums_ok(B: int, H: int, W: int, C: int, K: int, dtype: int) -> bool:
@@ -855,8 +703,8 @@ def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, run
 
 # Deferred BatchNorm (late-fusion stack, training): the [BN -> ReLU] of a narrow block is applied by the NEXT block's conv and
 # weight-gradient kernels while they stage its pre-BN output, so the normalised tensor (205 MB at B = 32, 224 x 224 x 32) is
-# neither written nor read.  EGAZE_BN_DEFER=0 materialises it as before (A/B runs; the parity test compares the two).
-BN_DEFER = _os.environ.get("EGAZE_BN_DEFER", "1") != "0"
+# neither written nor read.  BN_DEFER = False materialises it as before (test_deferred_batchnorm_matches_materialised compares the two).
+BN_DEFER = True
 BN_DEFER_STATS = {"deferred": 0}
 
 
@@ -933,18 +781,29 @@ EVAL_FOLD_STATS = {"folded": 0}
 INFER_CALL = False      # set by utils.conv_bn_relu_pool right before ConvBNReLUPool.apply: the block runs under torch.no_grad()
 
 
+def bn_fold_key(weight, bias, gamma, beta, running_mean, running_var, eps: float):
+    return (_tag(weight), None if bias is None else _tag(bias), _tag(running_mean), _tag(running_var),
+            None if gamma is None else _tag(gamma), None if beta is None else _tag(beta), float(eps))
+
+
+def bn_fold_is_warm(weight, bias, gamma, beta, running_mean, running_var, eps: float) -> bool:
+    """True when the folded tensors cached on ``weight`` match the current parameters / statistics (so that
+    bn_folded_conv launches nothing): what a hipGraph capture needs -- a cold OR stale cache takes the unfolded path."""
+    hit = getattr(weight, "_egz_fold", None)
+    return hit is not None and hit[0] == bn_fold_key(weight, bias, gamma, beta, running_mean, running_var, eps)
+
+
 def bn_folded_conv(weight, bias, gamma, beta, running_mean, running_var, eps: float):
     """-> (w', b') of the folded block, cached on ``weight`` (pass the module's own parameter / buffer objects).  Not to be
     called inside a hipGraph capture before the cache is warm (the fold itself is a few stock elementwise kernels, once per
     weight change)."""
     coef = bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
-    key = (_tag(weight), None if bias is None else _tag(bias), _tag(running_mean), _tag(running_var),
-           None if gamma is None else _tag(gamma), None if beta is None else _tag(beta), float(eps))
+    key = bn_fold_key(weight, bias, gamma, beta, running_mean, running_var, eps)
     hit = getattr(weight, "_egz_fold", None)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]
     if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("bn_folded_conv: cold cache inside a hipGraph capture (run one eager forward first)")
+        raise RuntimeError("bn_folded_conv: cold or stale cache inside a hipGraph capture (callers check bn_fold_is_warm)")
     with torch.no_grad():
         K = weight.shape[0]
         wf = hit[1] if hit is not None else torch.empty_like(weight.detach())
@@ -994,7 +853,7 @@ def bn_relu_pool_bwd(y: torch.Tensor, dout: torch.Tensor, coef: torch.Tensor, po
     return dy, dg, db
 
 
-FIRST_FUSE = _os.environ.get("EGAZE_FIRST_FUSE", "1") != "0"        # A/B knob of bn_bwd_first_wgrad
+FIRST_FUSE = True        # first block of a narrow stack: BatchNorm backward + weight gradient in one pass
 
 
 def bn_bwd_first_wgrad_ok(C: int, K: int, pool: bool) -> bool:

@@ -15,7 +15,7 @@ import torch.nn as nn
 from .. import hipops as H
 
 batch_size = 1
-B1_FUSED = os.environ.get("EGAZE_LSTM_B1", "1") != "0"     # A/B knob: 0 = always the sequence path
+B1_FUSED = True      # T = 1, B = 1 steps on the fused single-step kernels (False: always the sequence path; test_hip_at flips it)
 
 
 class _LSTMNetFn(torch.autograd.Function):

@@ -13,18 +13,16 @@ import torch
 
 ENABLED = os.environ.get("EGAZE_STREAMS", "1") != "0"
 _SIDE = {}
-# Helper-stream kinds that exist ONCE per device instead of once per parent stream (comma separated).  HIP multiplexes
+# Helper-stream kinds that exist ONCE per device instead of once per parent stream.  HIP multiplexes
 # streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; more is 17 % slower, profiles/r02_hw_queues_ab.txt) and streams that
 # share a queue run FIFO.  One weight-gradient stream for both encoders keeps the step at main + encoder_t + wgrad + one
 # more (the AT stream, the H2D copy stream or the RCCL comm stream): the step time is unchanged (35.4 vs 35.3 ms) and the
 # prefetched H2D copy overlaps fully (fp32 loader: 36.2 vs 38.0 ms per step; profiles/r02_hw_queues_ab.txt).
-_SHARED = set(filter(None, os.environ.get("EGAZE_SHARED_STREAMS", "wgrad,adam").split(",")))
+_SHARED = {"wgrad"}
 
 
-# Helper-stream kinds created with LOW priority (comma separated; A/B knob).  A weight-gradient kernel holds the whole
-# register file of the CUs it runs on, so a small kernel of the layer chain that becomes ready meanwhile waits for one of
-# its blocks to retire -- and then competes with the weight gradient's own pending blocks for the slot.
-_LOW_PRIO = set(filter(None, os.environ.get("EGAZE_LOW_PRIO_STREAMS", "").split(",")))
+# (A low-priority helper stream and a high-priority main stream were tried in rounds 2 / 3: priority serialises instead of
+# interleaving -- 42.7 vs 35.6 ms -- and the switches were removed.)
 
 
 def side_stream(kind: str) -> torch.cuda.Stream:
@@ -33,14 +31,7 @@ def side_stream(kind: str) -> torch.cuda.Stream:
     key = (cur.device.index, 0 if kind in _SHARED else cur.cuda_stream, kind)
     st = _SIDE.get(key)
     if st is None:
-        st = None
-        if kind in _LOW_PRIO:
-            try:
-                st = torch.cuda.Stream(device=cur.device, priority=1)
-            except Exception:           # this build has no priority below "normal"
-                st = None
-        if st is None:
-            st = torch.cuda.Stream(device=cur.device)
+        st = torch.cuda.Stream(device=cur.device)
         _SIDE[key] = st
     return st
 

@@ -61,9 +61,6 @@ int egz_conv3x3_ups_dgrad(const float* dy, const float* wp, float* dx, int B, in
  * egz_conv3x3_fwd_split: flags as egz_conv3x3_fwd (bits 0-1, 4-5) plus bit2 = the 16-tap data gradient of an
  * upsampled conv (then C / K are the GEMM's reduction / output channel counts). */
 int egz_pack_w3x3_split(const float* w, void* wp, int C, int K, int kind, int dtype, hipStream_t stream);
-/* All split packings of a model in one launch (after the optimizer step).  table (device memory): nrows x 8 int64 =
- * {w, wp, C, K, kind, dtype, nelem = taps * Cp * Kp, first block}, rows ordered by first block, 2048 elements per block. */
-int egz_pack_w3x3_split_multi(const void* table, int nrows, int total_blocks, hipStream_t stream);
 /* Optional tile schedule of egz_conv3x3_fwd_split (flags bit 14 = 0x4000): tiles beyond the last full round of resident
  * blocks are run split-K through `workspace` (raw partial accumulators) and reduced in a fixed order;
  * egz_conv3x3_fwd_split_ws_bytes gives the workspace size (0 without the flag: workspace may then be NULL). */
@@ -87,11 +84,6 @@ int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode);
 /* rows of stat_partial ([rows][2][K] doubles) of an epi 2 / epi 5 launch of egz_conv3x3_fwd_streamed (mode 0) */
 int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K);
 int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t stream);
-/* Several fragment-ordered packings in one launch (the bucketed optimizer tail).  table (device): nrows x 8 int64
- * [w, wq, C, K, kind 4..7, dtype 1|2, pairs = Np * Rp (padded columns x padded reduction channels), first block]; a row owns
- * ceil(pairs / egz_pack_w3x3_split_frag_multi_per_block()) consecutive blocks; total_blocks = their sum. */
-int egz_pack_w3x3_split_frag_multi_per_block(void);
-int egz_pack_w3x3_split_frag_multi(const void* table, int nrows, int total_blocks, hipStream_t stream);
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
                              const float* mask_src, unsigned int* absmax_out, const float* bn_coef, float* minmax_out,

@@ -70,35 +70,7 @@ def main():
     torch.cuda.synchronize()
     flat_p_2 = opt.flat_p.detach().cpu().clone()
 
-    # (3) the overlapped optimizer tail under data parallelism: a bucket is stepped on the side stream right behind ITS
-    #     all-reduce, during the backward pass.  Same two steps from the same state, with and without it: bit-identical.
-    def snapshot():
-        return (opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_v.clone(), opt.step_count,
-                {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k})
-
-    def restore(s):
-        opt.flat_p.copy_(s[0]); opt.flat_m.copy_(s[1]); opt.flat_v.copy_(s[2]); opt.step_count = s[3]
-        sd = model.state_dict()
-        for k, v in s[4].items():
-            sd[k].copy_(v)
-        H.bump_weight_epoch()
-
-    def two_steps():
-        for _ in range(2):
-            fwd_bwd()
-            opt.step()
-        torch.cuda.synchronize()
-        return opt.flat_p.detach().cpu().clone()
-
-    snap = snapshot()
-    p_plain = two_steps()
-    restore(snap)
-    opt.overlap_with_backward(True)
-    p_tail = two_steps()
-    tail_stats = dict(opt._tail.stats) if opt._tail is not None else {}
-    opt.overlap_with_backward(False)
     torch.save({"rank": rank, "g_local": gathered, "g_sum": g_sum, "flat_p": flat_p_2,
-                "tail_equal": bool(torch.equal(p_plain, p_tail)), "tail_stats": tail_stats, "flat_p_tail": p_tail,
                 "losses": losses, "n_buckets": len(red.buckets), "grad_scale": opt.grad_scale,
                 "layout": [(n, o, p.numel()) for (n, p), o in zip(model.named_parameters(), opt.offsets)],
                 "buckets": [tuple(b) for b in red.buckets]},

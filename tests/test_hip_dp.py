@@ -3,9 +3,7 @@ all-reduce over gloo -- split-half kernels, HIP side streams, FusedAdam, dp.Grad
   (a) the reduced gradient equals the sum of the two single-process gradients, bit for bit (2-rank sum is commutative
       and every kernel is deterministic), so the bucket hooks fired after every producer stream had finished;
   (b) replicas hold bit-identical parameters after two Adam steps, and they moved;
-  (c) `bench.py --gpus 2` launches itself and reports n_gpus == 2;
-  (d) with FusedAdam.overlap_with_backward() the buckets are stepped on the side stream right behind their own all-reduce,
-      during the backward pass, and two steps give bit-identical parameters to the plain reduce-then-step path."""
+  (c) `bench.py --gpus 2` launches itself and reports n_gpus == 2."""
 import json
 import os
 import socket
@@ -29,8 +27,7 @@ def _free_port():
 
 def _env():
     env = dict(os.environ)
-    env.update(EGAZE_SINGLE_DEVICE="1", EGAZE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               EGAZE_DP_TAIL="1")          # (d): the opt-in overlapped optimizer tail behind the all-reduces
+    env.update(EGAZE_SINGLE_DEVICE="1", EGAZE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("EGAZE_PRECISION", None)
     env.pop("EGAZE_STREAMS", None)
     return env
@@ -51,10 +48,6 @@ def test_two_ranks_one_gpu_real_model(tmp_path):
         assert o["n_buckets"] >= 4 and o["grad_scale"] == 0.5
         assert torch.equal(o["g_sum"], g0 + g1), (o["g_sum"] - (g0 + g1)).abs().max()
     assert torch.equal(obs[0]["flat_p"], obs[1]["flat_p"])              # (b)
-    for o in obs:                                                       # (d) overlapped optimizer tail behind the all-reduces
-        assert o["tail_equal"], "overlapped tail changed the result"
-        assert o["tail_stats"].get("in_backward", 0) >= 2, o["tail_stats"]
-    assert torch.equal(obs[0]["flat_p_tail"], obs[1]["flat_p_tail"])
     assert all(l == l for o in obs for l in o["losses"])                # finite
     assert obs[0]["losses"] != obs[1]["losses"]                         # per-rank batches, per-rank losses
 

@@ -365,3 +365,64 @@ def test_cat2_planes_matches_torch_cat():
     f = torch.rand(3, 1, 20, 12, generator=g).to(DEV)
     w = torch.rand(3, 1, 20, 12, generator=g).to(DEV)
     assert torch.equal(H.cat2_planes(f, w), torch.cat((f, w), dim=1))
+
+
+def test_lf_epoch_trailing_partial_batch_and_interrupted_epoch(monkeypatch):
+    """LF._run with the captured step: an epoch of full batches followed by a PARTIAL last batch (which takes the
+    eager path while the optimizer is still in capturable mode) ends with the same parameters, Adam moments and step count as
+    the launch-by-launch epoch, and the state dict carries the right step; an exception inside the loop still leaves the
+    optimizer out of capturable mode with the host step count synced."""
+    import egaze_amd.LF as lf_mod
+    from egaze_amd.floss import floss
+    from egaze_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(21)
+
+    def batch(n):
+        return {k: torch.rand(n, 1, 224, 224, generator=g) for k in ('im', 'gt', 'feat')}
+    loader = [batch(4) for _ in range(5)] + [batch(2)]
+
+    def shell():
+        torch.manual_seed(7)
+        s = object.__new__(lf_mod.LF)
+        s.model = build()
+        s.model.train()
+        s.device = torch.device(DEV)
+        s.criterion = floss().to(DEV)
+        s.optimizer = FusedAdam(s.model.parameters(), lr=1e-3)
+        s.epochnow = 0
+        return s
+    res = []
+    for graphed in (False, True):
+        monkeypatch.setattr(lf_mod, "LF_GRAPH", graphed)
+        s = shell()
+        loss, _, _ = s._run(loader, True, 10 ** 9)
+        torch.cuda.synchronize()
+        assert not s.optimizer.capturable and s.optimizer.step_count == 6
+        sd = s.optimizer.state_dict()
+        assert float(sd["state"][0]["step"]) == 6.0
+        res.append((loss, s.optimizer.flat_p.clone(), s.optimizer.flat_m.clone(), s.optimizer.flat_v.clone()))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+    # an interrupted epoch: the fourth batch raises inside the loop (after the capture)
+    monkeypatch.setattr(lf_mod, "LF_GRAPH", True)
+    s = shell()
+
+    def broken():
+        for i, b in enumerate(loader):
+            if i == 4:
+                raise KeyboardInterrupt
+            yield b
+
+    class L:
+        def __iter__(self):
+            return broken()
+
+        def __len__(self):
+            return len(loader)
+    with pytest.raises(KeyboardInterrupt):
+        s._run(L(), True, 10 ** 9)
+    torch.cuda.synchronize()
+    # (the loader runs one batch ahead of the step: the interrupt arrives while step 3 or 4 is the last one issued)
+    assert not s.optimizer.capturable and s.optimizer.step_count in (3, 4)
+    assert int(s.optimizer.step_dev[0].item()) == s.optimizer.step_count

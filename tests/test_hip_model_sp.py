@@ -289,6 +289,20 @@ def test_model_sp_grads_vs_fp64(monkeypatch):
     assert sum(ok for ok, _ in results) >= 2, results
 
 
+def test_model_sp_grads_vs_fp64_all_surveyed_seeds(monkeypatch):
+    """The seed survey itself as a test (GRAD_SEEDS above were picked from it after the fact).  On EVERY seed 0..11
+    every gradient tensor agrees with the fp64 truth in direction and size (cosine >= 0.995, norm within 3 %: asserted inside
+    _grads_vs_fp64) and the forward map is within the fp32 reference's own error class; and -- without choosing -- at least
+    half of the twelve inputs are free of ReLU / max-pool subgradient flips and then match tightly (round-3 survey: 8 of 12 in
+    this summation order, 7 of 12 in the split-K one; the fp32 CPU reference against fp64 flips on some of the others too)."""
+    import egaze_amd.hipops as H
+    monkeypatch.setattr(H, "SPLITK", False)
+    results = [_grads_vs_fp64(seed) for seed in range(12)]
+    tight = [r[1][0] for r in results if r[0]]
+    print("grads-vs-fp64, all surveyed seeds: tight on", tight)
+    assert len(tight) >= 6, results
+
+
 def test_floss_golden_bit_exact_weights():
     import egaze_amd.hipops as h
     gold = np.load(os.path.join(GOLDEN, "floss.npz"))
@@ -559,56 +573,6 @@ def test_graphed_eval_forward_matches_eager_and_follows_weight_updates():
     model.train()
     with pytest.raises(RuntimeError):
         g(*a)
-
-
-def test_overlapped_optimizer_tail_matches_plain_step():
-    """FusedAdam.overlap_with_backward(): the Adam update of a bucket of parameters and the rebuild of their packed weights
-    run on a side stream DURING the backward pass, as soon as the bucket's gradients are final (what SP.trainSP / bench.py
-    enable -- their loops call step() right after backward(), SP.py:136-137).  Three training steps with it on must leave
-    parameters, both Adam moments and the BN running statistics bit-identical to three plain steps, several buckets must have
-    been stepped inside backward(), and the next forward must find its packings fresh (no pack launch in front of the convs)."""
-    import egaze_amd.hipops as H
-    from egaze_amd import optim, streams
-    from egaze_amd.floss import floss
-    from egaze_amd.optim import FusedAdam
-    if H.PRECISION != "split" or not streams.ENABLED or not optim._OVERLAP:
-        pytest.skip("the overlapped tail needs HIP streams; the packing it checks is the default mode's")
-    results = []
-    for overlap in (False, True):
-        model, _ = build_model()
-        model.train()
-        crit = floss().to(DEV)
-        opt = FusedAdam(model.parameters(), lr=1e-4)
-        if overlap:
-            optim._OverlappedTail.BUCKET_BYTES, keep = 4 * 1024 * 1024, optim._OverlappedTail.BUCKET_BYTES
-            opt.overlap_with_backward(True)
-            optim._OverlappedTail.BUCKET_BYTES = keep
-            assert len(opt._tail.buckets) >= 8
-        opt.zero_grad()
-        early, losses = 0, []
-        for i in range(3):
-            x_s, x_t, gt, _ = synth.synth_sp_batch(2, 64, seed=60 + i)
-            out = model(x_s.to(DEV), x_t.to(DEV))
-            loss = crit(out, gt.to(DEV).view(out.size()))
-            loss.backward()
-            if overlap:
-                early += sum(opt._tail.done)
-            opt.step()
-            opt.zero_grad()
-            losses.append(loss.item())
-        if overlap:
-            assert early >= 3 * (len(opt._tail.buckets) - 2), (early, len(opt._tail.buckets))
-            w = model.decoder[0].weight
-            key = (H._uid(w), "fwd_frag", H.F16X3)
-            assert key in H._PACKED and H._PACKED[key][0] == H._tag(w)       # rebuilt by the tail, not left for the forward
-        torch.cuda.synchronize()
-        results.append((losses, opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_v.clone(),
-                        {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
-    (l0, p0, m0, v0, b0), (l1, p1, m1, v1, b1) = results
-    assert l0 == l1, (l0, l1)
-    assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
-    for k in b0:
-        assert torch.equal(b0[k], b1[k]), k
 
 
 def test_eval_batchnorm_folded_into_conv(monkeypatch):

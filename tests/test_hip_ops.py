@@ -467,52 +467,6 @@ def test_conv3x3_split_half_upsample(dtype, tol):
     assert rel(nchw(dx), xd.grad) < tol
 
 
-def test_repack_params_multi_launch():
-    """One-launch refresh of all split packings (egz_pack_w3x3_split_multi) == the per-tensor pack kernels, for every
-    layout / dtype, and the cache treats the refreshed entries as current."""
-    h = H()
-    ws = [torch.nn.Parameter(rnd(64, 32, 3, 3, seed=61).to(DEV)), torch.nn.Parameter(rnd(128, 64, 3, 3, seed=62).to(DEV)),
-          torch.nn.Parameter(rnd(96, 160, 3, 3, seed=63).to(DEV))]
-    kinds = [("fwd", 1), ("dgrad", 2), ("ups_fwd", 1), ("ups_dgrad", 2), ("fwd", 2)]
-    for w in ws:
-        for kind, dt in kinds:
-            h.packed_weight(w, kind, dt)
-    with torch.no_grad():
-        for i, w in enumerate(ws):
-            w.data.copy_(rnd(*w.shape, seed=70 + i).to(DEV))         # in place, like the fused optimizer
-    h.touch_params(ws)
-    assert h.repack_params(ws) == len(ws) * len(kinds)
-    multi = {(i, kind, dt): h.packed_weight(w, kind, dt).clone() for i, w in enumerate(ws) for kind, dt in kinds}
-    h.bump_weight_epoch()                                             # force the per-tensor path
-    for i, w in enumerate(ws):
-        for kind, dt in kinds:
-            assert torch.equal(h.packed_weight(w, kind, dt), multi[(i, kind, dt)]), (i, kind, dt)
-
-
-def test_refresh_packings_multi_launch():
-    """The bucketed optimizer tail's one-launch refresh of fragment-ordered packings (egz_pack_w3x3_split_frag_multi, kinds
-    4-7) == the per-tensor egz_pack_w3x3_split_frag launches, bit for bit; plane-ordered packings in the same set go through
-    their own kernels; entries count as current afterwards."""
-    h = H()
-    ws = [torch.nn.Parameter(rnd(64, 32, 3, 3, seed=61).to(DEV)), torch.nn.Parameter(rnd(128, 64, 3, 3, seed=62).to(DEV)),
-          torch.nn.Parameter(rnd(96, 160, 3, 3, seed=63).to(DEV)), torch.nn.Parameter(rnd(32, 8, 3, 3, seed=64).to(DEV))]
-    kinds = [("fwd_frag", 1), ("dgrad_frag", 1), ("dgrad_frag", 2), ("ups_dgrad_frag", 1), ("ups_fwd_frag", 1), ("fwd", 1)]
-    for w in ws:
-        for kind, dt in kinds:
-            h.packed_weight(w, kind, dt)
-    with torch.no_grad():
-        for i, w in enumerate(ws):
-            w.data.copy_(rnd(*w.shape, seed=80 + i).to(DEV))         # in place, like the fused optimizer
-    h.touch_params(ws)
-    assert h.refresh_packings_multi(ws) == len(ws) * len(kinds)
-    assert h.refresh_packings_multi(ws) == 0                          # nothing is stale (and nothing was asked for since)
-    multi = {(i, kind, dt): h.packed_weight(w, kind, dt).clone() for i, w in enumerate(ws) for kind, dt in kinds}
-    h.bump_weight_epoch()                                             # force the per-tensor path
-    for i, w in enumerate(ws):
-        for kind, dt in kinds:
-            assert torch.equal(h.packed_weight(w, kind, dt), multi[(i, kind, dt)]), (i, kind, dt)
-
-
 def test_split_kernels_shape_fuzz():
     """Geometry dispatch fuzz: random (B, H, W, C, K) through every split-half kernel family (halo patch / halo raster run /
     per-tap gather forward and data gradient, 9-tap and phase-form weight gradients, upsample forms) against the exact-f32
@@ -783,72 +737,6 @@ def test_conv3x3_streamed_splitk(B, Hh, Ww, C, K, monkeypatch):
         assert st
         dx = h.conv3x3_dgrad(dyd, wq, C, dtype=1, streamed=True)
         assert rel(nchw(dx), dref) < 2e-6
-
-
-def test_conv3x3_streamed_tile8(monkeypatch):
-    """The 8-wave 256 x 128 tile configuration of the streamed kernel (opt-in, EGAZE_TILE8): plain and upsample-gradient
-    launches against the 4-wave tiles -- same values up to fp32 summation order, same BN partial sums."""
-    h = H()
-    for (B, Hh, Ww, C, K) in [(2, 16, 32, 64, 128), (3, 28, 28, 64, 256), (1, 56, 56, 32, 128), (2, 14, 14, 128, 512)]:
-        x = nhwc(rnd(B, C, Hh, Ww, seed=81))
-        w = rnd(K, C, 3, 3, seed=82, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
-        b = rnd(K, seed=83, scale=0.1).to(DEV)
-        wp, st = h.conv_weight(w, "fwd", 1, x, K)
-        assert st
-        monkeypatch.setattr(h, "TILE8", "0")
-        y0, s0 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
-        monkeypatch.setattr(h, "TILE8", "all")
-        assert h._tile8(B, Hh, Ww, C, K, 0) == 0x10
-        y1, s1 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
-        assert rel(y1, y0) < 2e-6 and rel(s1.sum(0), s0.sum(0)) < 1e-6, (B, Hh, Ww, C, K)
-    for (B, Hl, Wl, C, K) in [(2, 16, 32, 128, 64), (3, 28, 28, 128, 64)]:
-        w = rnd(K, C, 3, 3, seed=84, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
-        dy = nhwc(rnd(B, K, 2 * Hl, 2 * Wl, seed=85))
-        wq, st = h.conv_weight(w, "ups_dgrad", 1, dy, C)
-        assert st
-        monkeypatch.setattr(h, "TILE8", "0")
-        d0 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
-        monkeypatch.setattr(h, "TILE8", "all")
-        d1 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
-        assert rel(d1, d0) < 2e-6, (B, Hl, Wl, C, K)
-
-
-def test_conv3x3_streamed_tile16(monkeypatch):
-    """The 4-wave 256 x 128 tile with one wave per SIMD and eight accumulator tiles per wave (EGAZE_TILE16): plain launches with
-    every epilogue (bias, bias + ReLU + abs-max... via the fold, bias + BN partial sums incl. the two 128-row stat rows a wave
-    owns) and the upsample data gradient against the default tiles and against fp64."""
-    h = H()
-    for (B, Hh, Ww, C, K) in [(2, 16, 32, 64, 128), (3, 28, 28, 64, 256), (1, 56, 56, 32, 128), (2, 14, 14, 128, 512),
-                              (5, 13, 9, 32, 128), (2, 48, 16, 32, 128)]:
-        xc = rnd(B, C, Hh, Ww, seed=81)
-        x = nhwc(xc)
-        wc = rnd(K, C, 3, 3, seed=82, scale=(2.0 / (9 * C)) ** 0.5)
-        w = wc.to(DEV)
-        bc = rnd(K, seed=83, scale=0.1)
-        b = bc.to(DEV)
-        ref = F.conv2d(xc.double(), wc.double(), bc.double(), padding=1)
-        wp, st = h.conv_weight(w, "fwd", 1, x, K)
-        assert st
-        monkeypatch.setattr(h, "TILE16", "0")
-        y0, s0 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
-        monkeypatch.setattr(h, "TILE16", "all")
-        assert h._tile8(B, Hh, Ww, C, K, 0) == 0x20
-        y1, s1 = h.conv3x3_fwd(x, wp, b, K, epi=2, dtype=1, streamed=True)
-        assert rel(nchw(y1), ref) < 2e-6, (B, Hh, Ww, C, K)
-        assert rel(y1, y0) < 2e-6 and rel(s1.sum(0), s0.sum(0)) < 1e-6, (B, Hh, Ww, C, K)
-        assert s1.shape == s0.shape                                            # one stat row per 128 output pixels, both tiles
-        y2, _ = h.conv3x3_fwd(x, wp, b, K, epi=1, dtype=1, streamed=True)
-        assert rel(nchw(y2), F.relu(ref)) < 2e-6
-    for (B, Hl, Wl, C, K) in [(2, 16, 32, 128, 64), (3, 28, 28, 128, 64)]:
-        w = rnd(K, C, 3, 3, seed=84, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
-        dy = nhwc(rnd(B, K, 2 * Hl, 2 * Wl, seed=85))
-        wq, st = h.conv_weight(w, "ups_dgrad", 1, dy, C)
-        assert st
-        monkeypatch.setattr(h, "TILE16", "0")
-        d0 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
-        monkeypatch.setattr(h, "TILE16", "all")
-        d1 = h.conv3x3_ups_dgrad(dy, wq, C, dtype=1, streamed=True)
-        assert rel(d1, d0) < 2e-6, (B, Hl, Wl, C, K)
 
 
 def test_conv3x3_streamed_shape_fuzz():
