@@ -6,6 +6,7 @@ tanh(target_i) (off-by-one), the loss also crosses video boundaries, and ``prevt
 checkpoint is rewritten whenever the epoch loss is below 999."""
 import math
 import os
+import time
 
 import numpy as np
 import torch
@@ -92,9 +93,23 @@ def crop_mean_weight(feature, maxind, size):
     if feature.is_cuda:
         from . import hipops as H
         from .functions import to_nhwc
+        if isinstance(maxind, torch.Tensor) and maxind.is_cuda:         # gaze points already on the device: no host round trip
+            return H.crop_mean(to_nhwc(feature), maxind, size, 16)
         return H.crop_mean(to_nhwc(feature), [list(map(int, m)) for m in maxind], size, 16)
     c = crop_feature(feature, maxind, size).contiguous()
     return c.view(c.size(0), c.size(1), -1).mean(2)
+
+
+def get_weighted_batch(chn_weights, feature):
+    """get_weighted for every frame of a chunk: chn_weights (n,512), feature (n,512,14,14) -> (n,14,14), each map
+    min-max normalised on its own (AT.py:58-66 applied per frame).  One launch on the GPU (one block per frame)."""
+    if feature.is_cuda:
+        from . import hipops as H
+        from .functions import to_nhwc
+        return H.weighted_minmax(to_nhwc(feature), chn_weights.reshape(feature.size(0), -1).contiguous().float())
+    f = torch.sum(feature * chn_weights.view(feature.size(0), -1, 1, 1), 1)
+    f = f - f.flatten(1).min(1)[0].view(-1, 1, 1)
+    return f / f.flatten(1).max(1)[0].view(-1, 1, 1)
 
 
 def get_weighted(chn_weight, feature):
@@ -327,10 +342,11 @@ class AT():
         """pred = SP gaze map, feat = AT-weighted conv5_3 map, both written as uint8 PNGs (AT.py:199-253).
 
         The same sequential LSTM state as the reference's batch-1 loop, but the frames of the (batch-1) loader are gathered
-        ``chunk`` at a time: the SP forward (eval mode, every sample independent), the uint8 quantisation, the gaze-point
-        metric and the crop means run once per chunk on the device; only the recurrent step, the weighted map and the image
-        hand-over stay per frame.  ``chunk=1`` is the reference's schedule.  A batched forward is NOT bitwise equal to a
-        batch-1 forward (the conv launches pick tile / split-K geometry by batch size, i.e. another fp32 summation order),
+        ``chunk`` at a time: staging (every frame copied into its row of one device buffer per field, on a copy stream, while the
+        previous chunk computes), the SP forward (eval mode, every sample independent), the uint8 quantisation, the gaze-point metric, the crop means, the weighted maps and their quantisation
+        run once per chunk on the device; the recurrence runs as ONE lstmnet call over the chunk's saccade frames (batch 1, state
+        carried in and out), and only the image hand-over (host I/O) stays per frame.  ``chunk=1`` is the reference's schedule.
+        A batched forward is NOT bitwise equal to a batch-1 forward (the conv launches pick tile / split-K geometry by batch size, i.e. another fp32 summation order),
         and ``(255 * output).to(uint8)`` truncates: a 1-ulp difference next to an integer flips that pixel by one level.
         Against the reference's own output the chunked path differs by +-1 LSB on < 0.2 % of the pixels
         (tests/test_hip_config5.py), the same class of difference as chunk=1 vs the reference's CPU arithmetic; pass
@@ -343,46 +359,139 @@ class AT():
         self.lstm.eval()
         hidden = None
 
-        def flush(samples):
+        # Two chunks in flight: while the GPU works on chunk k (queued, results copied to pinned memory asynchronously), the host
+        # stages the frames of chunk k + 1 row by row on a copy stream; chunk k's images are handed over (host I/O) when chunk
+        # k + 1 has been queued.  The LSTM state is carried on the device in stream order, so the chunks stay sequential.
+        from . import streams
+        use_copy_stream = self.device.type == 'cuda' and streams.ENABLED
+        copy_stream = streams.side_stream("h2d") if use_copy_stream else None
+        keys = ('image', 'flow', 'gt')
+        prof = getattr(self, "extract_profile", None)                 # optional dict: phase -> seconds (tools/bench_pipeline.py)
+
+        def mark(name, t0):
+            if prof is not None:
+                torch.cuda.synchronize()
+                prof[name] = prof.get(name, 0.0) + time.perf_counter() - t0
+            return time.perf_counter()
+
+        class _Chunk:
+            def __init__(self):
+                self.samples, self.bufs, self.sig, self.done, self.out = [], None, None, None, None
+
+            def add(self, sample, cap):
+                """Stage one frame: every field goes straight into its row of ONE device buffer per field (no device-side cat),
+                in the loader's own dtype -- bytes for raw_u8 datasets, normalised by one kernel per field at launch."""
+                sig = tuple((sample[k].dtype, tuple(sample[k].shape[1:])) for k in keys)
+                if self.bufs is None or sig != self.sig or self.bufs[keys[0]].shape[0] < cap:
+                    self.sig = sig
+                    self.bufs = {k: torch.empty((cap,) + tuple(sample[k].shape[1:]), dtype=sample[k].dtype, device=dev_)
+                                 for k in keys}
+                    if copy_stream is not None:       # (the blocks may have been freed by work still queued on this stream)
+                        copy_stream.wait_stream(torch.cuda.current_stream())
+                i = len(self.samples)
+                t0 = time.perf_counter()
+                if copy_stream is not None:
+                    with torch.cuda.stream(copy_stream):
+                        for k in keys:
+                            self.bufs[k][i:i + 1].copy_(sample[k], non_blocking=True)
+                else:
+                    for k in keys:
+                        self.bufs[k][i:i + 1].copy_(sample[k].to(dev_))
+                if prof is not None:
+                    prof["stage_host"] = prof.get("stage_host", 0.0) + time.perf_counter() - t0
+                self.samples.append(sample)
+
+        dev_ = self.device
+
+        def launch(ch):
+            """Queue the whole device side of a chunk; nothing here waits for the GPU."""
             nonlocal hidden
-            if not samples:
-                return
-            n = len(samples)
-            # stage the frames one by one (each crosses PCIe as it is: bytes for raw_u8 datasets) and stack them on the device
-            staged = [stage_batch(sm, self.device) for sm in samples]
-            input_s, input_t, target = (staged[0][k] if n == 1 else torch.cat([st[k] for st in staged], 0) for k in range(3))
+            n = len(ch.samples)
+            t0 = time.perf_counter()
+            if copy_stream is not None:
+                torch.cuda.current_stream().wait_stream(copy_stream)
+            input_s, input_t, target = stage_batch({k: ch.bufs[k][:n] for k in keys}, self.device)
+            t0 = mark("normalise", t0)
             del features_blobs[:]
             output = self.model(input_s, input_t)                     # (n,1,224,224)
             feature_s = features_blobs[0]                             # (n,512,14,14)
+            t0 = mark("sp_forward", t0)
             quant = (255 * output).to(torch.uint8)                    # np.uint8(255 * x): truncation, on the device
             # computeAAEAUC's third value is the GROUND-TRUTH arg-max, used as the "predicted" gaze point
             # (AT.py:221-224); evaluated on the quantised map like the reference, by the device kernel
-            _, _, pred_gp = computeAAEAUC(quant.float().squeeze(1), target.squeeze(1))
+            if self.device.type == 'cuda' and not self.align:
+                # the same device kernel computeAAEAUC uses, its gaze point kept on the device (no read-back in the chunk)
+                from . import hipops as H
+                pred_gp = H.aae_auc(quant.float().squeeze(1), target.squeeze(1))[:, 2:4].to(torch.int32).contiguous()
+            else:
+                _, _, pred_gp = computeAAEAUC(quant.float().squeeze(1), target.squeeze(1))
+            t0 = mark("metric", t0)
             if self.align:
                 chn_weights = crop_align_mean(feature_s, pred_gp, self.crop_size)            # (n,512)
             else:
                 chn_weights = crop_mean_weight(feature_s, pred_gp, self.crop_size)           # (n,512)
-            feats = []
-            for i, sm in enumerate(samples):                          # the recurrent part: frame by frame, state carried
-                chn_weight = chn_weights[i:i + 1]
-                if int(sm['fixsac']) != 1:
-                    hidden = repackage_hidden(hidden)
-                    chn_weight, hidden = self.lstm(chn_weight.unsqueeze(0), hidden)
-                    chn_weight = chn_weight.squeeze(0)
-                feats.append(get_weighted(chn_weight, feature_s[i:i + 1]).reshape(1, feature_s.size(2), feature_s.size(3)))
-            outims = quant.cpu().numpy()                              # one read-back per chunk, after everything was queued
-            featims = np.uint8(255 * torch.cat(feats, 0).cpu().numpy())
-            for i, sm in enumerate(samples):
+            t0 = mark("crop", t0)
+            # The recurrent part.  A fixation frame (fixsac == 1) keeps its crop mean and leaves the state alone; the saccade
+            # frames of the chunk, in order, are ONE lstmnet call over T' = their count steps at batch 1 (inputs known up front,
+            # state carried in and out): the same recurrence as the reference's frame-by-frame calls (AT.py:240-246).
+            sacc = [i for i, sm in enumerate(ch.samples) if int(sm['fixsac']) != 1]
+            if sacc:
+                idx = torch.tensor(sacc, device=chn_weights.device)
+                hidden = repackage_hidden(hidden)
+                seq, hidden = self.lstm(chn_weights.index_select(0, idx).unsqueeze(1), hidden)      # (T',1,512)
+                chn_weights = chn_weights.index_copy(0, idx, seq.squeeze(1))
+            t0 = mark("lstm", t0)
+            feats = get_weighted_batch(chn_weights, feature_s)        # (n,14,14): one launch for the chunk (AT.py:58-66 per frame)
+            featq = (255 * feats).to(torch.uint8)                     # np.uint8(255 * x) on the device
+            if self.device.type == 'cuda':
+                if ch.out is None or ch.out[0].shape[0] < n:
+                    ch.out = (torch.empty(quant.shape, dtype=torch.uint8).pin_memory(),
+                              torch.empty(featq.shape, dtype=torch.uint8).pin_memory())
+                ch.out[0][:n].copy_(quant, non_blocking=True)          # two read-backs per chunk, asynchronous
+                ch.out[1][:n].copy_(featq, non_blocking=True)
+                ch.done = torch.cuda.Event()
+                ch.done.record()
+            else:
+                ch.out, ch.done = (quant, featq), None
+            mark("weighted_readback", t0)
+
+        def finish(ch):
+            """Hand the images of a queued chunk over (host I/O) once its results have landed."""
+            if not ch.samples:
+                return
+            t0 = time.perf_counter()
+            if ch.done is not None:
+                ch.done.synchronize()
+            n = len(ch.samples)
+            outims, featims = ch.out[0][:n].numpy(), ch.out[1][:n].numpy()
+            for i, sm in enumerate(ch.samples):
                 currname = sm['imname'][0]
                 imwrite(os.path.join(pred_folder, currname), outims[i].squeeze())
                 imwrite(os.path.join(feat_folder, currname), resize(featims[i], (224, 224)))
+            ch.samples = []
+            if prof is not None:
+                prof["finish_host"] = prof.get("finish_host", 0.0) + time.perf_counter() - t0
 
-        pending = []
+        cap = max(1, int(chunk))
+        ring, cur, prev = [_Chunk(), _Chunk()], 0, None
+        kept = getattr(self, "_extract_buffers", None)               # device / pinned buffers survive across calls
+        if kept is not None:
+            for ch, (bufs, sig, out) in zip(ring, kept):
+                ch.bufs, ch.sig, ch.out = bufs, sig, out
         with torch.no_grad():
             for i, sample in _progress(enumerate(st_loader)):
-                pending.append(sample)
-                if len(pending) >= max(1, int(chunk)):
-                    flush(pending)
-                    pending = []
-            flush(pending)
+                ring[cur].add(sample, cap)
+                if len(ring[cur].samples) >= cap:
+                    launch(ring[cur])
+                    if prev is not None:
+                        finish(ring[prev])
+                    prev, cur = cur, 1 - cur
+            if ring[cur].samples:
+                launch(ring[cur])
+                if prev is not None:
+                    finish(ring[prev])
+                prev = cur
+            if prev is not None:
+                finish(ring[prev])
+        self._extract_buffers = [(ch.bufs, ch.sig, ch.out) for ch in ring]
         print('Finished extracting files for LF module!')

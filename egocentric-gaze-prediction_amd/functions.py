@@ -133,8 +133,12 @@ class ConvBNReLUPool(torch.autograd.Function):
             # for this one layer); the packed weight is padded the same way by the pack kernel
             xin = H.nchw_to_nhwc_pad(H._req(x.detach(), "network input (NCHW)"), 32)
             wp, st = H.conv_weight(weight, "fwd", H.F16X3, xin, K)
-            y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
-                                    epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3, streamed=st)
+            H.ALGO_CHANNELS[0] = C
+            try:
+                y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
+                                        epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3, streamed=st)
+            finally:
+                H.ALGO_CHANNELS[0] = None
         elif first:
             xin = H._req(x.detach(), "network input (NCHW)")
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training,
@@ -247,7 +251,11 @@ class ConvBNReLUPool(torch.autograd.Function):
         with fork("wgrad") as f:                # the weight gradient runs on a helper stream (both only read dy)
             if ng[1]:
                 if padded:
-                    dw = H.conv3x3_wgrad(xin, dy)[:, :C].contiguous()      # gradient of the zero-padded channels dropped
+                    H.ALGO_CHANNELS[0] = C
+                    try:
+                        dw = H.conv3x3_wgrad(xin, dy)[:, :C].contiguous()      # gradient of the zero-padded channels dropped
+                    finally:
+                        H.ALGO_CHANNELS[0] = None
                 else:
                     if first:
                         dw = H.conv_first_wgrad(xin, dy, out=sw)

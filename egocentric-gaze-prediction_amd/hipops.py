@@ -422,6 +422,11 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
     return am
 
 
+# FLOP accounting of a launch over a zero-PADDED operand (the 20-channel flow stack runs as 32 channels): the algorithmic count
+# prices the real channels (the padded count over-stated the step's FLOPs by 0.3 %).  Set around the launch.
+ALGO_CHANNELS = [None]
+
+
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
                 epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None,
                 streamed: bool = False, bn_in: Optional[torch.Tensor] = None, want_minmax: bool = False):
@@ -459,7 +464,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
               "egz_conv3x3_fwd_split")
         return y, None
     if dtype and streamed:       # wp = fragment-ordered packing (conv_weight): weights L2 -> registers, halo through LDS
-        PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
+        PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * (ALGO_CHANNELS[0] or C))
         ns = LIB.egz_conv3x3_streamed_splits(B, H, W, C, K) if (SPLITK and epi <= EPI_BIAS_STATS) else 1
         if ns > 1:      # few pixel tiles (batch-1 inference, 14 x 14 layers at small batches): split the channel blocks
             if epi == EPI_BIAS_STATS:   # the fix-up pass emits one partial row per 32 pixels
@@ -644,7 +649,7 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
                 xam = absmax_of(x)         # ... and the activation operand by its own (the forward pass left it on x)
     nb = LIB.egz_conv3x3_wgrad_ws_bytes(B, H, W, C, K, flags)
     ws = workspace(nb, x.device)
-    PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * C)
+    PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * (ALGO_CHANNELS[0] or C))
     check(LIB.egz_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), B, H, W, C, K, flags, ws.data_ptr(),
                                 ws.numel(), _p(am), _p(xam), _p(x_bn), _stream()), "egz_conv3x3_wgrad")
     return dw

@@ -26,7 +26,7 @@ from egaze_amd.utils import cfg, make_layers
 from egaze_amd import synthetic
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--frames", type=int, default=64)
+ap.add_argument("--frames", type=int, default=128)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 
@@ -62,13 +62,33 @@ with tempfile.TemporaryDirectory() as d:
                "image": b["image"][i:i + 1], "flow": b["flow"][i:i + 1], "gt": b["gt"][i:i + 1]} for i in range(a.frames)]
     at_mod.imwrite = lambda path, arr: None                    # disk writes are not part of the path
     at_mod._progress = lambda it: it
-    at.extract_late(loader[:4], d + "/p/", d + "/f/")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    at.extract_late(loader, d + "/p/", d + "/f/")
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.frames
-    print(f"AT.extract_late (frames in host memory, no PNG writes): {dt*1e3:.2f} ms per frame, {1/dt:.0f} frames/s")
+    at_mod.resize = lambda arr, size: arr                       # (the x16 resize of the 14 x 14 map is host image I/O like the PNG write)
+    rs8 = np.random.RandomState(1)
+    loader_u8 = [{"imname": s["imname"], "fixsac": s["fixsac"],
+                  "image": torch.from_numpy(rs8.randint(0, 256, (1, 3, 224, 224)).astype(np.uint8)),
+                  "flow": torch.from_numpy(rs8.randint(0, 256, (1, 20, 224, 224)).astype(np.uint8)),
+                  "gt": (s["gt"] * 255).to(torch.uint8)} for s in loader]
+    # gaze_full.py hands extract_late a DataLoader(pin_memory=True): the in-memory stand-in pins its samples the same way
+    for ld_ in (loader, loader_u8):
+        for s in ld_:
+            for k in ("image", "flow", "gt"):
+                s[k] = s[k].contiguous().pin_memory()
+    for tag, ld in (("fp32 frames (the reference loader's format)", loader), ("uint8 frames (this build's STDataset(raw_u8=True))", loader_u8)):
+        at.extract_late(ld[:33], d + "/p/", d + "/f/")
+        dts = []
+        for _ in range(3):                                        # the steady state of a long extraction: best of three passes
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            at.extract_late(ld, d + "/p/", d + "/f/")
+            torch.cuda.synchronize()
+            dts.append((time.perf_counter() - t0) / a.frames)
+        print("   passes, ms per frame:", [round(v * 1e3, 3) for v in dts])
+        dt = min(dts)
+        at.extract_profile = {}
+        at.extract_late(ld, d + "/p/", d + "/f/")
+        print("   phases, ms per frame (each phase synchronised):", {k: round(v / a.frames * 1e3, 3) for k, v in at.extract_profile.items()})
+        at.extract_profile = None
+        print(f"AT.extract_late, {tag} in host memory, no PNG writes / resize: {dt*1e3:.2f} ms per frame, {1/dt:.0f} frames/s")
 
 lf = late_fusion().to(dev).train()
 crit = floss().to(dev)
