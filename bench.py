@@ -317,7 +317,7 @@ def main():
         # -> tools/pmc_traffic.py; gfx950 FETCH half-count corrected).  The profile is stamped with a hash of the kernel
         # sources it was taken from: if the kernels changed since, the number is NOT quoted (traffic = null).
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if not split or tj.get("kernel_src_sha") == kernel_src_sha():
@@ -340,7 +340,7 @@ def main():
                                    "launches, exact-f32 MFMA)") +
                                   "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
                                   "timed with HIP events on the launch stream with stream concurrency off, as in "
-                                  "profiles/r03_bench_b32_kernel_stats_streams0.txt",
+                                  "profiles/r04_bench_b32_kernel_stats_streams0.txt",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,

@@ -83,6 +83,83 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
     }
 }
 
+// Fast path of egz_gemm (round 4): M, N multiples of 64, K a multiple of 64, unit stride along ONE index of each operand, 16-byte
+// aligned rows.  The generic kernel above fetches every operand element with a scalar, bounds-checked load (16 loads and ~200
+// address / predicate instructions per thread per 32-deep slab, one wave per SIMD): 30 us for the 512 x 2048 x 512 products of
+// the AT step against an 8 us exact-f32 MFMA floor, and the 17 GEMMs are half of the step's device time.  Here a slab is 64
+// deep, every thread moves four float4 per operand per slab, and nothing in the loop is predicated.  Same exact-f32 MFMA,
+// same k order within an accumulator: results are bit-identical to the generic kernel.
+constexpr int FK = 64, FLD = 68;                   // slab depth; LDS row pitch (16-byte aligned rows, 4-row skew of the banks)
+template <bool A_KFAST, bool B_NFAST>
+__global__ __launch_bounds__(256) void gemm_fast_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                        float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                        int K, long lda, long ldb, long ldc, int flags) {
+    __shared__ __attribute__((aligned(16))) float As[2][FK * FLD];   // [k][m]
+    __shared__ __attribute__((aligned(16))) float Bs[2][FK * FLD];   // [k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    // A_KFAST: A[m * lda + k] (row-major M x K): thread -> (m = e >> 4, k4 = e & 15), e = tid + 256 j: one float4 along k
+    // else     A[k * lda + m] (m contiguous):     thread -> (k = e >> 4, m4 = e & 15): one float4 along m
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, hi = e >> 4, lo4 = (e & 15) * 4;
+            ra[j] = A_KFAST ? *reinterpret_cast<const f32x4*>(A + (long)(m0 + hi) * lda + k0 + lo4)
+                            : *reinterpret_cast<const f32x4*>(A + (long)(k0 + hi) * lda + m0 + lo4);
+            rb[j] = B_NFAST ? *reinterpret_cast<const f32x4*>(Bm + (long)(k0 + hi) * ldb + n0 + lo4)
+                            : *reinterpret_cast<const f32x4*>(Bm + (long)(n0 + hi) * ldb + k0 + lo4);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = tid + 256 * j, hi = e >> 4, lo4 = (e & 15) * 4;
+            if (A_KFAST) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) As[buf][(lo4 + q) * FLD + hi] = ra[j][q];
+            } else {
+                *reinterpret_cast<f32x4*>(&As[buf][hi * FLD + lo4]) = ra[j];
+            }
+            if (B_NFAST) {
+                *reinterpret_cast<f32x4*>(&Bs[buf][hi * FLD + lo4]) = rb[j];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Bs[buf][(lo4 + q) * FLD + hi] = rb[j][q];
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk = K / FK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nk; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nk) gload((s + 1) * FK);
+        const float* Ab = As[buf] + hl * FLD + wm * 32 + l31;
+        const float* Bb = Bs[buf] + hl * FLD + wn * 32 + l31;
+#pragma unroll
+        for (int t = 0; t < FK / 2; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[(2 * t) * FLD], Bb[(2 * t) * FLD], acc, 0, 0, 0);
+        if (s + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + l31;
+    const float bz = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + egz_acc_row(r, lane);
+        float v = acc[r] + bz;
+        if (flags & 1) v += C[(long)m * ldc + n];
+        if (flags & 2) v = fmaxf(v, 0.f);
+        C[(long)m * ldc + n] = v;
+    }
+}
+
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
 // gates: [B][4H] pre-activations (i,f,g,o); c_prev/h_out/c_out: [B][H]; act (saved for backward): [B][4H] activated gates
@@ -156,6 +233,18 @@ EGZ_API int egz_gemm(const float* A, const float* B, float* C, const float* bias
                      long sbk, long sbn, long ldc, int flags, hipStream_t st) {
     EGZ_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "egz_gemm: bad arguments");
     dim3 grid(egz_cdiv(N, GN), egz_cdiv(M, GM));
+    // fast path: whole 64 x 64 x 64 tiles, one unit stride per operand, float4-aligned rows (the AT step's products all qualify)
+    const bool a_k = (sak == 1), a_m = (sam == 1), b_n = (sbn == 1), b_k = (sbk == 1);
+    const long lda = a_k ? sam : sak, ldb = b_n ? sbk : sbn;
+    if (M % GM == 0 && N % GN == 0 && K % FK == 0 && (a_k || a_m) && (b_n || b_k) && lda % 4 == 0 && ldb % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0) {
+        if (a_k && b_n)       hipLaunchKernelGGL((gemm_fast_kernel<true, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
+        else if (a_k)         hipLaunchKernelGGL((gemm_fast_kernel<true, false>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
+        else if (b_n)         hipLaunchKernelGGL((gemm_fast_kernel<false, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
+        else                  hipLaunchKernelGGL((gemm_fast_kernel<false, false>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
+        EGZ_CHECK_LAUNCH("egz_gemm(fast)");
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, flags);
     EGZ_CHECK_LAUNCH("egz_gemm");
     return 0;
