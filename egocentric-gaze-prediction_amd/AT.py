@@ -146,7 +146,7 @@ class _GraphedSampleStep:
         self.one = torch.ones((), device=device)                          # d loss / d loss
         from .models import LSTMnet as _L
         # the (1, 1, C) step runs on the fused single-step path AND every gradient is written in full by a sink -- with
-        # EGAZE_DIRECT_GRADS=0 gradients go through AccumulateGrad and the flat buffer must be zeroed every step
+        # hipops.DIRECT_GRADS = False (tests): gradients go through AccumulateGrad and the flat buffer must be zeroed every step
         self.single_step = bool(_L.B1_FUSED) and bool(H.DIRECT_GRADS)
         self.loss = None                     # the loss tensor of the last step (a graph-owned tensor once captured)
         self.graph, self.calls = None, 0
