@@ -39,6 +39,8 @@ SIGNATURES = {
     "egz_conv3x3_fwd_split": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, S]),
     "egz_conv3x3_streamed_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_pack_w3x3_split_frag": (c_int, [P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_pack_w3x3_frag_blocks": (c_int, [c_int, c_int]),
+    "egz_pack_w3x3_frag_batch": (c_int, [P, c_int, c_int, S]),
     "egz_conv3x3_streamed_splits": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_fwd_streamed_splitk_stat_rows": (c_int, [c_int, c_int, c_int]),
     "egz_conv3x3_fwd_streamed_splitk_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

@@ -717,6 +717,94 @@ __global__ __launch_bounds__(256) void pack_split_frag_kernel(const float* __res
 }
 
 
+// All fragment-ordered packings an optimizer step made stale, in ONE launch (egz_pack_w3x3_frag_batch).  The per-layer kernel
+// above is launch-bound (~80 launches of 4-15 us per SP step, each in front of the convolution that needs it) and its 2-byte
+// stores keep it at ~0.7 TB/s.  Here a block owns one 32 (output channels) x 32 (input channels) x 9 tile of ONE weight tensor:
+// 32 contiguous 1152-byte runs of the OIHW tensor go through LDS (row pitch 289 words: the forward orientation walks rows, the
+// data-gradient orientation walks 9-word columns -- both conflict-free), and every thread item gathers the 8 reduction elements
+// of one lane of one fragment and writes its hi and lo halves as two 16-byte stores (1 KB contiguous per wave).  Same values,
+// same split as pack_split_frag_kernel (bit-identical packings: test_pack_frag_batch_matches_per_layer).
+// table: rows of 8 x int64 [w, wq, C, K, kind, dtype, first block, -] in device memory, sorted by first block.
+constexpr int PT_LD = 289;
+template <typename T>
+__device__ __forceinline__ void pack_frag_tile(const float* __restrict__ w, unsigned short* __restrict__ wq, int C, int K,
+                                               int kind, float scale, int tile, float* __restrict__ sw) {
+    const int Cp = (C + 31) & ~31, Kp = (K + 31) & ~31;
+    const int ncbc = Cp >> 5;
+    const int kb = tile / ncbc, cb = tile - kb * ncbc;
+    const int tid = threadIdx.x;
+    if (C % 32 == 0 && (reinterpret_cast<unsigned long long>(w) & 15) == 0) {
+        for (int idx = tid; idx < 32 * 72; idx += 256) {
+            const int i = idx / 72, q = idx - i * 72;
+            const int k = kb * 32 + i;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < K) v = *reinterpret_cast<const f32x4*>(w + ((long)k * C + cb * 32) * 9 + q * 4);
+            float* d = sw + i * PT_LD + q * 4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+    } else {
+        for (int idx = tid; idx < 32 * 288; idx += 256) {
+            const int i = idx / 288, q = idx - i * 288;
+            const int k = kb * 32 + i, c = cb * 32 + q / 9;
+            sw[i * PT_LD + q] = (k < K && c < C) ? w[(long)k * C * 9 + cb * 288 + q] : 0.f;
+        }
+    }
+    __syncthreads();
+    const bool fwd = (kind == 4 || kind == 7);
+    const int NS = (kind >= 6) ? 16 : 9;
+    const int nt32 = (fwd ? Kp : Cp) >> 5, ncb = (fwd ? Cp : Kp) >> 5;
+    const int ntile = fwd ? kb : cb, cblk = fwd ? cb : kb;
+    for (int it = tid; it < NS * 128; it += 256) {
+        const int lane = it & 63, ks = (it >> 6) & 1, si = it >> 7;
+        const int col = lane & 31, kk0 = ks * 16 + (lane >> 5) * 8;
+        const float* p = fwd ? sw + col * PT_LD + kk0 * 9 : sw + kk0 * PT_LD + col * 9;
+        const int estep = fwd ? 9 : PT_LD;
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float* pe = p + e * estep;
+            float v;
+            if (kind == 4) v = pe[si];
+            else if (kind == 5) v = pe[8 - si];
+            else {
+                float w9[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) w9[t] = pe[t];
+                v = frag_value9(w9, kind, si);
+            }
+            Half<T>::split(v * scale, h[e], l[e]);
+        }
+        const long s = (kind == 7) ? (long)(si >> 2) * (ncb * 4) + cblk * 4 + (si & 3) : (long)cblk * NS + si;
+        const long r = s * nt32 + ntile;
+        const long base = ((r * 2 + ks) * 2) * 512 + lane * 8;
+        u32x4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hv[e] = (unsigned)h[2 * e] | ((unsigned)h[2 * e + 1] << 16);
+            lv[e] = (unsigned)l[2 * e] | ((unsigned)l[2 * e + 1] << 16);
+        }
+        *reinterpret_cast<u32x4*>(wq + base) = hv;
+        *reinterpret_cast<u32x4*>(wq + base + 512) = lv;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_frag_batch_kernel(const long long* __restrict__ table, int n) {
+    __shared__ float sw[32 * PT_LD];
+    const int b = (int)blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                          // last row whose first block is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 8 + 6] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long long* d = table + lo * 8;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    unsigned short* wq = reinterpret_cast<unsigned short*>(d[1]);
+    const int C = (int)d[2], K = (int)d[3], kind = (int)d[4], tile = b - (int)d[6];
+    if (d[5] == 1) pack_frag_tile<_Float16>(w, wq, C, K, kind, F16_WSCALE, tile, sw);
+    else pack_frag_tile<__bf16>(w, wq, C, K, kind, 1.f, tile, sw);
+}
+
+
 // ---------------------------------------------------------------------------------------------------------
 // Persistent form for the narrowest layers (late_fusion.py:10-12: at most 32 reduction channels AND at most 32 GEMM columns,
 // patch geometry).  With one channel block the kernel above has nothing to pipeline inside a tile (fetch -> split -> barrier ->
@@ -1319,6 +1407,20 @@ EGZ_API int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int
     if (dtype == 1) hipLaunchKernelGGL(pack_split_frag_kernel<_Float16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, F16_WSCALE);
     else            hipLaunchKernelGGL(pack_split_frag_kernel<__bf16>, dim3(g), dim3(256), 0, st, w, o, C, K, kind, Np, Rp, 1.f);
     EGZ_CHECK_LAUNCH("egz_pack_w3x3_split_frag");
+    return 0;
+}
+
+// Blocks one weight tensor takes in an egz_pack_w3x3_frag_batch launch: one per 32 x 32 (output, input channel) tile.
+EGZ_API int egz_pack_w3x3_frag_blocks(int C, int K) { return ((C + 31) / 32) * ((K + 31) / 32); }
+
+// Rebuild many fragment-ordered packings in one launch (what an optimizer step leaves stale: ~80 packings per SP step).
+// table: n rows of 8 x int64 in DEVICE memory: [w pointer, wq pointer, C, K, kind (4..7), dtype (1 f16 / 2 bf16), first block,
+// unused]; first block = running sum of egz_pack_w3x3_frag_blocks over the rows before; total_blocks = the sum over all rows.
+// Every wq as for egz_pack_w3x3_split_frag, 16-byte aligned; the result is bit-identical to n calls of it.
+EGZ_API int egz_pack_w3x3_frag_batch(const long long* table, int n, int total_blocks, hipStream_t st) {
+    EGZ_CHECK_ARG(table && n > 0 && total_blocks > 0, "egz_pack_w3x3_frag_batch: bad arguments");
+    hipLaunchKernelGGL(pack_frag_batch_kernel, dim3(total_blocks), dim3(256), 0, st, table, n);
+    EGZ_CHECK_LAUNCH("egz_pack_w3x3_frag_batch");
     return 0;
 }
 

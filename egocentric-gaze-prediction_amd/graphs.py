@@ -104,9 +104,17 @@ class GraphedTrainStep:
                 self._unit()
             self.opt.step_count = count          # the capture ran the host side of step() without executing anything
             self.graph = g
+            self._versions = [p._version for p in self.opt.params]
             g.replay()
             self.opt.note_replays(1)
         else:
+            # the captured step rebuilds the packed weights AFTER its Adam update (FusedAdam.step -> H.refresh_packings), so its
+            # forward pass trusts them: parameters overwritten from outside between two replays (load_state_dict, copy_)
+            # must be repacked here
+            versions = [p._version for p in self.opt.params]
+            if versions != self._versions:
+                H.refresh_packings(self.opt.params, force=True)
+                self._versions = versions
             self.graph.replay()
             self.opt.note_replays(1)
         return self.out

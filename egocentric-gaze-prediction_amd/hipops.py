@@ -274,6 +274,53 @@ def packed_weight(w: torch.Tensor, kind: str, dtype: int = 0) -> torch.Tensor:
     return buf
 
 
+BATCH_REPACK = True       # FusedAdam.step() rebuilds the stale fragment-ordered packings of its parameters in ONE launch
+#                           (False: each packing is rebuilt lazily in front of the first launch that needs it;
+#                           test_pack_frag_batch_matches_per_layer flips it)
+_BATCH_TABLES = {}
+
+
+def refresh_packings(params, force: bool = False) -> int:
+    """Rebuild, in one launch on the current stream, every fragment-ordered split packing of ``params`` that went stale and
+    that some launch has used since its last rebuild (egz_pack_w3x3_frag_batch; bit-identical to the lazy per-layer rebuilds).
+    Returns the number of packings rebuilt.  Packings nobody asked for since the last rebuild (eval-only kinds, a layer whose
+    geometry changed) stay stale and are rebuilt lazily by packed_weight().  ``force``: every existing fragment-ordered packing
+    of ``params``, stale by its tag or not (a captured training step whose parameters were overwritten between two replays)."""
+    if not BATCH_REPACK or not (_USED or force):
+        return 0
+    ids = {getattr(p, "_egz_uid", None) for p in params}
+    todo = []
+    for key in sorted(k for k in (_PACKED if force else _USED) if k[0] in ids and k[2] and _PACK_FN[k[1]][2] >= 4):
+        hit = _PACKED.get(key)
+        w = hit[2]() if hit is not None else None
+        if w is None:
+            _USED.discard(key)
+            continue
+        if force or hit[0] != _tag(w):
+            todo.append((key, w, hit[1]))
+    if not todo:
+        return 0
+    sig = tuple((key, w.data_ptr(), buf.data_ptr()) for key, w, buf in todo)
+    ent = _BATCH_TABLES.get(sig)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            return 0                      # the table is built by an eager step (GraphedTrainStep's warm-up); lazy rebuilds until then
+        rows, nb = [], 0
+        for key, w, buf in todo:
+            K, C = w.shape[0], w.shape[1]
+            rows.append([w.data_ptr(), buf.data_ptr(), C, K, _PACK_FN[key[1]][2], key[2], nb, 0])
+            nb += LIB.egz_pack_w3x3_frag_blocks(C, K)
+        if len(_BATCH_TABLES) > 64:
+            _BATCH_TABLES.clear()
+        ent = (torch.tensor(rows, dtype=torch.int64).to(todo[0][1].device), nb)
+        _BATCH_TABLES[sig] = ent
+    check(LIB.egz_pack_w3x3_frag_batch(ent[0].data_ptr(), len(todo), ent[1], _stream()), "egz_pack_w3x3_frag_batch")
+    for key, w, buf in todo:
+        _PACKED[key] = (_tag(w), buf, weakref.ref(w))
+        _USED.discard(key)
+    return len(todo)
+
+
 # ----------------------------------------------------------------------------- gradient sinks
 class GradSink:
     """Where a parameter's gradient lands when the parameter lives in a fused optimizer's flat buffers (optim.FusedAdam):

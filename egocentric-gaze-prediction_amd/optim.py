@@ -123,6 +123,7 @@ class FusedAdam:
             H.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
                         self.eps, self.step_count, self.grad_scale)
         H.touch_params(self.params)
+        H.refresh_packings(self.params)     # one launch for every packing this step made stale (the next forward finds them fresh)
 
     @property
     def param_groups(self):

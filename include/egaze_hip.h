@@ -84,6 +84,13 @@ int egz_conv3x3_streamed_ok(int B, int H, int W, int C, int K, int mode);
 /* rows of stat_partial ([rows][2][K] doubles) of an epi 2 / epi 5 launch of egz_conv3x3_fwd_streamed (mode 0) */
 int egz_conv3x3_streamed_stat_rows(int B, int H, int W, int C, int K);
 int egz_pack_w3x3_split_frag(const float* w, void* wq, int C, int K, int kind, int dtype, hipStream_t stream);
+/* Every fragment-ordered packing an optimizer step made stale in ONE launch (no reference counterpart: the reference's
+ * Conv2d reads its fp32 weights directly, utils.py:70; this is the repack after optim.Adam.step, SP.py:137).  table: n rows of
+ * 8 x int64 in DEVICE memory [w, wq, C, K, kind 4..7, dtype 1 f16 / 2 bf16, first block, unused]; first block = running sum of
+ * egz_pack_w3x3_frag_blocks(C, K) over the preceding rows, total_blocks = the sum over all rows.  Bit-identical to n calls of
+ * egz_pack_w3x3_split_frag. */
+int egz_pack_w3x3_frag_blocks(int C, int K);
+int egz_pack_w3x3_frag_batch(const long long* table, int n, int total_blocks, hipStream_t stream);
 int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, float* y, double* stat_partial, int B,
                              int H, int W, int C, int K, int epi, int dtype, int mode, const unsigned int* x_absmax,
                              const float* mask_src, unsigned int* absmax_out, const float* bn_coef, float* minmax_out,

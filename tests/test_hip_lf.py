@@ -333,14 +333,20 @@ def test_lf_train_step_graphed_matches_eager():
                 o = model(f, i)
                 return crit(o, t), o
             step = GraphedTrainStep(fwd_loss, opt, batches[0], warm=2)
-            for f, i, t in batches:
+            for n, (f, i, t) in enumerate(batches):
+                if n == 4:                # a parameter overwritten from outside between two REPLAYS: the replay must see it
+                    with torch.no_grad():
+                        model.fusion[3].weight.mul_(0.5)
                 l, o = step(f, i, t)
                 losses.append(l.item())
             assert step.graph is not None and opt.step_count == 5
             step.close()
             assert opt.step_count == 5
         else:
-            for f, i, t in batches:
+            for n, (f, i, t) in enumerate(batches):
+                if n == 4:
+                    with torch.no_grad():
+                        model.fusion[3].weight.mul_(0.5)
                 o = model(f, i)
                 l = crit(o, t)
                 opt.zero_grad()

@@ -875,3 +875,47 @@ def test_large_operand_routes_to_the_64bit_addressed_kernels(monkeypatch):
     assert h.conv_dtype("fwd", 128, 64, x) == h.F16X3
     monkeypatch.setattr(h, "_SPLIT_MAX_BYTES", 1024)
     assert h.conv_dtype("fwd", 128, 64, x) == h.F32 and h.conv_dtype("dgrad", 64, 128, x) == h.F32
+
+
+def test_pack_frag_batch_matches_per_layer(monkeypatch):
+    """egz_pack_w3x3_frag_batch (every stale fragment-ordered packing of an optimizer step in one launch, FusedAdam.step ->
+    hipops.refresh_packings) writes the same bytes as the per-layer egz_pack_w3x3_split_frag launches: all four kinds, both split
+    dtypes, full and padded (C or K < 32, unaligned base pointer) tensors; packings nobody used since their last rebuild stay
+    stale; ``force`` rebuilds fresh ones too."""
+    h = H()
+    shapes = [(64, 64), (128, 64), (64, 128), (512, 256), (32, 32), (32, 8), (8, 32), (20, 64)]
+    flat = torch.empty(sum(K * C * 9 for C, K in shapes) + 3, device=DEV)
+    ws, off = [], 3                                   # offset 3 floats: base pointers that are not 16-byte aligned
+    for i, (C, K) in enumerate(shapes):
+        w = flat[off:off + K * C * 9].view(K, C, 3, 3)
+        w.copy_(rnd(K, C, 3, 3, seed=40 + i, scale=0.05))
+        off += K * C * 9
+        ws.append(w)
+    kinds = [("fwd_frag", 1), ("dgrad_frag", 1), ("dgrad_frag", 2), ("ups_fwd_frag", 1), ("ups_dgrad_frag", 1), ("ups_dgrad_frag", 2)]
+
+    def pack_all():
+        return {(i, k, dt): h.packed_weight(w, k, dt) for i, w in enumerate(ws) for k, dt in kinds}
+
+    monkeypatch.setattr(h, "BATCH_REPACK", True)
+    first = pack_all()                                # lazy per-layer launches (nothing cached yet)
+    for w in ws:
+        w.mul_(1.7)                                   # version bump: every packing is stale now
+    assert h.refresh_packings(ws) == len(first)       # ONE launch
+    batch = {k: v.clone() for k, v in pack_all().items()}          # cache hits: the buffers the batch launch wrote
+    assert all(batch[k].data_ptr() != first[k].data_ptr() for k in first)
+    assert h.refresh_packings(ws) == 0                # fresh and not used since -> pack_all marked them used, but they are fresh
+    for w in ws:
+        w.add_(0.0)                                   # stale again, values unchanged
+    monkeypatch.setattr(h, "BATCH_REPACK", False)
+    assert h.refresh_packings(ws) == 0
+    lazy = pack_all()                                 # per-layer rebuilds of the same values
+    for k in lazy:
+        assert torch.equal(lazy[k].view(torch.int32), batch[k].view(torch.int32)), k
+    monkeypatch.setattr(h, "BATCH_REPACK", True)
+    want = {k: v.clone() for k, v in lazy.items()}
+    for v in lazy.values():
+        v.zero_()                                     # fresh by their tags, wrong by their bytes
+    assert h.refresh_packings(ws) == 0
+    assert h.refresh_packings(ws, force=True) == len(first)        # force rebuilds regardless of tags
+    for k in lazy:
+        assert torch.equal(lazy[k].view(torch.int32), want[k].view(torch.int32)), k
