@@ -1209,33 +1209,48 @@ def copy_into(dst: torch.Tensor, src: torch.Tensor):
     check(LIB.egz_copy(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "egz_copy")
 
 
-def lstm_seq_fwd(gx, w_hh, h0, c0, want_acts: bool = True):
-    """One nn.LSTM layer over all T steps: gx (T,B,4H) = x W_ih^T + b_ih + b_hh -> hs, cs (T,B,H), acts (T,B,4H) | None."""
-    _req(gx, "gx"); _req(w_hh, "w_hh"); _req(h0, "h0"); _req(c0, "c0")
-    T, B, H4 = gx.shape
+def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
+    """The stacked recurrence as a wavefront over (layer, step) (egz_lstm_wave_fwd): gx0 (T,B,4H) = layer 0's input projection
+    of every step (bias included); w_ih / w_hh / bsum: lists of L tensors (w_ih[0] / bsum[0] unused); h0, c0 (L,B,H)
+    -> hs, cs (L,T,B,H), acts (L,T,B,4H) | None, hn, cn (L,B,H)."""
+    _req(gx0, "gx0"); _req(h0, "h0"); _req(c0, "c0")
+    L = len(w_hh)
+    T, B, H4 = gx0.shape
     Hd = H4 // 4
-    hs = torch.empty((T, B, Hd), dtype=torch.float32, device=gx.device)
+    for l in range(L):
+        _req(w_hh[l], "w_hh")
+        if l:
+            _req(w_ih[l], "w_ih"); _req(bsum[l], "bias")
+            if tuple(w_ih[l].shape) != (H4, Hd):
+                raise RuntimeError("lstm_wave_fwd: the upper layers take the hidden size as their input size")
+    dev = gx0.device
+    hs = torch.empty((L, T, B, Hd), dtype=torch.float32, device=dev)
     cs = torch.empty_like(hs)
-    acts = torch.empty((T, B, H4), dtype=torch.float32, device=gx.device) if want_acts else None
-    PROF.note_flops("egz_lstm_seq_fwd", 2.0 * T * B * H4 * Hd)
-    check(LIB.egz_lstm_seq_fwd(gx.data_ptr(), w_hh.data_ptr(), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(),
-                               _p(acts), T, B, Hd, _stream()), "egz_lstm_seq_fwd")
-    return hs, cs, acts
+    acts = torch.empty((L, T, B, H4), dtype=torch.float32, device=dev) if want_acts else None
+    hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
+    cn = torch.empty_like(hn)
+    PROF.note_flops("egz_lstm_wave_fwd", 2.0 * T * B * H4 * Hd * (2 * L - 1))
+    check(LIB.egz_lstm_wave_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh),
+                                _ptr_table([None] + list(bsum[1:])), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(),
+                                _p(acts), hn.data_ptr(), cn.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_wave_fwd")
+    return hs, cs, acts, hn, cn
 
 
-def lstm_seq_bwd(dh_out, dhn, dcn, acts, cs, c0, w_hh_t):
-    """Backward through time of one layer -> (dgates (T,B,4H), dh0 (B,H), dc0 (B,H))."""
-    T, B, Hd = cs.shape
-    dgates = torch.empty((T, B, 4 * Hd), dtype=torch.float32, device=cs.device)
-    dh0 = torch.empty((B, Hd), dtype=torch.float32, device=cs.device)
+def lstm_wave_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh_t, w_ih_t):
+    """Backward through time of the stack -> (dgates (L,T,B,4H), dh0 (L,B,H), dc0 (L,B,H)); w_hh_t / w_ih_t: lists of the
+    transposed weights (H,4H) per layer (w_ih_t[0] unused)."""
+    L, T, B, Hd = cs.shape
+    dev = cs.device
+    dgates = torch.empty((L, T, B, 4 * Hd), dtype=torch.float32, device=dev)
+    dh0 = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
     dc0 = torch.empty_like(dh0)
-    for name, t in (("dh_out", dh_out), ("dhn", dhn), ("dcn", dcn)):
+    for name, t in (("dh_top", dh_top), ("dhn", dhn), ("dcn", dcn)):
         if t is not None:
             _req(t, name)
-    PROF.note_flops("egz_lstm_seq_bwd", 2.0 * (T + 1) * B * 4 * Hd * Hd)
-    check(LIB.egz_lstm_seq_bwd(_p(dh_out), _p(dhn), _p(dcn), acts.data_ptr(), cs.data_ptr(), c0.data_ptr(),
-                               w_hh_t.data_ptr(), dgates.data_ptr(), dh0.data_ptr(), dc0.data_ptr(), T, B, Hd, _stream()),
-          "egz_lstm_seq_bwd")
+    PROF.note_flops("egz_lstm_wave_bwd", 2.0 * (T + 1) * B * 4 * Hd * Hd * L + 2.0 * T * B * 4 * Hd * Hd * (L - 1))
+    check(LIB.egz_lstm_wave_bwd(_p(dh_top), _p(dhn), _p(dcn), acts.data_ptr(), cs.data_ptr(), c0.data_ptr(),
+                                _ptr_table(w_hh_t), _ptr_table([None] + list(w_ih_t[1:])), dgates.data_ptr(), dh0.data_ptr(),
+                                dc0.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_wave_bwd")
     return dgates, dh0, dc0
 
 

@@ -21,10 +21,12 @@ B1_FUSED = True      # T = 1, B = 1 steps on the fused single-step kernels (Fals
 class _LSTMNetFn(torch.autograd.Function):
     """input (T,B,C), h0/c0 (L,B,H), then per layer (w_ih, w_hh, b_ih, b_hh), then lin.weight, lin.bias.
 
-    Per layer: ONE batched GEMM for the input projections of all T steps, then the recurrence as T fused
-    [h W_hh^T + cell] launches issued by one C-ABI call (csrc/lstm_seq.hip); backward: T + 1 fused
-    [dgates W_hh + cell backward] launches, then batched GEMMs for dW_ih, dW_hh, db and the gradient into the layer
-    below.  Parameter gradients go straight into the optimizer's flat buffer when it offers a sink (hipops.GradSink)."""
+    ONE batched GEMM for the input projections of layer 0, then the stacked recurrence as a WAVEFRONT over (layer, step): launch
+    s runs step s - l of every layer l (csrc/lstm_seq.hip, egz_lstm_wave_fwd: T + L - 1 fused [[h_below | h] [W_ih | W_hh]^T +
+    cell] launches issued by one C-ABI call instead of T x L step launches and L - 1 more GEMMs); backward: T + L fused
+    [[dgates_next | dgates_above] [W_hh | W_ih_above] + cell backward] launches, then batched GEMMs for dW_ih, dW_hh, db and the
+    gradient into the tanh'd input.  Parameter gradients go straight into the optimizer's flat buffer when it offers a sink
+    (hipops.GradSink)."""
 
     @staticmethod
     def forward(ctx, inp, h0, c0, *params):
@@ -35,25 +37,17 @@ class _LSTMNetFn(torch.autograd.Function):
         h0c, c0c = H._req(h0.detach().contiguous(), "h0"), H._req(c0.detach().contiguous(), "c0")
         train = any(ctx.needs_input_grad)          # no-grad runs (AT.testLSTM, extract_late) skip the saved gate activations
         x = H.tanh_fwd(inp_c)
-        saved_layers = []
-        layer_in = x.view(T * B, C)
-        hn = torch.empty((L, B, Hd), dtype=torch.float32, device=inp.device)
-        cn = torch.empty_like(hn)
-        for l in range(L):
-            w_ih, w_hh, b_ih, b_hh = (p.detach() for p in params[4 * l:4 * l + 4])
-            bsum = H.add(b_ih, b_hh)
-            gx = H.linear_fwd(layer_in, w_ih, bias=bsum).view(T, B, 4 * Hd)      # all time steps at once
-            hs, cs, acts = H.lstm_seq_fwd(gx, H._req(w_hh, "w_hh"), h0c[l], c0c[l], want_acts=train)
-            saved_layers.append((layer_in, hs, cs, acts))
-            layer_in = hs.view(T * B, Hd)
-            H.copy_into(hn[l], hs[T - 1])
-            H.copy_into(cn[l], cs[T - 1])
+        w_ih = [params[4 * l].detach() for l in range(L)]
+        w_hh = [H._req(params[4 * l + 1].detach(), "w_hh") for l in range(L)]
+        bsum = [H.add(params[4 * l + 2].detach(), params[4 * l + 3].detach()) for l in range(L)]
+        gx0 = H.linear_fwd(x.view(T * B, C), w_ih[0], bias=bsum[0]).view(T, B, 4 * Hd)      # all time steps at once
+        hs, cs, acts, hn, cn = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0c, c0c, want_acts=train)
         lin_w, lin_b = params[-2].detach(), params[-1].detach()
-        out2d = H.linear_fwd(layer_in, lin_w, bias=lin_b, relu=True)
+        out2d = H.linear_fwd(hs[L - 1].view(T * B, Hd), lin_w, bias=lin_b, relu=True)
         # the node keeps the 2-D base and hands out a VIEW: the returned tensor (whose grad_fn is this node) must not be
         # stored on the node itself -- that reference cycle runs through C++ and is never collected, leaking the
         # saved T*B*4H activations of every step and keeping the step's AccumulateGrad nodes alive into the next one
-        ctx.saved = (x, h0c, c0c, saved_layers, out2d)
+        ctx.saved = (x, h0c, c0c, hs, cs, acts, out2d)
         ctx.params = list(params)
         ctx.dims = (T, B, C, Hd, L)
         ctx.set_materialize_grads(False)
@@ -63,10 +57,12 @@ class _LSTMNetFn(torch.autograd.Function):
     def backward(ctx, dout, dhn, dcn):
         if ctx.saved is None:
             raise RuntimeError("lstmnet: backward a second time through the same forward pass (activations were freed)")
-        x, h0c, c0c, saved_layers, out = ctx.saved
+        x, h0c, c0c, hs, cs, acts, out = ctx.saved
         params = ctx.params
         T, B, C, Hd, L = ctx.dims
         ng = ctx.needs_input_grad
+        if acts is None:
+            raise RuntimeError("lstmnet: backward through a forward pass that ran without gradient tracking")
         lin_w = params[-2].detach()
         if dout is None:
             dpre = torch.empty((T * B, out.shape[-1]), dtype=torch.float32, device=out.device)
@@ -75,39 +71,34 @@ class _LSTMNetFn(torch.autograd.Function):
             dpre = H.relu_bwd(out.view(T * B, -1), H._req(dout.contiguous().view(T * B, -1), "grad"))
         grads = [None] * len(params)
         sinks = [H.grad_sink(p, ng[3 + i]) for i, p in enumerate(params)]
-        h_top = saved_layers[-1][1].view(T * B, Hd)
+        h_top = hs[L - 1].view(T * B, Hd)
         if ng[3 + len(params) - 2]:
             grads[-2] = H.matmul_tn(dpre, h_top, out=sinks[-2])                  # d lin.weight = dpre^T h
         if ng[3 + len(params) - 1]:
             grads[-1] = H.colsum(dpre, out=sinks[-1])
-        dh_all = H.matmul_nn(dpre, lin_w).view(T, B, Hd)          # gradient into the top layer's outputs
-        dh0 = torch.empty((L, B, Hd), dtype=torch.float32, device=out.device)
-        dc0 = torch.empty_like(dh0)
-        for l in reversed(range(L)):
-            layer_in, hs, cs, acts = saved_layers[l]
-            if acts is None:
-                raise RuntimeError("lstmnet: backward through a forward pass that ran without gradient tracking")
-            w_ih, w_hh = params[4 * l].detach(), params[4 * l + 1].detach()
-            dgates, dh0_l, dc0_l = H.lstm_seq_bwd(dh_all, dhn[l].contiguous() if dhn is not None else None,
-                                                  dcn[l].contiguous() if dcn is not None else None, acts, cs, c0c[l],
-                                                  H.transpose2d(H._req(w_hh, "w_hh")))
-            H.copy_into(dh0[l], dh0_l)
-            H.copy_into(dc0[l], dc0_l)
-            dg2 = dgates.view(T * B, 4 * Hd)
+        dh_top = H.matmul_nn(dpre, lin_w).view(T, B, Hd)          # gradient into the top layer's outputs
+        w_hh_t = [H.transpose2d(H._req(params[4 * l + 1].detach(), "w_hh")) for l in range(L)]
+        w_ih_t = [None] + [H.transpose2d(H._req(params[4 * l].detach(), "w_ih")) for l in range(1, L)]
+        dgates, dh0, dc0 = H.lstm_wave_bwd(dh_top, dhn.contiguous() if dhn is not None else None,
+                                           dcn.contiguous() if dcn is not None else None, acts, cs, c0c, w_hh_t, w_ih_t)
+        for l in range(L):
+            layer_in = x.view(T * B, C) if l == 0 else hs[l - 1].view(T * B, Hd)
+            dg2 = dgates[l].view(T * B, 4 * Hd)
             if ng[3 + 4 * l]:
                 grads[4 * l] = H.matmul_tn(dg2, layer_in, out=sinks[4 * l])                     # d W_ih
             if ng[3 + 4 * l + 1]:       # d W_hh = sum_t dgates_t^T h_{t-1}: the t = 0 term sees h0, the rest hs[:-1]
-                g = H.matmul_tn(dgates[0], h0c[l], out=sinks[4 * l + 1])
+                g = H.matmul_tn(dgates[l, 0], h0c[l], out=sinks[4 * l + 1])
                 if T > 1:
-                    H.matmul_tn(dgates[1:].view((T - 1) * B, 4 * Hd), hs[:-1].view((T - 1) * B, Hd), out=g, accumulate=True)
+                    H.matmul_tn(dgates[l, 1:].view((T - 1) * B, 4 * Hd), hs[l, :-1].view((T - 1) * B, Hd), out=g, accumulate=True)
                 grads[4 * l + 1] = g
             if ng[3 + 4 * l + 2]:
                 grads[4 * l + 2] = H.colsum(dg2, out=sinks[4 * l + 2])
             if ng[3 + 4 * l + 3]:
                 grads[4 * l + 3] = H.colsum(dg2, out=sinks[4 * l + 3])
-            if l > 0 or ng[0]:
-                dh_all = H.matmul_nn(dg2, w_ih).view(T, B, -1)        # into the layer below / the tanh'd input
-        dinp = H.tanh_bwd(x, dh_all.contiguous()).view(T, B, C) if ng[0] else None
+        dinp = None
+        if ng[0]:
+            dh_in = H.matmul_nn(dgates[0].view(T * B, 4 * Hd), params[0].detach())        # into the tanh'd input
+            dinp = H.tanh_bwd(x, dh_in).view(T, B, C)
         for i, p in enumerate(params):
             if sinks[i] is not None:
                 H.grad_done(p)

@@ -255,14 +255,20 @@ int egz_lstm_cell_fwd(const float* gates, const float* c_prev, float* h_out, flo
                       hipStream_t stream);
 int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, const float* dh, const float* dc_in,
                       float* dgates, float* dc_prev, int B, int Hd, hipStream_t stream);
-/* nn.LSTM recurrence, one launch per time step, product and cell fused (models/LSTMnet.py:18,32-35 = torch's
- * nn.LSTM(512, 512, 2) forward / backward through time; AT.py:133-145).  gx [T][B][4H] = x W_ih^T + b_ih + b_hh;
- * w_hh [4H][H]; w_hh_t [H][4H]; hs, cs [T][B][H]; acts, dgates [T][B][4H]; H % 256 == 0. */
-int egz_lstm_seq_fwd(const float* gx, const float* w_hh, const float* h0, const float* c0, float* hs, float* cs,
-                     float* acts, int T, int B, int H, hipStream_t stream);
-int egz_lstm_seq_bwd(const float* dh_out, const float* dhn, const float* dcn, const float* acts, const float* cs,
-                     const float* c0, const float* w_hh_t, float* dgates, float* dh0, float* dc0, int T, int B, int H,
-                     hipStream_t stream);
+/* nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step) (models/LSTMnet.py:18,26-35: self.lstm(input, hidden)): launch
+ * s runs step s - l of every layer l, T + L - 1 dependent launches instead of T x L, the upper layers' input projections reduced
+ * in the same launch (K = 2H).  w_ih / w_hh / bsum: HOST arrays of L device pointers ([4H][H], [4H][H], [4H] = b_ih + b_hh;
+ * w_ih[0] / bsum[0] unused: gx0 [T][B][4H] = x W_ih0^T + b_ih0 + b_hh0 for every step); h0, c0, hn, cn: [L][B][H];
+ * hs, cs: [L][T][B][H]; acts: [L][T][B][4H] or null.  1 <= L <= 4, H % 256 == 0. */
+int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
+                      const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L, int T,
+                      int B, int H, hipStream_t stream);
+/* Its backward through time (autograd of the same call): T + L launches; the gradient w.r.t. a lower layer's outputs is formed
+ * inside the step launches (K = 8H).  dh_top: [T][B][H] or null; dhn, dcn: [L][B][H] or null; w_hh_t / w_ih_t: HOST arrays of L
+ * device pointers to the TRANSPOSED weights [H][4H] (w_ih_t[0] unused); dgates: [L][T][B][4H] out; dh0, dc0: [L][B][H] out. */
+int egz_lstm_wave_bwd(const float* dh_top, const float* dhn, const float* dcn, const float* acts, const float* cs,
+                      const float* c0, const float* const* w_hh_t, const float* const* w_ih_t, float* dgates, float* dh0,
+                      float* dc0, int L, int T, int B, int H, hipStream_t stream);
 /* The same network at T = 1, B = 1 -- the reference's own stepping (AT.py:127-145 training loop, AT.py:246 inference): the
  * whole step in ONE call (L + 1 launches forward, 2L + 1 backward; csrc/lstm_b1.hip).  params / grads: HOST arrays of
  * 4L + 2 device pointers in state-dict order (w_ih, w_hh, b_ih, b_hh per layer, lin.weight [N][H], lin.bias [N]); a null
