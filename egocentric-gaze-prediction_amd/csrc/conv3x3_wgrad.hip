@@ -764,6 +764,199 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Tap-packed form of the narrow kernel for K <= 8 filters (late_fusion.py:12: Conv2d(32, 8)).  With the nine taps as nine 32-column
+// tiles, three quarters of every MFMA of conv3x3_wgrad9_x3n_kernel multiply the zero padding of the 8 -> 32 column tile (the
+// launch was matrix-core bound: 107 us for 59 algorithmic GFLOP).  Here the SHIFT moves to the gradient operand,
+//     dw[c][k][tap] = sum_q x[q][c] * dy[q - off(tap)][k]          (q over the image, dy zero outside),
+// so the activation fragment of a 16-pixel run is read once, unshifted, and the GEMM columns are (tap, k) pairs: 72 columns in
+// three 32-column tiles (four taps each; the last tile carries tap 8 and three copies whose results are dropped) -- 9 MFMAs per 16
+// pixels instead of 27.  The per-lane addresses of ds_read_b64_tr_b16 make the gather free: a 16-lane group's four channel
+// chunks are (tap a, k 0-3), (tap a, k 4-7), (tap a + 1, k 0-3), (tap a + 1, k 4-7), each reading its own shifted pixel of the
+// staged dy halo ([halo pixel][8 k], 16 bytes per pixel).  Stage = the same R x WD = 64-pixel patch, wave w owns its w-th
+// 16-pixel run, partial tiles summed through LDS in wave order, [split][tap][C][K] partials for wgrad_reduce: as the kernel above.
+template <typename T, int R, int WD, bool BNIN>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3t_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
+    int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax,
+    const unsigned int* __restrict__ x_absmax, const float* __restrict__ x_bn) {
+    static_assert(R * WD == 64 && (WD == 32 || WD == 16), "patch = 64 pixels in rows of 16-pixel runs");
+    const float d_scale = W16<T>::scale(dy_absmax), d_inv = 1.f / d_scale;
+    const float x_scale = W16<T>::scale(x_absmax), x_inv = 1.f / x_scale;
+    constexpr int NP = R * WD;
+    constexpr int HPW = WD + 2, NH = (R + 2) * HPW;            // dy halo row width / halo pixels
+    constexpr int XH = NP * 32 + 32;                           // x plane stride (elements): [pixel][32 channels]
+    constexpr int DH = NH * 8 + 8;                             // dy plane stride: [halo pixel][8 k]
+    constexpr int XB = 2 * XH, DB = 2 * DH;
+    constexpr int NX = (NP * 8) / 256;                         // float4 x loads per thread (2)
+    constexpr int ND = (NH * 2 + 255) / 256;                   // float4 dy halo loads per thread (1 or 2)
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[2 * XB];
+    __shared__ __attribute__((aligned(16))) unsigned short Ds[2 * DB];
+    static_assert(sizeof(unsigned short) * 2 * XB >= 4 * 1024 * sizeof(float), "final reduction reuses the activation buffers");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.y;
+    const int cpr = (W + WD - 1) / WD, rpi = (H + R - 1) / R;
+    const long npatch = (long)B * rpi * cpr;
+    const long g0 = (long)split * patches_per_split;
+    const long g1 = (g0 + patches_per_split < npatch) ? (g0 + patches_per_split) : npatch;
+
+    // the dy resource starts (W + 1) * K floats early so that the (-1, -1) halo corner keeps lane offsets non-negative
+    const unsigned d_bias = (unsigned)(W + 1) * (unsigned)K * 4u;
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x), 0, (int)((unsigned)B * H * W * C * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t d_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(dy)) - d_bias, 0, (int)((unsigned)B * H * W * K * 4u + d_bias), 0x00020000);
+    unsigned x_vo[NX], x_rc[NX], d_vo[ND], d_rc[ND];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int i = tid + 256 * j, pp = i >> 3, c4 = i & 7;
+        x_vo[j] = (c4 * 4 < C) ? (unsigned)(((pp / WD) * W + pp % WD) * C * 4 + c4 * 16) : 0xFFFFFFFFu;
+        x_rc[j] = (unsigned)((pp / WD) << 8 | (pp % WD));
+    }
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int i = tid + 256 * j, pos = i >> 1, k4 = i & 1;
+        const int hr = pos / HPW, hx = pos - hr * HPW;
+        d_vo[j] = (pos < NH && k4 * 4 < K) ? (unsigned)((hr * W + hx) * K * 4 + k4 * 16) : 0xFFFFFFFFu;
+        d_rc[j] = (unsigned)(hr << 8 | hx);
+    }
+    f32x4 rx[NX], rd[ND];
+    unsigned rx_ok = 0;
+    f32x4 in_sc = {0.f, 0.f, 0.f, 0.f}, in_sh = {0.f, 0.f, 0.f, 0.f};
+    if (BNIN && (tid & 7) * 4 < C) {
+        in_sc = *reinterpret_cast<const f32x4*>(x_bn + 2 * C + (tid & 7) * 4);
+        in_sh = *reinterpret_cast<const f32x4*>(x_bn + 3 * C + (tid & 7) * 4);
+    }
+    int nx0 = (int)(g0 % cpr) * WD, ny0 = (int)((g0 / cpr) % rpi) * R, nb = (int)((g0 / cpr) / rpi);
+    auto gload = [&]() {
+        const int x0 = nx0, y0 = ny0;
+        const unsigned b = (unsigned)nb;
+        nx0 += WD;
+        if (nx0 >= cpr * WD) {
+            nx0 = 0;
+            ny0 += R;
+            if (ny0 >= rpi * R) {
+                ny0 = 0;
+                ++nb;
+            }
+        }
+        // valid dy halo rows hr in [rlo, rlo + rn], cols hx in [clo, clo + cn]  (source pixel = (y0 + hr - 1, x0 + hx - 1))
+        const unsigned rlo = (y0 == 0) ? 1u : 0u, rn = (unsigned)((H - y0 < R + 1) ? (H - y0) : (R + 1)) - rlo;
+        const unsigned clo = (x0 == 0) ? 1u : 0u, cn = (unsigned)((W - x0 < WD + 1) ? (W - x0) : (WD + 1)) - clo;
+        const unsigned so_x = (unsigned)((((b * H + y0) * W + x0) * C) * 4);
+        const unsigned so_d = (unsigned)((((b * H + y0) * W + x0) * K) * 4);         // + d_bias - d_bias
+        const unsigned rmax = (unsigned)(H - y0), cmax = (unsigned)(W - x0);
+        unsigned okm = 0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const bool ok = ((x_rc[j] >> 8) < rmax) && ((x_rc[j] & 255u) < cmax);
+            if (BNIN && ok && x_vo[j] != 0xFFFFFFFFu) okm |= 1u << j;
+            rx[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? x_vo[j] : 0xFFFFFFFFu, so_x, 0));
+        }
+        rx_ok = okm;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const bool ok = ((d_rc[j] >> 8) - rlo <= rn) && ((d_rc[j] & 255u) - clo <= cn);
+            rd[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, ok ? d_vo[j] : 0xFFFFFFFFu, so_d, 0));
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + 256 * j, pp = i >> 3, c4 = i & 7;
+            u32x2_t hi, lo;
+            if (BNIN) {
+                const float ms = ((rx_ok >> j) & 1u) ? x_scale : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rx[j][e] = fmaxf(__builtin_fmaf(rx[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
+                W16<T>::split4(rx[j], hi, lo);
+            } else {
+                W16<T>::split4(rx[j] * x_scale, hi, lo);
+            }
+            unsigned short* d = Xs + buf * XB + pp * 32 + c4 * 4;
+            *reinterpret_cast<u32x2_t*>(d) = hi;
+            *reinterpret_cast<u32x2_t*>(d + XH) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + 256 * j, pos = i >> 1, k4 = i & 1;
+            if (pos < NH) {
+                u32x2_t hi, lo;
+                W16<T>::split4(rd[j] * d_scale, hi, lo);
+                unsigned short* d = Ds + buf * DB + pos * 8 + k4 * 4;
+                *reinterpret_cast<u32x2_t*>(d) = hi;
+                *reinterpret_cast<u32x2_t*>(d + DH) = lo;
+            }
+        }
+    };
+
+    // transpose-read addressing (see conv3x3_wgrad9_x3_kernel): lane u of a 16-lane group hands in pixel (u >> 2) of the group's
+    // four, chunk (u & 3); group g covers reduction elements 8 (g >> 1) .. +7 and the columns / channels 16 (g & 1) .. +15
+    const int u = lane & 15, hh = lane >> 5, gh = (lane >> 4) & 1;
+    const int lp = 8 * hh + (u >> 2);                          // pixel of the wave's 16-pixel run (first read; the second: + 4)
+    const EGZ_LDS unsigned short* Xl = (const EGZ_LDS unsigned short*)(Xs) + (16 * wave + lp) * 32 + 16 * gh + 4 * (u & 3);
+    // dy: column chunk (u & 3) of group half gh of tile j = (tap 4 j + 2 gh + ((u & 3) >> 1), k quad (u & 3) & 1)
+    const int prow = (WD == 32) ? (wave >> 1) : wave, pcol = ((WD == 32) ? 16 * (wave & 1) : 0) + lp;
+    int doff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int tap = 4 * j + 2 * gh + ((u & 3) >> 1);
+        tap = tap > 8 ? 8 : tap;
+        const int oy = tap / 3 - 1, ox = tap % 3 - 1;
+        doff[j] = ((prow + 1 - oy) * HPW + (pcol + 1 - ox)) * 8 + ((u & 3) & 1) * 4;
+    }
+    const EGZ_LDS unsigned short* Dl = (const EGZ_LDS unsigned short*)(Ds);
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (g0 < g1) {
+        gload();
+        lstore(0);
+    }
+    __syncthreads();
+    for (long g = g0; g < g1; ++g) {
+        const int buf = (int)((g - g0) & 1);
+        if (g + 1 < g1) gload();
+        const EGZ_LDS unsigned short* Xb = Xl + buf * XB;
+        const EGZ_LDS unsigned short* Db = Dl + buf * DB;
+        const typename W16<T>::vec8 xh = W16<T>::frag(Xb, Xb + 4 * 32);
+        const typename W16<T>::vec8 xl = W16<T>::frag(Xb + XH, Xb + XH + 4 * 32);
+        typename W16<T>::vec8 dh[3], dl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                           // (the second read: 4 pixels further along the run = 4 halo columns)
+            dh[j] = W16<T>::frag(Db + doff[j], Db + doff[j] + 4 * 8);
+            dl[j] = W16<T>::frag(Db + DH + doff[j], Db + DH + doff[j] + 4 * 8);
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                acc[j] = W16<T>::mfma(term == 0 ? xl : xh, term == 1 ? dl[j] : dh[j], acc[j]);
+        if (g + 1 < g1) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    // the four waves' partial tiles, summed in wave order through LDS (one column tile = four taps at a time)
+    float* red = reinterpret_cast<float*>(Xs);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[j][r];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int e = tid + 256 * m, r = e >> 6, ln = e & 63;
+            const float v = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+            const int c = egz_acc_row(r, ln), n = ln & 31, tap = 4 * j + (n >> 3), k = n & 7;
+            if (c < C && k < K && tap < 9) part[((long)split * 9 + tap) * C * K + (long)c * K + k] = v * d_inv * x_inv;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Split-half weight gradient of [nearest x2 upsample -> conv3x3] in phase form (4/9 of the MACs of the folded 9-tap form):
 //   dWeff[py][px][a][b][c][k] = sum_{b,y,x} X[y+a+py-1][x+b+px-1][c] * dY[2y+py][2x+px][k]      (LOW-res y, x)
 // One block = one 64(c) x 64(k) tile of BOTH column phases of one row phase py (blockIdx.z): 8 accumulators per wave
@@ -1428,8 +1621,18 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
             if (x_bn) hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
             else      hipLaunchKernelGGL((conv3x3_wgrad9_x3n_kernel<TT, RR, WW, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
         } while (0)
+#define EGZ_W9T(TT, RR, WW)                                                                                                   \
+        do {                                                                                                                  \
+            if (x_bn) hipLaunchKernelGGL((conv3x3_wgrad9_x3t_kernel<TT, RR, WW, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
+            else      hipLaunchKernelGGL((conv3x3_wgrad9_x3t_kernel<TT, RR, WW, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
+        } while (0)
+        if (K <= 8 && !(flags & 0x4000)) {       // few filters: (tap, k) pairs as GEMM columns (0x4000 keeps the nine-tile form: A/B runs)
+            if (dy_absmax) { if (WD == 32) EGZ_W9T(_Float16, 2, 32); else EGZ_W9T(_Float16, 4, 16); }
+            else           { if (WD == 32) EGZ_W9T(__bf16, 2, 32); else EGZ_W9T(__bf16, 4, 16); }
+        } else
         if (dy_absmax) { if (WD == 32) EGZ_W9N(_Float16, 2, 32); else EGZ_W9N(_Float16, 4, 16); }
         else           { if (WD == 32) EGZ_W9N(__bf16, 2, 32); else EGZ_W9N(__bf16, 4, 16); }
+#undef EGZ_W9T
 #undef EGZ_W9N
         EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap split, narrow)");
         return wgrad_reduce(part, dw, C, K, S, st);

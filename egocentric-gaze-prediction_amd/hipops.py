@@ -676,6 +676,10 @@ def colsum_f64(stat: torch.Tensor, ncols_out: int, out: Optional[torch.Tensor] =
 WGRAD_SPLIT = 0x2000       # egz_conv3x3_wgrad flag: split-half arithmetic (bf16 x3, or f16 x3 when dy_absmax is passed)
 
 
+WGRAD_TAPPACK = True      # K <= 8 filters on the narrow kernel: (tap, k) pairs as GEMM columns (False: nine zero-padded 32-column tiles;
+#                           test_conv3x3_wgrad_split flips it)
+
+
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0,
                   precision: Optional[str] = None, out: Optional[torch.Tensor] = None,
                   x_bn: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -685,7 +689,7 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
     B, H, W, K = dy.shape
     C = x.shape[3]
     dw = _out(out, (K, C, 3, 3), x.device)
-    flags = (1 if ups else 0) | variant_flag
+    flags = (1 if ups else 0) | variant_flag | (0 if WGRAD_TAPPACK else 0x4000)
     am = xam = None
     prec = precision or PRECISION
     if prec in ("split", "split_bf16", "split_f16"):

@@ -121,8 +121,10 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     (2, 16, 32, 32, 32, False), (1, 28, 28, 32, 8, False), (2, 9, 7, 32, 32, False), (1, 24, 48, 32, 16, False),
     # ... and the narrow kernel (one 32 x 32 tile, waves split the 64-pixel patch 2x32 / 4x16): odd / short row counts, C < 32
     (2, 15, 32, 32, 8, False), (1, 10, 16, 8, 32, False), (1, 33, 224, 32, 32, False), (3, 3, 64, 12, 4, False),
+    # ... K <= 8: the tap-packed form ((tap, k) pairs as GEMM columns, the shift on the gradient operand): 4 x 16 and 2 x 32 patches
+    (1, 48, 48, 32, 8, False), (2, 17, 16, 32, 8, False), (1, 224, 224, 32, 8, False), (2, 6, 96, 20, 4, False), (1, 1, 16, 32, 8, False),
 ])
-def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups):
+def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups, monkeypatch):
     """f16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes; dy scaled by its abs-max): patch geometries 1x32 / 2x16 / 4x8,
     masked narrow rows (28 in 32, 14 and 12 in 16), odd row counts, upsample-fused gather.  Compared with the fp64
     weight gradient; the exact-f32 kernel is held to the same bound for reference."""
@@ -141,6 +143,11 @@ def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups):
     assert e_f32 < 1e-5
     assert e_bf16 < 2e-5
     assert e_f16 < 2e-6
+    if K <= 8 and C <= 32 and Ww % 16 == 0 and not ups:          # the nine-tile form of the narrow kernel, which K <= 8 no longer takes by default
+        monkeypatch.setattr(h, "WGRAD_TAPPACK", False)
+        e_old = rel(h.conv3x3_wgrad(nhwc(x), nhwc(dy), precision="split_f16").cpu().double(), w.grad)
+        print(f"wgrad err vs fp64, nine zero-padded column tiles: f16x3 {e_old:.2e}")
+        assert e_old < 2e-6
 
 
 @pytest.mark.parametrize("C", [3, 20])
