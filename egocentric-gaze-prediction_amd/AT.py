@@ -139,11 +139,14 @@ class _GraphedSampleStep:
     eagerly through the same function (they are real training steps), then the step is captured once and replayed."""
     WARM = 3
 
-    def __init__(self, lstm, criterion, optimizer, device, width):
+    def __init__(self, lstm, criterion, optimizer, device, width, ring=None):
         self.lstm, self.criterion, self.opt = lstm, criterion, optimizer
+        # ``ring``: device float tensor in which the loss of every step is parked, slot = (optimizer steps completed before the
+        # step) % len(ring) -- written by the loss kernel itself off the optimizer's device-side step counter, so reading the
+        # losses back once per ring costs no launch per replay
+        self.ring = ring
         self.both = torch.zeros((2, 1, 1, width), device=device)          # (input, target) of the step: ONE host copy fills it
         self.state = torch.zeros((2, lstm.num_layer, 1, lstm.num_channel), device=device)      # (h, c)
-        self.one = torch.ones((), device=device)                          # d loss / d loss
         from .models import LSTMnet as _L
         # the (1, 1, C) step runs on the fused single-step path AND every gradient is written in full by a sink -- with
         # hipops.DIRECT_GRADS = False (tests): gradients go through AccumulateGrad and the flat buffer must be zeroed every step (ADVICE r3)
@@ -154,24 +157,25 @@ class _GraphedSampleStep:
 
     def _unit(self):
         pred, (hn, cn) = self.lstm(self.both[0], (self.state[0], self.state[1]))
-        loss = MSELoss.apply(pred, self.both[1], True)       # criterion(pred, tanh(target)) in one kernel (AT.py:138)
+        # criterion(pred, tanh(target)) AND its gradient for the unit seed of loss.backward() in one kernel (AT.py:138-141), which
+        # also parks the loss in the ring: the backward pass starts at the network's output
+        loss, dpred = H.mse_fwd_grad(H._req(pred.detach().contiguous(), "pred"), self.both[1].view_as(pred).contiguous(), True,
+                                     self.ring, self.opt.step_dev if self.ring is not None else None)
         # every gradient of a batch-1 step is written in full by the backward kernels (csrc/lstm_b1.hip): no zero fill
         self.opt.zero_grad(all_overwritten=self.single_step)
-        loss.backward(gradient=self.one)                     # a static seed: no fill kernel per replay
+        pred.backward(gradient=dpred.view_as(pred))
         self.opt.step()
         # (hn, cn) share one buffer on the single-step path: one copy carries the state over -- after the backward pass,
         # which reads the incoming state
         base = getattr(hn, "_base", None)
-        from . import hipops as H
         if base is not None and base is getattr(cn, "_base", None) and base.numel() == self.state.numel() and base.is_contiguous():
             H.copy_into(self.state, base.detach())
         else:
             H.copy_into(self.state[0], hn.detach().contiguous())
             H.copy_into(self.state[1], cn.detach().contiguous())
-        self.loss = loss.detach()
+        self.loss = loss
 
     def reset_state(self):
-        from . import hipops as H
         H.fill_zero(self.state)
 
     def step(self, host_pair):
@@ -185,7 +189,7 @@ class _GraphedSampleStep:
             g = torch.cuda.CUDAGraph()
             count = self.opt.step_count
             with torch.cuda.graph(g):
-                H.ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()))
+                H.ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()), eager=False)
                 self._unit()
             self.opt.step_count = count        # the capture ran the host side of step() without executing anything
             self.graph = g
@@ -247,13 +251,15 @@ class AT():
         RING = 64
         losses = AverageMeter()
         runner, stage, prev_inp, reset = None, None, None, True
-        ring, pending = None, 0
+        ring, pending, first = None, 0, 0
 
         def drain():
-            nonlocal pending
+            nonlocal pending, first
             if pending:
-                for v in ring[:pending].cpu().tolist():       # one synchronising read-back for `pending` samples
-                    losses.update(v)
+                vals = ring.cpu().tolist()                      # one synchronising read-back for `pending` samples
+                for i in range(pending):                        # slot of a step = optimizer steps completed before it
+                    losses.update(vals[(first + i) % len(vals)])
+                first += pending
                 pending = 0
         try:
             for i, sample in enumerate(loader):
@@ -261,7 +267,8 @@ class AT():
                 if stage is None:
                     stage = torch.empty((RING // 2, 2, n), dtype=torch.float32).pin_memory()
                     ring = torch.zeros(RING // 2, device=self.device)
-                    runner = _GraphedSampleStep(self.lstm, self.criterion_lstm, self.optimizer_lstm, self.device, n)
+                    runner = _GraphedSampleStep(self.lstm, self.criterion_lstm, self.optimizer_lstm, self.device, n, ring=ring)
+                    first = self.optimizer_lstm.step_count
                 same = int(sample['same'])
                 if prev_inp is not None:
                     # step on the previous sample's input (forward) scored against THIS sample's target
@@ -270,7 +277,7 @@ class AT():
                     slot[1].copy_(sample['gt'].reshape(-1))
                     if reset:
                         runner.reset_state()
-                    ring[pending:pending + 1].copy_(runner.step(slot).reshape(1), non_blocking=True)
+                    runner.step(slot)
                     pending += 1
                     if pending == RING // 2:
                         drain()

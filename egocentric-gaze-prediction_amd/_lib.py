@@ -97,6 +97,7 @@ SIGNATURES = {
     "egz_floss_bwd": (c_int, [P, P, P, P, P, c_long, S]),
     "egz_mse_fwd": (c_int, [P, P, P, c_long, P, c_size_t, c_int, S]),
     "egz_mse_bwd": (c_int, [P, P, P, P, c_long, c_int, S]),
+    "egz_mse_fwd_grad": (c_int, [P, P, P, P, c_long, c_int, P, c_int, P, S]),
     # --- AT: generic f32-MFMA GEMM + LSTM cell
     "egz_gemm": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, S]),
     "egz_lstm_cell_fwd": (c_int, [P, P, P, P, P, c_int, c_int, S]),

@@ -295,6 +295,31 @@ __global__ __launch_bounds__(256) void mse_small_kernel(const float* __restrict_
     if (threadIdx.x == 0) loss[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
 }
 
+// mse_small_kernel + the gradient w.r.t. a for a unit seed, da = (2 / n) (a - b) (mse_bwd_kernel's arithmetic with gout = 1), in the
+// same launch; optionally parks the loss in ring[counter[0] % ring_n] (the AT per-sample loop reads its losses back once per ring:
+// the slot index follows the optimizer's device-side step counter, so the captured step needs no copy launch per replay).
+__global__ __launch_bounds__(256) void mse_small_grad_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ loss, float* __restrict__ da, long n, int tanh_b,
+                                                             float* __restrict__ ring, int ring_n, const int* __restrict__ counter) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const float s = 1.f * 2.f / (float)n;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float d = a[i] - (tanh_b ? tanhf(b[i]) : b[i]);
+        da[i] = s * d;
+        acc += (double)(d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)(((red[0] + red[1]) + (red[2] + red[3])) / (double)n);
+        loss[0] = v;
+        if (ring) ring[*static_cast<const volatile int*>(counter) % ring_n] = v;
+    }
+}
+
 constexpr int LOSS_BLOCKS = 1024;
 constexpr int HEAD_BLOCKS = 1024;
 
@@ -445,6 +470,18 @@ EGZ_API int egz_mse_fwd(const float* a, const float* b, float* loss_out, long n,
     EGZ_CHECK_LAUNCH("egz_mse_fwd");
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, st, part, grid, (double)n, loss_out);
     EGZ_CHECK_LAUNCH("egz_mse_fwd(final)");
+    return 0;
+}
+// nn.MSELoss forward AND its gradient for a unit seed in one single-block launch (n <= 4096: AT.py:138-141 on one (1, 1, 512)
+// sample: loss = criterion(pred, tanh(target)); loss.backward()).  loss_out = mean((a - b')^2), da = (2 / n) (a - b') with b' = b or
+// tanh(b): bit-identical to egz_mse_fwd + egz_mse_bwd(grad_out = 1).  ring (optional): the loss is also stored to
+// ring[counter[0] % ring_n] (counter = a device int, e.g. the step counter of egz_adam_step_dev).
+EGZ_API int egz_mse_fwd_grad(const float* a, const float* b, float* loss_out, float* da, long n, int tanh_b, float* ring,
+                             int ring_n, const int* counter, hipStream_t st) {
+    EGZ_CHECK_ARG(a && b && loss_out && da && n > 0 && n <= 4096, "egz_mse_fwd_grad: bad arguments (n <= 4096)");
+    EGZ_CHECK_ARG(!ring || (ring_n > 0 && counter), "egz_mse_fwd_grad: a ring needs its size and a counter");
+    hipLaunchKernelGGL(mse_small_grad_kernel, dim3(1), dim3(256), 0, st, a, b, loss_out, da, n, tanh_b, ring, ring_n, counter);
+    EGZ_CHECK_LAUNCH("egz_mse_fwd_grad");
     return 0;
 }
 EGZ_API int egz_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, long n, int tanh_b,

@@ -387,12 +387,15 @@ class _AbsmaxArena:
         self.waited = set()
         self.capture_seq = 0
 
-    def capture_begin(self, device):
+    def capture_begin(self, device, eager: bool = True):
         """First statement inside a hipGraph capture (graphs.py, AT.py): the capture's buffers come from a chunk of its own whose
-        fill is captured HERE, on the capture's origin stream, before any side stream forks."""
+        fill is captured HERE, on the capture's origin stream, before any side stream forks.  ``eager=False``: a capture that
+        stays on one stream and may not take a buffer at all (the AT per-sample step: its replay would zero 32 KB for nothing,
+        one 4.6 us launch per sample) -- the chunk is then created by the first take() inside the capture."""
         self.capture_seq += 1
         self.chunk = None
-        self.take(device)
+        if eager:
+            self.take(device)
 
     def take(self, device) -> torch.Tensor:
         if not self.elems:
@@ -1134,6 +1137,18 @@ def mse_fwd(a: torch.Tensor, b: torch.Tensor, tanh_target: bool = False) -> torc
     check(LIB.egz_mse_fwd(a.data_ptr(), b.data_ptr(), loss.data_ptr(), a.numel(), ws.data_ptr(), ws.numel(),
                           int(tanh_target), _stream()), "egz_mse_fwd")
     return loss
+
+
+def mse_fwd_grad(a: torch.Tensor, b: torch.Tensor, tanh_target: bool = False, ring: Optional[torch.Tensor] = None,
+                 counter: Optional[torch.Tensor] = None):
+    """(loss, d loss / d a) of nn.MSELoss in one launch (n <= 4096; the AT per-sample step).  ``ring`` / ``counter``: the loss is
+    also parked in ring[counter[0] % len(ring)] (counter: a device int32 tensor, e.g. FusedAdam.step_dev)."""
+    _req(a, "a"); _req(b, "b")
+    loss = torch.empty((), dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a)
+    check(LIB.egz_mse_fwd_grad(a.data_ptr(), b.data_ptr(), loss.data_ptr(), da.data_ptr(), a.numel(), int(tanh_target),
+                               _p(ring), 0 if ring is None else ring.numel(), _p(counter), _stream()), "egz_mse_fwd_grad")
+    return loss, da
 
 
 def mse_bwd(a, b, grad_out, tanh_target: bool = False) -> torch.Tensor:

@@ -245,6 +245,10 @@ int egz_floss_bwd(const float* inp, const float* target, const float* weights, c
 int egz_mse_fwd(const float* a, const float* b, float* loss_out, long n, void* workspace, size_t ws_bytes, int tanh_b,
                 hipStream_t stream);
 int egz_mse_bwd(const float* a, const float* b, const float* grad_out, float* da, long n, int tanh_b, hipStream_t stream);
+/* nn.MSELoss + its gradient for a unit seed in ONE single-block launch, n <= 4096 (AT.py:138-141 on one (1, 1, 512) sample);
+ * bit-identical to egz_mse_fwd + egz_mse_bwd(grad_out = 1).  ring (optional): the loss is also parked in ring[counter[0] % ring_n]. */
+int egz_mse_fwd_grad(const float* a, const float* b, float* loss_out, float* da, long n, int tanh_b, float* ring, int ring_n,
+                     const int* counter, hipStream_t stream);
 
 /* ---- AT: nn.LSTM(512,512,2) + nn.Linear + tanh (models/LSTMnet.py:18-37) from a strided f32-MFMA GEMM and fused
  *      cell kernels.  egz_gemm: C[M][N] (row stride ldc) = op(A) op(B) (+C if flags&1) (+bias[n]) (ReLU if flags&2),

@@ -259,3 +259,24 @@ def test_fused_adam_device_step_counter():
         assert opt.step_count == 6
         out[cap] = p.detach().cpu()
     assert rel(out[True].numpy(), out[False].numpy()) < 1e-6
+
+
+def test_mse_fwd_grad_matches_two_calls():
+    """egz_mse_fwd_grad (loss + its gradient for a unit seed in one single-block launch, the AT per-sample step) against egz_mse_fwd +
+    egz_mse_bwd(grad_out = 1): bit-identical; the loss is parked in ring[counter % len(ring)]."""
+    import egaze_amd.hipops as H
+    g = torch.Generator().manual_seed(4)
+    for n, tanh_t in ((512, True), (512, False), (37, True), (4096, False)):
+        a = torch.randn(n, generator=g).to(DEV)
+        b = torch.rand(n, generator=g).to(DEV)
+        one = torch.ones((), device=DEV)
+        l0, d0 = H.mse_fwd(a, b, tanh_t), H.mse_bwd(a, b, one, tanh_t)
+        ring = torch.full((8,), -1.0, device=DEV)
+        counter = torch.tensor([21, 0], dtype=torch.int32, device=DEV)
+        l1, d1 = H.mse_fwd_grad(a, b, tanh_t, ring, counter)
+        assert torch.equal(l0, l1) and torch.equal(d0, d1)
+        want = torch.full((8,), -1.0)
+        want[21 % 8] = l0.item()
+        assert torch.equal(ring.cpu(), want)
+        l2, d2 = H.mse_fwd_grad(a, b, tanh_t)
+        assert torch.equal(l0, l2) and torch.equal(d0, d2)
