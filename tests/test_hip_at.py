@@ -280,3 +280,37 @@ def test_mse_fwd_grad_matches_two_calls():
         assert torch.equal(ring.cpu(), want)
         l2, d2 = H.mse_fwd_grad(a, b, tanh_t)
         assert torch.equal(l0, l2) and torch.equal(d0, d2)
+
+
+@pytest.mark.parametrize("L,T,B", [(1, 1, 2), (1, 5, 20), (2, 2, 33), (3, 4, 7), (2, 16, 1)])
+def test_lstm_wavefront_vs_torch(L, T, B):
+    """egz_lstm_wave_fwd / _bwd (the stacked recurrence as a wavefront over (layer, step)) against torch's nn.LSTM on the CPU, fp64:
+    one to three layers, a single step, ragged batch tiles (B = 20, 33: rows past the batch in the last 16 / 32-row tile), gradients
+    flowing in through the outputs AND the returned state, out through the input and the initial state."""
+    from egaze_amd.models.LSTMnet import lstmnet
+    torch.manual_seed(L * 100 + T * 10 + B)
+    net = lstmnet(num_layer=L).to(DEV)
+    ref = torch.nn.LSTM(512, 512, L).double()
+    lin = torch.nn.Linear(512, 512).double()
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            p.copy_(getattr(net.lstm, name).detach().cpu().double())
+        lin.weight.copy_(net.lin.weight.detach().cpu().double())
+        lin.bias.copy_(net.lin.bias.detach().cpu().double())
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(T, B, 512, generator=g)
+    h0, c0 = torch.randn(L, B, 512, generator=g) * 0.3, torch.randn(L, B, 512, generator=g) * 0.3
+    wo, wh, wc = torch.randn(T, B, 512, generator=g), torch.randn(L, B, 512, generator=g), torch.randn(L, B, 512, generator=g)
+    xd, hd, cd = (t.to(DEV).requires_grad_(True) for t in (x, h0, c0))
+    out, (hn, cn) = net(xd, (hd, cd))
+    ((out * wo.to(DEV)).sum() + (hn * wh.to(DEV)).sum() + (cn * wc.to(DEV)).sum()).backward()
+    xr, hr, cr = (t.double().requires_grad_(True) for t in (x, h0, c0))
+    o, (rh, rc) = ref(torch.tanh(xr), (hr, cr))
+    ro = torch.relu(lin(o))
+    ((ro * wo.double()).sum() + (rh * wh.double()).sum() + (rc * wc.double()).sum()).backward()
+    assert rel(out.detach().cpu().numpy(), ro.detach().numpy()) < 2e-5
+    assert rel(hn.detach().cpu().numpy(), rh.detach().numpy()) < 2e-5 and rel(cn.detach().cpu().numpy(), rc.detach().numpy()) < 2e-5
+    assert rel(xd.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+    assert rel(hd.grad.cpu().numpy(), hr.grad.numpy()) < 1e-4 and rel(cd.grad.cpu().numpy(), cr.grad.numpy()) < 1e-4
+    for name, p in ref.named_parameters():
+        assert rel(getattr(net.lstm, name).grad.cpu().numpy(), p.grad.numpy()) < 2e-4, name
