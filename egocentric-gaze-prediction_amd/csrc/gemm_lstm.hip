@@ -89,44 +89,59 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 // the AT step against an 8 us exact-f32 MFMA floor, and the 17 GEMMs are half of the step's device time.  Here a slab is 64
 // deep, every thread moves four float4 per operand per slab, and nothing in the loop is predicated.  Same exact-f32 MFMA,
 // same k order within an accumulator: results are bit-identical to the generic kernel.
-constexpr int FK = 64, FLD = 68;                   // slab depth; LDS row pitch (16-byte aligned rows, 4-row skew of the banks)
-template <bool A_KFAST, bool B_NFAST>
-__global__ __launch_bounds__(256) void gemm_fast_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                        float* __restrict__ C, const float* __restrict__ bias, int M, int N,
-                                                        int K, long lda, long ldb, long ldc, int flags) {
-    __shared__ __attribute__((aligned(16))) float As[2][FK * FLD];   // [k][m]
-    __shared__ __attribute__((aligned(16))) float Bs[2][FK * FLD];   // [k][n]
+constexpr int FK = 64;                             // slab depth
+// WMW x WNW waves of 32 x 32: block tile (32 WMW) x (32 WNW), 64 WMW WNW threads.  2 x 2 = the 64 x 64 tile; 1 x 1 (one wave per
+// block) for products that would otherwise leave CUs empty (egz_gemm picks the tile).
+template <int WMW, int WNW, bool A_KFAST, bool B_NFAST>
+__global__ __launch_bounds__(64 * WMW * WNW) void gemm_fast_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                                  float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                                  int K, long lda, long ldb, long ldc, int flags) {
+    constexpr int TM = 32 * WMW, TN = 32 * WNW, NTHR = 64 * WMW * WNW;
+    constexpr int LDA_ = TM + 4, LDB_ = TN + 4;                // LDS row pitch (16-byte aligned rows, 4-row skew of the banks)
+    constexpr int NA = (TM * FK / 4) / NTHR, NB = (TN * FK / 4) / NTHR;       // float4 per thread per slab: 8 / WNW, 8 / WMW
+    __shared__ __attribute__((aligned(16))) float As[2][FK * LDA_];   // [k][m]
+    __shared__ __attribute__((aligned(16))) float Bs[2][FK * LDB_];   // [k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hl = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
-    // A_KFAST: A[m * lda + k] (row-major M x K): thread -> (m = e >> 4, k4 = e & 15), e = tid + 256 j: one float4 along k
-    // else     A[k * lda + m] (m contiguous):     thread -> (k = e >> 4, m4 = e & 15): one float4 along m
-    f32x4 ra[4], rb[4];
-    auto gload = [&](int k0) {
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    // A_KFAST: A[m * lda + k] (row-major M x K): thread -> (m = e >> 4, k4 = e & 15): one float4 along k (16 per row of 64 k)
+    // else     A[k * lda + m] (m contiguous):     thread -> (k = e / (TM / 4), m4 = e % (TM / 4)): one float4 along m
+    // TWO slabs in flight in registers (sets 0 / 1): a slab's MFMAs take 0.85 us, a fetch from L2 ~1.5 us -- with one slab in
+    // flight every one of the K / 64 iterations waited for its successor's fetch (15 - 21 us for products whose MFMA work is 7 us)
+    f32x4 ra[2][NA], rb[2][NB];
+    auto gload = [&](int k0, const int set) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = tid + 256 * j, hi = e >> 4, lo4 = (e & 15) * 4;
-            ra[j] = A_KFAST ? *reinterpret_cast<const f32x4*>(A + (long)(m0 + hi) * lda + k0 + lo4)
-                            : *reinterpret_cast<const f32x4*>(A + (long)(k0 + hi) * lda + m0 + lo4);
-            rb[j] = B_NFAST ? *reinterpret_cast<const f32x4*>(Bm + (long)(k0 + hi) * ldb + n0 + lo4)
-                            : *reinterpret_cast<const f32x4*>(Bm + (long)(n0 + hi) * ldb + k0 + lo4);
+        for (int j = 0; j < NA; ++j) {
+            const int e = tid + NTHR * j;
+            if (A_KFAST) ra[set][j] = *reinterpret_cast<const f32x4*>(A + (long)(m0 + (e >> 4)) * lda + k0 + (e & 15) * 4);
+            else         ra[set][j] = *reinterpret_cast<const f32x4*>(A + (long)(k0 + e / (TM / 4)) * lda + m0 + (e % (TM / 4)) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int e = tid + NTHR * j;
+            if (B_NFAST) rb[set][j] = *reinterpret_cast<const f32x4*>(Bm + (long)(k0 + e / (TN / 4)) * ldb + n0 + (e % (TN / 4)) * 4);
+            else         rb[set][j] = *reinterpret_cast<const f32x4*>(Bm + (long)(n0 + (e >> 4)) * ldb + k0 + (e & 15) * 4);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const int set) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = tid + 256 * j, hi = e >> 4, lo4 = (e & 15) * 4;
+        for (int j = 0; j < NA; ++j) {
+            const int e = tid + NTHR * j;
             if (A_KFAST) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) As[buf][(lo4 + q) * FLD + hi] = ra[j][q];
+                for (int q = 0; q < 4; ++q) As[buf][((e & 15) * 4 + q) * LDA_ + (e >> 4)] = ra[set][j][q];
             } else {
-                *reinterpret_cast<f32x4*>(&As[buf][hi * FLD + lo4]) = ra[j];
+                *reinterpret_cast<f32x4*>(&As[buf][(e / (TM / 4)) * LDA_ + (e % (TM / 4)) * 4]) = ra[set][j];
             }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int e = tid + NTHR * j;
             if (B_NFAST) {
-                *reinterpret_cast<f32x4*>(&Bs[buf][hi * FLD + lo4]) = rb[j];
+                *reinterpret_cast<f32x4*>(&Bs[buf][(e / (TN / 4)) * LDB_ + (e % (TN / 4)) * 4]) = rb[set][j];
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) Bs[buf][(lo4 + q) * FLD + hi] = rb[j][q];
+                for (int q = 0; q < 4; ++q) Bs[buf][((e & 15) * 4 + q) * LDB_ + (e >> 4)] = rb[set][j][q];
             }
         }
     };
@@ -134,19 +149,25 @@ __global__ __launch_bounds__(256) void gemm_fast_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int nk = K / FK;
-    gload(0);
-    lstore(0);
+    gload(0, 0);
+    if (nk > 1) gload(FK, 1);
+    lstore(0, 0);                                              // slab 0 -> LDS image 0; set 0 is free again
+    if (nk > 2) gload(2 * FK, 0);
     __syncthreads();
-    for (int s = 0; s < nk; ++s) {
+    auto slab = [&](const int s, const int set_next) {          // image s & 1 holds slab s; register set `set_next` holds slab s + 1
         const int buf = s & 1;
-        if (s + 1 < nk) gload((s + 1) * FK);
-        const float* Ab = As[buf] + hl * FLD + wm * 32 + l31;
-        const float* Bb = Bs[buf] + hl * FLD + wn * 32 + l31;
+        const float* Ab = As[buf] + hl * LDA_ + wm * 32 + l31;
+        const float* Bb = Bs[buf] + hl * LDB_ + wn * 32 + l31;
 #pragma unroll
         for (int t = 0; t < FK / 2; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[(2 * t) * FLD], Bb[(2 * t) * FLD], acc, 0, 0, 0);
-        if (s + 1 < nk) lstore(buf ^ 1);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[(2 * t) * LDA_], Bb[(2 * t) * LDB_], acc, 0, 0, 0);
+        if (s + 1 < nk) lstore(buf ^ 1, set_next);
+        if (s + 3 < nk) gload((s + 3) * FK, set_next);          // the set just stored is free: slab s + 3 (s + 2 is in the other set)
         __syncthreads();
+    };
+    for (int s = 0; s < nk; s += 2) {                           // (two slabs per trip: the register sets keep compile-time names)
+        slab(s, 1);
+        if (s + 1 < nk) slab(s + 1, 0);
     }
     const int n = n0 + wn * 32 + l31;
     const float bz = bias ? bias[n] : 0.f;
@@ -233,15 +254,26 @@ EGZ_API int egz_gemm(const float* A, const float* B, float* C, const float* bias
                      long sbk, long sbn, long ldc, int flags, hipStream_t st) {
     EGZ_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "egz_gemm: bad arguments");
     dim3 grid(egz_cdiv(N, GN), egz_cdiv(M, GM));
-    // fast path: whole 64 x 64 x 64 tiles, one unit stride per operand, float4-aligned rows (the AT step's products all qualify)
+    // fast path: whole 64-deep slabs of whole tiles, one unit stride per operand, float4-aligned rows (the AT step's products all qualify)
     const bool a_k = (sak == 1), a_m = (sam == 1), b_n = (sbn == 1), b_k = (sbk == 1);
     const long lda = a_k ? sam : sak, ldb = b_n ? sbk : sbn;
     if (M % GM == 0 && N % GN == 0 && K % FK == 0 && (a_k || a_m) && (b_n || b_k) && lda % 4 == 0 && ldb % 4 == 0 &&
         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0) {
-        if (a_k && b_n)       hipLaunchKernelGGL((gemm_fast_kernel<true, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
-        else if (a_k)         hipLaunchKernelGGL((gemm_fast_kernel<true, false>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
-        else if (b_n)         hipLaunchKernelGGL((gemm_fast_kernel<false, true>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
-        else                  hipLaunchKernelGGL((gemm_fast_kernel<false, false>), grid, dim3(256), 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);
+        // tile: 64 x 64 when that fills the chip, else 32 x 32 (a 512 x 512 output is 64 tiles of 64 x 64 on 256 CUs: 18.1 -> 15.1 us;
+        // smaller tiles on products that already give every CU a block are SLOWER -- 19.7 -> 24.9 us at 512 x 2048 -- their weight
+        // of fetches per MFMA doubles; profiles/r04_ab_notes.txt)
+        const long t64 = (long)(M / 64) * (N / 64);
+        const int tile = t64 >= 256 ? 0 : 2;
+#define EGZ_GF(WMW, WNW)                                                                                                        \
+        do {                                                                                                                   \
+            const dim3 g(N / (32 * WNW), M / (32 * WMW)), b(64 * WMW * WNW);                                                   \
+            if (a_k && b_n)  hipLaunchKernelGGL((gemm_fast_kernel<WMW, WNW, true, true>), g, b, 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);   \
+            else if (a_k)    hipLaunchKernelGGL((gemm_fast_kernel<WMW, WNW, true, false>), g, b, 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);  \
+            else if (b_n)    hipLaunchKernelGGL((gemm_fast_kernel<WMW, WNW, false, true>), g, b, 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags);  \
+            else             hipLaunchKernelGGL((gemm_fast_kernel<WMW, WNW, false, false>), g, b, 0, st, A, B, C, bias, M, N, K, lda, ldb, ldc, flags); \
+        } while (0)
+        if (tile == 0) EGZ_GF(2, 2); else EGZ_GF(1, 1);
+#undef EGZ_GF
         EGZ_CHECK_LAUNCH("egz_gemm(fast)");
         return 0;
     }
