@@ -44,7 +44,8 @@ struct WaveFwdLayer {
     const float* w_hh;     // [4H][H]
     const float* h0;       // [B][H]
     const float* c0;
-    float* hs;             // [T][B][H]
+    float* hs;             // [T][B][H]; the [B][H] slot in FRONT of it receives a copy of h0 (h_{t-1} of every step is then one
+                           // contiguous [T][B][H] block: d W_hh is ONE batched product)
     float* cs;
     float* acts;           // [T][B][4H] or null
     float* hn;             // [B][H]: the returned final state (written by step T - 1)
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int
             p.hn[o] = hv_;
             p.cn[o] = c;
         }
+        if (t == 0) p.hs[o - bh] = h_prev[o];                  // slot -1 = h0
         if (p.acts) {
             float* aa = p.acts + ((long)t * B + b) * 4 * H + j0 + u;
             aa[0] = gi; aa[H] = gf; aa[2 * H] = gg; aa[3 * H] = go;
@@ -224,7 +226,9 @@ __global__ __launch_bounds__(512) void lstm_wave_bwd_kernel(const WaveBwd a, int
 // The stacked recurrence of nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step): T + L - 1 launches (see
 // lstm_wave_fwd_kernel).  Host arrays of L device pointers: w_ih[l] / bsum[l] ([4H][H] / [4H] = b_ih + b_hh; entry 0 unused:
 // layer 0's input projection arrives as gx0 [T][B][4H], bias included), w_hh[l] [4H][H]; h0, c0: [L][B][H];
-// hs, cs: [L][T][B][H] out; acts: [L][T][B][4H] out or null; hn, cn: [L][B][H] out (the final state).  1 <= L <= 4, H % 256 == 0.
+// hs: [L][T + 1][B][H] out -- slot 0 of a layer = a copy of its h0, slots 1 .. T = h_1 .. h_T (so h_{t-1} for t = 1 .. T is the
+// contiguous block of slots 0 .. T - 1); cs: [L][T][B][H] out; acts: [L][T][B][4H] out or null; hn, cn: [L][B][H] out (the final
+// state).  1 <= L <= 4, H % 256 == 0.
 EGZ_API int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
                               const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L,
                               int T, int B, int H, hipStream_t st) {
@@ -236,7 +240,7 @@ EGZ_API int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const 
     for (int l = 0; l < L; ++l) {
         EGZ_CHECK_ARG(w_hh[l] && (l == 0 || (w_ih[l] && bsum[l])), "egz_lstm_wave_fwd: null weight pointer (layer %d)", l);
         a.l[l] = WaveFwdLayer{l ? nullptr : gx0, l ? bsum[l] : nullptr, l ? w_ih[l] : nullptr, w_hh[l], h0 + l * bh, c0 + l * bh,
-                              hs + (long)l * T * bh, cs + (long)l * T * bh, acts ? acts + (long)l * T * 4 * bh : nullptr,
+                              hs + ((long)l * (T + 1) + 1) * bh, cs + (long)l * T * bh, acts ? acts + (long)l * T * 4 * bh : nullptr,
                               hn + l * bh, cn + l * bh};
     }
     for (int s = 0; s < T + L - 1; ++s) {

@@ -1231,7 +1231,8 @@ def copy_into(dst: torch.Tensor, src: torch.Tensor):
 def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
     """The stacked recurrence as a wavefront over (layer, step) (egz_lstm_wave_fwd): gx0 (T,B,4H) = layer 0's input projection
     of every step (bias included); w_ih / w_hh / bsum: lists of L tensors (w_ih[0] / bsum[0] unused); h0, c0 (L,B,H)
-    -> hs, cs (L,T,B,H), acts (L,T,B,4H) | None, hn, cn (L,B,H)."""
+    -> hs_ext (L,T+1,B,H) [slot 0 of a layer = its h0, slots 1..T = the outputs], cs (L,T,B,H), acts (L,T,B,4H) | None,
+    hn, cn (L,B,H)."""
     _req(gx0, "gx0"); _req(h0, "h0"); _req(c0, "c0")
     L = len(w_hh)
     T, B, H4 = gx0.shape
@@ -1243,8 +1244,8 @@ def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
             if tuple(w_ih[l].shape) != (H4, Hd):
                 raise RuntimeError("lstm_wave_fwd: the upper layers take the hidden size as their input size")
     dev = gx0.device
-    hs = torch.empty((L, T, B, Hd), dtype=torch.float32, device=dev)
-    cs = torch.empty_like(hs)
+    hs = torch.empty((L, T + 1, B, Hd), dtype=torch.float32, device=dev)
+    cs = torch.empty((L, T, B, Hd), dtype=torch.float32, device=dev)
     acts = torch.empty((L, T, B, H4), dtype=torch.float32, device=dev) if want_acts else None
     hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
     cn = torch.empty_like(hn)

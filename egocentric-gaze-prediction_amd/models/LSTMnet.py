@@ -41,9 +41,10 @@ class _LSTMNetFn(torch.autograd.Function):
         w_hh = [H._req(params[4 * l + 1].detach(), "w_hh") for l in range(L)]
         bsum = [H.add(params[4 * l + 2].detach(), params[4 * l + 3].detach()) for l in range(L)]
         gx0 = H.linear_fwd(x.view(T * B, C), w_ih[0], bias=bsum[0]).view(T, B, 4 * Hd)      # all time steps at once
+        # hs: (L, T + 1, B, H) -- slot 0 of a layer holds its h0, slots 1 .. T the outputs
         hs, cs, acts, hn, cn = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0c, c0c, want_acts=train)
         lin_w, lin_b = params[-2].detach(), params[-1].detach()
-        out2d = H.linear_fwd(hs[L - 1].view(T * B, Hd), lin_w, bias=lin_b, relu=True)
+        out2d = H.linear_fwd(hs[L - 1, 1:].view(T * B, Hd), lin_w, bias=lin_b, relu=True)
         # the node keeps the 2-D base and hands out a VIEW: the returned tensor (whose grad_fn is this node) must not be
         # stored on the node itself -- that reference cycle runs through C++ and is never collected, leaking the
         # saved T*B*4H activations of every step and keeping the step's AccumulateGrad nodes alive into the next one
@@ -71,7 +72,7 @@ class _LSTMNetFn(torch.autograd.Function):
             dpre = H.relu_bwd(out.view(T * B, -1), H._req(dout.contiguous().view(T * B, -1), "grad"))
         grads = [None] * len(params)
         sinks = [H.grad_sink(p, ng[3 + i]) for i, p in enumerate(params)]
-        h_top = hs[L - 1].view(T * B, Hd)
+        h_top = hs[L - 1, 1:].view(T * B, Hd)
         if ng[3 + len(params) - 2]:
             grads[-2] = H.matmul_tn(dpre, h_top, out=sinks[-2])                  # d lin.weight = dpre^T h
         if ng[3 + len(params) - 1]:
@@ -82,15 +83,12 @@ class _LSTMNetFn(torch.autograd.Function):
         dgates, dh0, dc0 = H.lstm_wave_bwd(dh_top, dhn.contiguous() if dhn is not None else None,
                                            dcn.contiguous() if dcn is not None else None, acts, cs, c0c, w_hh_t, w_ih_t)
         for l in range(L):
-            layer_in = x.view(T * B, C) if l == 0 else hs[l - 1].view(T * B, Hd)
+            layer_in = x.view(T * B, C) if l == 0 else hs[l - 1, 1:].view(T * B, Hd)
             dg2 = dgates[l].view(T * B, 4 * Hd)
             if ng[3 + 4 * l]:
                 grads[4 * l] = H.matmul_tn(dg2, layer_in, out=sinks[4 * l])                     # d W_ih
-            if ng[3 + 4 * l + 1]:       # d W_hh = sum_t dgates_t^T h_{t-1}: the t = 0 term sees h0, the rest hs[:-1]
-                g = H.matmul_tn(dgates[l, 0], h0c[l], out=sinks[4 * l + 1])
-                if T > 1:
-                    H.matmul_tn(dgates[l, 1:].view((T - 1) * B, 4 * Hd), hs[l, :-1].view((T - 1) * B, Hd), out=g, accumulate=True)
-                grads[4 * l + 1] = g
+            if ng[3 + 4 * l + 1]:       # d W_hh = sum_t dgates_t^T h_{t-1}: slots 0 .. T - 1 of hs are (h0, h_1 .. h_{T-1}), one product
+                grads[4 * l + 1] = H.matmul_tn(dg2, hs[l, :T].view(T * B, Hd), out=sinks[4 * l + 1])
             if ng[3 + 4 * l + 2]:
                 grads[4 * l + 2] = H.colsum(dg2, out=sinks[4 * l + 2])
             if ng[3 + 4 * l + 3]:

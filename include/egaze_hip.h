@@ -263,7 +263,8 @@ int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, con
  * s runs step s - l of every layer l, T + L - 1 dependent launches instead of T x L, the upper layers' input projections reduced
  * in the same launch (K = 2H).  w_ih / w_hh / bsum: HOST arrays of L device pointers ([4H][H], [4H][H], [4H] = b_ih + b_hh;
  * w_ih[0] / bsum[0] unused: gx0 [T][B][4H] = x W_ih0^T + b_ih0 + b_hh0 for every step); h0, c0, hn, cn: [L][B][H];
- * hs, cs: [L][T][B][H]; acts: [L][T][B][4H] or null.  1 <= L <= 4, H % 256 == 0. */
+ * hs: [L][T + 1][B][H] (slot 0 of a layer = a copy of its h0, slots 1 .. T = the outputs); cs: [L][T][B][H]; acts: [L][T][B][4H]
+ * or null.  1 <= L <= 4, H % 256 == 0. */
 int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
                       const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L, int T,
                       int B, int H, hipStream_t stream);
