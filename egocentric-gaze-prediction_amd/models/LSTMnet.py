@@ -89,10 +89,16 @@ class _LSTMNetFn(torch.autograd.Function):
                 grads[4 * l] = H.matmul_tn(dg2, layer_in, out=sinks[4 * l])                     # d W_ih
             if ng[3 + 4 * l + 1]:       # d W_hh = sum_t dgates_t^T h_{t-1}: slots 0 .. T - 1 of hs are (h0, h_1 .. h_{T-1}), one product
                 grads[4 * l + 1] = H.matmul_tn(dg2, hs[l, :T].view(T * B, Hd), out=sinks[4 * l + 1])
-            if ng[3 + 4 * l + 2]:
-                grads[4 * l + 2] = H.colsum(dg2, out=sinks[4 * l + 2])
-            if ng[3 + 4 * l + 3]:
-                grads[4 * l + 3] = H.colsum(dg2, out=sinks[4 * l + 3])
+            # d b_ih = d b_hh = the column sums of dgates: summed once, the second one is a copy of the first
+            gb = None
+            for i in (4 * l + 2, 4 * l + 3):
+                if not ng[3 + i]:
+                    continue
+                if gb is None:
+                    gb = grads[i] = H.colsum(dg2, out=sinks[i])
+                else:
+                    grads[i] = H._out(sinks[i], tuple(gb.shape), gb.device)
+                    H.copy_into(grads[i], gb)
         dinp = None
         if ng[0]:
             dh_in = H.matmul_nn(dgates[0].view(T * B, 4 * Hd), params[0].detach())        # into the tanh'd input
