@@ -78,11 +78,14 @@ def align_window_weights(gp, size, cells=14, scale=16):
 def crop_align_mean(feature, maxind, size):
     """chn_weight of the ``--align`` path: spatial mean of crop_align_feature(feature, maxind, size) (AT.py:41-56 + :229).
     On the GPU it is one small kernel on the 14 x 14 map (no x16 upsampled tensor, no tensor-library interpolation)."""
-    if feature.is_cuda and feature.size(2) == feature.size(3):
+    if feature.is_cuda:
+        if feature.size(2) != feature.size(3):
+            raise NotImplementedError("crop_align_mean on the device is built for square feature maps (the reference's 14 x 14)")
         from . import hipops as H
         from .functions import to_nhwc
         wm = np.stack([align_window_weights(list(map(int, m)), size, feature.size(2)) for m in maxind])
         return H.pixel_weighted_sum(to_nhwc(feature), wm)
+    # host tensors: the reference's own formulation (what the device kernel is checked against, tests/test_hip_metrics.py)
     c = crop_align_feature(feature, maxind, size).contiguous()
     return c.view(c.size(0), c.size(1), -1).mean(2)
 
@@ -96,6 +99,7 @@ def crop_mean_weight(feature, maxind, size):
         if isinstance(maxind, torch.Tensor) and maxind.is_cuda:         # gaze points already on the device: no host round trip
             return H.crop_mean(to_nhwc(feature), maxind, size, 16)
         return H.crop_mean(to_nhwc(feature), [list(map(int, m)) for m in maxind], size, 16)
+    # host tensors: the reference's own formulation (the device kernel's comparison baseline, tests/test_hip_metrics.py)
     c = crop_feature(feature, maxind, size).contiguous()
     return c.view(c.size(0), c.size(1), -1).mean(2)
 
@@ -107,6 +111,7 @@ def get_weighted_batch(chn_weights, feature):
         from . import hipops as H
         from .functions import to_nhwc
         return H.weighted_minmax(to_nhwc(feature), chn_weights.reshape(feature.size(0), -1).contiguous().float())
+    # host tensors: AT.py:58-66 per frame (the device kernel's comparison baseline, tests/test_hip_metrics.py)
     f = torch.sum(feature * chn_weights.view(feature.size(0), -1, 1, 1), 1)
     f = f - f.flatten(1).min(1)[0].view(-1, 1, 1)
     return f / f.flatten(1).max(1)[0].view(-1, 1, 1)
@@ -114,10 +119,13 @@ def get_weighted_batch(chn_weights, feature):
 
 def get_weighted(chn_weight, feature):
     """Channel-weighted sum of the (1,512,14,14) map, min-max normalised (AT.py:58-66)."""
-    if feature.is_cuda and feature.size(0) == 1:
+    if feature.is_cuda:
+        if feature.size(0) != 1:
+            raise NotImplementedError("get_weighted takes one frame, like its call sites (AT.py:246); use get_weighted_batch")
         from . import hipops as H
         from .functions import to_nhwc
         return H.weighted_minmax(to_nhwc(feature), chn_weight.reshape(1, -1).contiguous().float())
+    # host tensors: the reference's own lines (the device kernel's comparison baseline, tests/test_hip_metrics.py)
     feature = torch.sum(feature * chn_weight.view(1, 512, 1, 1), 1)
     feature = feature - torch.min(feature)
     return feature / torch.max(feature)
@@ -188,8 +196,7 @@ class _GraphedSampleStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             count = self.opt.step_count
-            with torch.cuda.graph(g):
-                H.ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()), eager=False)
+            with H.capture(g, eager_arena=False):
                 self._unit()
             self.opt.step_count = count        # the capture ran the host side of step() without executing anything
             self.graph = g
@@ -257,6 +264,12 @@ class AT():
             nonlocal pending, first
             if pending:
                 vals = ring.cpu().tolist()                      # one synchronising read-back for `pending` samples
+                # the slots are addressed by the DEVICE step counter (egz_mse_fwd_grad parks a loss in ring[counter % len]):
+                # an eager optimizer step, a load_state_dict or a skipped replay between two drains would shift them
+                # silently -- the counter is read back with the ring and must be where the host thinks it is
+                done = int(self.optimizer_lstm.step_dev[0].item())
+                if done != first + pending:
+                    raise RuntimeError(f"AT loss ring out of step: device counter {done}, host expected {first + pending}")
                 for i in range(pending):                        # slot of a step = optimizer steps completed before it
                     losses.update(vals[(first + i) % len(vals)])
                 first += pending

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4(ra[j] * a_scale, hi, lo);
+            Half<T>::split4s(ra[j], a_scale, hi, lo);
             *reinterpret_cast<u32x2*>(Ah + a_lds[j]) = hi;
             *reinterpret_cast<u32x2*>(Ah + APL + a_lds[j]) = lo;
         }

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
         for (int j = 0; j < NJ / 2; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4(ra[half * RAOFF + j] * a_scale, hi, lo);
+            Half<T>::split4s(ra[half * RAOFF + j], a_scale, hi, lo);
             unsigned short* d = Ah + abuf * ABUF + lds_slot(half * (NJ / 2) + j);
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
         for (int j = 0; j < NJ / 2; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4(rp[j] * a_scale, hi, lo);
+            Half<T>::split4s(rp[j], a_scale, hi, lo);
             unsigned short* d = Ah + lds_slot(NJ / 2 + j);
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                         } else if (ls && i >= MR && i - MR < NH) {
                             const int j = i - MR;
                             u32x2 hi, lo;
-                            Half<T>::split4(ra[lhalf * RAOFF + j] * a_scale, hi, lo);
+                            Half<T>::split4s(ra[lhalf * RAOFF + j], a_scale, hi, lo);
                             unsigned short* d = Ah + (abuf ^ 1) * ABUF + lds_slot(lhalf * NH + j);
                             *reinterpret_cast<u32x2*>(d) = hi;
                             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
                 for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf(__builtin_fmaf(ra[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
                 Half<T>::split4(ra[j], hi, lo);
             } else {
-                Half<T>::split4(ra[j] * a_scale, hi, lo);
+                Half<T>::split4s(ra[j], a_scale, hi, lo);
             }
             unsigned short* d = Ah + abuf * ABUF + a_lds[j];
             *reinterpret_cast<u32x2*>(d) = hi;
@@ -971,7 +971,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf(__builtin_fmaf(ra[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
             Half<T>::split4(ra[j], hi, lo);
         } else {
-            Half<T>::split4(ra[j] * a_scale, hi, lo);
+            Half<T>::split4s(ra[j], a_scale, hi, lo);
         }
         unsigned short* d = Ah + abuf * ABUF + a_lds[j];
         *reinterpret_cast<u32x2*>(d) = hi;

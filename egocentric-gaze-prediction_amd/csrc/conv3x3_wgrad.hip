@@ -292,6 +292,7 @@ template <typename T> struct W16;
 template <> struct W16<__bf16> {
     typedef bf16x8_t vec8;
     static __device__ __forceinline__ void split4(const f32x4 v, u32x2_t& hi, u32x2_t& lo) { bf16_split4(v, hi, lo); }
+    static __device__ __forceinline__ void split4s(const f32x4 v, const float s, u32x2_t& hi, u32x2_t& lo) { bf16_split4(v * s, hi, lo); }
     static __device__ __forceinline__ vec8 frag(const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) {
         const bf16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p0);
         const bf16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((EGZ_LDS bf16x4_t*)p1);
@@ -303,6 +304,15 @@ template <> struct W16<__bf16> {
 template <> struct W16<_Float16> {
     typedef f16x8_t vec8;
     static __device__ __forceinline__ void split4(const f32x4 v, u32x2_t& hi, u32x2_t& lo) { f16_split4(v, hi, lo); }
+    static __device__ __forceinline__ void split4s(const f32x4 v, const float s, u32x2_t& hi, u32x2_t& lo) {
+#ifdef EGZ_TIMING_NOSPLIT
+        const u32x4_t b = __builtin_bit_cast(u32x4_t, v);      // timing-only variant, see x3_split.h
+        hi = u32x2_t{b[0] & 0x7bff7bffu, b[1] & 0x7bff7bffu};
+        lo = u32x2_t{b[2] & 0x7bff7bffu, b[3] & 0x7bff7bffu};
+#else
+        f16_split4(v * s, hi, lo);
+#endif
+    }
     static __device__ __forceinline__ vec8 frag(const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) { return tr_frag(p0, p1); }
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float scale(const unsigned int* am) { return absmax_scale(am); }
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4(rx[j] * x_scale, hi, lo);
+                W16<T>::split4s(rx[j], x_scale, hi, lo);
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const int i = tid + 256 * j;
             const int pp = i >> 4, k4 = i & 15;
             u32x2_t hi, lo;
-            W16<T>::split4(rd[j] * d_scale, hi, lo);
+            W16<T>::split4s(rd[j], d_scale, hi, lo);
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
             *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
@@ -681,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
                     for (int e = 0; e < 4; ++e) rx[j][e] = fmaxf(__builtin_fmaf(rx[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
                     W16<T>::split4(rx[j], hi, lo);
                 } else {
-                    W16<T>::split4(rx[j] * x_scale, hi, lo);
+                    W16<T>::split4s(rx[j], x_scale, hi, lo);
                 }
                 unsigned short* d = Xs + buf * XB + pos * 32 + c4 * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
@@ -692,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
         for (int j = 0; j < ND; ++j) {
             const int i = tid + 256 * j, pp = i >> 3, k4 = i & 7;
             u32x2_t hi, lo;
-            W16<T>::split4(rd[j] * d_scale, hi, lo);
+            W16<T>::split4s(rd[j], d_scale, hi, lo);
             unsigned short* d = Ds + buf * DB + pp * 32 + k4 * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
             *reinterpret_cast<u32x2_t*>(d + DH) = lo;
@@ -871,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3t_kernel(
                 for (int e = 0; e < 4; ++e) rx[j][e] = fmaxf(__builtin_fmaf(rx[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
                 W16<T>::split4(rx[j], hi, lo);
             } else {
-                W16<T>::split4(rx[j] * x_scale, hi, lo);
+                W16<T>::split4s(rx[j], x_scale, hi, lo);
             }
             unsigned short* d = Xs + buf * XB + pp * 32 + c4 * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
@@ -882,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3t_kernel(
             const int i = tid + 256 * j, pos = i >> 1, k4 = i & 1;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4(rd[j] * d_scale, hi, lo);
+                W16<T>::split4s(rd[j], d_scale, hi, lo);
                 unsigned short* d = Ds + buf * DB + pos * 8 + k4 * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + DH) = lo;
@@ -1058,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4(rx_[j] * x_scale, hi, lo);
+                W16<T>::split4s(rx_[j], x_scale, hi, lo);
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
@@ -1069,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int i = tid + 256 * j;
             const int slot = i >> 4, k4 = i & 15;
             u32x2_t hi, lo;
-            W16<T>::split4(rd[j] * d_scale, hi, lo);
+            W16<T>::split4s(rd[j], d_scale, hi, lo);
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + slot * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
             *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
@@ -1626,7 +1636,9 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
             if (x_bn) hipLaunchKernelGGL((conv3x3_wgrad9_x3t_kernel<TT, RR, WW, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
             else      hipLaunchKernelGGL((conv3x3_wgrad9_x3t_kernel<TT, RR, WW, false>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr, x_bn); \
         } while (0)
-        if (K <= 8 && !(flags & 0x4000)) {       // few filters: (tap, k) pairs as GEMM columns (0x4000 keeps the nine-tile form: A/B runs)
+        // few filters: (tap, k) pairs as GEMM columns (0x4000 keeps the nine-tile form: A/B runs).  The kernel fetches dy as one float4
+        // per k-quad at a pixel stride of 4 K bytes: K is 4 or 8 here (K % 4 == 0 is an argument check above)
+        if ((K == 4 || K == 8) && !(flags & 0x4000)) {
             if (dy_absmax) { if (WD == 32) EGZ_W9T(_Float16, 2, 32); else EGZ_W9T(_Float16, 4, 16); }
             else           { if (WD == 32) EGZ_W9T(__bf16, 2, 32); else EGZ_W9T(__bf16, 4, 16); }
         } else

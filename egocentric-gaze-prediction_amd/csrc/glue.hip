@@ -167,12 +167,28 @@ __global__ __launch_bounds__(256) void cat2_planes_kernel(const f32x4* __restric
         out[(2 * b + 1) * hw4 + r] = g[i];
     }
 }
+// (planes whose size is not a multiple of 4 floats, or operands that are not 16-byte aligned: one float per thread item)
+__global__ __launch_bounds__(256) void cat2_planes_scalar_kernel(const float* __restrict__ f, const float* __restrict__ g,
+                                                                 float* __restrict__ out, long hw, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / hw, r = i - b * hw;
+        out[2 * b * hw + r] = f[i];
+        out[(2 * b + 1) * hw + r] = g[i];
+    }
+}
 }  // namespace
 
-// f, g: [B][1][H][W] (HW % 4 == 0, 16-byte aligned) -> out [B][2][H][W]: the late-fusion stack's input (late_fusion.py:19)
+// f, g: [B][1][H][W] -> out [B][2][H][W]: the late-fusion stack's input (late_fusion.py:19).  16-byte copies when HW % 4 == 0
+// and all three pointers are 16-byte aligned, 4-byte copies otherwise.
 EGZ_API int egz_cat2_planes(const float* f, const float* g, float* out, int B, long HW, hipStream_t st) {
-    EGZ_CHECK_ARG(f && g && out && B > 0 && HW > 0 && HW % 4 == 0, "egz_cat2_planes: bad arguments (HW must be a multiple of 4)");
-    EGZ_CHECK_ARG(((uintptr_t)f | (uintptr_t)g | (uintptr_t)out) % 16 == 0, "egz_cat2_planes: pointers must be 16-byte aligned");
+    EGZ_CHECK_ARG(f && g && out && B > 0 && HW > 0, "egz_cat2_planes: bad arguments");
+    if (HW % 4 != 0 || ((uintptr_t)f | (uintptr_t)g | (uintptr_t)out) % 16 != 0) {
+        const long n = (long)B * HW;
+        const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+        hipLaunchKernelGGL(cat2_planes_scalar_kernel, dim3(grid), dim3(256), 0, st, f, g, out, HW, n);
+        EGZ_CHECK_LAUNCH("egz_cat2_planes");
+        return 0;
+    }
     const long n4 = (long)B * HW / 4;
     const int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
     hipLaunchKernelGGL(cat2_planes_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(f),

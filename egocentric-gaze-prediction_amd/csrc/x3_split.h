@@ -37,6 +37,17 @@ template <> struct Half<_Float16> {
             lo[e] = __builtin_bit_cast(unsigned, l);
         }
     }
+    // split4 of v * scale.  (EGZ_TIMING_NOSPLIT: a timing-only build variant for the pre-split-activation go / no-go -- the
+    // operand is taken as if it already held [4 hi halves | 4 lo halves]; garbage numerics, two bit-ops per quad.)
+    static __device__ __forceinline__ void split4s(const f32x4 v, const float scale, u32x2& hi, u32x2& lo) {
+#ifdef EGZ_TIMING_NOSPLIT
+        const u32x4 b = __builtin_bit_cast(u32x4, v);
+        hi = u32x2{b[0] & 0x7bff7bffu, b[1] & 0x7bff7bffu};
+        lo = u32x2{b[2] & 0x7bff7bffu, b[3] & 0x7bff7bffu};
+#else
+        split4(v * scale, hi, lo);
+#endif
+    }
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
@@ -59,6 +70,7 @@ template <> struct Half<__bf16> {
             lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(x - hf, bf16x2));
         }
     }
+    static __device__ __forceinline__ void split4s(const f32x4 v, const float scale, u32x2& hi, u32x2& lo) { split4(v * scale, hi, lo); }
     static __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }

@@ -23,6 +23,9 @@ import torch
 import torch.distributed as dist
 
 
+_MODE = os.environ.get("EGAZE_DP_MODE", "default")      # experiment switch of round 5 (tools/dp_world1.py); resolved below
+
+
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, params: Sequence[torch.nn.Parameter], offsets: Sequence[int],
                  bucket_bytes: int = 25 * 1024 * 1024, group=None, flat_param: Optional[torch.Tensor] = None,
@@ -104,8 +107,14 @@ class GradReducer:
                 if sid != comm.cuda_stream:
                     comm.wait_stream(st)
             with torch.cuda.stream(comm):
-                self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
-                                                     async_op=True))
+                if _MODE == "skip":
+                    pass
+                elif _MODE == "sync":
+                    dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+                    self._sync_comm = comm
+                else:
+                    self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
+                                                         async_op=True))
                 if self.record_events:
                     # the library runs the collective on its own stream, ordered after `comm`; the handle's wait() orders a
                     # stream after the collective -- make `comm` wait and mark that point
@@ -148,8 +157,15 @@ class GradReducer:
                     self._launch(b)
         finally:
             self._in_wait = False
-        for h in self._handles:
-            h.wait()
+        if _MODE == "lastwait":
+            if self._handles:
+                self._handles[-1].wait()
+        else:
+            for h in self._handles:
+                h.wait()
+        if getattr(self, "_sync_comm", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._sync_comm)
+            self._sync_comm = None
         self.stats["steps"] += 1
         self._reset()
 

@@ -454,6 +454,21 @@ class FlossLoss(torch.autograd.Function):
         return H.floss_bwd(x, t, weights if ctx.weighted else None, g), None, None
 
 
+class Cat2Planes(torch.autograd.Function):
+    """``torch.cat((f, g), 1)`` of two (B, 1, H, W) maps as one kernel (models/late_fusion.py:19).  The gradient of a
+    concatenation is its two halves: views of the incoming gradient, no kernel."""
+
+    @staticmethod
+    def forward(ctx, f, g):
+        if f.dim() != 4 or f.shape != g.shape or f.shape[1] != 1:
+            raise RuntimeError(f"late_fusion: two (B, 1, H, W) maps expected, got {tuple(f.shape)} and {tuple(g.shape)}")
+        return H.cat2_planes(f.detach().contiguous(), g.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout[:, 0:1], dout[:, 1:2]
+
+
 class MSELoss(torch.autograd.Function):
     """nn.MSELoss (AT.py:83).  ``tanh_target``: the loss against tanh(target) -- the reference's
     ``criterion(pred, tanh(target))`` (AT.py:138) without a separate tanh pass over the target."""

@@ -43,8 +43,7 @@ class GraphedModule:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            H.ABSMAX_ARENA.capture_begin(self.static_in[0].device)
+        with torch.no_grad(), H.capture(self.graph):
             self.static_out = self.module(*self.static_in)
         self.epoch = self._signature()
 
@@ -99,8 +98,7 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             count = self.opt.step_count
-            with torch.cuda.graph(g):
-                H.ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()))
+            with H.capture(g):
                 self._unit()
             self.opt.step_count = count          # the capture ran the host side of step() without executing anything
             self.graph = g

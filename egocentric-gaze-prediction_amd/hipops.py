@@ -278,6 +278,7 @@ BATCH_REPACK = True       # FusedAdam.step() rebuilds the stale fragment-ordered
 #                           (False: each packing is rebuilt lazily in front of the first launch that needs it;
 #                           test_pack_frag_batch_matches_per_layer flips it)
 _BATCH_TABLES = {}
+_BATCH_PINNED = set()          # tables whose launch was captured into a hipGraph: never evicted
 
 
 def refresh_packings(params, force: bool = False) -> int:
@@ -302,19 +303,31 @@ def refresh_packings(params, force: bool = False) -> int:
         return 0
     sig = tuple((key, w.data_ptr(), buf.data_ptr()) for key, w, buf in todo)
     ent = _BATCH_TABLES.get(sig)
-    if ent is None:
-        if torch.cuda.is_current_stream_capturing():
-            return 0                      # the table is built by an eager step (GraphedTrainStep's warm-up); lazy rebuilds until then
-        rows, nb = [], 0
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None and capturing:
+        # No table for THIS set inside a hipGraph capture (the warm-up step before the capture touched another set: an eval
+        # pass in between, a table eviction): building one needs a host -> device copy, which a capture cannot hold.  The
+        # per-key pack launches need no table and are capturable -- the captured step then repacks exactly this set on every
+        # replay (returning 0 here left every replay after the first on stale packed weights).
         for key, w, buf in todo:
-            K, C = w.shape[0], w.shape[1]
-            rows.append([w.data_ptr(), buf.data_ptr(), C, K, _PACK_FN[key[1]][2], key[2], nb, 0])
-            nb += LIB.egz_pack_w3x3_frag_blocks(C, K)
-        if len(_BATCH_TABLES) > 64:
-            _BATCH_TABLES.clear()
-        ent = (torch.tensor(rows, dtype=torch.int64).to(todo[0][1].device), nb)
-        _BATCH_TABLES[sig] = ent
-    check(LIB.egz_pack_w3x3_frag_batch(ent[0].data_ptr(), len(todo), ent[1], _stream()), "egz_pack_w3x3_frag_batch")
+            check(LIB.egz_pack_w3x3_split_frag(w.data_ptr(), buf.data_ptr(), w.shape[1], w.shape[0], _PACK_FN[key[1]][2], key[2],
+                                               _stream()), "egz_pack_w3x3_split_frag")
+    else:
+        if ent is None:
+            rows, nb = [], 0
+            for key, w, buf in todo:
+                K, C = w.shape[0], w.shape[1]
+                rows.append([w.data_ptr(), buf.data_ptr(), C, K, _PACK_FN[key[1]][2], key[2], nb, 0])
+                nb += LIB.egz_pack_w3x3_frag_blocks(C, K)
+            if len(_BATCH_TABLES) > 64:
+                # (a table a captured graph replays from must stay alive: its launch baked the table's address in)
+                for k_ in [k_ for k_ in _BATCH_TABLES if k_ not in _BATCH_PINNED]:
+                    del _BATCH_TABLES[k_]
+            ent = (torch.tensor(rows, dtype=torch.int64).to(todo[0][1].device), nb)
+            _BATCH_TABLES[sig] = ent
+        if capturing:
+            _BATCH_PINNED.add(sig)
+        check(LIB.egz_pack_w3x3_frag_batch(ent[0].data_ptr(), len(todo), ent[1], _stream()), "egz_pack_w3x3_frag_batch")
     for key, w, buf in todo:
         _PACKED[key] = (_tag(w), buf, weakref.ref(w))
         _USED.discard(key)
@@ -374,36 +387,54 @@ class _AbsmaxArena:
     """Zero-filled abs-max buffers (egz_common.h: the producers fold their maxima in with atomic max, so a buffer must start at
     zero).  Buffers are cut from chunks that ONE fill zeroes (a chunk serves ~250 buffers = about one SP step); a chunk is
     filled on the stream that was current when it was created and every other stream that takes a buffer from it waits for
-    that fill once.  A hipGraph capture gets chunks of its own: the captured fill re-zeroes them on every replay, and buffers
-    handed out before / after the capture are never touched by it."""
+    that fill once.  A hipGraph capture gets ONE chunk of its own (CAPTURE_CHUNK buffers), created by ``capture()`` below on
+    the capture's origin stream before any side stream forks: the captured fill re-zeroes it on every replay, buffers handed
+    out before / after the capture are never touched by it, and a capture that needs more buffers than the chunk holds raises
+    (a second chunk created mid-capture on a forked stream would not be ordered before the other streams' atomic maxima --
+    ADVICE r4).  Captures must go through ``capture()``: take() inside a capture that did not raises."""
     CHUNK = 256
+    CAPTURE_CHUNK = 1024
 
     def __init__(self):
         self.elems = 0
         self.chunk = None
+        self.size = 0
         self.used = 0
         self.tag = None
         self.event = None
         self.waited = set()
         self.capture_seq = 0
+        self.in_capture = False
 
     def capture_begin(self, device, eager: bool = True):
-        """First statement inside a hipGraph capture (graphs.py, AT.py): the capture's buffers come from a chunk of its own whose
+        """First statement inside a hipGraph capture (``capture()``): the capture's buffers come from a chunk of its own whose
         fill is captured HERE, on the capture's origin stream, before any side stream forks.  ``eager=False``: a capture that
-        stays on one stream and may not take a buffer at all (the AT per-sample step: its replay would zero 32 KB for nothing,
-        one 4.6 us launch per sample) -- the chunk is then created by the first take() inside the capture."""
+        stays on one stream and may not take a buffer at all (the AT per-sample step: its replay would zero the chunk for
+        nothing, one launch per sample) -- the chunk is then created by the first take() inside the capture."""
         self.capture_seq += 1
         self.chunk = None
+        self.in_capture = True
         if eager:
             self.take(device)
+
+    def capture_end(self):
+        self.in_capture = False
+        self.chunk = None                 # the next eager take() starts a chunk of its own
 
     def take(self, device) -> torch.Tensor:
         if not self.elems:
             self.elems = int(LIB.egz_absmax_elems())
         capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and not self.in_capture:
+            raise RuntimeError("abs-max arena: a hipGraph capture that did not go through hipops.capture() asked for a buffer "
+                               "(it would share the previous capture's chunk)")
         tag = (capturing, self.capture_seq if capturing else 0, str(device))
-        if self.chunk is None or self.used == self.CHUNK or tag != self.tag:
-            self.chunk = torch.zeros(self.CHUNK * self.elems, dtype=torch.int32, device=device)
+        if self.chunk is None or self.used == self.size or tag != self.tag:
+            if capturing and self.chunk is not None and tag == self.tag:
+                raise RuntimeError(f"abs-max arena: the capture needs more than {self.size} abs-max buffers "
+                                   "(raise _AbsmaxArena.CAPTURE_CHUNK)")
+            self.size = self.CAPTURE_CHUNK if capturing else self.CHUNK
+            self.chunk = torch.zeros(self.size * self.elems, dtype=torch.int32, device=device)
             self.used, self.tag = 0, tag
             if capturing:
                 self.event = None                    # inside a capture the forked streams are ordered by the capture graph itself
@@ -422,6 +453,30 @@ class _AbsmaxArena:
 
 
 ABSMAX_ARENA = _AbsmaxArena()
+
+
+class capture:
+    """``with hipops.capture(graph[, eager_arena=False]): ...`` = ``torch.cuda.graph(graph)`` plus what this package's launches
+    need inside a capture: the abs-max arena's per-capture chunk (see _AbsmaxArena).  Every capture site of the package goes
+    through here (graphs.GraphedModule / GraphedTrainStep, AT._GraphedSampleStep)."""
+
+    def __init__(self, graph, eager_arena: bool = True, **kw):
+        self.ctx = torch.cuda.graph(graph, **kw)
+        self.eager_arena = eager_arena
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        try:
+            ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()), eager=self.eager_arena)
+        except BaseException:
+            ABSMAX_ARENA.capture_end()
+            self.ctx.__exit__(None, None, None)
+            raise
+        return self
+
+    def __exit__(self, *exc):
+        ABSMAX_ARENA.capture_end()
+        return self.ctx.__exit__(*exc)
 
 
 def _new_absmax(device) -> torch.Tensor:

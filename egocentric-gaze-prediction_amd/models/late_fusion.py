@@ -7,7 +7,7 @@ argument order of the caller matters (LF.py:90 passes (feat, im); run_spatialstr
 import torch
 import torch.nn as nn
 
-from .. import hipops as H
+from ..functions import Cat2Planes
 from ..utils import FusedSequential, init_like_reference
 
 
@@ -25,12 +25,11 @@ class late_fusion(nn.Module):
         self._initialize_weights()
 
     def forward(self, f, g):
-        if (f.is_cuda and f.dim() == 4 and f.shape == g.shape and f.shape[1] == 1 and f.dtype == g.dtype == torch.float32
-                and f.is_contiguous() and g.is_contiguous() and (f.shape[2] * f.shape[3]) % 4 == 0
-                and not (f.requires_grad or g.requires_grad) and f.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0):
-            fused = H.cat2_planes(f, g)                  # (B,2,H,W) NCHW: read directly by the first conv kernel
-        else:
-            fused = torch.cat((f, g), dim=1)
+        if not (f.is_cuda and g.is_cuda):
+            raise RuntimeError("late_fusion: expected HIP ('cuda') tensors -- this package has no CPU path")
+        # (B,2,H,W) NCHW in one kernel (functions.Cat2Planes: any alignment, gradients flow to f and g as views): read directly
+        # by the first conv kernel
+        fused = Cat2Planes.apply(f, g)
         return self.fusion(fused, fuse_sigmoid=True)     # fusion stack + self.final fused
 
     def _initialize_weights(self):

@@ -233,23 +233,34 @@ def _aae_auc_one(out_sq, tar_sq, npix):
     return angle, 1 - float(fp) / npix, [i, j]
 
 
-def _aae_auc_device(output, target):
-    """GPU tensors in, same return values: the maps stay in HBM, one kernel per batch (csrc/metrics.hip), 6 doubles
-    per sample come back.  Shapes as the reference's callers produce them after ``.squeeze()``: (B,224,224) or (224,224)."""
+def aae_auc_rows(output, target):
+    """The device half of computeAAEAUC: GPU maps in, a (B, 6) float64 DEVICE tensor out (csrc/metrics.hip: AAE deg, fp count,
+    gaze row / col, centroid row / col per sample) -- no read-back, capturable into a hipGraph (LF._run parks the rows of
+    several iterations and reads them back together).  Returns (rows, single)."""
     from . import hipops as H
     o = output.detach().to(torch.float32).squeeze()
     t = target.detach().to(torch.float32).squeeze()
     single = o.ndim == 2
     if single:
         o, t = o.unsqueeze(0), t.unsqueeze(0)
-    res = H.aae_auc(o.contiguous(), t.contiguous()).cpu().numpy()
-    npix_h, npix_w = o.shape[1], o.shape[2]
+    return H.aae_auc(o.contiguous(), t.contiguous()), single
+
+
+def aae_auc_from_rows(res, single=False, npix_h=224, npix_w=224):
+    """The host half: the rows of aae_auc_rows (a numpy (B, 6) array) -> computeAAEAUC's return values."""
     gp = [[int(r[2]), int(r[3])] for r in res]
     if single:
         return float(res[0, 0]), 1 - float(res[0, 1]) / (npix_h * npix_w), gp
     aae = [float(r[0]) for r in res]
     auc = [1 - float(r[1]) / npix_w / npix_h for r in res]
     return np.mean(aae), np.mean(auc), gp
+
+
+def _aae_auc_device(output, target):
+    """GPU tensors in, same return values: the maps stay in HBM, one kernel per batch (csrc/metrics.hip), 6 doubles
+    per sample come back.  Shapes as the reference's callers produce them after ``.squeeze()``: (B,224,224) or (224,224)."""
+    rows, single = aae_auc_rows(output, target)
+    return aae_auc_from_rows(rows.cpu().numpy(), single, int(output.shape[-2]), int(output.shape[-1]))
 
 
 def computeAAEAUC(output, target):

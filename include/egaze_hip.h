@@ -308,7 +308,7 @@ int egz_aae_auc(const float* out, const float* gt, int B, int H, int W, const do
                 double* res, hipStream_t stream);
 
 /* torch.cat((f, g), dim=1) of two one-channel maps, the late-fusion stack's input (models/late_fusion.py:19):
- * f, g [B][1][H][W] -> out [B][2][H][W]; HW % 4 == 0, 16-byte aligned pointers. */
+ * f, g [B][1][H][W] -> out [B][2][H][W]; 16-byte copies when HW % 4 == 0 and the pointers are 16-byte aligned, 4-byte ones otherwise. */
 int egz_cat2_planes(const float* f, const float* g, float* out, int B, long HW, hipStream_t stream);
 /* Input pipeline on the device (data/STdatas.py:50-68, data/lateDataset.py:22-33): uint8 planes [...][C][plane] ->
  * (u8 / 255 - mean[c]) / std[c] in fp32, the reference's three correctly-rounded operations (bit-exact). */

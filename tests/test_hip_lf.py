@@ -311,10 +311,15 @@ def test_bilinear_up_and_u8_center_of_mass(align):
         assert np.array_equal(gp[b].cpu().numpy(), np.floor(want).astype(np.int32))
 
 
-def test_lf_train_step_graphed_matches_eager():
+@pytest.mark.parametrize("table_miss", [False, True])
+def test_lf_train_step_graphed_matches_eager(table_miss):
     """LF.trainLate's iteration (LF.py:90-100) captured into one hipGraph (graphs.GraphedTrainStep) vs the same steps issued
     launch by launch: identical losses, outputs, parameters, BN running statistics and Adam state after five steps -- the
-    capture changes how the step is issued (every weight-gradient fork joins back), not what it computes."""
+    capture changes how the step is issued (every weight-gradient fork joins back), not what it computes.
+    ``table_miss``: the one-launch repack's pointer table for the step's packings is NOT cached when the capture
+    starts (another packing set was touched since the warm-up steps / the table cache was evicted) -- the captured step must
+    still repack after its Adam update on every replay (it falls back to the capturable per-packing launches)."""
+    import egaze_amd.hipops as H
     from egaze_amd.floss import floss
     from egaze_amd.graphs import GraphedTrainStep
     from egaze_amd.optim import FusedAdam
@@ -337,6 +342,9 @@ def test_lf_train_step_graphed_matches_eager():
                 if n == 4:                # a parameter overwritten from outside between two REPLAYS: the replay must see it
                     with torch.no_grad():
                         model.fusion[3].weight.mul_(0.5)
+                if n == 2 and table_miss:           # the call that captures finds no table for its packing set
+                    H._BATCH_TABLES.clear()
+                    H._BATCH_PINNED.clear()
                 l, o = step(f, i, t)
                 losses.append(l.item())
             assert step.graph is not None and opt.step_count == 5
@@ -371,6 +379,20 @@ def test_cat2_planes_matches_torch_cat():
     f = torch.rand(3, 1, 20, 12, generator=g).to(DEV)
     w = torch.rand(3, 1, 20, 12, generator=g).to(DEV)
     assert torch.equal(H.cat2_planes(f, w), torch.cat((f, w), dim=1))
+    # every device input takes the kernel (no stock-torch branch left in late_fusion.forward): planes that are not
+    # a multiple of four floats, operands that are not 16-byte aligned, and inputs that require grad (the gradient of a
+    # concatenation = the two halves of the incoming gradient)
+    from egaze_amd.functions import Cat2Planes
+    odd = torch.rand(2 * 7 * 9 + 1, generator=g).to(DEV)
+    fo, wo = odd[1:].view(2, 1, 7, 9), odd[:-1].view(2, 1, 7, 9)                    # fo is 4-byte aligned only
+    assert torch.equal(Cat2Planes.apply(fo, wo), torch.cat((fo, wo), dim=1))
+    fr, wr = f.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    out = Cat2Planes.apply(fr, wr)
+    seed = torch.rand(out.shape, generator=g).to(DEV)
+    out.backward(seed)
+    assert torch.equal(fr.grad, seed[:, 0:1]) and torch.equal(wr.grad, seed[:, 1:2])
+    with pytest.raises(RuntimeError):
+        Cat2Planes.apply(f, w[:, :, :10])
 
 
 def test_lf_epoch_trailing_partial_batch_and_interrupted_epoch(monkeypatch):
@@ -401,13 +423,15 @@ def test_lf_epoch_trailing_partial_batch_and_interrupted_epoch(monkeypatch):
     for graphed in (False, True):
         monkeypatch.setattr(lf_mod, "LF_GRAPH", graphed)
         s = shell()
-        loss, _, _ = s._run(loader, True, 10 ** 9)
+        loss, auc, aae = s._run(loader, True, 3 if graphed else 10 ** 9)       # (graphed: a print + drain every 3 iterations)
         torch.cuda.synchronize()
         assert not s.optimizer.capturable and s.optimizer.step_count == 6
         sd = s.optimizer.state_dict()
         assert float(sd["state"][0]["step"]) == 6.0
-        res.append((loss, s.optimizer.flat_p.clone(), s.optimizer.flat_m.clone(), s.optimizer.flat_v.clone()))
-    assert res[0][0] == res[1][0]
+        res.append(((loss, auc, aae), s.optimizer.flat_p.clone(), s.optimizer.flat_m.clone(), s.optimizer.flat_v.clone()))
+    # the captured iteration carries the batch metric inside the graph and parks loss / AAE / AUC for a later read-back
+    # (LF.GraphedLateIteration): the epoch's three averages are the same numbers as the launch-by-launch loop's
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
     for a, b in zip(res[0][1:], res[1][1:]):
         assert torch.equal(a, b)
     # an interrupted epoch: the fourth batch raises inside the loop (after the capture)

@@ -165,3 +165,32 @@ def test_window_and_align_means_on_device():
         a_dev = ex.channel_weight(fd[:1], gt, 3, True).cpu()
         a_cpu = ex.channel_weight(feat[:1], gt, 3, True)
         assert np.allclose(a_dev.numpy(), a_cpu.numpy(), rtol=1e-4, atol=1e-6), ind
+
+
+def test_glue_device_paths_equal_their_host_branches():
+    """the AT / extraction glue keeps host branches (the reference's own formulations, AT.py:25-66,
+    extractLSTMw.py:46-81) next to the device kernels.  Every one of them against its device path on the same values: device
+    tensors never take a stock-torch route, host tensors reproduce the reference."""
+    from egaze_amd import AT as at
+    rs = np.random.RandomState(21)
+    feat = torch.from_numpy(np.abs(rs.standard_normal((4, 512, 14, 14))).astype(np.float32))
+    fd = feat.to(DEV).contiguous(memory_format=torch.channels_last)
+    gps = [[5, 220], [117, 60], [223, 0], [0, 113]]
+    w_host = at.crop_mean_weight(feat, gps, 3)
+    w_dev = at.crop_mean_weight(fd, gps, 3)
+    assert w_dev.is_cuda and np.allclose(w_dev.cpu().numpy(), w_host.numpy(), rtol=1e-6, atol=1e-7)
+    gp_dev = torch.tensor(gps, dtype=torch.int32, device=DEV)
+    assert torch.equal(at.crop_mean_weight(fd, gp_dev, 3), w_dev)                 # gaze points already on the device
+    a_host, a_dev = at.crop_align_mean(feat, gps, 3), at.crop_align_mean(fd, gps, 3)
+    assert np.abs(a_dev.cpu().numpy() - a_host.numpy()).max() < 1e-5 * np.abs(a_host.numpy()).max()
+    b_host, b_dev = at.get_weighted_batch(w_host, feat), at.get_weighted_batch(w_dev, fd)
+    assert tuple(b_dev.shape) == (4, 14, 14) and np.abs(b_dev.cpu().numpy() - b_host.numpy()).max() < 2e-6
+    for n in range(4):
+        one_host = at.get_weighted(w_host[n], feat[n:n + 1])
+        one_dev = at.get_weighted(w_dev[n], fd[n:n + 1])
+        assert np.abs(one_dev.cpu().numpy() - one_host.numpy()).max() < 2e-6
+        assert np.abs(one_dev.cpu().numpy() - b_host[n:n + 1].numpy()).max() < 2e-6
+    with pytest.raises(NotImplementedError):
+        at.get_weighted(w_dev[0], fd[:2])
+    with pytest.raises(NotImplementedError):
+        at.crop_align_mean(fd[:, :, :, :7].contiguous(), gps, 3)

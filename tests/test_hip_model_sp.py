@@ -156,6 +156,7 @@ def test_model_sp_train_step_headline_size():
     loss = criterion(output, gt.to(DEV).view(output.size()))
     loss.backward()
     got = {k: p.grad.detach().double().norm().item() for k, p in model.named_parameters()}
+    full = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}     # every gradient tensor, element-wise below
     out_hip, loss_hip = output.detach().cpu(), loss.item()
     sd_hip = {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if "running" in k}
     del output, loss
@@ -175,6 +176,32 @@ def test_model_sp_train_step_headline_size():
     print(f"B=32 224x224: worst gradient-norm deviation {worst:.2e} over {len(grads)} tensors")
     for k, v in sd_hip.items():
         assert rel(v.numpy(), sd[k].numpy()) < 1e-4, k
+    # Element-wise, in the launch geometry the bench times (default split-K decisions, default streams, 3136 / 6272 tiles per
+    # launch): a mis-indexed tile that preserves a norm does not preserve the entries.  Every tensor: direction and
+    # size (cosine >= 0.995, norm within 3 %); the named weight tensors (decoder head and tail, fusion, first flow conv, last
+    # RGB conv), every bias and every BatchNorm affine parameter: >= 98 % of the entries within 2e-3 of max |ref|
+    # (mostly_close: a ReLU / max-pool subgradient flip moves single filters, an indexing bug moves everything).  Biases in
+    # front of a train-mode BatchNorm have analytically zero gradients (functions._zero_bias_grad): those must be ~0 here.
+    gabs = max(g.abs().max().item() for g in grads.values())
+    named = {"decoder.28.weight", "decoder.24.weight", "fusion.weight", "features_t.0.weight", "features_s.40.weight"}
+    worst_frac, worst_cos, checked = 1.0, 1.0, 0
+    for k, ref in grads.items():
+        g = full[k]
+        assert tuple(g.shape) == tuple(ref.shape), k
+        if ref.abs().max().item() < 1e-5 * gabs:
+            assert g.abs().max().item() < 1e-4 * gabs, k
+            continue
+        c, rn = cos_norm(g.numpy(), ref.numpy())
+        worst_cos = min(worst_cos, c)
+        assert c >= 0.995 and abs(rn - 1) <= 0.03, (k, c, rn)
+        if k in named or k.endswith(".bias") or ref.dim() == 1:
+            good, frac = mostly_close(g.numpy(), ref.numpy())
+            worst_frac = min(worst_frac, frac)
+            checked += 1
+            assert good, (k, frac)
+    assert checked >= len(named) + 40
+    print(f"B=32 224x224 element-wise: worst cosine {worst_cos:.6f} over all tensors; {checked} tensors (named weights, biases, "
+          f"BN affine) with >= {worst_frac:.4f} of their entries within 2e-3 of max|ref|")
 
 
 # Element-wise gradient checks at 32 x 32.  The encoders end at 2 x 2 (B = 3: twelve samples per channel), so ONE

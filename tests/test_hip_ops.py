@@ -123,6 +123,7 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     (2, 15, 32, 32, 8, False), (1, 10, 16, 8, 32, False), (1, 33, 224, 32, 32, False), (3, 3, 64, 12, 4, False),
     # ... K <= 8: the tap-packed form ((tap, k) pairs as GEMM columns, the shift on the gradient operand): 4 x 16 and 2 x 32 patches
     (1, 48, 48, 32, 8, False), (2, 17, 16, 32, 8, False), (1, 224, 224, 32, 8, False), (2, 6, 96, 20, 4, False), (1, 1, 16, 32, 8, False),
+    (1, 20, 48, 32, 4, False), (2, 9, 16, 8, 4, False),        # K = 4 on the 4 x 16 patch (the entry point requires K % 4 == 0: 4 and 8 are the tap-packed widths)
 ])
 def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups, monkeypatch):
     """f16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes; dy scaled by its abs-max): patch geometries 1x32 / 2x16 / 4x8,
