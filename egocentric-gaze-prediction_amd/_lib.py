@@ -51,10 +51,11 @@ SIGNATURES = {
     "egz_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "egz_conv3x3_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, P, S]),
     "egz_conv3x3_wgrad_narrow_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "egz_conv3x3_wgrad_presplit_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     # --- first encoder conv (NCHW input, Cin 3 / 20)
     "egz_conv_first_stat_rows": (c_int, [c_int, c_int, c_int]),
     "egz_conv_first_stat_rows_for": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, S]),
+    "egz_conv_first_fwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, S]),
     "egz_conv_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "egz_conv_first_wgrad": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, S]),
     # --- BatchNorm / ReLU / pool / fusion max / misc streaming passes
@@ -63,7 +64,10 @@ SIGNATURES = {
                                 c_size_t, S]),
     "egz_bn_finalize_deferred": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P, P,
                                          c_int, P, S]),
+    "egz_bn_finalize_bound": (c_int, [P, c_int, c_int, c_double, P, P, P, P, c_float, c_float, P, P, P, P, P, P,
+                                      c_size_t, P, P, S]),
     "egz_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P, S]),
+    "egz_bn_relu_pool_fwd_presplit": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_bn_relu_pool_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, S]),
     "egz_bn_relu_pool_bwd_ws_bytes": (c_size_t, [c_int]),
     "egz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,

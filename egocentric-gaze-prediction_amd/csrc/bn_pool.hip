@@ -6,6 +6,7 @@
 // Channel reductions: every block keeps fp64 per-channel partials, writes them to a small workspace and a
 // second tiny kernel sums them in a fixed order (deterministic, no atomics).
 #include "egz_common.h"
+#include "x3_split.h"
 #include <cstdlib>
 
 namespace {
@@ -50,9 +51,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part2, int nparts,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ scale,
-                                   float* __restrict__ shift, long long* __restrict__ num_batches_tracked) {
+                                   float* __restrict__ shift, long long* __restrict__ num_batches_tracked,
+                                   const unsigned int* __restrict__ minmax, unsigned int* __restrict__ absmax_out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+    if (k >= K) return;                                 // (K % 64 == 0 whenever minmax is given: whole waves stay)
     if (k == 0 && num_batches_tracked) *num_batches_tracked += 1;      // BatchNorm2d bookkeeping, same launch
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll 16                                   // independent loads in flight; the sum keeps its fixed order
@@ -74,6 +76,20 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part2, int nparts,
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
         running_mean[k] = (1.f - momentum) * running_mean[k] + momentum * (float)mean;
         running_var[k] = (1.f - momentum) * running_var[k] + momentum * (float)unbiased;
+    }
+    if (minmax) {
+        // the exact maximum of relu(fma(y, scale, shift)) over this channel from the channel's max / min of y (the map is
+        // monotonic in y): the f16 x3 scale of the block output is known BEFORE the pass that writes it runs, so that pass
+        // can store pre-split pairs (egz_bn_relu_pool_fwd_presplit).  minmax: order-preserving integer images of max y
+        // (slot k) and max -y (slot K + k), conv3x3_igemm_x3s.hip.
+        auto from_ordered = [](unsigned int u) -> float {
+            return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+        };
+        const float ymax = from_ordered(minmax[k]), ymin = -from_ordered(minmax[K + k]);
+        float bound = fmaxf(fmaxf(__builtin_fmaf(ymax, sc, shift[k]), __builtin_fmaf(ymin, sc, shift[k])), 0.f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o));
+        if ((threadIdx.x & 63) == 0) absmax_commit(absmax_out, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), bound);
     }
 }
 
@@ -185,12 +201,17 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------ BN-apply + ReLU (+pool) forward
-template <bool POOL>
+// SPLIT (round 5): `absmax` is an INPUT -- the exact max of what this pass writes (egz_bn_finalize_bound) -- and the output is
+// stored PRE-SPLIT: per 4-channel quad the 16 bytes [4 hi halves | 4 lo halves] of the f16 pair of value * absmax_scale(absmax),
+// exactly the pair the consuming convolution / weight-gradient kernels would form while staging the fp32 value (same
+// footprint; those kernels then stage without a split: conv3x3_igemm_x3s_kernel<..., PRE>, conv3x3_wgrad9_x3_kernel<..., XPRE>).
+template <bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __restrict__ y,
                                                                const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
                                                                float* __restrict__ out, int B, int H, int W, int K,
                                                                unsigned int* __restrict__ absmax) {
+    const float a_scale = SPLIT ? absmax_scale(absmax) : 1.f;
     const int K4 = K >> 2;
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const long n = (long)B * Ho * Wo * K4;
@@ -222,10 +243,16 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const float* __re
                 r[e] = fmaxf(fmaxf(a, c), 0.f);
             }
         }
-        *reinterpret_cast<f32x4*>(out + pix * K + c4 * 4) = r;
-        amx = fmaxf(amx, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+        if constexpr (SPLIT) {
+            x3::u32x2 hi, lo;
+            x3::Half<_Float16>::split4(r * a_scale, hi, lo);
+            *reinterpret_cast<x3::u32x4*>(out + pix * K + c4 * 4) = x3::u32x4{hi[0], hi[1], lo[0], lo[1]};
+        } else {
+            *reinterpret_cast<f32x4*>(out + pix * K + c4 * 4) = r;
+            amx = fmaxf(amx, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+        }
     }
-    block_absmax_commit(amx, absmax);
+    if constexpr (!SPLIT) block_absmax_commit(amx, absmax);
 }
 
 // dz at the four (or one) input positions of an output pixel: ReLU mask and first-max-wins pool routing
@@ -653,8 +680,39 @@ EGZ_API int egz_bn_finalize(const double* stat_partial, int rows, int K, double 
         nparts = RED_ROWS;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, src, nparts, K, count, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift, num_batches_tracked);
+                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift, num_batches_tracked,
+                       nullptr, nullptr);
     EGZ_CHECK_LAUNCH("egz_bn_finalize");
+    return 0;
+}
+
+// egz_bn_finalize that also bounds the block output: minmax = the 2 K uints egz_conv3x3_fwd_streamed's minmax_out received on the
+// 64- / 128-column tiles (order-preserving images of the per-channel max of y and of -y), absmax_out (egz_absmax layout,
+// zero-filled by the caller) receives the EXACT max of relu(y * scale + shift) over the whole tensor -- what
+// egz_bn_relu_pool_fwd_presplit needs before it writes the first element.  K % 64 == 0.
+EGZ_API int egz_bn_finalize_bound(const double* stat_partial, int rows, int K, double count, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                  float* mean_out, float* invstd_out, float* scale, float* shift,
+                                  long long* num_batches_tracked, void* workspace, size_t ws_bytes,
+                                  const unsigned int* minmax, unsigned int* absmax_out, hipStream_t st) {
+    EGZ_CHECK_ARG(stat_partial && mean_out && invstd_out && scale && shift && workspace && minmax && absmax_out,
+                  "egz_bn_finalize_bound: null pointer");
+    EGZ_CHECK_ARG(K % 64 == 0, "egz_bn_finalize_bound: K=%d must be a multiple of 64", K);
+    EGZ_CHECK_ARG(ws_bytes >= (size_t)RED_ROWS * 2 * K * sizeof(double), "egz_bn_finalize_bound: workspace too small");
+    EGZ_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "egz_bn_finalize_bound: running stats must come in pairs");
+    double* part2 = static_cast<double*>(workspace);
+    const double* src = stat_partial;
+    int nparts = rows;
+    if (rows > RED_ROWS) {
+        int rc = colsum_partial<double>(stat_partial, part2, rows, 2 * K, st);
+        if (rc) return rc;
+        src = part2;
+        nparts = RED_ROWS;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(egz_cdiv(K, 128)), dim3(128), 0, st, src, nparts, K, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean_out, invstd_out, scale, shift, num_batches_tracked,
+                       minmax, absmax_out);
+    EGZ_CHECK_LAUNCH("egz_bn_finalize_bound");
     return 0;
 }
 
@@ -698,6 +756,22 @@ EGZ_API int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float
     if (pool) hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, absmax);
     else      hipLaunchKernelGGL(bn_relu_pool_fwd_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, absmax);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_fwd");
+    return 0;
+}
+
+// egz_bn_relu_pool_fwd with the output stored PRE-SPLIT (see bn_relu_pool_fwd_kernel): absmax is an INPUT here, the exact max of
+// the output (egz_bn_finalize_bound).  The consumers are egz_conv3x3_fwd_streamed(mode | 0x100) and egz_conv3x3_wgrad(flags |
+// 0x8000); nothing else can read the tensor.
+EGZ_API int egz_bn_relu_pool_fwd_presplit(const float* y, const float* scale, const float* shift, float* out, int B, int H,
+                                          int W, int K, int pool, const unsigned int* absmax, hipStream_t st) {
+    EGZ_CHECK_ARG(y && scale && shift && out && absmax, "egz_bn_relu_pool_fwd_presplit: null pointer");
+    EGZ_CHECK_ARG(K % 4 == 0, "egz_bn_relu_pool_fwd_presplit: K=%d must be a multiple of 4", K);
+    EGZ_CHECK_ARG(!pool || (H % 2 == 0 && W % 2 == 0), "egz_bn_relu_pool_fwd_presplit: pooled map must be even");
+    const long n = (long)B * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (K / 4);
+    unsigned int* am = const_cast<unsigned int*>(absmax);
+    if (pool) hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<true, true>), dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, am);
+    else      hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<false, true>), dim3(ew_grid(n)), dim3(256), 0, st, y, scale, shift, out, B, H, W, K, am);
+    EGZ_CHECK_LAUNCH("egz_bn_relu_pool_fwd_presplit");
     return 0;
 }
 

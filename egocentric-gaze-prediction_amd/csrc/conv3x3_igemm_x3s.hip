@@ -23,6 +23,7 @@
 //     so the activation halo is fetched into ONE L2 instead of up to four.
 #include "egz_common.h"
 #include "x3_split.h"
+#include <type_traits>
 
 
 
@@ -81,12 +82,25 @@ enum { PLAIN = 0, UPSD = 1, UPSF = 2 };
 // packing) -- 4/9 of the MACs.  A tile is (phase, low-res pixel tile, column tile), the phase innermost in the tile order so that
 // the four phases of a pixel tile meet in one L2; the tap shifts ((a + p - 1, b + q - 1), a, b in {0, 1}) are block-uniform
 // run-time values, the staged image is the plain low-res halo, and the rows go out to the strided hi-res positions.
-template <typename T, int WM, int EPI, bool PATCH, int MODE>
+// PRE (round 5): x holds PRE-SPLIT activations -- per 4-channel quad the 16 bytes [4 hi halves | 4 lo halves] of the f16 pair of
+// (value * absmax_scale(a_absmax)), written by the pass that produced the tensor (egz_bn_relu_pool_fwd, presplit form; same
+// footprint as fp32).  The staging then moves the quad into the hi / lo planes of the LDS image without touching the vector
+// ALU: ~3.5 VALU per staged float gone from a kernel that sits at the chip's power limit (profiles/r05_presplit_gonogo.txt).
+// The pair is bit-identical to what the split-at-staging form computes, so is the result.
+// mm_out (EPI_BIAS_STATS, wide tiles): 2 K uints, ZERO-FILLED by the caller: order-preserving integer images of the per-channel
+// max of y (slot k) and of -y (slot K + k), folded in with atomic max (exact and order independent: deterministic) -- what
+// egz_bn_finalize needs to bound the [BatchNorm -> ReLU] output BEFORE the pass that writes it runs.
+__device__ __forceinline__ unsigned int ordered_bits(float f) {
+    const unsigned int b = __float_as_uint(f);
+    return b ^ (((int)b < 0) ? 0xffffffffu : 0x80000000u);
+}
+template <typename T, int WM, int EPI, bool PATCH, int MODE, bool PRE = false>
 __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ wq, const float* __restrict__ bias,
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
     int mt, int total, const unsigned int* __restrict__ a_absmax, const float* __restrict__ mask_src,
-    unsigned int* __restrict__ absmax_out, int nsplit) {
+    unsigned int* __restrict__ absmax_out, int nsplit, unsigned int* __restrict__ mm_out) {
+    static_assert(!PRE || (MODE == PLAIN && std::is_same<T, _Float16>::value), "pre-split operands: plain convolutions, f16 x3");
     using G = Geo<WM>;
     constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
     constexpr int MR = G::MR, RPW = G::RPW, NTHR = G::NTHR, SPP = G::SPP;
@@ -304,11 +318,21 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         for (int j = 0; j < NJ / 2; ++j)
             ra[half * RAOFF + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[half * (NJ / 2) + j], so, 0));
     };
+    // one staged quad -> its hi / lo halves (PRE: the quad already holds them)
+    auto split_q = [&](const f32x4 v, u32x2& hi, u32x2& lo) {
+        if constexpr (PRE) {
+            const u32x4 b = __builtin_bit_cast(u32x4, v);
+            hi = u32x2{b[0], b[1]};
+            lo = u32x2{b[2], b[3]};
+        } else {
+            Half<T>::split4s(v, a_scale, hi, lo);
+        }
+    };
     auto lstore_a = [&](const int abuf, const int half) {
 #pragma unroll
         for (int j = 0; j < NJ / 2; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4s(ra[half * RAOFF + j], a_scale, hi, lo);
+            split_q(ra[half * RAOFF + j], hi, lo);
             unsigned short* d = Ah + abuf * ABUF + lds_slot(half * (NJ / 2) + j);
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -358,7 +382,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
         for (int j = 0; j < NJ / 2; ++j) {
             u32x2 hi, lo;
-            Half<T>::split4s(rp[j], a_scale, hi, lo);
+            split_q(rp[j], hi, lo);
             unsigned short* d = Ah + lds_slot(NJ / 2 + j);
             *reinterpret_cast<u32x2*>(d) = hi;
             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -427,7 +451,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                         } else if (ls && i >= MR && i - MR < NH) {
                             const int j = i - MR;
                             u32x2 hi, lo;
-                            Half<T>::split4s(ra[lhalf * RAOFF + j], a_scale, hi, lo);
+                            split_q(ra[lhalf * RAOFF + j], hi, lo);
                             unsigned short* d = Ah + (abuf ^ 1) * ABUF + lds_slot(lhalf * NH + j);
                             *reinterpret_cast<u32x2*>(d) = hi;
                             *reinterpret_cast<u32x2*>(d + APL) = lo;
@@ -506,6 +530,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     constexpr int SR = (RPW > 128) ? RPW / 128 : 1;            // 128-row stat rows a wave owns (2 on the 256-row waves)
     double s1 = 0.0, s2 = 0.0, s1b[SR], s2b[SR];
     float amx = 0.f;
+    float cmx = -INFINITY, cmn = INFINITY;                      // mm_out: this lane's column max / min of y
     // The result goes out through BUFFER stores whose per-lane byte offset is out of range for rows / columns that do not exist
     // (dropped by the hardware): no per-lane branch around a store.  With `if (valid) y[...] = v` every store sat in its own
     // basic block and the wait-count pass put s_waitcnt vmcnt(0) in front of each one -- 32-64 stores per wave, each waiting
@@ -573,6 +598,8 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                 if (EPI == EPI_BIAS_STATS) {                   // (fp64 per element: the variance is a difference of these two
                     s1 += (double)vs;                          //  sums, and fp32 partial sums over 16 rows already cost the
                     s2 += (double)vs * (double)vs;             //  gradients their fp32-class accuracy -- test_model_sp_grads_vs_fp64)
+                    cmx = fmaxf(cmx, ok ? v : -INFINITY);
+                    cmn = fminf(cmn, ok ? v : INFINITY);
                 }
                 continue;
             }
@@ -599,6 +626,18 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
             for (int w = 1; w < NTHR / 64; ++w) m = fmaxf(m, samax[w]);
             absmax_commit(absmax_out, (unsigned)gt, m);
+        }
+    }
+    if (EPI == EPI_BIAS_STATS && mm_out) {                      // block-uniform
+        cmx = fmaxf(cmx, __shfl_xor(cmx, 32));
+        cmn = fminf(cmn, __shfl_xor(cmn, 32));
+        if (hl == 0 && nok) {
+            unsigned int* pm = mm_out + col;
+            const unsigned int umx = ordered_bits(cmx), umn = ordered_bits(-cmn);
+            if (umx > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                __hip_atomic_fetch_max(pm, umx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (umn > __hip_atomic_load(pm + K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                __hip_atomic_fetch_max(pm + K, umn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS || EPI == EPI_BNSUMS) {
@@ -1285,8 +1324,8 @@ int launch_x3s_splitk(int epi, const float* x, const unsigned short* wq, const f
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
     const int total = mt * (Kp / G::BN) * nsplit;
     const dim3 grid(((total + 7) / 8) * 8);
-    if (patch) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, true, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit);
-    else       hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, false, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit);
+    if (patch) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, true, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit, nullptr);
+    else       hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, 1, EPI_PARTIAL, false, PLAIN>), grid, dim3(G::NTHR), 0, st, x, wq, nullptr, part, nullptr, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, nullptr, nullptr, nsplit, nullptr);
     EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed_splitk");
     const dim3 fg(egz_cdiv(M, FIX_ROWS), egz_cdiv(K, 64));
     if (epi == EPI_BIAS) hipLaunchKernelGGL(splitk_fixup_kernel<EPI_BIAS>, fg, dim3(256), 0, st, part, bias, y, stat, M, K, nsplit, nullptr);
@@ -1299,7 +1338,7 @@ int launch_x3s_splitk(int epi, const float* x, const unsigned short* wq, const f
 template <typename T, int WM, int MODE>
 int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* bias, float* y, double* stat, int B, int H,
                int W, int C, int K, float out_scale, const unsigned int* a_absmax, const float* mask_src,
-               unsigned int* absmax_out, hipStream_t st) {
+               unsigned int* absmax_out, hipStream_t st, unsigned int* mm_out = nullptr, bool pre = false) {
     using G = Geo<WM>;
     const int Ho = (MODE != PLAIN) ? H / 2 : H, Wo = (MODE != PLAIN) ? W / 2 : W;
     const long M = (long)B * Ho * Wo;
@@ -1308,8 +1347,23 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
     const int total = mt * (Kp / G::BN) * ((MODE == UPSF) ? 4 : 1);
     const dim3 grid(((total + 7) / 8) * 8);
-#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1)
+#define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out)
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS) absmax_out = nullptr;
+    if (pre) {                         // pre-split activation operand: the training forward of the wide encoder layers
+        if constexpr (MODE == PLAIN && (WM == 1 || WM == 2) && std::is_same<T, _Float16>::value) {
+            if (epi != EPI_BIAS_STATS) {
+                egz_set_error("egz_conv3x3_fwd_streamed: a pre-split operand is taken by the BatchNorm-statistics epilogue (epi 2) only");
+                return (int)hipErrorInvalidValue;
+            }
+            if (patch) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, EPI_BIAS_STATS, true, PLAIN, true>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out);
+            else       hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, EPI_BIAS_STATS, false, PLAIN, true>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out);
+            EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed(pre-split)");
+            return 0;
+        } else {
+            egz_set_error("egz_conv3x3_fwd_streamed: pre-split operands exist for plain convs on the 128- / 64-column tiles");
+            return (int)hipErrorInvalidValue;
+        }
+    }
     if constexpr (MODE == UPSF) {                                   // decoder blocks: bias + ReLU (or plain bias)
         if (epi != EPI_BIAS && epi != EPI_BIAS_RELU) {
             egz_set_error("egz_conv3x3_fwd_streamed: the upsample forward has the bias and bias + ReLU epilogues only");
@@ -1437,12 +1491,22 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                                      const unsigned int* x_absmax, const float* mask_src, unsigned int* absmax_out,
                                      const float* bn_coef, float* minmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
+    // mode | 0x100 (mode 0, f16 x3, epi 2, K % 64 == 0, C % 32 == 0): x holds PRE-SPLIT activations (egz_bn_relu_pool_fwd's
+    // presplit form; x_absmax = the abs-max the pairs were scaled with)
+    const bool pre = (mode & 0x100) != 0;
+    mode &= 0xff;
+    EGZ_CHECK_ARG(!pre || (mode == 0 && dtype == 1 && epi == EPI_BIAS_STATS && K % 64 == 0 && C % 32 == 0 && x_absmax && !bn_coef),
+                  "egz_conv3x3_fwd_streamed: a pre-split operand needs mode 0, dtype 1, epi 2, K %% 64 == 0, C %% 32 == 0 and x_absmax");
     // epi 0 / 1 / 2 with bn_coef: x is a pre-BatchNorm tensor, normalised + ReLU'd while it is staged (narrow geometry only);
-    // minmax_out (epi 2, narrow geometry): [egz_conv3x3_streamed_stat_rows][2][K] per-channel max / min of y
-    EGZ_CHECK_ARG(!((bn_coef && epi != EPI_BNSUMS) || minmax_out) || (mode == 0 && x3p_narrow_ok(B, H, W, C, K) && (dtype == 1 || dtype == 2) &&
+    // minmax_out (epi 2): narrow geometry: [egz_conv3x3_streamed_stat_rows][2][K] per-channel max / min rows of y;
+    // 64- / 128-column tiles (K % 64 == 0): 2 K uints, zero-filled by the caller: order-preserving integer images of the
+    // per-channel max of y and of -y (atomic max; egz_bn_finalize's `minmax` argument)
+    const bool wide_mm = minmax_out && K % 64 == 0 && mode == 0 && epi == EPI_BIAS_STATS && !bn_coef;
+    EGZ_CHECK_ARG(wide_mm || !((bn_coef && epi != EPI_BNSUMS) || minmax_out) || (mode == 0 && x3p_narrow_ok(B, H, W, C, K) && (dtype == 1 || dtype == 2) &&
                   epi != EPI_MASK_SUMS && (!minmax_out || epi == EPI_BIAS_STATS)),
-                  "egz_conv3x3_fwd_streamed: a deferred-BatchNorm input (bn_coef) / minmax_out exist on the narrow persistent kernel "
-                  "only (C, K <= 32, H and W multiples of 16; minmax_out with epi 2)");
+                  "egz_conv3x3_fwd_streamed: a deferred-BatchNorm input (bn_coef) exists on the narrow persistent kernel only (C, K <= 32, "
+                  "H and W multiples of 16); minmax_out needs epi 2 and that geometry or K %% 64 == 0");
+    unsigned int* mmw = wide_mm ? reinterpret_cast<unsigned int*>(minmax_out) : nullptr;
     if (epi == EPI_BNSUMS) {       // data gradient + the BatchNorm-backward sums of the layer below
         EGZ_CHECK_ARG((dtype == 1 || dtype == 2) && mode == 0 && mask_src && bn_coef && stat_partial && !bias &&
                       egz_conv3x3_streamed_ok(B, H, W, C, K, 0) && (x3p_narrow_ok(B, H, W, C, K) || K % 64 == 0),
@@ -1481,12 +1545,12 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         return launch_x3s<__bf16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
     if (K % 128 == 0) {
-        if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-        return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre);
+        return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw);
     }
     if (K % 64 == 0) {
-        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
-        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre);
+        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw);
     }
     EGZ_CHECK_ARG(!(absmax_out && epi == EPI_BIAS_RELU), "egz_conv3x3_fwd_streamed: the abs-max epilogue exists for 64- and "
                   "128-column tiles only (K %% 64 == 0)");

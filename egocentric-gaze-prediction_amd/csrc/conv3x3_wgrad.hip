@@ -335,7 +335,10 @@ __device__ __forceinline__ void wgrad_block(int& tile, int& split) {
     }
 }
 
-template <typename T, bool UPS, int R, int WD>
+// XPRE (round 5): x holds PRE-SPLIT activations ([4 hi halves | 4 lo halves] per 4-channel quad, scaled by
+// absmax_scale(x_absmax); egz_bn_relu_pool_fwd's presplit form) -- the halo staging copies the quad into the two planes of the
+// LDS image without a split on the vector ALU (two thirds of this kernel's staged floats are x: its halo is 1.9x the patch).
+template <typename T, bool UPS, int R, int WD, bool XPRE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
     int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax,
@@ -496,7 +499,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4s(rx[j], x_scale, hi, lo);
+                if constexpr (XPRE) {
+                    const u32x4_t bq = __builtin_bit_cast(u32x4_t, rx[j]);
+                    hi = u32x2_t{bq[0], bq[1]};
+                    lo = u32x2_t{bq[2], bq[3]};
+                } else {
+                    W16<T>::split4s(rx[j], x_scale, hi, lo);
+                }
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
                 *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
@@ -1565,6 +1574,15 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
 // 1 when a plain split-half weight gradient of this geometry runs on the narrow kernel (C, K <= 32, W % 16 == 0, 32-bit
 // buffer offsets) -- the only one that takes a deferred-BatchNorm activation operand (x_bn)
+// 1 when egz_conv3x3_wgrad(flags 0x2000 [| 0x8000]) of a plain conv runs on conv3x3_wgrad9_x3_kernel, i.e. can take a pre-split
+// x operand: C, K multiples of 64, a patch geometry for this width, operands below 4 GiB.
+EGZ_API int egz_conv3x3_wgrad_presplit_ok(int B, int H, int W, int C, int K) {
+    if (B <= 0 || H <= 0 || W <= 0 || C % 64 != 0 || K % 64 != 0) return 0;
+    const unsigned long long xb = 4ull * B * H * W * C + 4ull * (W + 1) * C, db = 4ull * B * H * W * K;
+    if (xb >= (1ull << 32) || db >= (1ull << 32)) return 0;
+    return pick_patch_x3(W, C, K, 0x2000) != 0;
+}
+
 EGZ_API int egz_conv3x3_wgrad_narrow_ok(int B, int H, int W, int C, int K) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || C % 4 || K % 4) return 0;
     const unsigned long long xb = 4ull * B * H * W * C + 4ull * (W + 1) * C, db = 4ull * B * H * W * K;
@@ -1590,6 +1608,11 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         const unsigned long long db = 4ull * B * H * W * K;
         if (xb >= (1ull << 32) || db >= (1ull << 32)) flags &= ~0x2000;      // too large: exact-f32 kernels (64-bit addressing)
     }
+    // flags 0x8000: x holds pre-split activations (see conv3x3_wgrad9_x3_kernel) -- only where that kernel runs
+    const bool xpre = (flags & 0x8000) != 0;
+    EGZ_CHECK_ARG(!xpre || egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) && (flags & 0x2000) && !ups && dy_absmax && x_absmax && !x_bn,
+                  "egz_conv3x3_wgrad: a pre-split x operand (flags 0x8000) needs the split-half 9-tap kernel's geometry "
+                  "(egz_conv3x3_wgrad_presplit_ok), f16 x3 (dy_absmax, x_absmax) and a plain conv");
     float* part = static_cast<float*>(workspace);
     const long nred = (long)9 * C * K;
     if (ups && !(flags & 0x1000)) {
@@ -1656,10 +1679,15 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         const int pps = (int)((np + S - 1) / S);
         dim3 grid(((C + 63) / 64) * ((K + 63) / 64), S);
 #define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
+#define EGZ_W9P(RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<_Float16, false, RR, WW, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, x_absmax)
 #define EGZ_W9T(TT)                                                                                                    \
         if (ups) { if (WD == 32) EGZ_W9X(TT, true, 1, 32); else if (WD == 16) EGZ_W9X(TT, true, 2, 16); else EGZ_W9X(TT, true, 4, 8); } \
         else     { if (WD == 32) EGZ_W9X(TT, false, 1, 32); else if (WD == 16) EGZ_W9X(TT, false, 2, 16); else EGZ_W9X(TT, false, 4, 8); }
+        if (xpre) {                // pre-split x operand (flags 0x8000): f16 x3, plain conv
+            if (WD == 32) EGZ_W9P(1, 32); else if (WD == 16) EGZ_W9P(2, 16); else EGZ_W9P(4, 8);
+        } else
         if (dy_absmax) { EGZ_W9T(_Float16) } else { EGZ_W9T(__bf16) }
+#undef EGZ_W9P
 #undef EGZ_W9T
 #undef EGZ_W9X
         EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap split)");

@@ -134,7 +134,7 @@ constexpr int FD_BLOCKS = 512;          // one round at two resident blocks per 
 template <int CIN, int PX, bool STATS, int KQ>
 __global__ __launch_bounds__(256) void conv_first_direct_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
-    double* __restrict__ stat, int B, int H, int W, int ppb, float* __restrict__ mm_out) {
+    double* __restrict__ stat, int B, int H, int W, int ppb, float* __restrict__ mm_out, unsigned int* __restrict__ mm_ord) {
     constexpr int K = 4 * KQ, NT = CIN * 9, PL = 256 / KQ;
     __shared__ double red[4][KQ][8];
     __shared__ float rmm[4][KQ][8];
@@ -235,14 +235,23 @@ __global__ __launch_bounds__(256) void conv_first_direct_kernel(
 #pragma unroll
             for (int wv = 0; wv < 4; ++wv) t += red[wv][col >> 2][which * 4 + (col & 3)];
             stat[((long)blockIdx.x * 2 + which) * K + col] = t;
-            if (mm_out) {
+            if (mm_out || mm_ord) {
                 float r = rmm[0][col >> 2][which * 4 + (col & 3)];
 #pragma unroll
                 for (int wv = 1; wv < 4; ++wv) {
                     const float o = rmm[wv][col >> 2][which * 4 + (col & 3)];
                     r = which ? fminf(r, o) : fmaxf(r, o);
                 }
-                mm_out[((long)blockIdx.x * 2 + which) * K + col] = r;
+                if (mm_out) mm_out[((long)blockIdx.x * 2 + which) * K + col] = r;
+                if (mm_ord) {
+                    // the 2 K-uint form egz_bn_finalize_bound reads (conv3x3_igemm_x3s.hip): order-preserving images of max y
+                    // (slot col) and max -y (slot K + col), folded in with atomic max -- exact and order independent
+                    const unsigned int b = __float_as_uint(which ? -r : r);
+                    const unsigned int u = b ^ (((int)b < 0) ? 0xffffffffu : 0x80000000u);
+                    unsigned int* pm = mm_ord + which * K + col;
+                    if (u > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        __hip_atomic_fetch_max(pm, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
@@ -389,11 +398,13 @@ EGZ_API int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K) {
 
 // x: [B][C][H][W] (NCHW, as the reference DataLoader yields it), w: (64, C, 3, 3), y: [B][H][W][64].
 // minmax_out (optional; C <= 3 -> 32 with stat_partial only): [rows][2][32] per-channel max / min of y, rows as stat_partial.
+// minmax_ordered (optional, same conditions): 2 K uints, zero-filled by the caller -- the atomic form egz_bn_finalize_bound reads.
 EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias, float* y, double* stat_partial,
-                               int B, int H, int W, int C, int K, float* minmax_out, hipStream_t st) {
+                               int B, int H, int W, int C, int K, float* minmax_out, unsigned int* minmax_ordered,
+                               hipStream_t st) {
     EGZ_CHECK_ARG(x && w && y, "egz_conv_first_fwd: null pointer");
-    EGZ_CHECK_ARG(!minmax_out || (stat_partial && first_direct_ok(C, K) && (long)B * H * W * K < (1l << 31)),
-                  "egz_conv_first_fwd: minmax_out exists on the direct kernel only (C <= 3 -> 32 / 64 filters, with stat_partial)");
+    EGZ_CHECK_ARG(!(minmax_out || minmax_ordered) || (stat_partial && first_direct_ok(C, K) && (long)B * H * W * K < (1l << 31)),
+                  "egz_conv_first_fwd: minmax_out / minmax_ordered exist on the direct kernel only (C <= 3 -> 32 / 64 filters, with stat_partial)");
     EGZ_CHECK_ARG(K == 64 || K == 32, "egz_conv_first_fwd: Cout must be 64 or 32 (got %d)", K);
     EGZ_CHECK_ARG(C > 0 && C <= 64 && B > 0 && H > 0 && W > 0, "egz_conv_first_fwd: bad shape");
     const long M = (long)B * H * W;
@@ -401,8 +412,8 @@ EGZ_API int egz_conv_first_fwd(const float* x, const float* w, const float* bias
         const int ppb = first_direct_ppb(M, W, K), nb = egz_cdiv(M, ppb);
 #define EGZ_FD3(CC, PP, QQ)                                                                                                    \
     do {                                                                                                                       \
-        if (stat_partial) hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, true, QQ>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, minmax_out); \
-        else              hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, false, QQ>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, (float*)nullptr); \
+        if (stat_partial) hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, true, QQ>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, minmax_out, minmax_ordered); \
+        else              hipLaunchKernelGGL((conv_first_direct_kernel<CC, PP, false, QQ>), dim3(nb), dim3(256), 0, st, x, w, bias, y, stat_partial, B, H, W, ppb, (float*)nullptr, (unsigned int*)nullptr); \
     } while (0)
 #define EGZ_FD2(CC, PP)                                                                                                        \
     do {                                                                                                                       \

@@ -23,14 +23,25 @@ import torch
 import torch.distributed as dist
 
 
-_MODE = os.environ.get("EGAZE_DP_MODE", "default")      # experiment switch of round 5 (tools/dp_world1.py); resolved below
+_raw_stream_fn = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _raw_current_stream(dev_index):
+    if _raw_stream_fn is not None:
+        return _raw_stream_fn(dev_index if dev_index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
+_MODE = os.environ.get("EGAZE_DP_MODE", "lastwait")
+_GEOMETRIC = os.environ.get("EGAZE_DP_BUCKETS", "halving") != "equal"      # experiment switch of round 5 (tools/dp_world1.py); resolved below
 
 
 class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, params: Sequence[torch.nn.Parameter], offsets: Sequence[int],
                  bucket_bytes: int = 25 * 1024 * 1024, group=None, flat_param: Optional[torch.Tensor] = None,
-                 force: Optional[bool] = None, record_events: bool = False):
-        """``force``: install the hooks and issue the collectives even at world size 1 (default: EGAZE_DP_FORCE=1) -- a
+                 force: Optional[bool] = None, record_events: bool = False, geometric: bool = True):
+        """``geometric``: bucket sizes halve along the backward pass (see below; False: equal buckets of ``bucket_bytes``).
+        ``force``: install the hooks and issue the collectives even at world size 1 (default: EGAZE_DP_FORCE=1) -- a
         1-rank RCCL all-reduce is legal and runs the same code path (comm stream, async handles, the joins in front of
         the optimizer step), which is how the ``nccl`` path is exercised on a one-GPU box (tests/test_hip_rccl.py,
         ``bench.py`` extra.rccl_world1).  ``record_events``: keep a HIP event per bucket launch (tests)."""
@@ -51,6 +62,14 @@ class GradReducer:
         self._launched: List[bool] = []
         order = sorted(range(len(params)), key=lambda i: offsets[i], reverse=True)
         cur_end, cur_start, cur_n = None, None, 0
+        # Bucket sizes halve along the backward pass: a bucket closes when it holds max(bucket_bytes, half of the gradient bytes
+        # still to come).  Every bucket hand-over costs event records / stream waits on the compute streams (~35 of each per SP
+        # step with seven 25 MB buckets: +0.5 ms per step at world size 1, profiles/r05_dp_world1.txt), so few buckets are
+        # cheaper -- but what the step waits for at its end is the LAST bucket's collective, so that one stays small: 186 MB of
+        # SP gradients become 93 + 47 + 25 + 21 MB instead of 7 x 25 + 11.
+        remaining = sum((p.numel() + 3) // 4 * 4 for p in params) * 4
+        geometric = geometric and _GEOMETRIC
+        target = max(bucket_bytes, remaining // 2) if geometric else bucket_bytes
         for i in order:
             start, end = offsets[i], offsets[i] + (params[i].numel() + 3) // 4 * 4
             if cur_end is None:
@@ -58,11 +77,15 @@ class GradReducer:
             cur_start = start
             cur_n += 1
             self.bucket_of[i] = len(self.buckets)
-            if (cur_end - cur_start) * 4 >= bucket_bytes:
+            if (cur_end - cur_start) * 4 >= target:
                 self.buckets.append([cur_start, cur_end, cur_n])
+                remaining -= (cur_end - cur_start) * 4
+                target = max(bucket_bytes, remaining // 2) if geometric else bucket_bytes
                 cur_end, cur_n = None, 0
         if cur_n:
             self.buckets.append([cur_start, cur_end, cur_n])
+        self._stream_objs = {}
+        self._dev_index = flat_grad.device.index if flat_grad.is_cuda else None
         self._reset()
         self._hooks = []
         if self.active:
@@ -100,12 +123,17 @@ class GradReducer:
             # before a single collective ran (profiles/r04_dp_world1.txt).
             from . import streams
             comm = streams.comm_stream(self.flat_grad.device)
-            producers = dict(self._producers[b])
             cur = torch.cuda.current_stream()
+            producers = dict(self._producers[b])
             producers[cur.cuda_stream] = cur
             for sid, st in producers.items():
-                if sid != comm.cuda_stream:
-                    comm.wait_stream(st)
+                if sid == comm.cuda_stream:
+                    continue
+                if st is None:                    # noted by its raw handle only: the Stream object, once per distinct stream
+                    st = self._stream_objs.get(sid)
+                    if st is None:
+                        st = self._stream_objs[sid] = torch.cuda.ExternalStream(sid, device=self.flat_grad.device)
+                comm.wait_stream(st)
             with torch.cuda.stream(comm):
                 if _MODE == "skip":
                     pass
@@ -137,9 +165,16 @@ class GradReducer:
                 return
             self._fired[i] = True
             if self.flat_grad.is_cuda:
-                for st in (torch.cuda.current_stream(), producer):
-                    if st is not None:
-                        self._producers[b][st.cuda_stream] = st
+                # The producing streams are noted by their RAW handles: torch.cuda.current_stream() builds a Stream object
+                # through several Python layers (~10 us per call; 215 parameters report per SP step = 2 ms of host time inside
+                # backward -- what the data-parallel path cost at world 1 in round 4, profiles/r05_dp_world1.txt).  A Stream
+                # object is looked up (once per distinct stream) only when a bucket is launched.
+                prod = self._producers[b]
+                raw = _raw_current_stream(self._dev_index)
+                if raw not in prod:
+                    prod[raw] = None
+                if producer is not None and producer.cuda_stream not in prod:
+                    prod[producer.cuda_stream] = producer
             self._pending[b] -= 1
             if self._pending[b] == 0 and not self._launched[b]:
                 self._launch(b)
@@ -157,7 +192,9 @@ class GradReducer:
                     self._launch(b)
         finally:
             self._in_wait = False
-        if _MODE == "lastwait":
+        if _MODE == "lastwait" and self.flat_grad.is_cuda and dist.get_backend(self.group) == "nccl":
+            # RCCL runs a process group's collectives of one device in issue order on ONE internal stream: ordering the
+            # optimizer's stream behind the LAST bucket orders it behind all of them (one stream wait instead of one per bucket)
             if self._handles:
                 self._handles[-1].wait()
         else:
@@ -191,10 +228,10 @@ class GradReducer:
 
 
 def attach(optimizer, bucket_bytes: int = 25 * 1024 * 1024, group=None, force: Optional[bool] = None,
-           record_events: bool = False) -> GradReducer:
+           record_events: bool = False, geometric: bool = True) -> GradReducer:
     """Wire a GradReducer to a FusedAdam: reduce before the step, average inside the Adam kernel."""
     red = GradReducer(optimizer.flat_g, optimizer.params, optimizer.offsets, bucket_bytes, group, optimizer.flat_p,
-                      force=force, record_events=record_events)
+                      force=force, record_events=record_events, geometric=geometric)
     optimizer.pre_step_hooks.append(red.wait)
     optimizer.grad_scale = red.grad_scale
     if red.active:

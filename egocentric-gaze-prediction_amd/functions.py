@@ -24,14 +24,19 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """Logical (B,C,H,W) tensor -> contiguous (B,H,W,C) buffer (zero-copy when already channels_last).  The abs-max scalar
     the producing kernel attached to ``x`` (hipops.carry_absmax) follows the values."""
     am = getattr(x, "_egz_absmax", None)
+    pre = getattr(x, "_egz_presplit", False)
     x = x.detach()
     xp = x.permute(0, 2, 3, 1)
     if not xp.is_contiguous():
+        if pre:
+            raise RuntimeError("a pre-split activation was re-laid out (it holds f16 pairs, not fp32 values)")
         if not x.is_contiguous():
             x = x.contiguous()
         xp = H.nchw_to_nhwc(x)
     if am is not None:
         xp._egz_absmax = am
+    if pre:
+        xp._egz_presplit = True
     return xp
 
 
@@ -128,6 +133,15 @@ class ConvBNReLUPool(torch.autograd.Function):
         defer = bool(training and not pool and next_k and out_buf is None and not padded and (C <= 32 or first)
                      and (not first or (C <= 3 and K == 32))
                      and H.bn_defer_ok(Bx, Hx, Wx, K, next_k, first))
+        # x holds pre-split activations (the block below stored f16 pairs, hipops.PRESPLIT): this block's convolution and weight
+        # gradient stage them without a split
+        pre_in = bool(getattr(x, "_egz_presplit", False))
+        if pre_in and (first or padded or not training or bn_in is not None):
+            raise RuntimeError("a pre-split activation reached a block that cannot take it")
+        # ... and this block's own output goes out pre-split when its consumer is the next conv-BN-ReLU block of the stack and
+        # that block's launches can take it (the wide VGG layers, utils.py:64-76)
+        presplit_out = bool(training and next_k and out_buf is None and not defer
+                            and H.presplit_ok(Bx, Hx // 2 if pool else Hx, Wx // 2 if pool else Wx, K, next_k))
         if padded:
             # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
             # for this one layer); the packed weight is padded the same way by the pack kernel
@@ -136,13 +150,14 @@ class ConvBNReLUPool(torch.autograd.Function):
             H.ALGO_CHANNELS[0] = C
             try:
                 y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
-                                        epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3, streamed=st)
+                                        epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3, streamed=st,
+                                        want_bound=presplit_out)
             finally:
                 H.ALGO_CHANNELS[0] = None
         elif first:
             xin = H._req(x.detach(), "network input (NCHW)")
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training,
-                                       want_minmax=defer)
+                                       want_minmax=defer, want_bound=presplit_out)
         else:
             bn_src = getattr(x, "_egz_bn_src", None) if training else None
             xin = to_nhwc(x)
@@ -167,7 +182,7 @@ class ConvBNReLUPool(torch.autograd.Function):
                 raise RuntimeError("deferred BatchNorm: the convolution did not land on the streamed split-half kernel")
             y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
                                     epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt, streamed=st,
-                                    bn_in=bn_in, want_minmax=defer)
+                                    bn_in=bn_in, want_minmax=defer, pre_in=pre_in, want_bound=presplit_out)
         B, Hh, Ww, _ = y.shape
         if training and not first and C <= 32 and K <= 32 and ctx.needs_input_grad[0]:
             # narrow (late-fusion) layer: build the data-gradient packing now -- in the backward pass the 5 us pack launch sits
@@ -184,17 +199,22 @@ class ConvBNReLUPool(torch.autograd.Function):
             out = y
             out._egz_absmax = am
         else:
+            mm = getattr(y, "_egz_mm", None) if presplit_out else None      # (absent: the conv took a route without the bound)
+            pam = None
             if training:
                 coef = H.bn_finalize(stat, float(B * Hh * Ww), gamma.detach(), beta.detach(), running_mean,
-                                     running_var, momentum, eps, nbt)
+                                     running_var, momentum, eps, nbt, mm=mm)
+                if mm is not None:
+                    coef, pam = coef
             else:
                 coef = H.bn_eval_coeffs(gamma, beta, running_mean, running_var, eps)
-            out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf)
+            out = H.bn_relu_pool_fwd(y, coef, pool, out=out_buf, presplit_am=pam)
         # max |xin| (left on xin by its producer, or by the conv launch above): the weight gradient scales x with it
         ctx.save_for_backward(xin, y, coef, weight, bias, gamma, beta, getattr(xin, "_egz_absmax", None),
                               *(bn_src if bn_src is not None else (None, None)))
         ctx.cfg = (training, pool, first, C, K, padded)
         ctx.deferred_in = bn_in is not None
+        ctx.x_pre = pre_in
         if bn_in is not None and bn_src is None:
             ctx.deferred_coef = bn_in                  # (no fused BN sums: the weight gradient still needs the coefficients)
         res = from_nhwc(out)
@@ -263,7 +283,7 @@ class ConvBNReLUPool(torch.autograd.Function):
                         x_bn = None
                         if ctx.deferred_in:
                             x_bn = bn_coef if bn_coef is not None else ctx.deferred_coef
-                        dw = H.conv3x3_wgrad(xin, dy, out=sw, x_bn=x_bn)
+                        dw = H.conv3x3_wgrad(xin, dy, out=sw, x_bn=x_bn, x_pre=ctx.x_pre)
         dx = data_grad()
         # (the coefficient rows of a deferred input are read by the detached weight-gradient kernel too: keep them alive for it)
         _close_fork(f, sw, dw, xin, dy, (bn_coef if bn_coef is not None else getattr(ctx, "deferred_coef", None))

@@ -511,6 +511,8 @@ def carry_absmax(dst: torch.Tensor, src) -> torch.Tensor:
     am = getattr(src, "_egz_absmax", None) if isinstance(src, torch.Tensor) and src.dtype != torch.int32 else src
     if am is not None:
         dst._egz_absmax = am
+    if isinstance(src, torch.Tensor) and getattr(src, "_egz_presplit", False):
+        dst._egz_presplit = True          # (the tensor holds f16 pairs, not fp32 values: see PRESPLIT)
     return dst
 
 
@@ -527,6 +529,35 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
     return am
 
 
+# Pre-split activations (round 5).  Every split-half launch re-derives the f16 hi / lo pair of each staged
+# activation from fp32 on the vector ALU -- ~3.5 instructions per staged float inside kernels that sit at the chip's power limit
+# (timing-only builds without the split: conv fwd / dgrad -4 ... -5 %, weight gradient -7.5 % on the microbenchmark, more inside
+# the step: profiles/r05_presplit_gonogo.txt).  Where the producer of an activation is a streaming pass that knows the
+# tensor's EXACT abs-max before it writes the first element, it stores the pair instead of the fp32 value (same 4 bytes per
+# element): the [BatchNorm -> ReLU (-> pool)] pass of an encoder block whose consumer is the next block's convolution.  The
+# abs-max comes from the per-channel max / min of the conv output (atomic max in the conv's statistics epilogue) pushed through
+# the BatchNorm's monotonic map by egz_bn_finalize_bound.  Consumers (the next conv's forward and weight gradient) then stage
+# the pair without touching the vector ALU; the pair is bit-identical to the one they would have formed, so every result is.
+# EGAZE_PRESPLIT=0 keeps fp32 activations everywhere (A/B runs; test_presplit_activations_bit_identical flips the constant).
+PRESPLIT = _os.environ.get("EGAZE_PRESPLIT", "1") != "0"
+PRESPLIT_STATS = {"produced": 0, "fwd": 0, "wgrad": 0}
+
+
+def presplit_ok(B: int, H: int, W: int, C: int, K_next: int) -> bool:
+    """Can the (B, H, W, C) output of a train-mode [BN -> ReLU (-> pool)] block be stored pre-split for a consuming 3x3 conv
+    with K_next filters?  Needs the f16 x3 policy with forward scaling, the streamed kernel's 64- / 128-column tiles without
+    split-K for the consumer's forward and the split-half 9-tap kernel for its weight gradient."""
+    if not (PRESPLIT and PRECISION == "split" and GRAD_SPLIT == "f16" and FWD_SCALE and STREAMED):
+        return False
+    if C % 64 != 0 or K_next % 64 != 0 or C > 512 or 4 * B * H * W * C >= _SPLIT_MAX_BYTES:
+        return False
+    if not LIB.egz_conv3x3_streamed_ok(B, H, W, C, K_next, 0):
+        return False
+    if SPLITK and LIB.egz_conv3x3_streamed_splits(B, H, W, C, K_next) > 1:
+        return False
+    return bool(LIB.egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K_next))
+
+
 # FLOP accounting of a launch over a zero-PADDED operand (the 20-channel flow stack runs as 32 channels): the algorithmic count
 # prices the real channels (VERDICT r3: the padded count over-stated the step's FLOPs by 0.3 %).  Set around the launch.
 ALGO_CHANNELS = [None]
@@ -534,15 +565,23 @@ ALGO_CHANNELS = [None]
 
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
                 epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None,
-                streamed: bool = False, bn_in: Optional[torch.Tensor] = None, want_minmax: bool = False):
+                streamed: bool = False, bn_in: Optional[torch.Tensor] = None, want_minmax: bool = False,
+                pre_in: bool = False, want_bound: bool = False):
     """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups.
     ups: False | 'fold' (3x3 taps on the virtual upsampled image, wp = 'fwd' packing) | 'phase' or True (four 2x2
     phase convolutions on the low-res input, 4/9 of the MACs, wp = 'ups_fwd' packing).
     ``bn_in``: x is the PRE-BatchNorm output of the block below and bn_in its (4, C) coefficients -- the kernel normalises +
     ReLUs while staging x (deferred BatchNorm; narrow streamed geometry only, x must carry the abs-max of the normalised
     values).  ``want_minmax``: with EPI_BIAS_STATS on the narrow kernel, also return y's per-channel max / min rows as
-    ``y._egz_minmax`` (what the deferred BatchNorm of THIS layer needs)."""
+    ``y._egz_minmax`` (what the deferred BatchNorm of THIS layer needs).
+    ``pre_in``: x holds PRE-SPLIT activations (bn_relu_pool_fwd(presplit_am=...); x must carry the abs-max they were scaled
+    with) -- plain streamed f16 x3 launch with the statistics epilogue only.  ``want_bound`` (EPI_BIAS_STATS on the streamed
+    kernel's 64- / 128-column tiles, unsplit): also fold y's per-channel max / min into a 2 K-uint buffer, returned as
+    ``y._egz_mm`` (input of bn_finalize(..., mm=...)); absent when the launch took another route."""
     _req(x, "x")
+    if pre_in and not (dtype == F16X3 and streamed and not ups and epi == EPI_BIAS_STATS and bn_in is None
+                       and getattr(x, "_egz_absmax", None) is not None):
+        raise RuntimeError("a pre-split activation reached a launch that cannot take it")
     if (bn_in is not None or want_minmax) and not (dtype and streamed and not ups):
         raise RuntimeError("deferred BatchNorm operands exist on the streamed narrow kernel only")
     B, Hin, Win, C = x.shape
@@ -571,6 +610,8 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     if dtype and streamed:       # wp = fragment-ordered packing (conv_weight): weights L2 -> registers, halo through LDS
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * (ALGO_CHANNELS[0] or C))
         ns = LIB.egz_conv3x3_streamed_splits(B, H, W, C, K) if (SPLITK and epi <= EPI_BIAS_STATS) else 1
+        if ns > 1 and pre_in:
+            raise RuntimeError("a pre-split activation reached a split-K launch (hipops.presplit_ok excludes them)")
         if ns > 1:      # few pixel tiles (batch-1 inference, 14 x 14 layers at small batches): split the channel blocks
             if epi == EPI_BIAS_STATS:   # the fix-up pass emits one partial row per 32 pixels
                 stat = torch.empty((LIB.egz_conv3x3_fwd_streamed_splitk_stat_rows(B, H, W), 2, K), dtype=torch.float64,
@@ -588,10 +629,17 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
             if want_minmax:
                 mm = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
                 y._egz_minmax = mm
+            elif want_bound and K % 64 == 0 and K <= 512:
+                mm = _new_absmax(x.device)              # 2 K <= 1024 zero-filled uints: per-channel max of y and of -y
+                y._egz_mm = mm
+        if pre_in:
+            PRESPLIT_STATS["fwd"] += 1
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, 0, _p(absmax), None, _p(amo), _p(bn_in), _p(mm), _stream()),
-              "egz_conv3x3_fwd_split")
+                                           epi, dtype, 0x100 if pre_in else 0, _p(absmax), None, _p(amo), _p(bn_in), _p(mm),
+                                           _stream()), "egz_conv3x3_fwd_split")
         return y, stat
+    if pre_in:
+        raise RuntimeError("a pre-split activation reached a launch that is not on the streamed kernel")
     if dtype:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         sflags = (flags & 0x33) | (tile_flag & 0x6000)      # 0x4000: split-K tail schedule, 0x2000: no halo-tile kernel
@@ -740,7 +788,7 @@ WGRAD_TAPPACK = True      # K <= 8 filters on the narrow kernel: (tap, k) pairs 
 
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_flag: int = 0,
                   precision: Optional[str] = None, out: Optional[torch.Tensor] = None,
-                  x_bn: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  x_bn: Optional[torch.Tensor] = None, x_pre: bool = False) -> torch.Tensor:
     """-> dw (K, C, 3, 3); ``out`` = a contiguous K*C*9 destination (a gradient sink) written instead of a fresh tensor.
     ``x_bn``: x is a pre-BatchNorm tensor, normalised + ReLU'd while it is staged (deferred BatchNorm, narrow kernel only)."""
     _req(x, "x"); _req(dy, "dy")
@@ -756,6 +804,13 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
             am = absmax_of(dy)             # f16 x3 with dy scaled by its abs-max; bf16 x3 otherwise
             if FWD_SCALE:
                 xam = absmax_of(x)         # ... and the activation operand by its own (the forward pass left it on x)
+    if x_pre:      # x holds pre-split activations (see PRESPLIT): the split-half 9-tap kernel copies the pairs into its LDS image
+        if not (flags & WGRAD_SPLIT and am is not None and getattr(x, "_egz_absmax", None) is not None and not ups and x_bn is None
+                and LIB.egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K)):
+            raise RuntimeError("a pre-split activation reached a weight-gradient launch that cannot take it")
+        xam = x._egz_absmax
+        flags |= 0x8000
+        PRESPLIT_STATS["wgrad"] += 1
     nb = LIB.egz_conv3x3_wgrad_ws_bytes(B, H, W, C, K, flags)
     ws = workspace(nb, x.device)
     PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * (ALGO_CHANNELS[0] or C))
@@ -765,22 +820,26 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
 
 
 def conv_first_fwd(x_nchw: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], stats: bool,
-                   want_minmax: bool = False):
-    """``want_minmax`` (direct kernel, C <= 3 -> 32 filters, with stats): y's per-channel max / min rows as y._egz_minmax."""
+                   want_minmax: bool = False, want_bound: bool = False):
+    """``want_minmax`` (direct kernel, C <= 3 -> 32 filters, with stats): y's per-channel max / min rows as y._egz_minmax.
+    ``want_bound`` (direct kernel, with stats): the 2 K-uint atomic form as y._egz_mm (see conv3x3_fwd)."""
     _req(x_nchw, "x"); _req(w, "weight")
     B, C, H, W = x_nchw.shape
     K = w.shape[0]
     y = torch.empty((B, H, W, K), dtype=torch.float32, device=x_nchw.device)
-    stat = mm = None
+    stat = mm = mmo = None
     if stats:
         rows = LIB.egz_conv_first_stat_rows_for(B, H, W, C, K)
         stat = torch.empty((rows, 2, K), dtype=torch.float64, device=y.device)
         if want_minmax:
             mm = torch.empty((rows, 2, K), dtype=torch.float32, device=y.device)
             y._egz_minmax = mm
+        if want_bound and C <= 3 and K in (32, 64) and B * H * W * K < 2 ** 31:
+            mmo = _new_absmax(y.device)
+            y._egz_mm = mmo
     PROF.note_flops("egz_conv_first_fwd", 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv_first_fwd(x_nchw.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                 _p(mm), _stream()), "egz_conv_first_fwd")
+                                 _p(mm), _p(mmo), _stream()), "egz_conv_first_fwd")
     return y, stat
 
 
@@ -798,8 +857,10 @@ def conv_first_wgrad(x_nchw: torch.Tensor, dy: torch.Tensor, out: Optional[torch
 
 # ----------------------------------------------------------------------------- BN / ReLU / pool
 def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, running_var, momentum: float,
-                eps: float, num_batches_tracked: Optional[torch.Tensor] = None):
-    """``num_batches_tracked``: the BatchNorm's int64 counter on the device, incremented by the same launch."""
+                eps: float, num_batches_tracked: Optional[torch.Tensor] = None, mm: Optional[torch.Tensor] = None):
+    """``num_batches_tracked``: the BatchNorm's int64 counter on the device, incremented by the same launch.
+    ``mm``: the per-channel max / min buffer of the conv output (conv3x3_fwd(want_bound=True)) -> returns (coef, abs-max buffer
+    holding the EXACT max of relu(y * scale + shift)) instead of coef alone."""
     rows, _, K = stat.shape
     if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or not num_batches_tracked.is_cuda):
         raise RuntimeError("num_batches_tracked: expected an int64 HIP tensor")
@@ -808,6 +869,13 @@ def bn_finalize(stat: torch.Tensor, count: float, gamma, beta, running_mean, run
     ws = workspace(LIB.egz_bn_ws_bytes(K), dev)
     if running_mean is not None:        # written behind torch's back: invalidate what is cached on it (bn_eval_coeffs)
         running_mean._egz_epoch = getattr(running_mean, "_egz_epoch", 0) + 1
+    if mm is not None:
+        am = _new_absmax(dev)
+        check(LIB.egz_bn_finalize_bound(stat.data_ptr(), rows, K, float(count), _p(gamma), _p(beta), _p(running_mean),
+                                        _p(running_var), momentum, eps, coef[0].data_ptr(), coef[1].data_ptr(),
+                                        coef[2].data_ptr(), coef[3].data_ptr(), _p(num_batches_tracked), ws.data_ptr(),
+                                        ws.numel(), mm.data_ptr(), am.data_ptr(), _stream()), "egz_bn_finalize_bound")
+        return coef, am
     check(LIB.egz_bn_finalize(stat.data_ptr(), rows, K, float(count), _p(gamma), _p(beta), _p(running_mean),
                               _p(running_var), momentum, eps, coef[0].data_ptr(), coef[1].data_ptr(),
                               coef[2].data_ptr(), coef[3].data_ptr(), _p(num_batches_tracked), ws.data_ptr(), ws.numel(),
@@ -933,10 +1001,21 @@ def bn_folded_conv(weight, bias, gamma, beta, running_mean, running_var, eps: fl
     return wf, bf
 
 
-def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def bn_relu_pool_fwd(y: torch.Tensor, coef: torch.Tensor, pool: bool, out: Optional[torch.Tensor] = None,
+                     presplit_am: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``presplit_am``: the exact abs-max of the output (bn_finalize(..., mm=...)): the output is then stored PRE-SPLIT (f16
+    hi / lo pairs in the fp32 footprint, see PRESPLIT) and tagged ``_egz_presplit``; only conv3x3_fwd(pre_in=True) and
+    conv3x3_wgrad(x_pre=True) can read it."""
     _req(y, "y")
     B, H, W, K = y.shape
     out = _out(out, (B, H // 2, W // 2, K) if pool else (B, H, W, K), y.device)
+    if presplit_am is not None:
+        check(LIB.egz_bn_relu_pool_fwd_presplit(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), out.data_ptr(), B, H, W, K,
+                                                int(pool), presplit_am.data_ptr(), _stream()), "egz_bn_relu_pool_fwd_presplit")
+        out._egz_absmax = presplit_am
+        out._egz_presplit = True
+        PRESPLIT_STATS["produced"] += 1
+        return out
     am = _new_absmax(y.device) if _want_fwd_absmax() else None
     check(LIB.egz_bn_relu_pool_fwd(y.data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), out.data_ptr(), B, H, W, K,
                                    int(pool), _p(am), _stream()), "egz_bn_relu_pool_fwd")

@@ -131,6 +131,16 @@ int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, 
  * relu(x * scale + shift) is applied while x is staged (deferred BatchNorm, late_fusion.py:11-12), x_absmax = the max of the
  * normalised values.  Only where egz_conv3x3_wgrad_narrow_ok(B, H, W, C, K) (C, K <= 32, W % 16 == 0, flags 0x2000). */
 int egz_conv3x3_wgrad_narrow_ok(int B, int H, int W, int C, int K);
+/* Pre-split activations (round 5; the x operand of the encoder convolutions, utils.py:64-76).  The [BatchNorm -> ReLU (-> pool)]
+ * pass that writes a block output can store it as f16 hi / lo PAIRS instead of fp32 -- per 4-channel quad the 16 bytes
+ * [4 hi halves | 4 lo halves] of (value * 2^s), s from the tensor's exact abs-max, the very pair the split-half kernels
+ * would form while staging the fp32 value (same footprint, bit-identical products).  Consumers: egz_conv3x3_fwd_streamed with
+ * mode | 0x100 (mode 0, dtype 1, epi 2, K % 64 == 0, C % 32 == 0, x_absmax = the abs-max the pairs were scaled with) and
+ * egz_conv3x3_wgrad with flags | 0x8000 where egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) (C, K multiples of 64, the
+ * split-half 9-tap kernel's geometry; flags 0x2000, dy_absmax and x_absmax given, plain conv).  Producer chain:
+ * egz_conv3x3_fwd_streamed(epi 2, K % 64 == 0, minmax_out = 2 K zero-filled uints: order-preserving images of the per-channel
+ * max of y and of -y) -> egz_bn_finalize_bound -> egz_bn_relu_pool_fwd_presplit. */
+int egz_conv3x3_wgrad_presplit_ok(int B, int H, int W, int C, int K);
 
 /* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
  *      per data/STdatas.py:50-73) and Conv2d(2,32) (models/late_fusion.py:10).  K in {64, 32}. */
@@ -138,9 +148,10 @@ int egz_conv_first_stat_rows(int B, int H, int W);
 int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K);   /* rows of stat_partial egz_conv_first_fwd writes for C -> K
                                                                         * (C <= 3: the direct kernel, one row per block) */
 int egz_conv_first_fwd(const float* x_nchw, const float* w, const float* bias, float* y_nhwc, double* stat_partial,
-                       int B, int H, int W, int C, int K, float* minmax_out, hipStream_t stream);
+                       int B, int H, int W, int C, int K, float* minmax_out, unsigned int* minmax_ordered, hipStream_t stream);
 /* minmax_out (optional; C <= 3 with stat_partial): [rows][2][K] per-channel max / min of y, rows as
- * stat_partial -- input of egz_bn_finalize_deferred. */
+ * stat_partial -- input of egz_bn_finalize_deferred.  minmax_ordered (optional, same conditions): 2 K zero-filled uints, the
+ * atomic-max form egz_bn_finalize_bound reads (see egz_conv3x3_wgrad_presplit_ok). */
 size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C);
 int egz_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw, int B, int H, int W, int C, int K,
                          void* workspace, size_t ws_bytes, hipStream_t stream);
@@ -161,8 +172,19 @@ int egz_bn_finalize_deferred(const double* stat_partial, int rows, int K, double
                              float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
                              float* invstd_out, float* scale, float* shift, long long* num_batches_tracked,
                              const float* minmax, int mm_rows, unsigned int* absmax_out, hipStream_t stream);
+/* egz_bn_finalize that also bounds the block output: minmax as written by egz_conv3x3_fwd_streamed on the 64- / 128-column tiles
+ * (2 K uints), absmax_out (egz_absmax layout, zero-filled by the caller) receives the EXACT max of relu(y * scale + shift)
+ * (the map is monotonic in y per channel).  K % 64 == 0. */
+int egz_bn_finalize_bound(const double* stat_partial, int rows, int K, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, float* mean_out,
+                          float* invstd_out, float* scale, float* shift, long long* num_batches_tracked, void* workspace,
+                          size_t ws_bytes, const unsigned int* minmax, unsigned int* absmax_out, hipStream_t stream);
 int egz_bn_eval_coeffs(int K, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, hipStream_t stream);
+/* egz_bn_relu_pool_fwd with the output stored pre-split (see egz_conv3x3_wgrad_presplit_ok): absmax is an INPUT, the exact max of
+ * the output from egz_bn_finalize_bound. */
+int egz_bn_relu_pool_fwd_presplit(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W,
+                                  int K, int pool, const unsigned int* absmax, hipStream_t stream);
 int egz_bn_relu_pool_fwd(const float* y, const float* scale, const float* shift, float* out, int B, int H, int W,
                          int K, int pool, unsigned int* absmax, hipStream_t stream);   /* absmax: optional, max |out| */
 size_t egz_bn_relu_pool_bwd_ws_bytes(int K);

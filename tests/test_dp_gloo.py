@@ -45,7 +45,7 @@ def _worker(rank, world, port, q):
             flat_p[o:o + p.numel()].copy_(p.reshape(-1))
             p.data = flat_p[o:o + p.numel()].view(p.shape)
             p.grad = flat_g[o:o + p.numel()].view(p.shape)
-    red = GradReducer(flat_g, params, offsets, bucket_bytes=4096, flat_param=flat_p)
+    red = GradReducer(flat_g, params, offsets, bucket_bytes=4096, flat_param=flat_p, geometric=False)
     assert len(red.buckets) >= 2
     g = torch.Generator().manual_seed(1)
     x, y = torch.randn(8, 37, generator=g), torch.randn(8, 3, generator=g)
@@ -90,6 +90,35 @@ def test_grad_reducer_two_ranks():
     for rank in range(world):
         for step in range(2):
             assert torch.allclose(res[rank][2][step], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_bucket_sizes_halve_along_the_backward_pass():
+    """dp.GradReducer's default bucket policy: walking the parameters in backward order a bucket closes when it holds
+    max(bucket_bytes, half of the gradient bytes still to come) -- few hand-overs, a small last bucket.  Every parameter is in
+    exactly one bucket, buckets are contiguous and in backward order; ``geometric=False`` gives equal buckets."""
+    sys.path.insert(0, ROOT)
+    import egaze_amd  # noqa: F401
+    from egaze_amd.dp import GradReducer
+    sizes = [1728, 64, 36864, 64] + [589824, 256] * 12 + [2359296, 512] * 10 + [64, 1]      # an SP-like size profile, ~31 M floats
+    params = [torch.nn.Parameter(torch.empty(n)) for n in sizes]
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(off)
+    for geometric in (True, False):
+        red = GradReducer(flat, params, offsets, bucket_bytes=8 << 20, geometric=geometric)
+        assert not red.active                                   # no process group: no hooks, but the buckets are cut
+        b = red.buckets
+        assert b[0][1] == off and b[-1][0] == 0 and all(b[i][0] == b[i + 1][1] for i in range(len(b) - 1))
+        assert sum(x[2] for x in b) == len(params) and set(red.bucket_of) == set(range(len(params)))
+        nbytes = [(e - s_) * 4 for s_, e, _ in b]
+        if geometric:
+            assert nbytes[0] >= off * 4 // 2 and len(b) <= 6
+            assert all(nbytes[i] >= nbytes[i + 1] * 0.6 for i in range(len(b) - 2))     # (non-increasing up to parameter granularity)
+        else:
+            assert len(b) >= 12 and max(nbytes) < (8 << 20) + 4 * 2359296
+        print("geometric" if geometric else "equal", [round(v / 2 ** 20, 1) for v in nbytes])
 
 
 def test_rank_shard_sampler_partitions_and_pads():
@@ -181,7 +210,7 @@ def _sink_worker(rank, world, port, q):
     g_local = flat_g.clone()
     gathered = [torch.empty_like(g_local) for _ in range(world)]
     dist.all_gather(gathered, g_local)
-    red = GradReducer(flat_g, ps, offsets, bucket_bytes=2048, flat_param=flat_p)
+    red = GradReducer(flat_g, ps, offsets, bucket_bytes=2048, flat_param=flat_p, geometric=False)
     early = []
     launch = red._launch
 
@@ -280,7 +309,7 @@ def _forced_worker(rank, world, port, q):
     plain = flat_g.clone()
     idle = GradReducer(flat_g, params, offsets, bucket_bytes=512)              # world 1, not forced: a no-op
     assert not idle.active
-    red = GradReducer(flat_g, params, offsets, bucket_bytes=512, force=True)
+    red = GradReducer(flat_g, params, offsets, bucket_bytes=512, force=True, geometric=False)
     assert red.active and red.world == 1 and len(red.buckets) >= 2
     flat_g.zero_()
     (net(x) ** 2).sum().backward()

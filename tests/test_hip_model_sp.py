@@ -330,6 +330,45 @@ def test_model_sp_grads_vs_fp64_all_surveyed_seeds(monkeypatch):
     assert len(tight) >= 6, results
 
 
+@pytest.mark.parametrize("batch,size,splitk", [(2, 224, False), (2, 224, True), (3, 96, True)])
+def test_presplit_activations_bit_identical(batch, size, splitk, monkeypatch):
+    """hipops.PRESPLIT (round 5): the encoder blocks hand their outputs to the next block's convolution and weight gradient as
+    pre-split f16 pairs.  The pairs are the ones those kernels would form themselves, so the whole training step -- gaze map,
+    loss, every gradient, BatchNorm running statistics -- is BIT-IDENTICAL to the step with fp32 activations, and at 224 x 224
+    most encoder blocks take the route (the first RGB block and the last block of each encoder keep fp32)."""
+    import egaze_amd.hipops as H
+    from egaze_amd.floss import floss
+    res = []
+    # (at batch 2 the deep layers have few tiles and take split-K launches, which keep fp32 operands; with split-K off every
+    # eligible block takes the route, as at batch 32)
+    monkeypatch.setattr(H, "SPLITK", splitk)
+    for pre in (False, True):
+        monkeypatch.setattr(H, "PRESPLIT", pre)
+        for k in H.PRESPLIT_STATS:
+            H.PRESPLIT_STATS[k] = 0
+        model, _ = build_model()
+        x_s, x_t, gt, _ = synth.synth_sp_batch(batch, size, seed=9)
+        model.train()
+        out = model(x_s.to(DEV), x_t.to(DEV))
+        loss = floss().to(DEV)(out, gt.to(DEV).view(out.size()))
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in model.named_parameters()},
+                    {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k}, dict(H.PRESPLIT_STATS)))
+    (o0, l0, g0, r0, st0), (o1, l1, g1, r1, st1) = res
+    assert st0["produced"] == 0
+    print("pre-split blocks:", st1)
+    assert st1["produced"] == st1["fwd"] == st1["wgrad"]
+    if size == 224 and not splitk:
+        assert st1["produced"] >= 22, st1               # 12 of the 13 blocks of each encoder minus ... (the last block feeds the fusion)
+    assert st1["produced"] >= 1
+    assert torch.equal(o0, o1) and l0 == l1
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+
+
 def test_floss_golden_bit_exact_weights():
     import egaze_amd.hipops as h
     gold = np.load(os.path.join(GOLDEN, "floss.npz"))

@@ -927,3 +927,62 @@ def test_pack_frag_batch_matches_per_layer(monkeypatch):
     assert h.refresh_packings(ws, force=True) == len(first)        # force rebuilds regardless of tags
     for k in lazy:
         assert torch.equal(lazy[k].view(torch.int32), want[k].view(torch.int32)), k
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C,K,pool", [
+    (2, 32, 32, 64, 64, False),       # 256 x 64 tile, 16 x 16 patches; weight gradient on 4 x 8 patches? (W < 112: 1 x 32)
+    (1, 112, 112, 64, 128, True),     # pooled producer -> 56 x 56 consumer
+    (2, 28, 28, 128, 256, False),     # raster-run geometry, masked 8-wide weight-gradient patches
+    (3, 14, 14, 256, 128, False),     # 14 x 14: raster run, 2 x 16 masked patches
+    (1, 224, 224, 64, 64, False),     # the 224-wide layers: 4 x 8 patches
+    (2, 56, 56, 128, 64, True),       # pooled to 28 x 28, 64-column consumer
+])
+def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch):
+    """Pre-split activations (hipops.PRESPLIT, round 5): conv (statistics epilogue + per-channel max / min) -> egz_bn_finalize_bound
+    -> egz_bn_relu_pool_fwd_presplit -> consumer conv forward (mode | 0x100) and weight gradient (flags | 0x8000).
+    (a) the bound is the EXACT maximum of the block output (== the abs-max the fp32 form measures in its own pass);
+    (b) the stored pairs are exactly the pairs the consumers form while staging the fp32 tensor, so the consumer's forward
+        output, its BatchNorm partial sums and its weight gradient are BIT-IDENTICAL to the fp32-activation path."""
+    h = H()
+    monkeypatch.setattr(h, "SPLITK", False)              # (the small test shapes would otherwise take split-K launches)
+    x0 = rnd(B, 64, Hh, Ww, seed=301)
+    w0 = rnd(C, 64, 3, 3, seed=302, scale=(2.0 / (9 * 64)) ** 0.5)
+    b0 = rnd(C, seed=303, scale=0.1)
+    gam, bet = 1.0 + 0.3 * rnd(C, seed=304), 0.2 * rnd(C, seed=305)
+    x0d, w0d = nhwc(x0), w0.to(DEV)
+    wp0, st0 = h.conv_weight(w0d, "fwd", h.F16X3, x0d, C)
+    assert st0
+    y, stat = h.conv3x3_fwd(x0d, wp0, b0.to(DEV), C, epi=h.EPI_BIAS_STATS, dtype=h.F16X3, streamed=True, want_bound=True)
+    mm = y._egz_mm
+    # the per-channel max / min images against the tensor itself
+    yc = y.reshape(-1, C)
+    u = mm[:2 * C].view(torch.int32).cpu().numpy().astype(np.uint32)
+    dec = np.where(u & 0x80000000, u ^ np.uint32(0x80000000), ~u).astype(np.uint32).view(np.float32)
+    assert np.array_equal(dec[:C], yc.max(0).values.cpu().numpy())
+    assert np.array_equal(-dec[C:2 * C], yc.min(0).values.cpu().numpy())
+    n = float(B * Hh * Ww)
+    coef, am = h.bn_finalize(stat, n, gam.to(DEV), bet.to(DEV), None, None, 0.1, 1e-5, mm=mm)
+    coef_ref = h.bn_finalize(stat, n, gam.to(DEV), bet.to(DEV), None, None, 0.1, 1e-5)
+    assert torch.equal(coef, coef_ref)
+    out_ref = h.bn_relu_pool_fwd(y, coef, pool)
+    assert float(h.absmax_value(am)) == float(h.absmax_value(out_ref._egz_absmax)) == float(out_ref.max())
+    out_pre = h.bn_relu_pool_fwd(y, coef, pool, presplit_am=am)
+    assert out_pre._egz_presplit and out_pre.shape == out_ref.shape
+    Ho, Wo = out_ref.shape[1], out_ref.shape[2]
+    assert h.presplit_ok(B, Ho, Wo, C, K)
+    # consumer: forward + statistics
+    w1 = rnd(K, C, 3, 3, seed=306, scale=(2.0 / (9 * C)) ** 0.5).to(DEV)
+    b1 = rnd(K, seed=307, scale=0.1).to(DEV)
+    wp1, st1 = h.conv_weight(w1, "fwd", h.F16X3, out_ref, K)
+    assert st1
+    y_ref, s_ref = h.conv3x3_fwd(out_ref, wp1, b1, K, epi=h.EPI_BIAS_STATS, dtype=h.F16X3, streamed=True)
+    y_pre, s_pre = h.conv3x3_fwd(out_pre, wp1, b1, K, epi=h.EPI_BIAS_STATS, dtype=h.F16X3, streamed=True, pre_in=True)
+    assert torch.equal(y_ref, y_pre) and torch.equal(s_ref, s_pre)
+    # consumer: weight gradient
+    dy = nhwc(rnd(B, K, Ho, Wo, seed=308, scale=1e-3))
+    dw_ref = h.conv3x3_wgrad(out_ref, dy, precision="split_f16")
+    dw_pre = h.conv3x3_wgrad(out_pre, dy, precision="split_f16", x_pre=True)
+    assert torch.equal(dw_ref, dw_pre)
+    # a consumer that cannot take the pairs refuses them
+    with pytest.raises(RuntimeError):
+        h.conv3x3_fwd(out_pre, wp1, b1, K, epi=h.EPI_BIAS, dtype=h.F16X3, streamed=True, pre_in=True)

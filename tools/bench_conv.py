@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--shape", action="append", default=[], help="extra shape C,K,H,B (plain conv)")
     ap.add_argument("--dtype", type=int, default=0, help="1 = f16 x3 forward / 2 = bf16 x3 (split-half kernels)")
     ap.add_argument("--zero", action="store_true", help="all-zero operands (DVFS probe: same instruction stream, no data toggling)")
+    ap.add_argument("--relu", action="store_true", help="post-ReLU-like operands: x = relu(randn), dy masked the same way (half zeros)")
+    ap.add_argument("--presplit", action="store_true", help="also time the pre-split forms: forward with the per-channel max / min "
+                    "epilogue (+bound), forward / weight gradient over a pre-split x operand (pre)")
     ap.add_argument("--wflag", type=lambda v: int(v, 0), default=0, help="0x800 = per-tap wgrad kernel")
     a = ap.parse_args()
     dev = "cuda:0"
@@ -71,6 +74,8 @@ def main():
         dy = torch.randn(B, Hh, Hh, K, device=dev)
         if a.zero:
             x.zero_(); w.zero_(); dy.zero_()
+        if a.relu:
+            x.clamp_(min=0); dy.mul_((torch.randn_like(dy) > 0).float())
         flops = 2.0 * B * Hh * Hh * K * 9 * C
         fdt = a.dtype if (a.dtype and K % 64 == 0) else 0
         ddt = a.dtype if (a.dtype and C % 64 == 0) else 0
@@ -90,9 +95,30 @@ def main():
         if "wgrad" in a.what:
             t = timeit(lambda: H.conv3x3_wgrad(x, dy, ups=ups, variant_flag=a.wflag), a.iters)
             res.append(("wgrad", t))
+        if a.presplit and not ups and fdt == 1 and C % 64 == 0 and K % 64 == 0 and H.presplit_ok(B, Hh, Hh, C, K):
+            # a valid pre-split image of relu(x) (timing only: RNE halves instead of the kernels' RTZ hi half)
+            xr = x.clamp(min=0)
+            am = H.absmax_of(xr)
+            sc = 2.0 ** (13 - torch.frexp(H.absmax_value(am))[1].item())
+            xs = xr * sc
+            hi = xs.half()
+            lo = (xs - hi.float()).half()
+            pair = torch.cat((hi.view(B, hin, hin, C // 4, 4), lo.view(B, hin, hin, C // 4, 4)), dim=-1).contiguous()
+            xp = pair.view(torch.float32).view(B, hin, hin, C)
+            xp._egz_absmax, xp._egz_presplit = am, True
+            xr._egz_absmax = am
+            st2 = H.EPI_BIAS_STATS
+            for tag, fn in (("fwd(relu x)", lambda: H.conv3x3_fwd(xr, wp, bias, K, epi=st2, dtype=1, streamed=fst)),
+                            ("fwd+bound", lambda: H.conv3x3_fwd(xr, wp, bias, K, epi=st2, dtype=1, streamed=fst, want_bound=True)),
+                            ("fwd pre", lambda: H.conv3x3_fwd(xp, wp, bias, K, epi=st2, dtype=1, streamed=fst, pre_in=True)),
+                            ("fwd pre+bound", lambda: H.conv3x3_fwd(xp, wp, bias, K, epi=st2, dtype=1, streamed=fst, pre_in=True, want_bound=True)),
+                            ("wgrad(relu x)", lambda: H.conv3x3_wgrad(xr, dy, precision="split_f16")),
+                            ("wgrad pre", lambda: H.conv3x3_wgrad(xp, dy, precision="split_f16", x_pre=True))):
+                res.append((tag, timeit(fn, a.iters)))
         line = f"{name}  {flops/1e9:7.1f} GF"
         for k, t in res:
             tf = flops / (t * 1e-3) / 1e12
+            tot.setdefault(k, [0.0, 0.0])
             tot[k][0] += flops
             tot[k][1] += t
             line += f" | {k} {t*1e3:7.0f} us {tf:6.1f} TF {100*tf/PEAK:4.1f}%"
