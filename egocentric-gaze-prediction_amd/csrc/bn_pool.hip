@@ -85,7 +85,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part2, int nparts,
         auto from_ordered = [](unsigned int u) -> float {
             return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
         };
-        const float ymax = from_ordered(minmax[k]), ymin = -from_ordered(minmax[K + k]);
+        unsigned int umx = 0, umn = 0;                       // 1024 / (2 K) slot sets of 2 K uints (unused sets hold zeros = lowest)
+        for (int sl = 0; sl < (512 / K > 0 ? 512 / K : 1); ++sl) {
+            const unsigned int a = minmax[sl * 2 * K + k], b = minmax[sl * 2 * K + K + k];
+            umx = a > umx ? a : umx;
+            umn = b > umn ? b : umn;
+        }
+        const float ymax = from_ordered(umx), ymin = -from_ordered(umn);
         float bound = fmaxf(fmaxf(__builtin_fmaf(ymax, sc, shift[k]), __builtin_fmaf(ymin, sc, shift[k])), 0.f);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o));
@@ -686,8 +692,8 @@ EGZ_API int egz_bn_finalize(const double* stat_partial, int rows, int K, double 
     return 0;
 }
 
-// egz_bn_finalize that also bounds the block output: minmax = the 2 K uints egz_conv3x3_fwd_streamed's minmax_out received on the
-// 64- / 128-column tiles (order-preserving images of the per-channel max of y and of -y), absmax_out (egz_absmax layout,
+// egz_bn_finalize that also bounds the block output: minmax = the 1024 uints egz_conv3x3_fwd_streamed's minmax_out received on the
+// 64- / 128-column tiles (1024 / (2 K) sets of order-preserving images of the per-channel max of y and of -y), absmax_out (egz_absmax layout,
 // zero-filled by the caller) receives the EXACT max of relu(y * scale + shift) over the whole tensor -- what
 // egz_bn_relu_pool_fwd_presplit needs before it writes the first element.  K % 64 == 0.
 EGZ_API int egz_bn_finalize_bound(const double* stat_partial, int rows, int K, double count, const float* gamma,

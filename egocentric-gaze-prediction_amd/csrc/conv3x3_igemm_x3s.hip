@@ -87,8 +87,8 @@ enum { PLAIN = 0, UPSD = 1, UPSF = 2 };
 // footprint as fp32).  The staging then moves the quad into the hi / lo planes of the LDS image without touching the vector
 // ALU: ~3.5 VALU per staged float gone from a kernel that sits at the chip's power limit (profiles/r05_presplit_gonogo.txt).
 // The pair is bit-identical to what the split-at-staging form computes, so is the result.
-// mm_out (EPI_BIAS_STATS, wide tiles): 2 K uints, ZERO-FILLED by the caller: order-preserving integer images of the per-channel
-// max of y (slot k) and of -y (slot K + k), folded in with atomic max (exact and order independent: deterministic) -- what
+// mm_out (EPI_BIAS_STATS, wide tiles): 1024 uints, ZERO-FILLED by the caller = 1024 / (2 K) sets of 2 K: order-preserving integer images
+// of the per-channel max of y (slot k of a set) and of -y (slot K + k), folded in with atomic max (exact and order independent: deterministic) -- what
 // egz_bn_finalize needs to bound the [BatchNorm -> ReLU] output BEFORE the pass that writes it runs.
 __device__ __forceinline__ unsigned int ordered_bits(float f) {
     const unsigned int b = __float_as_uint(f);
@@ -531,6 +531,20 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     double s1 = 0.0, s2 = 0.0, s1b[SR], s2b[SR];
     float amx = 0.f;
     float cmx = -INFINITY, cmn = INFINITY;                      // mm_out: this lane's column max / min of y
+    // mm_out holds 1024 / (2 K) slot sets of 2 K uints (K = 64: eight): a tile folds into set (pixel tile % sets), so the
+    // blocks of a round spread their atomics over several lines per channel; the current slot values are requested HERE, in
+    // front of the store loop, and compared behind it -- read at the end they cost every tile one exposed L2 round trip
+    // (a tenth of a 64-channel tile's time).
+    unsigned int* mm_p = nullptr;
+    unsigned int seen_mx = 0, seen_mn = 0;
+    if (EPI == EPI_BIAS_STATS && mm_out) {                      // block-uniform
+        const int nsl = 512 / K > 0 ? 512 / K : 1;
+        mm_p = mm_out + (tile_m % nsl) * 2 * K + (nok ? col : 0);
+        if (hl == 0 && nok) {
+            seen_mx = __hip_atomic_load(mm_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen_mn = __hip_atomic_load(mm_p + K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // The result goes out through BUFFER stores whose per-lane byte offset is out of range for rows / columns that do not exist
     // (dropped by the hardware): no per-lane branch around a store.  With `if (valid) y[...] = v` every store sat in its own
     // basic block and the wait-count pass put s_waitcnt vmcnt(0) in front of each one -- 32-64 stores per wave, each waiting
@@ -598,8 +612,8 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                 if (EPI == EPI_BIAS_STATS) {                   // (fp64 per element: the variance is a difference of these two
                     s1 += (double)vs;                          //  sums, and fp32 partial sums over 16 rows already cost the
                     s2 += (double)vs * (double)vs;             //  gradients their fp32-class accuracy -- test_model_sp_grads_vs_fp64)
-                    cmx = fmaxf(cmx, ok ? v : -INFINITY);
-                    cmn = fminf(cmn, ok ? v : INFINITY);
+                    cmx = fmaxf(cmx, v);                       // (rows that do not exist: only in a raster run's last tile, redone below;
+                    cmn = fminf(cmn, v);                       //  the column test is at the commit)
                 }
                 continue;
             }
@@ -629,15 +643,28 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         }
     }
     if (EPI == EPI_BIAS_STATS && mm_out) {                      // block-uniform
+        if (!PATCH && m0 + BM > M) {
+            // the last tile of a raster run has rows past the image: the maxima above saw their (bias-only) values -- take them
+            // again over the rows that exist (a per-element select in the store loop cost 17 spilled registers)
+            cmx = -INFINITY;
+            cmn = INFINITY;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = Ro[wm * RPW + mr * 32 + egz_acc_row(r, lane)] >= 0;
+                    const float v = acc[mr][r] * out_scale + bz;
+                    cmx = fmaxf(cmx, ok ? v : -INFINITY);
+                    cmn = fminf(cmn, ok ? v : INFINITY);
+                }
+        }
         cmx = fmaxf(cmx, __shfl_xor(cmx, 32));
         cmn = fminf(cmn, __shfl_xor(cmn, 32));
         if (hl == 0 && nok) {
-            unsigned int* pm = mm_out + col;
+            // (seen_mx / seen_mn were requested before the store loop: an atomic is issued only where this tile raises the slot)
             const unsigned int umx = ordered_bits(cmx), umn = ordered_bits(-cmn);
-            if (umx > __hip_atomic_load(pm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                __hip_atomic_fetch_max(pm, umx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (umn > __hip_atomic_load(pm + K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                __hip_atomic_fetch_max(pm + K, umn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (umx > seen_mx) __hip_atomic_fetch_max(mm_p, umx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (umn > seen_mn) __hip_atomic_fetch_max(mm_p + K, umn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (EPI == EPI_BIAS_STATS || EPI == EPI_MASK_SUMS || EPI == EPI_BNSUMS) {
@@ -1501,7 +1528,7 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
     // minmax_out (epi 2): narrow geometry: [egz_conv3x3_streamed_stat_rows][2][K] per-channel max / min rows of y;
     // 64- / 128-column tiles (K % 64 == 0): 2 K uints, zero-filled by the caller: order-preserving integer images of the
     // per-channel max of y and of -y (atomic max; egz_bn_finalize's `minmax` argument)
-    const bool wide_mm = minmax_out && K % 64 == 0 && mode == 0 && epi == EPI_BIAS_STATS && !bn_coef;
+    const bool wide_mm = minmax_out && K % 64 == 0 && K <= 512 && mode == 0 && epi == EPI_BIAS_STATS && !bn_coef;
     EGZ_CHECK_ARG(wide_mm || !((bn_coef && epi != EPI_BNSUMS) || minmax_out) || (mode == 0 && x3p_narrow_ok(B, H, W, C, K) && (dtype == 1 || dtype == 2) &&
                   epi != EPI_MASK_SUMS && (!minmax_out || epi == EPI_BIAS_STATS)),
                   "egz_conv3x3_fwd_streamed: a deferred-BatchNorm input (bn_coef) exists on the narrow persistent kernel only (C, K <= 32, "

@@ -138,8 +138,8 @@ int egz_conv3x3_wgrad_narrow_ok(int B, int H, int W, int C, int K);
  * mode | 0x100 (mode 0, dtype 1, epi 2, K % 64 == 0, C % 32 == 0, x_absmax = the abs-max the pairs were scaled with) and
  * egz_conv3x3_wgrad with flags | 0x8000 where egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) (C, K multiples of 64, the
  * split-half 9-tap kernel's geometry; flags 0x2000, dy_absmax and x_absmax given, plain conv).  Producer chain:
- * egz_conv3x3_fwd_streamed(epi 2, K % 64 == 0, minmax_out = 2 K zero-filled uints: order-preserving images of the per-channel
- * max of y and of -y) -> egz_bn_finalize_bound -> egz_bn_relu_pool_fwd_presplit. */
+ * egz_conv3x3_fwd_streamed(epi 2, K % 64 == 0, K <= 512, minmax_out = 1024 zero-filled uints: 1024 / (2 K) sets of order-preserving
+ * images of the per-channel max of y and of -y) -> egz_bn_finalize_bound -> egz_bn_relu_pool_fwd_presplit. */
 int egz_conv3x3_wgrad_presplit_ok(int B, int H, int W, int C, int K);
 
 /* ---- first conv of a stack, small Cin, NCHW input: Conv2d(3,64) / Conv2d(20,64) (utils.py:70 at SP.py:53, inputs
@@ -150,7 +150,7 @@ int egz_conv_first_stat_rows_for(int B, int H, int W, int C, int K);   /* rows o
 int egz_conv_first_fwd(const float* x_nchw, const float* w, const float* bias, float* y_nhwc, double* stat_partial,
                        int B, int H, int W, int C, int K, float* minmax_out, unsigned int* minmax_ordered, hipStream_t stream);
 /* minmax_out (optional; C <= 3 with stat_partial): [rows][2][K] per-channel max / min of y, rows as
- * stat_partial -- input of egz_bn_finalize_deferred.  minmax_ordered (optional, same conditions): 2 K zero-filled uints, the
+ * stat_partial -- input of egz_bn_finalize_deferred.  minmax_ordered (optional, same conditions): 1024 zero-filled uints (the first 2 K are written), the
  * atomic-max form egz_bn_finalize_bound reads (see egz_conv3x3_wgrad_presplit_ok). */
 size_t egz_conv_first_wgrad_ws_bytes(int B, int H, int W, int C);
 int egz_conv_first_wgrad(const float* x_nchw, const float* dy_nhwc, float* dw, int B, int H, int W, int C, int K,
@@ -173,7 +173,7 @@ int egz_bn_finalize_deferred(const double* stat_partial, int rows, int K, double
                              float* invstd_out, float* scale, float* shift, long long* num_batches_tracked,
                              const float* minmax, int mm_rows, unsigned int* absmax_out, hipStream_t stream);
 /* egz_bn_finalize that also bounds the block output: minmax as written by egz_conv3x3_fwd_streamed on the 64- / 128-column tiles
- * (2 K uints), absmax_out (egz_absmax layout, zero-filled by the caller) receives the EXACT max of relu(y * scale + shift)
+ * (1024 uints), absmax_out (egz_absmax layout, zero-filled by the caller) receives the EXACT max of relu(y * scale + shift)
  * (the map is monotonic in y per channel).  K % 64 == 0. */
 int egz_bn_finalize_bound(const double* stat_partial, int rows, int K, double count, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float momentum, float eps, float* mean_out,

@@ -177,31 +177,40 @@ def test_model_sp_train_step_headline_size():
     for k, v in sd_hip.items():
         assert rel(v.numpy(), sd[k].numpy()) < 1e-4, k
     # Element-wise, in the launch geometry the bench times (default split-K decisions, default streams, 3136 / 6272 tiles per
-    # launch): a mis-indexed tile that preserves a norm does not preserve the entries.  Every tensor: direction and
-    # size (cosine >= 0.995, norm within 3 %); the named weight tensors (decoder head and tail, fusion, first flow conv, last
-    # RGB conv), every bias and every BatchNorm affine parameter: >= 98 % of the entries within 2e-3 of max |ref|
-    # (mostly_close: a ReLU / max-pool subgradient flip moves single filters, an indexing bug moves everything).  Biases in
-    # front of a train-mode BatchNorm have analytically zero gradients (functions._zero_bias_grad): those must be ~0 here.
+    # launch): a mis-indexed tile that preserves a norm does not preserve the entries.  What the whole model can
+    # carry at this size, measured against an fp64 run of the same step (tests/report_headline_grads.py,
+    # profiles/r05_headline_grads.txt): everything ABOVE the two-stream max (decoder, bn) agrees entry by entry (100 % of the
+    # entries within 2e-3 of max |ref|, L2 1e-3 ... 1e-6 -- the fp32 reference's own distance from fp64); the max over the two
+    # streams and the encoders' top ReLUs flip on |z| ~ 1e-7 ties under ANY change of fp32 rounding, and from there down
+    # every encoder tensor of either implementation sits 0.5-1.1 % (L2) from the fp64 gradient -- the CPU fp32 reference itself
+    # has only 36-99 % of its entries within 2e-3 of the truth there.  So: every tensor: direction and size (cosine >= 0.9995,
+    # norm within 3 %); decoder.*, bn.*: >= 98 % of the entries within 2e-3 (fusion.weight, the first tensor below the max:
+    # >= 97 %); encoder tensors: relative L2 distance <= 3 % (observed 1.2 %, the reference's own 0.6-0.75 % plus ours).  The
+    # arithmetic of each convolution IN THIS GEOMETRY is pinned entry by entry without the flips by
+    # tests/test_hip_ops.py::test_conv_ops_elementwise_at_the_headline_geometry.
     gabs = max(g.abs().max().item() for g in grads.values())
-    named = {"decoder.28.weight", "decoder.24.weight", "fusion.weight", "features_t.0.weight", "features_s.40.weight"}
-    worst_frac, worst_cos, checked = 1.0, 1.0, 0
+    worst_frac, worst_cos, worst_l2, checked = 1.0, 1.0, 0.0, 0
     for k, ref in grads.items():
         g = full[k]
         assert tuple(g.shape) == tuple(ref.shape), k
-        if ref.abs().max().item() < 1e-5 * gabs:
+        if ref.abs().max().item() < 1e-5 * gabs:            # biases in front of a train-mode BatchNorm: analytically zero
             assert g.abs().max().item() < 1e-4 * gabs, k
             continue
         c, rn = cos_norm(g.numpy(), ref.numpy())
         worst_cos = min(worst_cos, c)
-        assert c >= 0.995 and abs(rn - 1) <= 0.03, (k, c, rn)
-        if k in named or k.endswith(".bias") or ref.dim() == 1:
-            good, frac = mostly_close(g.numpy(), ref.numpy())
+        assert c >= 0.9995 and abs(rn - 1) <= 0.03, (k, c, rn)
+        if k.startswith(("decoder.", "bn.", "fusion.")):
+            good, frac = mostly_close(g.numpy(), ref.numpy(), frac=0.97 if k.startswith("fusion.") else 0.98)
             worst_frac = min(worst_frac, frac)
             checked += 1
             assert good, (k, frac)
-    assert checked >= len(named) + 40
-    print(f"B=32 224x224 element-wise: worst cosine {worst_cos:.6f} over all tensors; {checked} tensors (named weights, biases, "
-          f"BN affine) with >= {worst_frac:.4f} of their entries within 2e-3 of max|ref|")
+        else:
+            l2 = float(np.linalg.norm(g.double().numpy() - ref.double().numpy()) / np.linalg.norm(ref.double().numpy()))
+            worst_l2 = max(worst_l2, l2)
+            assert l2 <= 3e-2, (k, l2)
+    assert checked >= 28
+    print(f"B=32 224x224 element-wise: worst cosine {worst_cos:.6f} over all tensors; {checked} decoder / bn / fusion tensors with >= "
+          f"{worst_frac:.4f} of their entries within 2e-3 of max|ref|; encoder tensors within {worst_l2:.2e} (L2) of the oracle")
 
 
 # Element-wise gradient checks at 32 x 32.  The encoders end at 2 x 2 (B = 3: twelve samples per channel), so ONE
