@@ -327,7 +327,7 @@ def main():
         # -> tools/pmc_traffic.py; gfx950 FETCH half-count corrected).  The profile is stamped with a hash of the kernel
         # sources it was taken from: if the kernels changed since, the number is NOT quoted (traffic = null).
         traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if not split or tj.get("kernel_src_sha") == kernel_src_sha():
@@ -350,7 +350,7 @@ def main():
                                    "launches, exact-f32 MFMA)") +
                                   "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
                                   "timed with HIP events on the launch stream with stream concurrency off, as in "
-                                  "profiles/r04_bench_b32_kernel_stats_streams0.txt",
+                                  "profiles/r05_bench_b32_kernel_stats_streams0.txt",
                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
                         "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
@@ -593,12 +593,14 @@ def main():
                                                     "bracketed by barrier + synchronize, max over ranks"},
                       "at_ms_per_step": at_ms,
                       "at_roofline": (None if not at_ms else
-                                      {"bound": "latency (batched f32-MFMA GEMMs + T dependent [recurrent product + cell] launches)",
+                                      {"bound": "latency (5 batched f32-MFMA GEMM launches + 37 dependent wavefront launches of uniform-K "
+                                                "[recurrent product + cell] / cross-layer product blocks)",
                                        "achieved": 3 * 4.56e9 * (args.batch / 32.0) / (at_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": 3 * 4.56e9 * (args.batch / 32.0) / (at_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                        "samples_per_s": 16 * args.batch / (at_ms * 1e-3),
                                        "note": "config 4 shape, T=16: 4.56 GFLOP forward, x3 for forward + backward (SURVEY.md 8d); "
-                                               "the step is ~150 dependent launches, not a matrix-core workload"}),
+                                               "the step is ~75 dependent launches of 5-20 us (18 + 19 recurrence launches, 5 GEMM "
+                                               "launches, ~30 small ones), not a matrix-core workload"}),
                       "lf_step": lf_block,
                       "at_note": ("AT alone (BASELINE config 4 shape): lstmnet T=16, B=%d forward + MSE + backward + Adam, "
                                   "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),

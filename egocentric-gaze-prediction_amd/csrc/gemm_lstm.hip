@@ -93,9 +93,9 @@ constexpr int FK = 64;                             // slab depth
 // WMW x WNW waves of 32 x 32: block tile (32 WMW) x (32 WNW), 64 WMW WNW threads.  2 x 2 = the 64 x 64 tile; 1 x 1 (one wave per
 // block) for products that would otherwise leave CUs empty (egz_gemm picks the tile).
 template <int WMW, int WNW, bool A_KFAST, bool B_NFAST>
-__global__ __launch_bounds__(64 * WMW * WNW) void gemm_fast_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
-                                                                  float* __restrict__ C, const float* __restrict__ bias, int M, int N,
-                                                                  int K, long lda, long ldb, long ldc, int flags) {
+__device__ __forceinline__ void gemm_fast_body(const float* __restrict__ A, const float* __restrict__ Bm,
+                                               float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                               int K, long lda, long ldb, long ldc, int flags) {
     constexpr int TM = 32 * WMW, TN = 32 * WNW, NTHR = 64 * WMW * WNW;
     constexpr int LDA_ = TM + 4, LDB_ = TN + 4;                // LDS row pitch (16-byte aligned rows, 4-row skew of the banks)
     constexpr int NA = (TM * FK / 4) / NTHR, NB = (TN * FK / 4) / NTHR;       // float4 per thread per slab: 8 / WNW, 8 / WMW
@@ -179,6 +179,27 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_fast_kernel(const float* 
         if (flags & 2) v = fmaxf(v, 0.f);
         C[(long)m * ldc + n] = v;
     }
+}
+
+template <int WMW, int WNW, bool A_KFAST, bool B_NFAST>
+__global__ __launch_bounds__(64 * WMW * WNW) void gemm_fast_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                                  float* __restrict__ C, const float* __restrict__ bias, int M, int N,
+                                                                  int K, long lda, long ldb, long ldc, int flags) {
+    gemm_fast_body<WMW, WNW, A_KFAST, B_NFAST>(A, Bm, C, bias, M, N, K, lda, ldb, ldc, flags);
+}
+// Up to 8 products of ONE shape / stride set in one launch (blockIdx.z picks the operands): the four weight-gradient products
+// dgates^T [x | h_prev] of the AT step's backward (models/LSTMnet.py:18 under autograd) are 256 tiles each -- one launch of 1024
+// tiles instead of four dependent-looking launches of one tile per CU.
+constexpr int GEMM_MAX_BATCH = 8;
+struct GemmPtrs {
+    const float* A[GEMM_MAX_BATCH];
+    const float* B[GEMM_MAX_BATCH];
+    float* C[GEMM_MAX_BATCH];
+};
+template <int WMW, int WNW, bool A_KFAST, bool B_NFAST>
+__global__ __launch_bounds__(64 * WMW * WNW) void gemm_fast_batched_kernel(const GemmPtrs p, int M, int N, int K, long lda, long ldb,
+                                                                          long ldc, int flags) {
+    gemm_fast_body<WMW, WNW, A_KFAST, B_NFAST>(p.A[blockIdx.z], p.B[blockIdx.z], p.C[blockIdx.z], nullptr, M, N, K, lda, ldb, ldc, flags);
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -279,6 +300,38 @@ EGZ_API int egz_gemm(const float* A, const float* B, float* C, const float* bias
     }
     hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, st, A, B, C, bias, M, N, K, sam, sak, sbk, sbn, ldc, flags);
     EGZ_CHECK_LAUNCH("egz_gemm");
+    return 0;
+}
+
+// count <= 8 products C_i = op(A_i) op(B_i) (+ C_i if flags & 1) of one shape and one stride set in ONE launch; A, B, C: HOST arrays
+// of `count` device pointers.  Geometries outside the fast path of egz_gemm (whole 64 x 64 x 64 tiles, one unit stride per
+// operand, 16-byte aligned rows) run as `count` egz_gemm calls.  No bias, no ReLU.
+EGZ_API int egz_gemm_batched(const float* const* A, const float* const* B, float* const* C, int count, int M, int N, int K,
+                             long sam, long sak, long sbk, long sbn, long ldc, int flags, hipStream_t st) {
+    EGZ_CHECK_ARG(A && B && C && count > 0 && count <= GEMM_MAX_BATCH && M > 0 && N > 0 && K > 0 && !(flags & 2),
+                  "egz_gemm_batched: bad arguments (1 <= count <= 8, no ReLU)");
+    const bool a_k = (sak == 1), a_m = (sam == 1), b_n = (sbn == 1), b_k = (sbk == 1);
+    const long lda = a_k ? sam : sak, ldb = b_n ? sbk : sbn;
+    bool fast = M % GM == 0 && N % GN == 0 && K % FK == 0 && (a_k || a_m) && (b_n || b_k) && lda % 4 == 0 && ldb % 4 == 0;
+    GemmPtrs p;
+    for (int i = 0; i < count; ++i) {
+        EGZ_CHECK_ARG(A[i] && B[i] && C[i], "egz_gemm_batched: null operand %d", i);
+        fast = fast && (reinterpret_cast<uintptr_t>(A[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(B[i]) & 15) == 0;
+        p.A[i] = A[i]; p.B[i] = B[i]; p.C[i] = C[i];
+    }
+    if (!fast) {
+        for (int i = 0; i < count; ++i) {
+            const int rc = egz_gemm(A[i], B[i], C[i], nullptr, M, N, K, sam, sak, sbk, sbn, ldc, flags, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    const dim3 g(N / 64, M / 64, count), b(256);
+    if (a_k && b_n)  hipLaunchKernelGGL((gemm_fast_batched_kernel<2, 2, true, true>), g, b, 0, st, p, M, N, K, lda, ldb, ldc, flags);
+    else if (a_k)    hipLaunchKernelGGL((gemm_fast_batched_kernel<2, 2, true, false>), g, b, 0, st, p, M, N, K, lda, ldb, ldc, flags);
+    else if (b_n)    hipLaunchKernelGGL((gemm_fast_batched_kernel<2, 2, false, true>), g, b, 0, st, p, M, N, K, lda, ldb, ldc, flags);
+    else             hipLaunchKernelGGL((gemm_fast_batched_kernel<2, 2, false, false>), g, b, 0, st, p, M, N, K, lda, ldb, ldc, flags);
+    EGZ_CHECK_LAUNCH("egz_gemm_batched");
     return 0;
 }
 

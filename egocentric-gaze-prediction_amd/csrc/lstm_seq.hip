@@ -4,17 +4,20 @@
 //   forward   gates_t = gx_t (or b + h_below,t W_ih^T) + h_{t-1} W_hh^T  ->  (i,f,g,o)  ->  c_t, h_t         lstm_wave_fwd_kernel
 //   backward  dh_t = dh_out_t (or dgates_above,t W_ih_above) + dgates_{t+1} W_hh ; cell backward -> dgates_t, dc_{t-1}
 //                                                                                                          lstm_wave_bwd_kernel
-// and the launches of the L stacked layers run as a WAVEFRONT (launch s = step s - l of every layer l; see the kernels).
+// and the launches of the L stacked layers run as a WAVEFRONT (see the kernels: launch s = step s - 2 l of every layer l plus the product blocks that feed the next launch).
 // A step is latency- and per-CU-bandwidth-bound (M = batch rows <= 32, 67 MFLOP per product, a block pulls 64-512 KB of
 // weights and state through one CU's L2 port): what counts is how many CUs pull the 4 MB of W out of L2 in parallel and how few
 // dependent launches a sequence costs.  A dependent kernel boundary costs ~1.5 us on MI355X, a device-wide barrier inside a
 // persistent kernel 4-7 us (MI355X_MICROARCH.md, persistent-kernel price list), so the sequence is plain launches issued back to
 // back by ONE C-ABI call (no host round trip per step):
-//   * forward: block = 4 hidden units x all four gates = 16 rows of W (N = 16), batch tile M = 16 (x2), K split over the 4
-//     waves; 128 blocks per layer for H = 512.  The block owns everything the cell of its 4 units needs, so the point-wise
-//     part runs in the epilogue and the pre-activations never touch memory.
-//   * backward: block = 16 batch rows x 16 hidden units, K = 4H (x2 below the top layer) split over 8 waves; the reduced dh
-//     tile feeds the cell backward of exactly those (row, unit) pairs in the epilogue, which emits dgates_t.
+//   * forward: block = 4 hidden units x all four gates = 16 rows of W (N = 16), batch tile M = 16 (x2), K = H split over the 4
+//     waves; 128 blocks per role and layer for H = 512.  The block owns everything the cell of its 4 units needs, so the
+//     point-wise part runs in the epilogue and the recurrent pre-activations never touch memory.
+//   * backward: block = 16 batch rows x 16 hidden units, K = 4H split over 8 waves; the reduced dh tile feeds the cell backward
+//     of exactly those (row, unit) pairs in the epilogue, which emits dgates_t.
+//   * round 5: the products that cross layers (an upper layer's input projection; the gradient a lower layer receives) are
+//     blocks of their own one launch ahead ("product role") -- every block of a launch has the same K, where round 4's
+//     lower- / upper-layer blocks carried two segments and set the length of every launch (15.9 -> 10.1 us backward).
 // Exact f32 on v_mfma_f32_16x16x4_f32.  Operands go global/L2 -> registers as 16-byte loads: within a group of 16
 // reduction indices lane (r = l & 15, q = l >> 4) takes k = 4q .. 4q+3 of ITS row and feeds them to 4 MFMAs; the k <-> MFMA
 // pairing is the same for A and B, and a reduction index may be visited in any order.
@@ -30,15 +33,19 @@ __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); 
 constexpr int FW_UNITS = 4;        // hidden units per forward block -> N = 16 gate rows
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Wavefront form of the stacked recurrence (nn.LSTM(512, 512, num_layers = L), models/LSTMnet.py:18): launch s runs step
-// t = s - l of EVERY layer l at once -- layer l's step t needs h of the layer below at the same t (launch s - 1) and its own
-// h at t - 1 (launch s - 1) -- so the T x L dependent step launches of the layer-by-layer form become T + L - 1, and the
-// batched input projection of the upper layers (one GEMM each) disappears: a block of layer l > 0 reduces over
-// [h_{l-1,t} | h_{l,t-1}] against [W_ih | W_hh] (K = 2H).  Same block shape, MFMA pairing and summation order per segment as
-// lstm_step_fwd_kernel; the two segments' partial sums are added segment 0 (W_hh) first.
+// Wavefront form of the stacked recurrence (nn.LSTM(512, 512, num_layers = L), models/LSTMnet.py:18).  Round 5 form: every block
+// reduces over K = H only.  The input projection of an upper layer, h_{l-1,t} W_ih_l^T + b, no longer rides in that layer's step
+// block (round 4: K = 2H there, and a launch lasts as long as its largest block) but in blocks of its own ("product role") one
+// launch earlier, which park the pre-activations in gxu[l][t] -- the form layer 0's projection (one batched GEMM over all T)
+// arrives in anyway.  Launch s runs, for every layer l,
+//   cell role     step t  = s - 2 l:         gates = gx_l[t] + h_{l,t-1} W_hh_l^T -> (i, f, g, o) -> c_t, h_t
+//   product role  step t' = s - 2 l + 1  (l >= 1):  gxu_l[t'] = b_l + h_{l-1,t'} W_ih_l^T
+// -- both read what launch s - 1 wrote.  T + 2 (L - 1) launches (18 for T = 16, L = 2) on (H / 4) x (B / 32) x (2 L - 1) blocks.
 constexpr int WAVE_MAX_L = 4;
 struct WaveFwdLayer {
-    const float* gx;       // layer 0: [T][B][4H] = x W_ih^T + b_ih + b_hh of every step; upper layers: null
+    const float* gx;       // [T][B][4H] pre-activations without the recurrent term: layer 0: x W_ih^T + b_ih + b_hh of every step
+                           // (the caller's batched GEMM); upper layers: gxu, written by the product role
+    float* gxu;            // upper layers: the same buffer, writable; layer 0: null
     const float* bsum;     // upper layers: [4H] = b_ih + b_hh
     const float* w_ih;     // upper layers: [4H][H]
     const float* w_hh;     // [4H][H]
@@ -54,15 +61,16 @@ struct WaveFwdLayer {
 struct WaveFwd { WaveFwdLayer l[WAVE_MAX_L]; };
 
 template <int MT>
-__global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int s, int T, int B, int H) {
+__global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int s, int L, int T, int B, int H) {
     __shared__ float red[4][MT][256];
-    const int layer = blockIdx.z, t = s - layer;
+    const bool prod = (int)blockIdx.z >= L;                    // block-uniform role
+    const int layer = prod ? (int)blockIdx.z - L + 1 : (int)blockIdx.z;
+    const int t = prod ? s - 2 * layer + 1 : s - 2 * layer;
     if (t < 0 || t >= T) return;
     const WaveFwdLayer& p = a.l[layer];
     const long bh = (long)B * H;
     const float* h_prev = t ? p.hs + (t - 1) * bh : p.h0;
     const float* c_prev = t ? p.cs + (t - 1) * bh : p.c0;
-    const float* x_in = layer ? a.l[layer - 1].hs + t * bh : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int j0 = blockIdx.x * FW_UNITS, b0 = blockIdx.y * (16 * MT);
@@ -71,10 +79,9 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nseg = layer ? 2 : 1;
-    for (int seg = 0; seg < nseg; ++seg) {
-        const float* wp = (seg ? p.w_ih : p.w_hh) + (long)wrow * H + k0 + 4 * q;
-        const float* src = seg ? x_in : h_prev;
+    {
+        const float* wp = (prod ? p.w_ih : p.w_hh) + (long)wrow * H + k0 + 4 * q;
+        const float* src = prod ? a.l[layer - 1].hs + t * bh : h_prev;
         const float* hp[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -114,8 +121,13 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = g * 4 + u;
-            const float base = layer ? p.bsum[g * H + j0 + u] : p.gx[((long)t * B + b) * 4 * H + g * H + j0 + u];
+            const float base = prod ? p.bsum[g * H + j0 + u] : p.gx[((long)t * B + b) * 4 * H + g * H + j0 + u];
             pre[g] = base + ((red[0][m][rr * 16 + n] + red[1][m][rr * 16 + n]) + (red[2][m][rr * 16 + n] + red[3][m][rr * 16 + n]));
+        }
+        if (prod) {                                            // the upper layer's pre-activations without its recurrent term
+            float* gg_ = p.gxu + ((long)t * B + b) * 4 * H + j0 + u;
+            gg_[0] = pre[0]; gg_[H] = pre[1]; gg_[2 * H] = pre[2]; gg_[3 * H] = pre[3];
+            continue;
         }
         const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
         const long o = (long)b * H + j0 + u;
@@ -135,10 +147,16 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int
     }
 }
 
-// Backward wavefront: launch s runs the cell backward of layer l at step t = T - 1 - s + (L - 1 - l) (the top layer leads by one
-// launch per layer below it), t = -1 being that layer's final product dh_0 = dgates_0 W_hh.  A block of layer l < L - 1 reduces
-// over [dgates_{l,t+1} | dgates_{l+1,t}] against [W_hh_l | W_ih_{l+1}] (both transposed: K = 8H): the gradient w.r.t. h_{l,t}
-// from the layer above is formed in the same launch instead of one batched GEMM per layer after the layer above has finished.
+// Backward wavefront (round 5 form).  Every block reduces over K = 4H only: the product that carries the gradient from the layer
+// above, dgates_{l+1,t} W_ih_{l+1}, no longer rides in the lower layer's step block (round 4: K = 8H there, 512 KB per block
+// through one CU, and a launch lasts as long as its largest block: 15.9-17.6 us against 9.8 for a K = 4H launch) but in blocks of
+// its own ("product role") one launch earlier, which park it in dhin[l][t]; the lower layer lags the upper one by TWO launches
+// instead of one.  Launch s runs, for every layer l,
+//   cell role     step t  = T - 1 - s + 2 (L - 1 - l):  dh_t = [top: dh_out_t | below: dhin_l[t]] + dgates_{l,t+1} W_hh_l, cell backward;
+//                 t = -1 is that layer's final product dh_0 = dgates_{l,0} W_hh_l;
+//   product role  step t' = T - s + 2 (L - 2 - l)  (l < L - 1):  dhin_l[t'] = dgates_{l+1,t'} W_ih_{l+1}
+// -- both read what launch s - 1 wrote.  T + 2 L - 1 launches (19 for T = 16, L = 2) of uniform K = 4H blocks on
+// (H / 16) x (B / 16) x (2 L - 1) blocks instead of T + L (18) launches with K = 8H blocks on x L.
 struct WaveBwdLayer {
     const float* w_hh_t;     // [H][4H]
     const float* w_ih_t_up;  // W_ih of the layer ABOVE, transposed [H][4H]; null for the top layer
@@ -151,13 +169,16 @@ struct WaveBwdLayer {
     float* dgates;           // [T][B][4H] out
     float* dh0;              // [B][H] out
     float* dc;               // [B][H] running cell-state gradient = dc0 out
+    float* dhin;             // lower layers: [T][B][H] = dgates_above,t W_ih_above (written by the product role); top: null
 };
 struct WaveBwd { WaveBwdLayer l[WAVE_MAX_L]; };
 
 __global__ __launch_bounds__(512) void lstm_wave_bwd_kernel(const WaveBwd a, int s, int L, int T, int B, int H) {
     __shared__ float red[8][256];
-    const int layer = blockIdx.z, t = T - 1 - s + (L - 1 - layer);
-    if (t < -1 || t >= T) return;
+    const bool prod = (int)blockIdx.z >= L;                    // block-uniform role
+    const int layer = prod ? (int)blockIdx.z - L : (int)blockIdx.z;
+    const int t = prod ? T - s + 2 * (L - 2 - layer) : T - 1 - s + 2 * (L - 1 - layer);
+    if (prod ? (t < 0 || t >= T) : (t < -1 || t >= T)) return;
     const WaveBwdLayer& p = a.l[layer];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -165,16 +186,16 @@ __global__ __launch_bounds__(512) void lstm_wave_bwd_kernel(const WaveBwd a, int
     const int K = 4 * H, kw = K / 8, k0 = wave * kw;
     const long bk = (long)B * K, bh = (long)B * H;
     const bool cell = t >= 0;
-    const float* dg_next = (t < T - 1) ? p.dgates + (long)(t + 1) * bk : nullptr;        // own layer, step t + 1 (t = -1: step 0)
-    const float* dg_up = (cell && layer < L - 1) ? a.l[layer + 1].dgates + (long)t * bk : nullptr;
+    // the one product of this block: [16 batch rows][4H] x [16 hidden units][4H]^T
+    const float* src = prod ? a.l[layer + 1].dgates + (long)t * bk                       // dgates of the layer above, step t
+                            : ((t < T - 1) ? p.dgates + (long)(t + 1) * bk : nullptr);     // own layer, step t + 1 (t = -1: step 0)
+    const float* wsrc = prod ? p.w_ih_t_up : p.w_hh_t;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int seg = 0; seg < 2; ++seg) {
-        const float* src = seg ? dg_up : dg_next;
-        if (!src) continue;
+    if (src) {
         int b = b0 + r;
         b = b < B ? b : B - 1;
         const float* ap = src + (long)b * K + k0 + 4 * q;
-        const float* bp = (seg ? p.w_ih_t_up : p.w_hh_t) + (long)(j0 + r) * K + k0 + 4 * q;
+        const float* bp = wsrc + (long)(j0 + r) * K + k0 + 4 * q;
         for (int g0 = 0; g0 < kw; g0 += 128) {
             f32x4 av[8], bv[8];
 #pragma unroll
@@ -198,12 +219,16 @@ __global__ __launch_bounds__(512) void lstm_wave_bwd_kernel(const WaveBwd a, int
             float rec = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) +
                         ((red[4][tid] + red[5][tid]) + (red[6][tid] + red[7][tid]));
             const long o = (long)b * H + j0 + j;
-            if (!dg_next && p.dhn) rec += p.dhn[o];                 // last step: the gradient w.r.t. the returned h_n
+            if (prod) {
+                p.dhin[(long)t * bh + o] = rec;
+                return;
+            }
+            if (!src && p.dhn) rec += p.dhn[o];                     // last step: the gradient w.r.t. the returned h_n
             if (!cell) {
                 p.dh0[o] = rec;
             } else {
-                const float dhv = (p.dh_out ? p.dh_out[(long)t * bh + o] : 0.f) + rec;
-                const float dcin = dg_next ? p.dc[o] : (p.dcn ? p.dcn[o] : 0.f);
+                const float dhv = (p.dh_out ? p.dh_out[(long)t * bh + o] : 0.f) + (p.dhin ? p.dhin[(long)t * bh + o] : 0.f) + rec;
+                const float dcin = src ? p.dc[o] : (p.dcn ? p.dcn[o] : 0.f);
                 const float* aa = p.acts + ((long)t * B + b) * K + j0 + j;
                 const float gi = aa[0], gf = aa[H], gg = aa[2 * H], go = aa[3 * H];
                 const float cv = p.cs[(long)t * bh + o];
@@ -223,42 +248,44 @@ __global__ __launch_bounds__(512) void lstm_wave_bwd_kernel(const WaveBwd a, int
 
 }  // namespace
 
-// The stacked recurrence of nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step): T + L - 1 launches (see
+// The stacked recurrence of nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step): T + 2 (L - 1) launches (see
 // lstm_wave_fwd_kernel).  Host arrays of L device pointers: w_ih[l] / bsum[l] ([4H][H] / [4H] = b_ih + b_hh; entry 0 unused:
 // layer 0's input projection arrives as gx0 [T][B][4H], bias included), w_hh[l] [4H][H]; h0, c0: [L][B][H];
 // hs: [L][T + 1][B][H] out -- slot 0 of a layer = a copy of its h0, slots 1 .. T = h_1 .. h_T (so h_{t-1} for t = 1 .. T is the
 // contiguous block of slots 0 .. T - 1); cs: [L][T][B][H] out; acts: [L][T][B][4H] out or null; hn, cn: [L][B][H] out (the final
-// state).  1 <= L <= 4, H % 256 == 0.
+// state); gxu: [L - 1][T][B][4H] scratch (the upper layers' input projections; may be null at L = 1).  1 <= L <= 4, H % 256 == 0.
 EGZ_API int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
-                              const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L,
-                              int T, int B, int H, hipStream_t st) {
-    EGZ_CHECK_ARG(gx0 && w_ih && w_hh && bsum && h0 && c0 && hs && cs && hn && cn, "egz_lstm_wave_fwd: null pointer");
+                              const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn,
+                              float* gxu, int L, int T, int B, int H, hipStream_t st) {
+    EGZ_CHECK_ARG(gx0 && w_ih && w_hh && bsum && h0 && c0 && hs && cs && hn && cn && (gxu || L == 1), "egz_lstm_wave_fwd: null pointer");
     EGZ_CHECK_ARG(L >= 1 && L <= WAVE_MAX_L && T > 0 && B > 0 && H > 0 && H % 256 == 0,
                   "egz_lstm_wave_fwd: L=%d T=%d B=%d H=%d (1 <= L <= 4, H a multiple of 256)", L, T, B, H);
     WaveFwd a;
     const long bh = (long)B * H;
     for (int l = 0; l < L; ++l) {
         EGZ_CHECK_ARG(w_hh[l] && (l == 0 || (w_ih[l] && bsum[l])), "egz_lstm_wave_fwd: null weight pointer (layer %d)", l);
-        a.l[l] = WaveFwdLayer{l ? nullptr : gx0, l ? bsum[l] : nullptr, l ? w_ih[l] : nullptr, w_hh[l], h0 + l * bh, c0 + l * bh,
+        float* gl = l ? gxu + (long)(l - 1) * T * 4 * bh : nullptr;
+        a.l[l] = WaveFwdLayer{l ? gl : gx0, gl, l ? bsum[l] : nullptr, l ? w_ih[l] : nullptr, w_hh[l], h0 + l * bh, c0 + l * bh,
                               hs + ((long)l * (T + 1) + 1) * bh, cs + (long)l * T * bh, acts ? acts + (long)l * T * 4 * bh : nullptr,
                               hn + l * bh, cn + l * bh};
     }
-    for (int s = 0; s < T + L - 1; ++s) {
-        if (B <= 16) hipLaunchKernelGGL(lstm_wave_fwd_kernel<1>, dim3(H / FW_UNITS, 1, L), dim3(256), 0, st, a, s, T, B, H);
-        else         hipLaunchKernelGGL(lstm_wave_fwd_kernel<2>, dim3(H / FW_UNITS, egz_cdiv(B, 32), L), dim3(256), 0, st, a, s, T, B, H);
+    for (int s = 0; s < T + 2 * (L - 1); ++s) {
+        if (B <= 16) hipLaunchKernelGGL(lstm_wave_fwd_kernel<1>, dim3(H / FW_UNITS, 1, 2 * L - 1), dim3(256), 0, st, a, s, L, T, B, H);
+        else         hipLaunchKernelGGL(lstm_wave_fwd_kernel<2>, dim3(H / FW_UNITS, egz_cdiv(B, 32), 2 * L - 1), dim3(256), 0, st, a, s, L, T, B, H);
     }
     EGZ_CHECK_LAUNCH("egz_lstm_wave_fwd");
     return 0;
 }
 
-// Backward through time of the same stack: T + L launches.  dh_top: [T][B][H] gradient w.r.t. the top layer's outputs (or null);
-// dhn, dcn: [L][B][H] gradients w.r.t. the returned final state (or null); acts, cs, c0 as written by / passed to the forward;
-// host arrays of L device pointers: w_hh_t[l] = W_hh_l transposed [H][4H], w_ih_t[l] = W_ih_l transposed [H][4H] (entry 0 unused);
-// dgates: [L][T][B][4H] out (the caller forms dW_ih, dW_hh, db and the input gradient from them); dh0, dc0: [L][B][H] out.
+// Backward through time of the same stack: T + 2 L - 1 launches (see lstm_wave_bwd_kernel).  dh_top: [T][B][H] gradient w.r.t. the top
+// layer's outputs (or null); dhn, dcn: [L][B][H] gradients w.r.t. the returned final state (or null); acts, cs, c0 as written by /
+// passed to the forward; host arrays of L device pointers: w_hh_t[l] = W_hh_l transposed [H][4H], w_ih_t[l] = W_ih_l transposed
+// [H][4H] (entry 0 unused); dgates: [L][T][B][4H] out (the caller forms dW_ih, dW_hh, db and the input gradient from them); dh0,
+// dc0: [L][B][H] out; dhin: [L - 1][T][B][H] scratch (the gradient each lower layer receives from the layer above; unused at L = 1).
 EGZ_API int egz_lstm_wave_bwd(const float* dh_top, const float* dhn, const float* dcn, const float* acts, const float* cs,
                               const float* c0, const float* const* w_hh_t, const float* const* w_ih_t, float* dgates, float* dh0,
-                              float* dc0, int L, int T, int B, int H, hipStream_t st) {
-    EGZ_CHECK_ARG(acts && cs && c0 && w_hh_t && w_ih_t && dgates && dh0 && dc0, "egz_lstm_wave_bwd: null pointer");
+                              float* dc0, float* dhin, int L, int T, int B, int H, hipStream_t st) {
+    EGZ_CHECK_ARG(acts && cs && c0 && w_hh_t && w_ih_t && dgates && dh0 && dc0 && (dhin || L == 1), "egz_lstm_wave_bwd: null pointer");
     EGZ_CHECK_ARG(L >= 1 && L <= WAVE_MAX_L && T > 0 && B > 0 && H > 0 && H % 256 == 0,
                   "egz_lstm_wave_bwd: L=%d T=%d B=%d H=%d (1 <= L <= 4, H a multiple of 256)", L, T, B, H);
     WaveBwd a;
@@ -267,10 +294,11 @@ EGZ_API int egz_lstm_wave_bwd(const float* dh_top, const float* dhn, const float
         EGZ_CHECK_ARG(w_hh_t[l] && (l == L - 1 || w_ih_t[l + 1]), "egz_lstm_wave_bwd: null weight pointer (layer %d)", l);
         a.l[l] = WaveBwdLayer{w_hh_t[l], l < L - 1 ? w_ih_t[l + 1] : nullptr, l == L - 1 ? dh_top : nullptr,
                               dhn ? dhn + l * bh : nullptr, dcn ? dcn + l * bh : nullptr, acts + (long)l * T * 4 * bh,
-                              cs + (long)l * T * bh, c0 + l * bh, dgates + (long)l * T * 4 * bh, dh0 + l * bh, dc0 + l * bh};
+                              cs + (long)l * T * bh, c0 + l * bh, dgates + (long)l * T * 4 * bh, dh0 + l * bh, dc0 + l * bh,
+                              l < L - 1 ? dhin + (long)l * T * bh : nullptr};
     }
-    const dim3 grid(H / 16, egz_cdiv(B, 16), L);
-    for (int s = 0; s < T + L; ++s) hipLaunchKernelGGL(lstm_wave_bwd_kernel, grid, dim3(512), 0, st, a, s, L, T, B, H);
+    const dim3 grid(H / 16, egz_cdiv(B, 16), 2 * L - 1);
+    for (int s = 0; s < T + 2 * L - 1; ++s) hipLaunchKernelGGL(lstm_wave_bwd_kernel, grid, dim3(512), 0, st, a, s, L, T, B, H);
     EGZ_CHECK_LAUNCH("egz_lstm_wave_bwd");
     return 0;
 }

@@ -1345,6 +1345,25 @@ def matmul_tn(a2d: torch.Tensor, b2d: torch.Tensor, out: Optional[torch.Tensor] 
                 accumulate=accumulate)
 
 
+def matmul_tn_batched(a_list, b_list, outs=None):
+    """[a^T @ b for a, b in zip(a_list, b_list)] in ONE launch (egz_gemm_batched): every a (R, M), every b (R, N) of one shape.
+    ``outs``: per product an M*N destination (a gradient sink) or None (a fresh tensor)."""
+    n = len(a_list)
+    R, M = a_list[0].shape
+    N = b_list[0].shape[1]
+    res = []
+    for i in range(n):
+        _req(a_list[i], "A"); _req(b_list[i], "B")
+        if tuple(a_list[i].shape) != (R, M) or tuple(b_list[i].shape) != (R, N):
+            raise RuntimeError("matmul_tn_batched: the products must share one shape")
+        o = None if outs is None else outs[i]
+        res.append(torch.empty((M, N), dtype=torch.float32, device=a_list[i].device) if o is None else _out(o, (M, N), a_list[i].device))
+    PROF.note_flops("egz_gemm", 2.0 * M * N * R * n)
+    check(LIB.egz_gemm_batched(_ptr_table(a_list), _ptr_table(b_list), _ptr_table(res), n, M, N, R, 1, M, N, 1, N, 0, _stream()),
+          "egz_gemm_batched")
+    return res
+
+
 def transpose2d(x: torch.Tensor) -> torch.Tensor:
     """[R][C] -> [C][R] (LDS-tiled; W_hh -> W_hh^T for the LSTM backward)."""
     _req(x, "x")
@@ -1383,10 +1402,12 @@ def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
     acts = torch.empty((L, T, B, H4), dtype=torch.float32, device=dev) if want_acts else None
     hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
     cn = torch.empty_like(hn)
+    # the upper layers' input projections, formed one launch ahead of the step that reads them
+    gxu = torch.empty((L - 1, T, B, H4), dtype=torch.float32, device=dev) if L > 1 else None
     PROF.note_flops("egz_lstm_wave_fwd", 2.0 * T * B * H4 * Hd * (2 * L - 1))
     check(LIB.egz_lstm_wave_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh),
                                 _ptr_table([None] + list(bsum[1:])), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(),
-                                _p(acts), hn.data_ptr(), cn.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_wave_fwd")
+                                _p(acts), hn.data_ptr(), cn.data_ptr(), _p(gxu), L, T, B, Hd, _stream()), "egz_lstm_wave_fwd")
     return hs, cs, acts, hn, cn
 
 
@@ -1401,10 +1422,12 @@ def lstm_wave_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh_t, w_ih_t):
     for name, t in (("dh_top", dh_top), ("dhn", dhn), ("dcn", dcn)):
         if t is not None:
             _req(t, name)
+    # the gradient each lower layer receives from the layer above, formed one launch ahead of the cell backward that reads it
+    dhin = torch.empty((L - 1, T, B, Hd), dtype=torch.float32, device=dev) if L > 1 else None
     PROF.note_flops("egz_lstm_wave_bwd", 2.0 * (T + 1) * B * 4 * Hd * Hd * L + 2.0 * T * B * 4 * Hd * Hd * (L - 1))
     check(LIB.egz_lstm_wave_bwd(_p(dh_top), _p(dhn), _p(dcn), acts.data_ptr(), cs.data_ptr(), c0.data_ptr(),
                                 _ptr_table(w_hh_t), _ptr_table([None] + list(w_ih_t[1:])), dgates.data_ptr(), dh0.data_ptr(),
-                                dc0.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_wave_bwd")
+                                dc0.data_ptr(), _p(dhin), L, T, B, Hd, _stream()), "egz_lstm_wave_bwd")
     return dgates, dh0, dc0
 
 

@@ -82,13 +82,25 @@ class _LSTMNetFn(torch.autograd.Function):
         w_ih_t = [None] + [H.transpose2d(H._req(params[4 * l].detach(), "w_ih")) for l in range(1, L)]
         dgates, dh0, dc0 = H.lstm_wave_bwd(dh_top, dhn.contiguous() if dhn is not None else None,
                                            dcn.contiguous() if dcn is not None else None, acts, cs, c0c, w_hh_t, w_ih_t)
+        # d W_ih = dgates^T layer_in, d W_hh = sum_t dgates_t^T h_{t-1} (slots 0 .. T - 1 of hs are (h0, h_1 .. h_{T-1}): one product
+        # each) -- all 2 L products of one shape in ONE launch when C == H (egz_gemm_batched)
+        prods = []
         for l in range(L):
             layer_in = x.view(T * B, C) if l == 0 else hs[l - 1, 1:].view(T * B, Hd)
             dg2 = dgates[l].view(T * B, 4 * Hd)
             if ng[3 + 4 * l]:
-                grads[4 * l] = H.matmul_tn(dg2, layer_in, out=sinks[4 * l])                     # d W_ih
-            if ng[3 + 4 * l + 1]:       # d W_hh = sum_t dgates_t^T h_{t-1}: slots 0 .. T - 1 of hs are (h0, h_1 .. h_{T-1}), one product
-                grads[4 * l + 1] = H.matmul_tn(dg2, hs[l, :T].view(T * B, Hd), out=sinks[4 * l + 1])
+                prods.append((4 * l, dg2, layer_in))
+            if ng[3 + 4 * l + 1]:
+                prods.append((4 * l + 1, dg2, hs[l, :T].view(T * B, Hd)))
+        if len(prods) > 1 and len({tuple(b.shape) for _, _, b in prods}) == 1 and len(prods) <= 8:
+            got = H.matmul_tn_batched([a for _, a, _ in prods], [b for _, _, b in prods], [sinks[i] for i, _, _ in prods])
+            for (i, _, _), g in zip(prods, got):
+                grads[i] = g
+        else:
+            for i, a, b in prods:
+                grads[i] = H.matmul_tn(a, b, out=sinks[i])
+        for l in range(L):
+            dg2 = dgates[l].view(T * B, 4 * Hd)
             # d b_ih = d b_hh = the column sums of dgates: summed once, the second one is a copy of the first
             gb = None
             for i in (4 * l + 2, 4 * l + 3):

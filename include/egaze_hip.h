@@ -277,25 +277,33 @@ int egz_mse_fwd_grad(const float* a, const float* b, float* loss_out, float* da,
  *      op(A)(m,k) = A[m*sam + k*sak], op(B)(k,n) = B[k*sbk + n*sbn].  Gate order i,f,g,o. */
 int egz_gemm(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, long sam, long sak,
              long sbk, long sbn, long ldc, int flags, hipStream_t stream);
+/* count <= 8 products of ONE shape and stride set in one launch (blockIdx.z picks the operands): the weight-gradient products
+ * dgates^T [x | h_prev] of nn.LSTM's backward (models/LSTMnet.py:18 under autograd).  A, B, C: HOST arrays of `count` device
+ * pointers; flags bit 0 = accumulate; no bias, no ReLU.  Outside egz_gemm's fast-path geometry: `count` egz_gemm calls. */
+int egz_gemm_batched(const float* const* A, const float* const* B, float* const* C, int count, int M, int N, int K, long sam,
+                     long sak, long sbk, long sbn, long ldc, int flags, hipStream_t stream);
 int egz_lstm_cell_fwd(const float* gates, const float* c_prev, float* h_out, float* c_out, float* act, int B, int Hd,
                       hipStream_t stream);
 int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, const float* dh, const float* dc_in,
                       float* dgates, float* dc_prev, int B, int Hd, hipStream_t stream);
 /* nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step) (models/LSTMnet.py:18,26-35: self.lstm(input, hidden)): launch
- * s runs step s - l of every layer l, T + L - 1 dependent launches instead of T x L, the upper layers' input projections reduced
- * in the same launch (K = 2H).  w_ih / w_hh / bsum: HOST arrays of L device pointers ([4H][H], [4H][H], [4H] = b_ih + b_hh;
+ * s runs step s - 2 l of every layer l and, one launch ahead of the step that consumes it, the input projection of each upper
+ * layer (gxu: [L - 1][T][B][4H] scratch, may be null at L = 1): T + 2 (L - 1) dependent launches of uniform K = H blocks instead of
+ * T x L step launches + L - 1 batched GEMMs.  w_ih / w_hh / bsum: HOST arrays of L device pointers ([4H][H], [4H][H], [4H] = b_ih + b_hh;
  * w_ih[0] / bsum[0] unused: gx0 [T][B][4H] = x W_ih0^T + b_ih0 + b_hh0 for every step); h0, c0, hn, cn: [L][B][H];
  * hs: [L][T + 1][B][H] (slot 0 of a layer = a copy of its h0, slots 1 .. T = the outputs); cs: [L][T][B][H]; acts: [L][T][B][4H]
  * or null.  1 <= L <= 4, H % 256 == 0. */
 int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
-                      const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L, int T,
-                      int B, int H, hipStream_t stream);
-/* Its backward through time (autograd of the same call): T + L launches; the gradient w.r.t. a lower layer's outputs is formed
- * inside the step launches (K = 8H).  dh_top: [T][B][H] or null; dhn, dcn: [L][B][H] or null; w_hh_t / w_ih_t: HOST arrays of L
- * device pointers to the TRANSPOSED weights [H][4H] (w_ih_t[0] unused); dgates: [L][T][B][4H] out; dh0, dc0: [L][B][H] out. */
+                      const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, float* gxu,
+                      int L, int T, int B, int H, hipStream_t stream);
+/* Its backward through time (autograd of the same call): T + 2 L - 1 launches of uniform K = 4H blocks; the gradient a lower layer
+ * receives from the layer above (dgates_above,t W_ih_above) is formed by blocks of its own one launch ahead of the cell backward
+ * that consumes it and parked in dhin.  dh_top: [T][B][H] or null; dhn, dcn: [L][B][H] or null; w_hh_t / w_ih_t: HOST arrays of L
+ * device pointers to the TRANSPOSED weights [H][4H] (w_ih_t[0] unused); dgates: [L][T][B][4H] out; dh0, dc0: [L][B][H] out;
+ * dhin: [L - 1][T][B][H] scratch (may be null at L = 1). */
 int egz_lstm_wave_bwd(const float* dh_top, const float* dhn, const float* dcn, const float* acts, const float* cs,
                       const float* c0, const float* const* w_hh_t, const float* const* w_ih_t, float* dgates, float* dh0,
-                      float* dc0, int L, int T, int B, int H, hipStream_t stream);
+                      float* dc0, float* dhin, int L, int T, int B, int H, hipStream_t stream);
 /* The same network at T = 1, B = 1 -- the reference's own stepping (AT.py:127-145 training loop, AT.py:246 inference): the
  * whole step in ONE call (L + 1 launches forward, 2L + 1 backward; csrc/lstm_b1.hip).  params / grads: HOST arrays of
  * 4L + 2 device pointers in state-dict order (w_ih, w_hh, b_ih, b_hh per layer, lin.weight [N][H], lin.bias [N]); a null

@@ -1,47 +1,47 @@
 #!/bin/bash
-# Collects the round's measurement artefacts on the GPU box into gpurun_out/profiles_r04/ (copy to profiles/ afterwards).
+# Collects the round's measurement artefacts on the GPU box into gpurun_out/profiles_r05/ (copy to profiles/ afterwards).
 # Usage: gpurun -- 'bash tools/collect_profiles.sh'
 set -x
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/profiles_r04
+O=$R/gpurun_out/profiles_r05
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-leg"
 
 # 2. rocprofv3 kernel stats, streams on / off (the roofline leg's configuration)
 rm -rf /tmp/ks1 /tmp/ks0
-rocprofv3 --kernel-trace --output-format csv -d /tmp/ks1 -o p -- $BENCH > /dev/null 2>&1
-python $R/tools/prof_summary.py /tmp/ks1 $O/r04_bench_b32_kernel_stats.txt "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-leg" > /dev/null
-python $R/tools/trace_mfma.py /tmp/ks1 > $O/r04_exposed_time.txt 2>&1
-EGAZE_STREAMS=0 rocprofv3 --kernel-trace --output-format csv -d /tmp/ks0 -o p -- $BENCH > /dev/null 2>&1
-python $R/tools/prof_summary.py /tmp/ks0 $O/r04_bench_b32_kernel_stats_streams0.txt "EGAZE_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-leg" > /dev/null
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/ks1 -o p -- $BENCH > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/ks1 $O/r05_bench_b32_kernel_stats.txt "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-leg" > /dev/null
+python $R/tools/trace_mfma.py /tmp/ks1 > $O/r05_exposed_time.txt 2>&1
+EGAZE_STREAMS=0 timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/ks0 -o p -- $BENCH > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/ks0 $O/r05_bench_b32_kernel_stats_streams0.txt "EGAZE_STREAMS=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-f32-leg" > /dev/null
 
 # 3. HBM traffic per launch (separate --pmc passes), conv fwd + dgrad family and wgrad family
 rm -rf /tmp/pf /tmp/pw
-EGAZE_STREAMS=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o p -- $BENCH > /dev/null 2>&1
-EGAZE_STREAMS=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o p -- $BENCH > /dev/null 2>&1
-python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw igemm_x3 $O/r04_pmc_traffic_conv_fwd_dgrad.json
-python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw wgrad9_x3,wgrad_ups_x3 $O/r04_pmc_traffic_wgrad.json
+EGAZE_STREAMS=0 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o p -- $BENCH > /dev/null 2>&1
+EGAZE_STREAMS=0 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o p -- $BENCH > /dev/null 2>&1
+python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw igemm_x3 $O/r05_pmc_traffic_conv_fwd_dgrad.json
+python $R/tools/pmc_traffic.py /tmp/pf /tmp/pw wgrad9_x3,wgrad_ups_x3 $O/r05_pmc_traffic_wgrad.json
 
 # 3b. the default bench line, after the traffic files so that it can quote them (bench.py reads profiles/ and checks
 #     the kernel-source hash stamped into them)
-cp $O/r04_pmc_traffic_conv_fwd_dgrad.json $O/r04_pmc_traffic_wgrad.json $R/profiles/
+cp $O/r05_pmc_traffic_conv_fwd_dgrad.json $O/r05_pmc_traffic_wgrad.json $R/profiles/
 cd /tmp
-python $R/bench.py > $O/r04_bench_b32.json 2> $O/r04_bench_b32.stderr
+timeout 900 python $R/bench.py > $O/r05_bench_b32.json 2> $O/r05_bench_b32.stderr
 
 # 4. SQ / GRBM counters of the conv kernels on three layer shapes
 cd $R
-bash tools/pmc_conv.sh gpurun_out/profiles_r04/r04_sq_counters_enc27_512x512_28 --dtype 1 --only enc27 --iters 5
-bash tools/pmc_conv.sh gpurun_out/profiles_r04/r04_sq_counters_enc10_128x128_112 --dtype 1 --only enc10 --iters 5
-bash tools/pmc_conv.sh gpurun_out/profiles_r04/r04_sq_counters_dec26_64x64_224 --dtype 1 --only dec26 --iters 5
+timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_enc27_512x512_28 --dtype 1 --only enc27 --iters 5
+timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_enc10_128x128_112 --dtype 1 --only enc10 --iters 5
+timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_dec26_64x64_224 --dtype 1 --only dec26 --iters 5
 
 # 5. DVFS probe: the same kernels on all-zero operands, and the conv microbenchmark on random data
-python tools/bench_conv.py --dtype 1 --iters 20 > $O/r04_conv_microbench.txt 2>&1
-python tools/bench_conv.py --dtype 1 --iters 20 --zero > $O/r04_conv_microbench_zero_operands.txt 2>&1
+timeout 600 python tools/bench_conv.py --dtype 1 --iters 20 > $O/r05_conv_microbench.txt 2>&1
+timeout 600 python tools/bench_conv.py --dtype 1 --iters 20 --zero > $O/r05_conv_microbench_zero_operands.txt 2>&1
 
 # 6. CPU baseline thread sweep (oracle SP train step, batch 8)
-for t in 8 16 32 64; do timeout 600 python tests/report_cpu_baseline_sweep.py $t 8; done > $O/r04_cpu_baseline_thread_sweep.txt 2>&1
-nproc >> $O/r04_cpu_baseline_thread_sweep.txt; lscpu | grep "Model name" >> $O/r04_cpu_baseline_thread_sweep.txt
+for t in 8 16 32 64; do timeout 600 python tests/report_cpu_baseline_sweep.py $t 8; done > $O/r05_cpu_baseline_thread_sweep.txt 2>&1
+nproc >> $O/r05_cpu_baseline_thread_sweep.txt; lscpu | grep "Model name" >> $O/r05_cpu_baseline_thread_sweep.txt
 ls -la $O
 
 # 7. LF (config 3): step time with / without the device-side metric, and its kernel stats

@@ -11,7 +11,7 @@ i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   rm -rf /tmp/pmc$i
-  rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- python $R/tools/bench_conv.py "$@" > /tmp/pmc$i.log 2>&1 || tail -5 /tmp/pmc$i.log
+  timeout 280 rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- python $R/tools/bench_conv.py "$@" > /tmp/pmc$i.log 2>&1 || tail -5 /tmp/pmc$i.log
 done
 python $R/tools/pmc_sq.py /tmp/pmc1 igemm_x3 wgrad9_x3 wgrad_ups_x3 > $R/$OUT.txt
 python $R/tools/pmc_sq.py /tmp/pmc2 igemm_x3 wgrad9_x3 wgrad_ups_x3 >> $R/$OUT.txt
