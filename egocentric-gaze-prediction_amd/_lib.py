@@ -107,7 +107,7 @@ SIGNATURES = {
     "egz_gemm_batched": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_long, c_int, S]),
     "egz_lstm_cell_fwd": (c_int, [P, P, P, P, P, c_int, c_int, S]),
     "egz_lstm_cell_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, S]),
-    "egz_lstm_wave_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_lstm_wave_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "egz_lstm_wave_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "egz_lstm_b1_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "egz_lstm_b1_fwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, S]),

@@ -4,20 +4,21 @@
 //   forward   gates_t = gx_t (or b + h_below,t W_ih^T) + h_{t-1} W_hh^T  ->  (i,f,g,o)  ->  c_t, h_t         lstm_wave_fwd_kernel
 //   backward  dh_t = dh_out_t (or dgates_above,t W_ih_above) + dgates_{t+1} W_hh ; cell backward -> dgates_t, dc_{t-1}
 //                                                                                                          lstm_wave_bwd_kernel
-// and the launches of the L stacked layers run as a WAVEFRONT (see the kernels: launch s = step s - 2 l of every layer l plus the product blocks that feed the next launch).
+// and the launches of the L stacked layers run as a WAVEFRONT (see the kernels).
 // A step is latency- and per-CU-bandwidth-bound (M = batch rows <= 32, 67 MFLOP per product, a block pulls 64-512 KB of
 // weights and state through one CU's L2 port): what counts is how many CUs pull the 4 MB of W out of L2 in parallel and how few
 // dependent launches a sequence costs.  A dependent kernel boundary costs ~1.5 us on MI355X, a device-wide barrier inside a
 // persistent kernel 4-7 us (MI355X_MICROARCH.md, persistent-kernel price list), so the sequence is plain launches issued back to
 // back by ONE C-ABI call (no host round trip per step):
-//   * forward: block = 4 hidden units x all four gates = 16 rows of W (N = 16), batch tile M = 16 (x2), K = H split over the 4
-//     waves; 128 blocks per role and layer for H = 512.  The block owns everything the cell of its 4 units needs, so the
-//     point-wise part runs in the epilogue and the recurrent pre-activations never touch memory.
+//   * forward: block = 4 hidden units x all four gates = 16 rows of W (N = 16), batch tile M = 16 (x2), K split over the 4
+//     waves; 128 blocks per layer for H = 512.  The block owns everything the cell of its 4 units needs, so the point-wise
+//     part runs in the epilogue and the pre-activations never touch memory.  An upper layer's block reduces over
+//     [h_below | h] (K = 2H): a forward launch costs ~9.2 us whether its blocks carry K = H or 2H (round 5 measured the
+//     projection as blocks of its own one launch ahead: 18 x 9.2 us instead of 17 x 9.4 -- not kept).
 //   * backward: block = 16 batch rows x 16 hidden units, K = 4H split over 8 waves; the reduced dh tile feeds the cell backward
-//     of exactly those (row, unit) pairs in the epilogue, which emits dgates_t.
-//   * round 5: the products that cross layers (an upper layer's input projection; the gradient a lower layer receives) are
-//     blocks of their own one launch ahead ("product role") -- every block of a launch has the same K, where round 4's
-//     lower- / upper-layer blocks carried two segments and set the length of every launch (15.9 -> 10.1 us backward).
+//     of exactly those (row, unit) pairs in the epilogue, which emits dgates_t.  Round 5: the product that carries the
+//     gradient from the layer above runs in blocks of its own one launch ahead ("product role") -- round 4's lower-layer
+//     blocks carried it as a second segment (K = 8H, 512 KB per block) and set the length of every launch: 15.9 -> 10.1 us.
 // Exact f32 on v_mfma_f32_16x16x4_f32.  Operands go global/L2 -> registers as 16-byte loads: within a group of 16
 // reduction indices lane (r = l & 15, q = l >> 4) takes k = 4q .. 4q+3 of ITS row and feeds them to 4 MFMAs; the k <-> MFMA
 // pairing is the same for A and B, and a reduction index may be visited in any order.
@@ -33,19 +34,15 @@ __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); 
 constexpr int FW_UNITS = 4;        // hidden units per forward block -> N = 16 gate rows
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Wavefront form of the stacked recurrence (nn.LSTM(512, 512, num_layers = L), models/LSTMnet.py:18).  Round 5 form: every block
-// reduces over K = H only.  The input projection of an upper layer, h_{l-1,t} W_ih_l^T + b, no longer rides in that layer's step
-// block (round 4: K = 2H there, and a launch lasts as long as its largest block) but in blocks of its own ("product role") one
-// launch earlier, which park the pre-activations in gxu[l][t] -- the form layer 0's projection (one batched GEMM over all T)
-// arrives in anyway.  Launch s runs, for every layer l,
-//   cell role     step t  = s - 2 l:         gates = gx_l[t] + h_{l,t-1} W_hh_l^T -> (i, f, g, o) -> c_t, h_t
-//   product role  step t' = s - 2 l + 1  (l >= 1):  gxu_l[t'] = b_l + h_{l-1,t'} W_ih_l^T
-// -- both read what launch s - 1 wrote.  T + 2 (L - 1) launches (18 for T = 16, L = 2) on (H / 4) x (B / 32) x (2 L - 1) blocks.
+// Wavefront form of the stacked recurrence (nn.LSTM(512, 512, num_layers = L), models/LSTMnet.py:18): launch s runs step
+// t = s - l of EVERY layer l at once -- layer l's step t needs h of the layer below at the same t (launch s - 1) and its own
+// h at t - 1 (launch s - 1) -- so the T x L dependent step launches of the layer-by-layer form become T + L - 1, and the
+// batched input projection of the upper layers (one GEMM each) disappears: a block of layer l > 0 reduces over
+// [h_{l-1,t} | h_{l,t-1}] against [W_ih | W_hh] (K = 2H).  Same block shape, MFMA pairing and summation order per segment as
+// lstm_step_fwd_kernel; the two segments' partial sums are added segment 0 (W_hh) first.
 constexpr int WAVE_MAX_L = 4;
 struct WaveFwdLayer {
-    const float* gx;       // [T][B][4H] pre-activations without the recurrent term: layer 0: x W_ih^T + b_ih + b_hh of every step
-                           // (the caller's batched GEMM); upper layers: gxu, written by the product role
-    float* gxu;            // upper layers: the same buffer, writable; layer 0: null
+    const float* gx;       // layer 0: [T][B][4H] = x W_ih^T + b_ih + b_hh of every step; upper layers: null
     const float* bsum;     // upper layers: [4H] = b_ih + b_hh
     const float* w_ih;     // upper layers: [4H][H]
     const float* w_hh;     // [4H][H]
@@ -61,16 +58,15 @@ struct WaveFwdLayer {
 struct WaveFwd { WaveFwdLayer l[WAVE_MAX_L]; };
 
 template <int MT>
-__global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int s, int L, int T, int B, int H) {
+__global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int s, int T, int B, int H) {
     __shared__ float red[4][MT][256];
-    const bool prod = (int)blockIdx.z >= L;                    // block-uniform role
-    const int layer = prod ? (int)blockIdx.z - L + 1 : (int)blockIdx.z;
-    const int t = prod ? s - 2 * layer + 1 : s - 2 * layer;
+    const int layer = blockIdx.z, t = s - layer;
     if (t < 0 || t >= T) return;
     const WaveFwdLayer& p = a.l[layer];
     const long bh = (long)B * H;
     const float* h_prev = t ? p.hs + (t - 1) * bh : p.h0;
     const float* c_prev = t ? p.cs + (t - 1) * bh : p.c0;
+    const float* x_in = layer ? a.l[layer - 1].hs + t * bh : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int j0 = blockIdx.x * FW_UNITS, b0 = blockIdx.y * (16 * MT);
@@ -79,9 +75,10 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-        const float* wp = (prod ? p.w_ih : p.w_hh) + (long)wrow * H + k0 + 4 * q;
-        const float* src = prod ? a.l[layer - 1].hs + t * bh : h_prev;
+    const int nseg = layer ? 2 : 1;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const float* wp = (seg ? p.w_ih : p.w_hh) + (long)wrow * H + k0 + 4 * q;
+        const float* src = seg ? x_in : h_prev;
         const float* hp[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -121,13 +118,8 @@ __global__ __launch_bounds__(256) void lstm_wave_fwd_kernel(const WaveFwd a, int
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int n = g * 4 + u;
-            const float base = prod ? p.bsum[g * H + j0 + u] : p.gx[((long)t * B + b) * 4 * H + g * H + j0 + u];
+            const float base = layer ? p.bsum[g * H + j0 + u] : p.gx[((long)t * B + b) * 4 * H + g * H + j0 + u];
             pre[g] = base + ((red[0][m][rr * 16 + n] + red[1][m][rr * 16 + n]) + (red[2][m][rr * 16 + n] + red[3][m][rr * 16 + n]));
-        }
-        if (prod) {                                            // the upper layer's pre-activations without its recurrent term
-            float* gg_ = p.gxu + ((long)t * B + b) * 4 * H + j0 + u;
-            gg_[0] = pre[0]; gg_[H] = pre[1]; gg_[2 * H] = pre[2]; gg_[3 * H] = pre[3];
-            continue;
         }
         const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
         const long o = (long)b * H + j0 + u;
@@ -248,30 +240,29 @@ __global__ __launch_bounds__(512) void lstm_wave_bwd_kernel(const WaveBwd a, int
 
 }  // namespace
 
-// The stacked recurrence of nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step): T + 2 (L - 1) launches (see
+// The stacked recurrence of nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step): T + L - 1 launches (see
 // lstm_wave_fwd_kernel).  Host arrays of L device pointers: w_ih[l] / bsum[l] ([4H][H] / [4H] = b_ih + b_hh; entry 0 unused:
 // layer 0's input projection arrives as gx0 [T][B][4H], bias included), w_hh[l] [4H][H]; h0, c0: [L][B][H];
 // hs: [L][T + 1][B][H] out -- slot 0 of a layer = a copy of its h0, slots 1 .. T = h_1 .. h_T (so h_{t-1} for t = 1 .. T is the
 // contiguous block of slots 0 .. T - 1); cs: [L][T][B][H] out; acts: [L][T][B][4H] out or null; hn, cn: [L][B][H] out (the final
-// state); gxu: [L - 1][T][B][4H] scratch (the upper layers' input projections; may be null at L = 1).  1 <= L <= 4, H % 256 == 0.
+// state).  1 <= L <= 4, H % 256 == 0.
 EGZ_API int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
-                              const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn,
-                              float* gxu, int L, int T, int B, int H, hipStream_t st) {
-    EGZ_CHECK_ARG(gx0 && w_ih && w_hh && bsum && h0 && c0 && hs && cs && hn && cn && (gxu || L == 1), "egz_lstm_wave_fwd: null pointer");
+                              const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L,
+                              int T, int B, int H, hipStream_t st) {
+    EGZ_CHECK_ARG(gx0 && w_ih && w_hh && bsum && h0 && c0 && hs && cs && hn && cn, "egz_lstm_wave_fwd: null pointer");
     EGZ_CHECK_ARG(L >= 1 && L <= WAVE_MAX_L && T > 0 && B > 0 && H > 0 && H % 256 == 0,
                   "egz_lstm_wave_fwd: L=%d T=%d B=%d H=%d (1 <= L <= 4, H a multiple of 256)", L, T, B, H);
     WaveFwd a;
     const long bh = (long)B * H;
     for (int l = 0; l < L; ++l) {
         EGZ_CHECK_ARG(w_hh[l] && (l == 0 || (w_ih[l] && bsum[l])), "egz_lstm_wave_fwd: null weight pointer (layer %d)", l);
-        float* gl = l ? gxu + (long)(l - 1) * T * 4 * bh : nullptr;
-        a.l[l] = WaveFwdLayer{l ? gl : gx0, gl, l ? bsum[l] : nullptr, l ? w_ih[l] : nullptr, w_hh[l], h0 + l * bh, c0 + l * bh,
+        a.l[l] = WaveFwdLayer{l ? nullptr : gx0, l ? bsum[l] : nullptr, l ? w_ih[l] : nullptr, w_hh[l], h0 + l * bh, c0 + l * bh,
                               hs + ((long)l * (T + 1) + 1) * bh, cs + (long)l * T * bh, acts ? acts + (long)l * T * 4 * bh : nullptr,
                               hn + l * bh, cn + l * bh};
     }
-    for (int s = 0; s < T + 2 * (L - 1); ++s) {
-        if (B <= 16) hipLaunchKernelGGL(lstm_wave_fwd_kernel<1>, dim3(H / FW_UNITS, 1, 2 * L - 1), dim3(256), 0, st, a, s, L, T, B, H);
-        else         hipLaunchKernelGGL(lstm_wave_fwd_kernel<2>, dim3(H / FW_UNITS, egz_cdiv(B, 32), 2 * L - 1), dim3(256), 0, st, a, s, L, T, B, H);
+    for (int s = 0; s < T + L - 1; ++s) {
+        if (B <= 16) hipLaunchKernelGGL(lstm_wave_fwd_kernel<1>, dim3(H / FW_UNITS, 1, L), dim3(256), 0, st, a, s, T, B, H);
+        else         hipLaunchKernelGGL(lstm_wave_fwd_kernel<2>, dim3(H / FW_UNITS, egz_cdiv(B, 32), L), dim3(256), 0, st, a, s, T, B, H);
     }
     EGZ_CHECK_LAUNCH("egz_lstm_wave_fwd");
     return 0;

@@ -1402,12 +1402,10 @@ def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
     acts = torch.empty((L, T, B, H4), dtype=torch.float32, device=dev) if want_acts else None
     hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
     cn = torch.empty_like(hn)
-    # the upper layers' input projections, formed one launch ahead of the step that reads them
-    gxu = torch.empty((L - 1, T, B, H4), dtype=torch.float32, device=dev) if L > 1 else None
     PROF.note_flops("egz_lstm_wave_fwd", 2.0 * T * B * H4 * Hd * (2 * L - 1))
     check(LIB.egz_lstm_wave_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh),
                                 _ptr_table([None] + list(bsum[1:])), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(),
-                                _p(acts), hn.data_ptr(), cn.data_ptr(), _p(gxu), L, T, B, Hd, _stream()), "egz_lstm_wave_fwd")
+                                _p(acts), hn.data_ptr(), cn.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_wave_fwd")
     return hs, cs, acts, hn, cn
 
 

@@ -287,15 +287,14 @@ int egz_lstm_cell_fwd(const float* gates, const float* c_prev, float* h_out, flo
 int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, const float* dh, const float* dc_in,
                       float* dgates, float* dc_prev, int B, int Hd, hipStream_t stream);
 /* nn.LSTM(H, H, num_layers = L) as a wavefront over (layer, step) (models/LSTMnet.py:18,26-35: self.lstm(input, hidden)): launch
- * s runs step s - 2 l of every layer l and, one launch ahead of the step that consumes it, the input projection of each upper
- * layer (gxu: [L - 1][T][B][4H] scratch, may be null at L = 1): T + 2 (L - 1) dependent launches of uniform K = H blocks instead of
- * T x L step launches + L - 1 batched GEMMs.  w_ih / w_hh / bsum: HOST arrays of L device pointers ([4H][H], [4H][H], [4H] = b_ih + b_hh;
+ * s runs step s - l of every layer l, T + L - 1 dependent launches instead of T x L, the upper layers' input projections reduced
+ * in the same launch (K = 2H).  w_ih / w_hh / bsum: HOST arrays of L device pointers ([4H][H], [4H][H], [4H] = b_ih + b_hh;
  * w_ih[0] / bsum[0] unused: gx0 [T][B][4H] = x W_ih0^T + b_ih0 + b_hh0 for every step); h0, c0, hn, cn: [L][B][H];
  * hs: [L][T + 1][B][H] (slot 0 of a layer = a copy of its h0, slots 1 .. T = the outputs); cs: [L][T][B][H]; acts: [L][T][B][4H]
  * or null.  1 <= L <= 4, H % 256 == 0. */
 int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
-                      const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, float* gxu,
-                      int L, int T, int B, int H, hipStream_t stream);
+                      const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L, int T,
+                      int B, int H, hipStream_t stream);
 /* Its backward through time (autograd of the same call): T + 2 L - 1 launches of uniform K = 4H blocks; the gradient a lower layer
  * receives from the layer above (dgates_above,t W_ih_above) is formed by blocks of its own one launch ahead of the cell backward
  * that consumes it and parked in dhin.  dh_top: [T][B][H] or null; dhn, dcn: [L][B][H] or null; w_hh_t / w_ih_t: HOST arrays of L
