@@ -72,6 +72,8 @@ SIGNATURES = {
     "egz_bn_relu_pool_bwd_ws_bytes": (c_size_t, [c_int]),
     "egz_bn_relu_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
                                      c_size_t, P, P, c_int, S]),
+    "egz_bn_relu_pool_bwd_presplit": (c_int, [P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P,
+                                              c_size_t, P, P, c_int, P, P, S]),
     "egz_bn_bwd_first_wgrad_ws_bytes": (c_size_t, [c_int, c_int]),
     "egz_bn_bwd_first_wgrad": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_int, S]),
     "egz_pairmax_fwd": (c_int, [P, P, c_long, S]),

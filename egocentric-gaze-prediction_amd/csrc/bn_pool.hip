@@ -369,9 +369,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // part: [nparts][2][K] -> dgamma, dbeta and the two per-channel means the apply pass needs
+// bound (absmax_out != null; K % 64 == 0): an upper bound of max |dy| of the apply pass that follows, before it runs --
+//   |dy| = |sc| |dz - m1 - xhat m2| <= |sc| (D + |m1| + X |m2|),  D = max |dout| (dout_absmax, from the kernel that produced dout),
+//   X = max |xhat| over the channel = max(|ymax - mean|, |ymin - mean|) invstd (y_minmax: the conv epilogue's per-channel max / min)
+// -- so that the apply pass can store dy as pre-split f16 pairs (bn_bwd_apply_kernel<..., SPLIT>).  Rigorous (every term is a
+// bound; 0.1 % slack covers the fp32 rounding of the apply pass), and tight: the dz term dominates and |dz| <= |dout|.
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int nparts, int K, double count,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ mdz, float* __restrict__ mdzx) {
+                                       float* __restrict__ mdz, float* __restrict__ mdzx,
+                                       const float* __restrict__ scale = nullptr, const float* __restrict__ mean = nullptr,
+                                       const float* __restrict__ invstd = nullptr, const unsigned int* __restrict__ y_minmax = nullptr,
+                                       const unsigned int* __restrict__ dout_absmax = nullptr,
+                                       unsigned int* __restrict__ absmax_out = nullptr) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     double s1 = 0.0, s2 = 0.0;
@@ -382,8 +391,26 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int npar
     }
     if (dbeta) dbeta[k] = (float)s1;
     if (dgamma) dgamma[k] = (float)s2;
-    mdz[k] = (float)(s1 / count);
-    mdzx[k] = (float)(s2 / count);
+    const float m1 = (float)(s1 / count), m2 = (float)(s2 / count);
+    mdz[k] = m1;
+    mdzx[k] = m2;
+    if (absmax_out) {                                     // (block-uniform; whole waves: K % 64 == 0, 64-thread blocks)
+        const float D = __uint_as_float(absmax_bits(dout_absmax));
+        unsigned int umx = 0, umn = 0;
+        for (int sl = 0; sl < (512 / K > 0 ? 512 / K : 1); ++sl) {
+            const unsigned int a = y_minmax[sl * 2 * K + k], b = y_minmax[sl * 2 * K + K + k];
+            umx = a > umx ? a : umx;
+            umn = b > umn ? b : umn;
+        }
+        auto from_ordered = [](unsigned int u) -> float { return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u); };
+        const float ymax = from_ordered(umx), ymin = -from_ordered(umn);
+        const float X = fmaxf(fabsf(ymax - mean[k]), fabsf(ymin - mean[k])) * invstd[k];
+        float bound = fabsf(scale[k]) * (D + fabsf(m1) + X * fabsf(m2)) * 1.001f;
+        if (!(bound < INFINITY)) bound = 0.f;             // (a non-finite gradient: scale 1, like absmax_scale on a NaN maximum)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o));
+        if ((threadIdx.x & 63) == 0) absmax_commit(absmax_out, blockIdx.x, bound);
+    }
 }
 
 // The finalize step inside a consumer kernel (K <= 64): every block sums the few partial rows ([nrows][2][K] fp64, written by
@@ -416,7 +443,10 @@ __device__ inline void bn_bwd_finalize_in_block(const double* __restrict__ rows,
 }
 
 // ------------------------------------------------------------------ BN backward, pass 2: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat))
-template <bool POOL, bool FIN = false>
+// SPLIT: absmax is an INPUT (the bound of bn_bwd_finalize_kernel) and dy is stored as pre-split f16 pairs scaled by
+// absmax_scale(absmax) (layout: bn_relu_pool_fwd_kernel); consumers: egz_conv3x3_fwd_streamed(mode | 0x100) as the data gradient's
+// operand, egz_conv3x3_wgrad(flags | 0x10000).
+template <bool POOL, bool FIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -432,6 +462,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         mdz = fm[0];
         mdzx = fm[1];
     }
+    const float a_scale = SPLIT ? absmax_scale(absmax) : 1.f;
+    auto put = [&](float* dst, const f32x4 r) {
+        if constexpr (SPLIT) {
+            x3::u32x2 hi, lo;
+            x3::Half<_Float16>::split4(r * a_scale, hi, lo);
+            *reinterpret_cast<x3::u32x4*>(dst) = x3::u32x4{hi[0], hi[1], lo[0], lo[1]};
+        } else {
+            *reinterpret_cast<f32x4*>(dst) = r;
+        }
+    };
     const int K4 = K >> 2;
     const int Ho = POOL ? (H >> 1) : H, Wo = POOL ? (W >> 1) : W;
     const long n = (long)B * Ho * Wo * K4;
@@ -457,7 +497,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 r[e] = sc[e] * (dz - m1[e] - xh * m2[e]);
                 amx = fmaxf(amx, fabsf(r[e]));
             }
-            *reinterpret_cast<f32x4*>(dy + pix * K + c4 * 4) = r;
+            put(dy + pix * K + c4 * 4, r);
         } else {
             const int xo = (int)(pix % Wo);
             const long t = pix / Wo;
@@ -482,10 +522,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dy + base + off[q]) = r[q];
+            for (int q = 0; q < 4; ++q) put(dy + base + off[q], r[q]);
         }
     }
-    block_absmax_commit(amx, absmax);
+    if constexpr (!SPLIT) block_absmax_commit(amx, absmax);
 }
 
 // ------------------------------------------------------------------ fusion: z = max(ys, yt) (ys wins ties)
@@ -787,10 +827,12 @@ EGZ_API size_t egz_bn_relu_pool_bwd_ws_bytes(int K) {
 
 // Backward of [BN(train) -> ReLU -> (pool)] given the saved pre-BN tensor y and the batch statistics.
 // dgamma/dbeta may be null (frozen BN).  dy gets the gradient w.r.t. y ([B][H][W][K]).
-EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift,
+static int bn_relu_pool_bwd_impl(const float* y, const float* dout, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
                                  int B, int H, int W, int K, int pool, void* workspace, size_t ws_bytes,
-                                 unsigned int* absmax, const double* sums, int sums_rows, hipStream_t st) {
+                                 unsigned int* absmax, const double* sums, int sums_rows, const unsigned int* y_minmax,
+                                 const unsigned int* dout_absmax, hipStream_t st) {
+    const bool presplit = y_minmax != nullptr;
     // sums (optional): [sums_rows][2][K] partial rows of (sum dz, sum dz * xhat) already accumulated by the producer of dout
     // (egz_conv3x3_fwd_streamed epi 5): the reduce pass over y and dout is skipped.
     EGZ_CHECK_ARG(y && dout && scale && shift && mean && invstd && dy && workspace, "egz_bn_relu_pool_bwd: null pointer");
@@ -811,7 +853,7 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
     float* mdz = reinterpret_cast<float*>(part2 + (size_t)RED_ROWS * 2 * K);
     float* mdzx = mdz + K;
     const size_t shm = (size_t)rpb * 2 * K * sizeof(double);
-    if (sums && sums_rows <= FIN_MAX_ROWS && K <= 64 && 256 % (2 * K) == 0 && fin_in_kernel()) {
+    if (!presplit && sums && sums_rows <= FIN_MAX_ROWS && K <= 64 && 256 % (2 * K) == 0 && fin_in_kernel()) {
         // few partial rows (persistent narrow kernel): the apply pass sums them itself -- no column-sum / finalize launches
         const long n = npix * K4;
         const int grid = ew_grid(n) < FIN_GRID ? ew_grid(n) : FIN_GRID;
@@ -836,14 +878,47 @@ EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float*
         fin = part2;
         nfin = RED_ROWS;
     }
+    const long n = npix * K4;
+    if (presplit) {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K,
+                           (double)B * H * W, dgamma, dbeta, mdz, mdzx, scale, mean, invstd, y_minmax, dout_absmax, absmax);
+        EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd_presplit(finalize)");
+        if (pool) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, true>), dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
+        else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false, true>), dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
+        EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd_presplit(apply)");
+        return 0;
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(egz_cdiv(K, 64)), dim3(64), 0, st, fin, nfin, K,
                        (double)B * H * W, dgamma, dbeta, mdz, mdzx);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(finalize)");
-    const long n = npix * K4;
     if (pool) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
     else      hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, y, dout, scale, shift, mean, invstd, mdz, mdzx, dy, B, H, W, K, absmax);
     EGZ_CHECK_LAUNCH("egz_bn_relu_pool_bwd(apply)");
     return 0;
+}
+
+EGZ_API int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
+                                 int B, int H, int W, int K, int pool, void* workspace, size_t ws_bytes,
+                                 unsigned int* absmax, const double* sums, int sums_rows, hipStream_t st) {
+    return bn_relu_pool_bwd_impl(y, dout, scale, shift, mean, invstd, dy, dgamma, dbeta, B, H, W, K, pool, workspace, ws_bytes,
+                                 absmax, sums, sums_rows, nullptr, nullptr, st);
+}
+
+// egz_bn_relu_pool_bwd with dy stored PRE-SPLIT (f16 hi / lo pairs, see egz_conv3x3_wgrad_presplit_ok): the pairs are scaled by a
+// BOUND of max |dy| that the finalize step derives before the apply pass runs -- from y_minmax (the 1024 uints the conv's
+// statistics epilogue wrote in the forward pass: per-channel max / min of y), dout_absmax (egz_absmax layout: max |dout|, from
+// the data-gradient kernel that produced dout) and the two per-channel sums -- and leaves in `absmax` (egz_absmax layout,
+// zero-filled by the caller), which the consumers take as dy's abs-max.  K % 64 == 0, K <= 512.
+EGZ_API int egz_bn_relu_pool_bwd_presplit(const float* y, const float* dout, const float* scale, const float* shift,
+                                          const float* mean, const float* invstd, float* dy, float* dgamma, float* dbeta,
+                                          int B, int H, int W, int K, int pool, void* workspace, size_t ws_bytes,
+                                          unsigned int* absmax, const double* sums, int sums_rows,
+                                          const unsigned int* y_minmax, const unsigned int* dout_absmax, hipStream_t st) {
+    EGZ_CHECK_ARG(absmax && y_minmax && dout_absmax && K % 64 == 0 && K <= 512,
+                  "egz_bn_relu_pool_bwd_presplit: needs absmax, y_minmax, dout_absmax and K %% 64 == 0, K <= 512");
+    return bn_relu_pool_bwd_impl(y, dout, scale, shift, mean, invstd, dy, dgamma, dbeta, B, H, W, K, pool, workspace, ws_bytes,
+                                 absmax, sums, sums_rows, y_minmax, dout_absmax, st);
 }
 
 

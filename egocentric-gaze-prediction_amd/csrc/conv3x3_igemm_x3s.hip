@@ -580,6 +580,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y_rs, mko[r], 0, 0);
                 const float yp = mkv[r];
                 const float dz = (mko[r] != 0xFFFFFFFFu && yp * csc + csh > 0.f) ? v : 0.f;
+                amx = fmaxf(amx, fabsf(v));                      // (rows / columns that do not exist hold zeros)
                 q1 += dz;
                 q2 += dz * ((yp - cmu) * cis);
             }
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                                                       ok ? (unsigned)(off + col) * 4u : 0xFFFFFFFFu, 0, 0);
                 const float vs = ok ? v : 0.f;
                 if (EPI == EPI_BIAS_RELU) amx = fmaxf(amx, vs);                  // (post-ReLU: vs >= 0)
+                if (EPI == EPI_BIAS) amx = fmaxf(amx, fabsf(vs));                // (data gradients: max |dx| bounds the next BatchNorm backward)
                 if (EPI == EPI_BIAS_STATS) {                   // (fp64 per element: the variance is a difference of these two
                     s1 += (double)vs;                          //  sums, and fp32 partial sums over 16 rows already cost the
                     s2 += (double)vs * (double)vs;             //  gradients their fp32-class accuracy -- test_model_sp_grads_vs_fp64)
@@ -628,7 +630,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             }
         }
     }
-    if ((EPI == EPI_MASK_SUMS || EPI == EPI_BIAS_RELU) && absmax_out) {           // block-uniform
+    if ((EPI == EPI_MASK_SUMS || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS || EPI == EPI_BNSUMS) && absmax_out) {   // block-uniform
         // per-tile max |value| -> the abs-max buffer (egz_common.h: one atomic max per tile at most).  EPI_BIAS_RELU:
         // the result is a post-ReLU activation that the next convolution splits into f16 halves -- its abs-max scales that split
 #pragma unroll
@@ -1375,15 +1377,19 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const int total = mt * (Kp / G::BN) * ((MODE == UPSF) ? 4 : 1);
     const dim3 grid(((total + 7) / 8) * 8);
 #define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out)
-    if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS) absmax_out = nullptr;
+    if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS && epi != EPI_BIAS && epi != EPI_BNSUMS) absmax_out = nullptr;
     if (pre) {                         // pre-split activation operand: the training forward of the wide encoder layers
         if constexpr (MODE == PLAIN && (WM == 1 || WM == 2) && std::is_same<T, _Float16>::value) {
-            if (epi != EPI_BIAS_STATS) {
-                egz_set_error("egz_conv3x3_fwd_streamed: a pre-split operand is taken by the BatchNorm-statistics epilogue (epi 2) only");
+#define EGZ_X3P(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, PLAIN, true>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out)
+            // epi 2: the training forward over pre-split activations; epi 0 / 5: data gradients over a pre-split gradient
+            if (epi == EPI_BIAS_STATS) { if (patch) EGZ_X3P(EPI_BIAS_STATS, true); else EGZ_X3P(EPI_BIAS_STATS, false); }
+            else if (epi == EPI_BIAS)  { if (patch) EGZ_X3P(EPI_BIAS, true); else EGZ_X3P(EPI_BIAS, false); }
+            else if (epi == EPI_BNSUMS) { if (patch) EGZ_X3P(EPI_BNSUMS, true); else EGZ_X3P(EPI_BNSUMS, false); }
+            else {
+                egz_set_error("egz_conv3x3_fwd_streamed: a pre-split operand is taken by epi 0 / 2 / 5 only");
                 return (int)hipErrorInvalidValue;
             }
-            if (patch) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, EPI_BIAS_STATS, true, PLAIN, true>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out);
-            else       hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, EPI_BIAS_STATS, false, PLAIN, true>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out);
+#undef EGZ_X3P
             EGZ_CHECK_LAUNCH("egz_conv3x3_fwd_streamed(pre-split)");
             return 0;
         } else {
@@ -1522,8 +1528,9 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
     // presplit form; x_absmax = the abs-max the pairs were scaled with)
     const bool pre = (mode & 0x100) != 0;
     mode &= 0xff;
-    EGZ_CHECK_ARG(!pre || (mode == 0 && dtype == 1 && epi == EPI_BIAS_STATS && K % 64 == 0 && C % 32 == 0 && x_absmax && !bn_coef),
-                  "egz_conv3x3_fwd_streamed: a pre-split operand needs mode 0, dtype 1, epi 2, K %% 64 == 0, C %% 32 == 0 and x_absmax");
+    EGZ_CHECK_ARG(!pre || (mode == 0 && dtype == 1 && (epi == EPI_BIAS_STATS || epi == EPI_BIAS || epi == EPI_BNSUMS) && K % 64 == 0 &&
+                           C % 32 == 0 && x_absmax && (!bn_coef || epi == EPI_BNSUMS)),
+                  "egz_conv3x3_fwd_streamed: a pre-split operand needs mode 0, dtype 1, epi 0 / 2 / 5, K %% 64 == 0, C %% 32 == 0 and x_absmax");
     // epi 0 / 1 / 2 with bn_coef: x is a pre-BatchNorm tensor, normalised + ReLU'd while it is staged (narrow geometry only);
     // minmax_out (epi 2): narrow geometry: [egz_conv3x3_streamed_stat_rows][2][K] per-channel max / min rows of y;
     // 64- / 128-column tiles (K % 64 == 0): 2 K uints, zero-filled by the caller: order-preserving integer images of the
@@ -1547,12 +1554,13 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
             return launch_x3p_narrow<__bf16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
         }
         // wide tiles: the coefficient rows travel in the kernel's (otherwise unused) bias argument
+        // (absmax_out, optional: max |y| -- the gradient's abs-max bounds the BatchNorm backward of the block below)
         if (K % 128 == 0) {
-            if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
-            return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
+            if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre);
+            return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st);
         }
-        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
-        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, nullptr, st);
+        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre);
+        return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st);
     }
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, mode), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d "
                   "mode=%d is not covered (see egz_conv3x3_streamed_ok)", B, H, W, C, K, mode);

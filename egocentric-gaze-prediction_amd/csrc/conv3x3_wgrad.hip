@@ -338,7 +338,8 @@ __device__ __forceinline__ void wgrad_block(int& tile, int& split) {
 // XPRE (round 5): x holds PRE-SPLIT activations ([4 hi halves | 4 lo halves] per 4-channel quad, scaled by
 // absmax_scale(x_absmax); egz_bn_relu_pool_fwd's presplit form) -- the halo staging copies the quad into the two planes of the
 // LDS image without a split on the vector ALU (two thirds of this kernel's staged floats are x: its halo is 1.9x the patch).
-template <typename T, bool UPS, int R, int WD, bool XPRE = false>
+// DPRE: the same for the gradient operand dy (egz_bn_relu_pool_bwd_presplit: pairs scaled by a BOUND of max |dy|, dy_absmax).
+template <typename T, bool UPS, int R, int WD, bool XPRE = false, bool DPRE = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, int B, int H, int W,
     int C, int K, int patches_per_split, const unsigned int* __restrict__ dy_absmax,
@@ -516,7 +517,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
             const int i = tid + 256 * j;
             const int pp = i >> 4, k4 = i & 15;
             u32x2_t hi, lo;
-            W16<T>::split4s(rd[j], d_scale, hi, lo);
+            if constexpr (DPRE) {
+                const u32x4_t bq = __builtin_bit_cast(u32x4_t, rd[j]);
+                hi = u32x2_t{bq[0], bq[1]};
+                lo = u32x2_t{bq[2], bq[3]};
+            } else {
+                W16<T>::split4s(rd[j], d_scale, hi, lo);
+            }
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
             *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
@@ -1609,9 +1616,9 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         if (xb >= (1ull << 32) || db >= (1ull << 32)) flags &= ~0x2000;      // too large: exact-f32 kernels (64-bit addressing)
     }
     // flags 0x8000: x holds pre-split activations (see conv3x3_wgrad9_x3_kernel) -- only where that kernel runs
-    const bool xpre = (flags & 0x8000) != 0;
-    EGZ_CHECK_ARG(!xpre || egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) && (flags & 0x2000) && !ups && dy_absmax && x_absmax && !x_bn,
-                  "egz_conv3x3_wgrad: a pre-split x operand (flags 0x8000) needs the split-half 9-tap kernel's geometry "
+    const bool xpre = (flags & 0x8000) != 0, dpre = (flags & 0x10000) != 0;
+    EGZ_CHECK_ARG(!(xpre || dpre) || (egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) && (flags & 0x2000) && !ups && dy_absmax && x_absmax && !x_bn),
+                  "egz_conv3x3_wgrad: a pre-split x / dy operand (flags 0x8000 / 0x10000) needs the split-half 9-tap kernel's geometry "
                   "(egz_conv3x3_wgrad_presplit_ok), f16 x3 (dy_absmax, x_absmax) and a plain conv");
     float* part = static_cast<float*>(workspace);
     const long nred = (long)9 * C * K;
@@ -1679,15 +1686,17 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         const int pps = (int)((np + S - 1) / S);
         dim3 grid(((C + 63) / 64) * ((K + 63) / 64), S);
 #define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
-#define EGZ_W9P(RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<_Float16, false, RR, WW, true>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, x_absmax)
+#define EGZ_W9Q(RR, WW, XP, DP) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<_Float16, false, RR, WW, XP, DP>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, x_absmax)
+#define EGZ_W9P(RR, WW) do { if (xpre && dpre) EGZ_W9Q(RR, WW, true, true); else if (xpre) EGZ_W9Q(RR, WW, true, false); else EGZ_W9Q(RR, WW, false, true); } while (0)
 #define EGZ_W9T(TT)                                                                                                    \
         if (ups) { if (WD == 32) EGZ_W9X(TT, true, 1, 32); else if (WD == 16) EGZ_W9X(TT, true, 2, 16); else EGZ_W9X(TT, true, 4, 8); } \
         else     { if (WD == 32) EGZ_W9X(TT, false, 1, 32); else if (WD == 16) EGZ_W9X(TT, false, 2, 16); else EGZ_W9X(TT, false, 4, 8); }
-        if (xpre) {                // pre-split x operand (flags 0x8000): f16 x3, plain conv
+        if (xpre || dpre) {        // pre-split x (flags 0x8000) and / or dy (0x10000) operand: f16 x3, plain conv
             if (WD == 32) EGZ_W9P(1, 32); else if (WD == 16) EGZ_W9P(2, 16); else EGZ_W9P(4, 8);
         } else
         if (dy_absmax) { EGZ_W9T(_Float16) } else { EGZ_W9T(__bf16) }
 #undef EGZ_W9P
+#undef EGZ_W9Q
 #undef EGZ_W9T
 #undef EGZ_W9X
         EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap split)");

@@ -32,8 +32,9 @@ def _raw_current_stream(dev_index):
     return torch.cuda.current_stream().cuda_stream
 
 
-_MODE = os.environ.get("EGAZE_DP_MODE", "lastwait")
-_GEOMETRIC = os.environ.get("EGAZE_DP_BUCKETS", "halving") != "equal"      # experiment switch of round 5 (tools/dp_world1.py); resolved below
+# (Round 5 measured the hand-over variants with environment switches -- equal / halving buckets, one stream wait per bucket /
+# for the last bucket only, synchronous collectives on the comm stream, hooks without a collective: profiles/r05_ab_notes.txt --
+# and resolved them: halving buckets, one wait under RCCL.  The switches are gone; ``geometric=False`` keeps equal buckets.)      # experiment switch of round 5 (tools/dp_world1.py); resolved below
 
 
 class GradReducer:
@@ -68,7 +69,6 @@ class GradReducer:
         # cheaper -- but what the step waits for at its end is the LAST bucket's collective, so that one stays small: 186 MB of
         # SP gradients become 93 + 47 + 25 + 21 MB instead of 7 x 25 + 11.
         remaining = sum((p.numel() + 3) // 4 * 4 for p in params) * 4
-        geometric = geometric and _GEOMETRIC
         target = max(bucket_bytes, remaining // 2) if geometric else bucket_bytes
         for i in order:
             start, end = offsets[i], offsets[i] + (params[i].numel() + 3) // 4 * 4
@@ -135,14 +135,8 @@ class GradReducer:
                         st = self._stream_objs[sid] = torch.cuda.ExternalStream(sid, device=self.flat_grad.device)
                 comm.wait_stream(st)
             with torch.cuda.stream(comm):
-                if _MODE == "skip":
-                    pass
-                elif _MODE == "sync":
-                    dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
-                    self._sync_comm = comm
-                else:
-                    self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
-                                                         async_op=True))
+                self._handles.append(dist.all_reduce(self.flat_grad[start:end], op=dist.ReduceOp.SUM, group=self.group,
+                                                     async_op=True))
                 if self.record_events:
                     # the library runs the collective on its own stream, ordered after `comm`; the handle's wait() orders a
                     # stream after the collective -- make `comm` wait and mark that point
@@ -192,7 +186,7 @@ class GradReducer:
                     self._launch(b)
         finally:
             self._in_wait = False
-        if _MODE == "lastwait" and self.flat_grad.is_cuda and dist.get_backend(self.group) == "nccl":
+        if self.flat_grad.is_cuda and dist.get_backend(self.group) == "nccl":
             # RCCL runs a process group's collectives of one device in issue order on ONE internal stream: ordering the
             # optimizer's stream behind the LAST bucket orders it behind all of them (one stream wait instead of one per bucket)
             if self._handles:
@@ -200,9 +194,6 @@ class GradReducer:
         else:
             for h in self._handles:
                 h.wait()
-        if getattr(self, "_sync_comm", None) is not None:
-            torch.cuda.current_stream().wait_stream(self._sync_comm)
-            self._sync_comm = None
         self.stats["steps"] += 1
         self._reset()
 

@@ -142,6 +142,9 @@ class ConvBNReLUPool(torch.autograd.Function):
         # that block's launches can take it (the wide VGG layers, utils.py:64-76)
         presplit_out = bool(training and next_k and out_buf is None and not defer
                             and H.presplit_ok(Bx, Hx // 2 if pool else Hx, Wx // 2 if pool else Wx, K, next_k))
+        # the per-channel max / min of y: bounds this block's output (presplit_out) and, in the backward pass, its gradient
+        want_mm = bool(presplit_out or (training and not defer and not first and not padded
+                                        and H.presplit_grad_ok(Bx, Hx, Wx, C, K)))
         if padded:
             # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
             # for this one layer); the packed weight is padded the same way by the pack kernel
@@ -151,13 +154,13 @@ class ConvBNReLUPool(torch.autograd.Function):
             try:
                 y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
                                         epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=H.F16X3, streamed=st,
-                                        want_bound=presplit_out)
+                                        want_bound=want_mm)
             finally:
                 H.ALGO_CHANNELS[0] = None
         elif first:
             xin = H._req(x.detach(), "network input (NCHW)")
             y, stat = H.conv_first_fwd(xin, weight.detach(), bias.detach() if bias is not None else None, training,
-                                       want_minmax=defer, want_bound=presplit_out)
+                                       want_minmax=defer, want_bound=want_mm)
         else:
             bn_src = getattr(x, "_egz_bn_src", None) if training else None
             xin = to_nhwc(x)
@@ -182,7 +185,7 @@ class ConvBNReLUPool(torch.autograd.Function):
                 raise RuntimeError("deferred BatchNorm: the convolution did not land on the streamed split-half kernel")
             y, stat = H.conv3x3_fwd(xin, wp, bias.detach() if bias is not None else None, K, ups=False,
                                     epi=H.EPI_BIAS_STATS if training else H.EPI_BIAS, dtype=dt, streamed=st,
-                                    bn_in=bn_in, want_minmax=defer, pre_in=pre_in, want_bound=presplit_out)
+                                    bn_in=bn_in, want_minmax=defer, pre_in=pre_in, want_bound=want_mm)
         B, Hh, Ww, _ = y.shape
         if training and not first and C <= 32 and K <= 32 and ctx.needs_input_grad[0]:
             # narrow (late-fusion) layer: build the data-gradient packing now -- in the backward pass the 5 us pack launch sits
@@ -215,6 +218,7 @@ class ConvBNReLUPool(torch.autograd.Function):
         ctx.cfg = (training, pool, first, C, K, padded)
         ctx.deferred_in = bn_in is not None
         ctx.x_pre = pre_in
+        ctx.y_mm = getattr(y, "_egz_mm", None) if training else None
         if bn_in is not None and bn_src is None:
             ctx.deferred_coef = bn_in                  # (no fused BN sums: the weight gradient still needs the coefficients)
         res = from_nhwc(out)
@@ -251,7 +255,14 @@ class ConvBNReLUPool(torch.autograd.Function):
                                                      sums=sums)
             return (None, _finish(weight, sw, dw), _finish(bias, sbias, db), _finish(gamma, sg, dgamma if ng[3] else None),
                     _finish(beta, sb, dbeta if ng[4] else None), None, None, None, None, None, None, None, None, None, None)
-        dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, to_nhwc(dout), coef, pool, out_dgamma=sg, out_dbeta=sb, sums=sums)
+        dn = to_nhwc(dout)
+        # dy as pre-split pairs (hipops.PRESPLIT_GRAD): needs max |dout| (left on dout by the data-gradient kernel that produced
+        # it) and the max / min of y (kept from the forward pass) for the bound, and consumers that can take the pairs
+        dout_am = getattr(dn, "_egz_absmax", None)
+        gpre = bool(not first and not padded and ctx.y_mm is not None and dout_am is not None
+                    and H.presplit_grad_ok(y.shape[0], y.shape[1], y.shape[2], C, K))
+        dy, dgamma, dbeta = H.bn_relu_pool_bwd(y, dn, coef, pool, out_dgamma=sg, out_dbeta=sb, sums=sums,
+                                               presplit=(dout_am, ctx.y_mm) if gpre else None)
 
         def data_grad():
             if not ng[0]:
@@ -262,11 +273,11 @@ class ConvBNReLUPool(torch.autograd.Function):
             wp, st = H.conv_weight(weight, "dgrad", dt, dy, C)
             if bn_y is not None and st and dt:
                 # narrow layer on top of a [BN -> ReLU] block: the same launch accumulates that BatchNorm's backward sums
-                dxn, bsum = H.conv3x3_dgrad_bnsums(dy, wp, C, dt, bn_y, bn_coef)
+                dxn, bsum = H.conv3x3_dgrad_bnsums(dy, wp, C, dt, bn_y, bn_coef, pre_in=gpre)
                 res = from_nhwc(dxn)
                 res._egz_bnsums = (bsum, res._version)
                 return res
-            return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
+            return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st, pre_in=gpre))
 
         with fork("wgrad") as f:                # the weight gradient runs on a helper stream (both only read dy)
             if ng[1]:
@@ -283,7 +294,7 @@ class ConvBNReLUPool(torch.autograd.Function):
                         x_bn = None
                         if ctx.deferred_in:
                             x_bn = bn_coef if bn_coef is not None else ctx.deferred_coef
-                        dw = H.conv3x3_wgrad(xin, dy, out=sw, x_bn=x_bn, x_pre=ctx.x_pre)
+                        dw = H.conv3x3_wgrad(xin, dy, out=sw, x_bn=x_bn, x_pre=ctx.x_pre, dy_pre=gpre)
         dx = data_grad()
         # (the coefficient rows of a deferred input are read by the detached weight-gradient kernel too: keep them alive for it)
         _close_fork(f, sw, dw, xin, dy, (bn_coef if bn_coef is not None else getattr(ctx, "deferred_coef", None))
@@ -411,7 +422,8 @@ class FusionBlock(torch.autograd.Function):
             wp, st = H.conv_weight(weight, "dgrad", dt, dy2, C)
             dx2 = H.conv3x3_dgrad(dy2, wp, C, dtype=dt, streamed=st)
             B = dx2.shape[0] // 2
-            return from_nhwc(dx2[:B]), from_nhwc(dx2[B:])
+            # (max |dx2| over BOTH halves rides on each: an upper bound is all the encoders' last BatchNorm backward needs)
+            return from_nhwc(H.carry_absmax(dx2[:B], dx2)), from_nhwc(H.carry_absmax(dx2[B:], dx2))
 
         with fork("wgrad") as f:
             if ng[2]:

@@ -192,6 +192,16 @@ int egz_bn_relu_pool_bwd(const float* y, const float* dout, const float* scale, 
                          const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int K,
                          int pool, void* workspace, size_t ws_bytes, unsigned int* absmax, const double* sums,
                          int sums_rows, hipStream_t stream);
+/* The same with dy stored PRE-SPLIT (f16 hi / lo pairs; see egz_conv3x3_wgrad_presplit_ok): scaled by a BOUND of max |dy| that the
+ * finalize step derives before the apply pass runs from y_minmax (the 1024 uints of egz_conv3x3_fwd_streamed's minmax_out for y),
+ * dout_absmax (max |dout|, egz_absmax layout: egz_conv3x3_fwd_streamed's absmax_out of the data gradient that produced dout)
+ * and the two per-channel sums; the bound is left in `absmax` (zero-filled by the caller) and is dy's abs-max for its consumers
+ * (egz_conv3x3_fwd_streamed mode | 0x100 with epi 0 / 5, egz_conv3x3_wgrad flags | 0x10000).  K % 64 == 0, K <= 512. */
+int egz_bn_relu_pool_bwd_presplit(const float* y, const float* dout, const float* scale, const float* shift, const float* mean,
+                                  const float* invstd, float* dy, float* dgamma, float* dbeta, int B, int H, int W, int K,
+                                  int pool, void* workspace, size_t ws_bytes, unsigned int* absmax, const double* sums,
+                                  int sums_rows, const unsigned int* y_minmax, const unsigned int* dout_absmax,
+                                  hipStream_t stream);
 /* Backward of a FIRST block [Conv2d(C -> K, 3x3) -> BatchNorm2d(train) -> ReLU] with C <= 3 and K = 32 (late_fusion.py:10-12)
  * or 64 (the RGB encoder, utils.py:70 at SP.py:53; the network input needs no data gradient): dgamma / dbeta and dw (K, C, 3, 3) in one pass
  * over y (pre-BN conv output, NHWC) and dout, x = the block input [B][C][H][W]; the gradient w.r.t. the conv output is never

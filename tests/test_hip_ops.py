@@ -986,7 +986,7 @@ def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch):
     assert torch.equal(dw_ref, dw_pre)
     # a consumer that cannot take the pairs refuses them
     with pytest.raises(RuntimeError):
-        h.conv3x3_fwd(out_pre, wp1, b1, K, epi=h.EPI_BIAS, dtype=h.F16X3, streamed=True, pre_in=True)
+        h.conv3x3_fwd(out_pre, wp1, b1, K, epi=h.EPI_BIAS_RELU, dtype=h.F16X3, streamed=True, pre_in=True)
 
 
 HEADLINE_SHAPES = [        # (Cin, Cout, H (output), upsampled): the 12 distinct conv geometries of the SP step
@@ -1037,3 +1037,59 @@ def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups):
         assert e_f < 2e-5 and e_d < 2e-5 and e_w < 5e-5, (e_f, e_d, e_w)
     finally:
         torch.set_num_threads(keep)
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C,K,pool", [
+    (2, 32, 32, 64, 64, False), (1, 112, 112, 64, 128, True), (2, 28, 28, 128, 256, False), (3, 14, 14, 256, 128, False),
+    (1, 224, 224, 64, 64, False), (2, 56, 56, 128, 64, True),
+])
+def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch):
+    """Pre-split GRADIENTS (hipops.PRESPLIT_GRAD): the BatchNorm backward of a C -> K block writes dy as f16 pairs scaled by a
+    bound of max |dy| derived in its finalize step (from max |dout|, the per-channel max / min of y and the two sums).
+    (a) the bound holds and is tight: max |dy| <= bound <= 8 max |dy|;  (b) dgamma / dbeta are untouched (torch.equal);
+    (c) the consumers -- data gradient (plain and with the BatchNorm-sums epilogue) and weight gradient -- agree with the
+    fp32-gradient launches to 2e-6 of max |ref| and with fp64 like them."""
+    h = H()
+    monkeypatch.setattr(h, "SPLITK", False)
+    x0 = rnd(B, C, Hh, Ww, seed=501).clamp_(min=0)
+    w = rnd(K, C, 3, 3, seed=502, scale=(2.0 / (9 * C)) ** 0.5)
+    b = rnd(K, seed=503, scale=0.1)
+    gam, bet = 1.0 + 0.3 * rnd(K, seed=504), 0.2 * rnd(K, seed=505)
+    xd, wd = nhwc(x0), w.to(DEV)
+    wp, st = h.conv_weight(wd, "fwd", h.F16X3, xd, K)
+    y, stat = h.conv3x3_fwd(xd, wp, b.to(DEV), K, epi=h.EPI_BIAS_STATS, dtype=h.F16X3, streamed=st, want_bound=True)
+    mm = y._egz_mm
+    coef = h.bn_finalize(stat, float(B * Hh * Ww), gam.to(DEV), bet.to(DEV), None, None, 0.1, 1e-5)
+    Ho, Wo = (Hh // 2, Ww // 2) if pool else (Hh, Ww)
+    dout = nhwc(rnd(B, K, Ho, Wo, seed=506, scale=3e-4))
+    dout_am = h.absmax_of(dout)
+    assert h.presplit_grad_ok(B, Hh, Ww, C, K)
+    dy_ref, dg_ref, db_ref = h.bn_relu_pool_bwd(y, dout, coef, pool)
+    dy_pre, dg_pre, db_pre = h.bn_relu_pool_bwd(y, dout, coef, pool, presplit=(dout_am, mm))
+    assert torch.equal(dg_ref, dg_pre) and torch.equal(db_ref, db_pre)
+    true_max, bound = float(dy_ref.abs().max()), float(h.absmax_value(dy_pre._egz_absmax))
+    print(f"max |dy| {true_max:.3e}, bound {bound:.3e} ({bound / true_max:.2f}x)")
+    assert true_max <= bound <= 8 * true_max
+    wq, sq = h.conv_weight(wd, "dgrad", h.F16X3, dy_ref, C)
+    dx_ref = h.conv3x3_dgrad(dy_ref, wq, C, dtype=h.F16X3, streamed=sq)
+    dx_pre = h.conv3x3_dgrad(dy_pre, wq, C, dtype=h.F16X3, streamed=sq, pre_in=True)
+    assert rel(dx_pre, dx_ref) < 2e-6
+    assert float(h.absmax_value(dx_pre._egz_absmax)) == float(dx_pre.abs().max())        # the data gradient's own abs-max
+    dw_ref = h.conv3x3_wgrad(xd, dy_ref, precision="split_f16")
+    dw_pre = h.conv3x3_wgrad(xd, dy_pre, precision="split_f16", dy_pre=True)
+    assert rel(dw_pre, dw_ref) < 2e-6
+    # against fp64 (the bound-scaled pairs are as accurate as the abs-max-scaled ones)
+    dyc = nchw(dy_ref).double()
+    wref = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    xin = x0.double().requires_grad_(True)
+    F.conv2d(xin, wref, None, padding=1).backward(dyc)
+    dxt = torch.nn.grad.conv2d_input(x0.shape, w.double(), dyc, padding=1)
+    assert rel(nchw(dx_pre), dxt) < 2e-6 and rel(dw_pre.cpu(), wref.grad) < 2e-6
+    if not pool and C % 64 == 0:
+        # the BatchNorm-sums epilogue over pairs: dx and the two sums of the block BELOW (its y / coefficients: reuse x0's role)
+        ybelow = nhwc(rnd(B, C, Hh, Ww, seed=507))
+        cbelow = torch.stack([0.1 * rnd(C, seed=508), 1.0 + 0.1 * rnd(C, seed=509).abs(), 1.0 + 0.2 * rnd(C, seed=510), 0.1 * rnd(C, seed=511)]).to(DEV).contiguous()
+        if h.bnsums_ok(B, Hh, Ww, C, K, h.F16X3):
+            d1, s1 = h.conv3x3_dgrad_bnsums(dy_ref, wq, C, h.F16X3, ybelow, cbelow)
+            d2, s2 = h.conv3x3_dgrad_bnsums(dy_pre, wq, C, h.F16X3, ybelow, cbelow, pre_in=True)
+            assert rel(d2, d1) < 2e-6 and rel(s2.sum(0), s1.sum(0)) < 1e-5

@@ -93,7 +93,7 @@ def main():
             break
     dist.destroy_process_group()
     fmt = lambda v: " ".join(f"{x:.3f}" for x in v)
-    print(f"mode {os.environ.get('EGAZE_DP_MODE', 'default')}: plain {fmt(res['plain'])} | group only {fmt(res['group'])} | reducer on "
+    print(f"plain {fmt(res['plain'])} | group only {fmt(res['group'])} | reducer on "
           f"{fmt(res['reducer'])} ms per step; buckets in backward {st['launched_in_backward']} / steps {st['steps']}")
 
 
