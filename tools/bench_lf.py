@@ -58,3 +58,18 @@ for metric in (False, True):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
     print(f"LF step B={a.batch} metric={'device AAE/AUC' if metric else 'off'} hipGraph replay: {dt*1e3:.2f} ms  {a.batch/dt:.0f} frames/s")
 g.close()
+
+# LF.trainLate's whole iteration as LF._run issues it (LF.GraphedLateIteration): the batch metric inside the captured step, loss / AAE /
+# AUC read back 16 iterations at a time
+from egaze_amd.LF import GraphedLateIteration
+it = GraphedLateIteration(model, crit, opt, (feat, im, gt))
+for _ in range(4): it(feat, im, gt)
+it.drain()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(a.steps):
+    it(feat, im, gt)
+    if it.full: it.drain()
+it.drain()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+print(f"LF iteration B={a.batch} (forward + floss + computeAAEAUC + backward + Adam, one hipGraph replay, deferred read-back): {dt*1e3:.2f} ms  {a.batch/dt:.0f} frames/s")
+it.close()

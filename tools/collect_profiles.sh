@@ -31,9 +31,9 @@ timeout 900 python $R/bench.py > $O/r05_bench_b32.json 2> $O/r05_bench_b32.stder
 
 # 4. SQ / GRBM counters of the conv kernels on three layer shapes
 cd $R
-timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_enc27_512x512_28 --dtype 1 --only enc27 --iters 5
-timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_enc10_128x128_112 --dtype 1 --only enc10 --iters 5
-timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_dec26_64x64_224 --dtype 1 --only dec26 --iters 5
+timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_enc27_512x512_28 --dtype 1 --only enc27 --iters 5 --presplit
+timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_enc10_128x128_112 --dtype 1 --only enc10 --iters 5 --presplit
+timeout 900 bash tools/pmc_conv.sh gpurun_out/profiles_r05/r05_sq_counters_dec26_64x64_224 --dtype 1 --only dec26 --iters 5 --presplit
 
 # 5. DVFS probe: the same kernels on all-zero operands, and the conv microbenchmark on random data
 timeout 600 python tools/bench_conv.py --dtype 1 --iters 20 > $O/r05_conv_microbench.txt 2>&1
@@ -46,3 +46,27 @@ ls -la $O
 
 # 7. LF (config 3): step time with / without the device-side metric, and its kernel stats
 bash tools/collect_lf.sh
+
+# 8. AT step (config 4 shape) alone: time and kernel stats
+cd /tmp
+{ timeout 300 python $R/tools/bench_at_step.py --steps 200 2>&1 | grep "AT step"; } > $O/r05_at_step.txt
+rm -rf /tmp/ats
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/ats -o p -- python $R/tools/bench_at_step.py --steps 50 > /dev/null 2>&1
+python $R/tools/prof_summary.py /tmp/ats /tmp/ats_stats.txt "python tools/bench_at_step.py --steps 50" > /dev/null
+head -26 /tmp/ats_stats.txt >> $O/r05_at_step.txt
+
+# 9. data-parallel path at world size 1 (three legs, two rounds)
+{ echo "# python tools/dp_world1.py --rounds 2 --steps 8   (ms per SP + AT step: no process group | RCCL group of one rank, nothing attached | dp.GradReducer on)"
+  timeout 600 python $R/tools/dp_world1.py --rounds 2 --steps 8 2>&1 | grep "^plain"; } > $O/r05_dp_world1.txt
+
+# 10. pre-split microbenchmark and the step with / without the pairs
+cd $R
+timeout 600 python tools/bench_conv.py --dtype 1 --iters 20 --presplit --what fwd,wgrad 2>&1 | grep -v amdgpu.ids > $O/r05_presplit_microbench.txt
+{ for rep in 1 2; do for v in "EGAZE_PRESPLIT=0" "EGAZE_PRESPLIT_GRAD=0" "EGAZE_PRESPLIT=1"; do
+    echo "--- $v"
+    env $v timeout 300 python bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-f32-leg --no-roofline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('ms/step %.3f  regions %s' % (d['ms_per_step'], [round(x,3) for x in d['extra']['timed_repeats']['ms_per_step']]))"
+  done; done; } > $O/r05_presplit_step_ab.txt 2>&1
+ls -la $O
