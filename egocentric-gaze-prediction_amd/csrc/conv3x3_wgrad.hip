@@ -9,6 +9,7 @@
 //   both operands are pixel-major in LDS ([pixel][channel]) which is exactly the MFMA A/B fragment
 //   order (lane -> consecutive channel) so every ds_read_b32 is conflict-free without padding.
 #include "egz_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -1534,7 +1535,11 @@ int pick_narrow_x3(int W, int C, int K, int flags) {
     return (W % 32 == 0) ? 32 : (W % 16 == 0) ? 16 : 0;
 }
 long npatch_x3n(int B, int H, int W, int WD) { return (long)B * ((H + 64 / WD - 1) / (64 / WD)) * (W / WD); }
-constexpr int X3_BLOCKS = 512;   // blocks per launch of the split-half kernel: one round of 2 resident blocks per CU
+// blocks per launch of the split-half kernel: one round of 2 resident blocks per CU.  (Round 5 measured fewer: 448 / 384 / 320 /
+// 256 blocks -> step +0.23 / +0.33 / +0.78 / +0.55 ms, the weight gradients alone 9.65 -> 11.2 ms at 384: a CU with ONE
+// resident block loses its latency hiding.  What does NOT cost anything is fewer CUs at two blocks each -- tools/micro/
+// cu_share_probe.py -- but the launch cannot choose that; profiles/r05_ab_notes.txt.)
+constexpr int X3_BLOCKS = 512;
 long npatch_x3(int B, int H, int W, int WD) { return (long)B * ((H + 32 / WD - 1) / (32 / WD)) * ((W + WD - 1) / WD); }
 
 int pick_bt(int C, int K, int flags) {

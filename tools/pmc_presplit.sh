@@ -10,5 +10,5 @@ timeout 280 rocprofv3 --pmc $P --kernel-trace --output-format csv -d /tmp/pps -o
 { echo "# rocprofv3 --pmc $P -- python tools/bench_conv.py --dtype 1 --only $SH --iters 5 --presplit --what fwd,wgrad"
   echo "# per launch; igemm ...Li0ELb0EE = forward over fp32 activations (split at staging), ...Li0ELb1EE = over pre-split pairs;"
   echo "# wgrad9 ...ELb0ELb0EE = fp32 x and dy, ...ELb1ELb0EE = pre-split x"
-  python $R/tools/pmc_sq.py /tmp/pps "x3s_kernelIDF16_Li1ELi2ELb1ELi0ELb0EE" "x3s_kernelIDF16_Li1ELi2ELb1ELi0ELb1EE" "x3s_kernelIDF16_Li2ELi2ELb1ELi0ELb0EE" "x3s_kernelIDF16_Li2ELi2ELb1ELi0ELb1EE" "x3s_kernelIDF16_Li1ELi2ELb0ELi0ELb0EE" "x3s_kernelIDF16_Li1ELi2ELb0ELi0ELb1EE" "ELb0ELb0EEvPKfS2_Pf" "ELb1ELb0EEvPKfS2_Pf"
+  python $R/tools/pmc_sq.py /tmp/pps "x3s_kernelIDF16_Li1ELi2ELb1ELi0ELb0EE" "x3s_kernelIDF16_Li1ELi2ELb1ELi0ELb1EE" "x3s_kernelIDF16_Li2ELi2ELb1ELi0ELb0EE" "x3s_kernelIDF16_Li2ELi2ELb1ELi0ELb1EE" "x3s_kernelIDF16_Li1ELi2ELb0ELi0ELb0EE" "x3s_kernelIDF16_Li1ELi2ELb0ELi0ELb1EE" "wgrad9_x3_kernelIDF16_Lb0ELi4ELi8ELb0ELb0E" "wgrad9_x3_kernelIDF16_Lb0ELi4ELi8ELb1ELb0E"
 } > $R/$OUT
