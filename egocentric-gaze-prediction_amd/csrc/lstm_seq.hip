@@ -293,3 +293,210 @@ EGZ_API int egz_lstm_wave_bwd(const float* dh_top, const float* dhn, const float
     EGZ_CHECK_LAUNCH("egz_lstm_wave_bwd");
     return 0;
 }
+
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary form of the forward wavefront for the AT network's geometry (nn.LSTM(512, 512, num_layers = 2),
+// models/LSTMnet.py:18; batch <= 32): ONE launch for the whole (layer, step) wavefront instead of T + 1.
+//   * grid = 128 unit slices x (1 or 2) batch tiles of 16 rows; a block owns 4 hidden units (x 4 gates = 16 weight rows) of
+//     BOTH layers for its 16 batch rows.  Its 16 x (512 + 1024) weights live in REGISTERS for the whole launch: wave w of the 8
+//     holds reduction indices 64 w .. 64 w + 63 of each 512-wide segment, 48 VGPRs per lane -- the MFMA B operand never moves
+//     again (12 MB of weights = 48 KB per block, x 2 batch tiles).
+//   * global step s runs layer 0's step t = s and layer 1's step t = s - 1; both read what step s - 1 published: h0_{s-1}
+//     (feeds W_hh_l0 and W_ih_l1: loaded once) and h1_{s-2}.  16 rows x 512 x 2 = 64 KB per block and step, the all-to-all
+//     that a step launch performs through the kernel boundary.
+//   * hand-off inside the launch (cdna_hip_programming.md, Guideline 16, R1): h is stored write-through (sc1, 16 bytes per
+//     lane), every storing wave drains vmcnt, one lane adds 1 to the arrival counter of its (batch tile, shard) -- 8 shards per
+//     tile, one per XCD under round-robin dispatch, 16 arrivals each -- consumers poll the 8 counters from 8 lanes (relaxed,
+//     s_sleep), then read h with sc1 loads (no fence on either side).  The two batch tiles never talk to each other.
+//   * the cell state stays in a register of the epilogue lane that owns the cell; cs / acts (only read after the launch) are
+//     stored AFTER the arrival.
+// Every block must be resident for the counters to fill: 128 or 256 blocks of 512 threads at 142 VGPRs = one block per CU, so the
+// launch needs that many CUs to come free (work of other streams drains by itself; a SECOND persistent launch of another process
+// on the same device could interleave with this one).  A poll that sees no progress for ~0.2 s therefore gives up and raises
+// the error word -- the launch then finishes with garbage and egz_lstm_persist_fwd's status word reports it -- instead of
+// hanging the queue.
+typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
+constexpr int PF_H = 512, PF_SHARDS = 8, PF_LINE = 32;       // counters one per 128-byte line
+struct PersistFwd {
+    const float* gx0;                       // [T][B][4H] layer 0's input projection, bias included
+    const float* w_hh0; const float* w_ih1; const float* w_hh1;      // [4H][H]
+    const float* bsum1;                     // [4H]
+    const float* h0; const float* c0;       // [2][B][H]
+    float* hs;                              // [2][T + 1][B][H], slot 0 of a layer receives its h0
+    float* cs;                              // [2][T][B][H]
+    float* acts;                            // [2][T][B][4H] or null
+    float* hn; float* cn;                   // [2][B][H]
+    unsigned int* sync;                     // [2 tiles][8 shards][32] arrival counters, then the error word at [512]
+};
+
+__global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd a, int T, int B) {
+    constexpr int H = PF_H;
+    __shared__ float red[2][8][256];
+    __shared__ int dead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int unit_blk = blockIdx.x, tile = blockIdx.y;
+    const int j0 = unit_blk * 4, b0 = tile * 16;
+    const long bh = (long)B * H;
+    if (tid == 0) dead = 0;
+    // --- the block's weights: row n = r of the 16 (gate r >> 2, unit r & 3), k = 64 wave + 16 u + 4 q .. + 3
+    const long wrow = (long)((r >> 2) * H + j0 + (r & 3)) * H + 64 * wave + 4 * q;
+    f32x4 w0[4], wi[4], wh[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        w0[u] = *reinterpret_cast<const f32x4*>(a.w_hh0 + wrow + 16 * u);
+        wi[u] = *reinterpret_cast<const f32x4*>(a.w_ih1 + wrow + 16 * u);
+        wh[u] = *reinterpret_cast<const f32x4*>(a.w_hh1 + wrow + 16 * u);
+    }
+    // --- A operand addressing: row b0 + r of a [B][H] slot of hs, same k as the weights
+    int brow = b0 + r;
+    brow = brow < B ? brow : B - 1;
+    const unsigned a_vo = (unsigned)((brow * H + 64 * wave + 4 * q) * 4);
+    const long hs_layer = (long)(T + 1) * bh;                  // floats per layer of hs
+    const __amdgpu_buffer_rsrc_t hs_rs = __builtin_amdgcn_make_buffer_rsrc(a.hs, 0, (int)(2 * hs_layer * 4), 0x00020000);
+    // --- epilogue role: threads 0..127 own one cell each: layer = tid >> 6, row = (tid & 63) >> 2, unit = tid & 3
+    const bool epi = tid < 128;
+    const int elayer = tid >> 6, erow = (tid & 63) >> 2, eu = tid & 3;
+    const int eb = b0 + erow;
+    const bool evalid = epi && eb < B;
+    const long eo = (long)(eb < B ? eb : B - 1) * H + j0 + eu;
+    float c_state = 0.f, bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi) {
+        c_state = a.c0[elayer * bh + eo];
+        if (elayer)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bs[g] = a.bsum1[g * H + j0 + eu];
+        // slot 0 of each layer = its h0: published like a step (arrival below), so step 0 reads it like any other
+        const float hv = a.h0[elayer * bh + eo];
+        if (evalid) __hip_atomic_store(a.hs + elayer * hs_layer + eo, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned int* cnt = a.sync + (tile * PF_SHARDS) * PF_LINE;
+    unsigned int* my_cnt = cnt + (unit_blk & (PF_SHARDS - 1)) * PF_LINE;
+    unsigned int* err = a.sync + 2 * PF_SHARDS * PF_LINE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    for (int s = 0; s <= T; ++s) {
+        const bool run0 = s < T, run1 = s >= 1;
+        // layer 0's pre-activation base of this step: in flight while the block waits
+        float base[4] = {bs[0], bs[1], bs[2], bs[3]};
+        if (epi && elayer == 0 && run0)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) base[g] = a.gx0[((long)s * B + (eb < B ? eb : B - 1)) * 4 * H + g * H + j0 + eu];
+        // --- wait until all 128 blocks of this tile have published step s - 1 (16 arrivals per shard and step, + the h0 one)
+        if (wave == 0 && !dead) {
+            const unsigned int target = 16u * (unsigned)(s + 1);
+            unsigned int spins = 0;
+            bool ok;
+            do {
+                const unsigned int v = lane < PF_SHARDS ? __hip_atomic_load(cnt + lane * PF_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                ok = __all(v >= target);
+                if (!ok) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 100000u) {
+                        if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        break;
+                    }
+                }
+            } while (!ok);
+        }
+        __syncthreads();
+        // --- operands: h0_{s-1} = slot s of layer 0, h1_{s-2} = slot s - 1 of layer 1 (sc1: served from the coherent level)
+        f32x4 x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x0[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hs_rs, a_vo + 64u * u, (unsigned)((long)s * bh * 4), 16));
+            x1[u] = run1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                               hs_rs, a_vo + 64u * u, (unsigned)((hs_layer + (long)(s - 1) * bh) * 4), 16))
+                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[u][e], w0[u][e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[u][e], wi[u][e], acc1, 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[u][e], wh[u][e], acc1, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][(4 * q + e) * 16 + r] = acc0[e];
+            red[1][wave][(4 * q + e) * 16 + r] = acc1[e];
+        }
+        __syncthreads();
+        // --- cells
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, hv = 0.f;
+        const int t = elayer ? s - 1 : s;
+        const bool act = epi && (elayer ? run1 : run0);
+        if (act) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* p = &red[elayer][0][erow * 16 + g * 4 + eu];
+                pre[g] = base[g] + (((p[0] + p[256]) + (p[512] + p[768])) + ((p[1024] + p[1280]) + (p[1536] + p[1792])));
+            }
+            gi = sigm(pre[0]); gf = sigm(pre[1]); gg = tanhf(pre[2]); go = sigm(pre[3]);
+            c_state = gf * c_state + gi * gg;
+            hv = go * tanhf(c_state);
+        }
+        // publish h_t: the 4 units of a row sit in 4 neighbouring lanes -> one 16-byte write-through store per row
+        if (epi) {
+            f32x4 h4;
+            h4[0] = __shfl(hv, (lane & ~3) + 0); h4[1] = __shfl(hv, (lane & ~3) + 1);
+            h4[2] = __shfl(hv, (lane & ~3) + 2); h4[3] = __shfl(hv, (lane & ~3) + 3);
+            if (act && evalid && eu == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, h4), hs_rs, (unsigned)((eb * H + j0) * 4),
+                                                       (unsigned)((elayer * hs_layer + (long)(t + 1) * bh) * 4), 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0 && s < T) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // what only the backward pass / the caller reads: after the arrival
+        if (act && evalid) {
+            a.cs[(elayer * (long)T + t) * bh + eo] = c_state;
+            if (a.acts) {
+                float* aa = a.acts + ((elayer * (long)T + t) * B + eb) * 4 * H + j0 + eu;
+                aa[0] = gi; aa[H] = gf; aa[2 * H] = gg; aa[3 * H] = go;
+            }
+            if (t == T - 1) {
+                a.hn[elayer * bh + eo] = hv;
+                a.cn[elayer * bh + eo] = c_state;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Words of the `sync` scratch of egz_lstm_persist_fwd (zeroed by the call itself); word [words - 32] is the error word: 0 = every hand-off arrived, 1 + s = a block gave up waiting in global step s.
+constexpr int PF_SYNC_WORDS = 2 * PF_SHARDS * PF_LINE + PF_LINE;
+EGZ_API int egz_lstm_persist_sync_words(void) { return PF_SYNC_WORDS; }
+
+// The same recurrence as egz_lstm_wave_fwd for L = 2, H = 512, B <= 32 in ONE persistent launch (lstm_persist_fwd_kernel): same
+// arguments and outputs (w_ih[0] / bsum[0] unused), plus `sync`: egz_lstm_persist_sync_words() uints of device scratch; after the
+// launch sync[words - 32] is 0, or 1 + s if a block's wait timed out in step s (outputs then undefined).  Returns
+// hipErrorNotSupported for any other geometry (the caller launches the wavefront instead).
+EGZ_API int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
+                                 const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn,
+                                 unsigned int* sync, int L, int T, int B, int H, hipStream_t st) {
+    EGZ_CHECK_ARG(gx0 && w_ih && w_hh && bsum && h0 && c0 && hs && cs && hn && cn && sync, "egz_lstm_persist_fwd: null pointer");
+    if (L != 2 || H != PF_H || B < 1 || B > 32 || T < 1) {
+        egz_set_error("egz_lstm_persist_fwd: L=%d T=%d B=%d H=%d (built for L = 2, H = 512, B <= 32)", L, T, B, H);
+        return (int)hipErrorNotSupported;
+    }
+    EGZ_CHECK_ARG(w_hh[0] && w_hh[1] && w_ih[1] && bsum[1], "egz_lstm_persist_fwd: null weight pointer");
+    const long bh = (long)B * H;
+    (void)bh;
+    PersistFwd a{gx0, w_hh[0], w_ih[1], w_hh[1], bsum[1], h0, c0, hs, cs, acts, hn, cn, sync};
+    hipError_t e = hipMemsetAsync(sync, 0, PF_SYNC_WORDS * sizeof(unsigned int), st);
+    if (e != hipSuccess) { egz_set_error("egz_lstm_persist_fwd: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(128, egz_cdiv(B, 16)), dim3(512), 0, st, a, T, B);
+    EGZ_CHECK_LAUNCH("egz_lstm_persist_fwd");
+    return 0;
+}

@@ -1448,6 +1448,20 @@ def copy_into(dst: torch.Tensor, src: torch.Tensor):
     check(LIB.egz_copy(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "egz_copy")
 
 
+# EGAZE_LSTM_PERSIST=1: the forward recurrence of the AT network as ONE persistent launch (egz_lstm_persist_fwd) where its geometry
+# allows (L = 2, H = 512, B <= 32); 0: always the T + L - 1 wavefront launches.
+LSTM_PERSIST = _os.environ.get("EGAZE_LSTM_PERSIST", "0") != "0"
+_PERSIST_SYNC: list = []
+
+
+def lstm_persist_status() -> int:
+    """Error word of the most recent persistent LSTM launch (synchronises): 0 = every in-launch hand-off arrived, 1 + s = a block
+    gave up waiting in global step s (the outputs of that launch are undefined)."""
+    if not _PERSIST_SYNC:
+        return 0
+    return int(_PERSIST_SYNC[0][-32].item())
+
+
 def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
     """The stacked recurrence as a wavefront over (layer, step) (egz_lstm_wave_fwd): gx0 (T,B,4H) = layer 0's input projection
     of every step (bias included); w_ih / w_hh / bsum: lists of L tensors (w_ih[0] / bsum[0] unused); h0, c0 (L,B,H)
@@ -1470,6 +1484,16 @@ def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
     hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
     cn = torch.empty_like(hn)
     PROF.note_flops("egz_lstm_wave_fwd", 2.0 * T * B * H4 * Hd * (2 * L - 1))
+    if LSTM_PERSIST and L == 2 and Hd == 512 and B <= 32:
+        # one persistent, weight-stationary launch (csrc/lstm_seq.hip, lstm_persist_fwd_kernel); its hand-off counters live in a
+        # scratch of this call's own (the launch zeroes it), kept reachable for lstm_persist_status()
+        sync = torch.empty((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
+        check(LIB.egz_lstm_persist_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh),
+                                       _ptr_table([None] + list(bsum[1:])), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(),
+                                       cs.data_ptr(), _p(acts), hn.data_ptr(), cn.data_ptr(), sync.data_ptr(), L, T, B, Hd,
+                                       _stream()), "egz_lstm_persist_fwd")
+        _PERSIST_SYNC[:] = [sync]
+        return hs, cs, acts, hn, cn
     check(LIB.egz_lstm_wave_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh),
                                 _ptr_table([None] + list(bsum[1:])), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(),
                                 _p(acts), hn.data_ptr(), cn.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_wave_fwd")

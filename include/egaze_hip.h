@@ -305,6 +305,16 @@ int egz_lstm_cell_bwd(const float* act, const float* c, const float* c_prev, con
 int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
                       const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn, int L, int T,
                       int B, int H, hipStream_t stream);
+/* The same forward recurrence for the AT network's own geometry (L = 2, H = 512, B <= 32) as ONE persistent, weight-stationary
+ * launch: each of 128 x ceil(B / 16) blocks keeps its 16 x 1536 weights in registers for the whole sequence and the blocks hand
+ * h_t to each other inside the launch (write-through stores + arrival counters, csrc/lstm_seq.hip).  Arguments and outputs as
+ * egz_lstm_wave_fwd, plus `sync`: egz_lstm_persist_sync_words() uints of device scratch (zeroed by the call); after the launch
+ * word [words - 32] is 0, or 1 + s when a block gave up waiting in global step s (outputs then undefined).  Any other geometry:
+ * returns hipErrorNotSupported (801) and launches nothing -- call egz_lstm_wave_fwd. */
+int egz_lstm_persist_sync_words(void);
+int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
+                         const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn,
+                         unsigned int* sync, int L, int T, int B, int H, hipStream_t stream);
 /* Its backward through time (autograd of the same call): T + 2 L - 1 launches of uniform K = 4H blocks; the gradient a lower layer
  * receives from the layer above (dgates_above,t W_ih_above) is formed by blocks of its own one launch ahead of the cell backward
  * that consumes it and parked in dhin.  dh_top: [T][B][H] or null; dhn, dcn: [L][B][H] or null; w_hh_t / w_ih_t: HOST arrays of L

@@ -314,3 +314,34 @@ def test_lstm_wavefront_vs_torch(L, T, B):
     assert rel(hd.grad.cpu().numpy(), hr.grad.numpy()) < 1e-4 and rel(cd.grad.cpu().numpy(), cr.grad.numpy()) < 1e-4
     for name, p in ref.named_parameters():
         assert rel(getattr(net.lstm, name).grad.cpu().numpy(), p.grad.numpy()) < 2e-4, name
+
+
+@pytest.mark.parametrize("T,B", [(16, 32), (1, 1), (3, 16), (5, 20), (16, 7)])
+def test_lstm_persistent_forward_matches_wavefront(T, B, monkeypatch):
+    """egz_lstm_persist_fwd (ONE weight-stationary launch, blocks hand h_t to each other inside it) against egz_lstm_wave_fwd (T + 1
+    launches) on the AT network's geometry (models/LSTMnet.py:18: nn.LSTM(512, 512, 2)): every output -- all h_t and c_t of both
+    layers, the gate activations the backward pass reads, the returned state.  Same products in another summation order (8 K-slices
+    of 64 instead of 4 of 128): equal to a few ulp.  40 calls on recycled buffers with fresh inputs: a hand-off that read a stale
+    line (the previous call's h at the same address) would show up as a mismatch; the status word must stay 0."""
+    from egaze_amd import hipops as H
+    g = torch.Generator().manual_seed(11)
+    w_ih = [None, (torch.randn(2048, 512, generator=g) * 0.05).to(DEV)]
+    w_hh = [(torch.randn(2048, 512, generator=g) * 0.05).to(DEV) for _ in range(2)]
+    bsum = [None, (torch.randn(2048, generator=g) * 0.1).to(DEV)]
+    for it in range(40 if (T, B) == (16, 32) else 3):
+        gx0 = torch.randn(T, B, 2048, generator=g).to(DEV)
+        h0, c0 = (torch.randn(2, B, 512, generator=g) * 0.5).to(DEV), (torch.randn(2, B, 512, generator=g) * 0.5).to(DEV)
+        monkeypatch.setattr(H, "LSTM_PERSIST", False)
+        want = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0)
+        monkeypatch.setattr(H, "LSTM_PERSIST", True)
+        got = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0)
+        assert H.lstm_persist_status() == 0
+        for name, a, b in zip(("hs", "cs", "acts", "hn", "cn"), got, want):
+            assert torch.allclose(a, b, rtol=0, atol=3e-6), (it, name, float((a - b).abs().max()))
+        del want, got
+    # no-grad form (no gate activations kept)
+    got = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts=False)
+    assert got[2] is None and H.lstm_persist_status() == 0
+    monkeypatch.setattr(H, "LSTM_PERSIST", False)
+    want = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts=False)
+    assert torch.allclose(got[0], want[0], rtol=0, atol=3e-6) and torch.allclose(got[3], want[3], rtol=0, atol=3e-6)
