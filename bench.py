@@ -253,7 +253,9 @@ def main():
         optimizer.zero_grad()
         if use_at:
             if at_stream is not None and streams.ENABLED:
-                with torch.cuda.stream(at_stream):
+                # beside the SP step's kernels: the wavefront form (the persistent LSTM kernels want every CU to themselves; the
+                # stand-alone AT leg below -- BASELINE config 4 -- runs them)
+                with torch.cuda.stream(at_stream), H.lstm_persistent(False):
                     at_step()
             else:
                 at_step()
@@ -297,6 +299,7 @@ def main():
     breakdown = None
     f32_ms = None
     at_ms = None
+    at_eager_ms = None
     pcie_ms = {}
     rccl = None
     lf_block = None
@@ -370,7 +373,27 @@ def main():
             for _ in range(20):
                 at_step()
             torch.cuda.synchronize()
-            at_ms = (time.perf_counter() - t1) / 20 * 1e3
+            at_eager_ms = (time.perf_counter() - t1) / 20 * 1e3
+            at_ms = at_eager_ms
+            if dist is None:
+                # the same step captured into ONE hipGraph and replayed (graphs.GraphedTrainStep -- what LF._run does for its
+                # iteration and AT.trainLSTM for its per-sample step): with the recurrence in two persistent launches the eager
+                # step is bound by the host issuing its ~40 launches and autograd nodes, not by the device
+                from egaze_amd.graphs import GraphedTrainStep
+
+                def at_forward_loss(x, tgt):
+                    pred, _ = lstm(x, (h0, c0))
+                    return MSELoss.apply(pred, tgt), pred
+                gat = GraphedTrainStep(at_forward_loss, opt_at, (at_in, at_tgt))
+                for _ in range(6):
+                    gat(at_in, at_tgt)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    gat(at_in, at_tgt)
+                torch.cuda.synchronize()
+                at_ms = (time.perf_counter() - t1) / 50 * 1e3
+                gat.close()
         if world == 1:
             # BASELINE config 5's last stage beside the headline (untimed leg): one LF.trainLate iteration (late_fusion forward
             # + floss + backward + Adam, LF.py:90-100) at the same batch, HBM-bound -- 88 MB of algorithmic traffic per frame
@@ -592,15 +615,17 @@ def main():
                                         "value_is": "the median region (value, ms_per_step); every region is --steps steps "
                                                     "bracketed by barrier + synchronize, max over ranks"},
                       "at_ms_per_step": at_ms,
+                      "at_eager_ms_per_step": at_eager_ms,
                       "at_roofline": (None if not at_ms else
-                                      {"bound": "latency (5 batched f32-MFMA GEMM launches + 37 dependent wavefront launches of uniform-K "
-                                                "[recurrent product + cell] / cross-layer product blocks)",
+                                      {"bound": "latency (5 batched f32-MFMA GEMM launches + the recurrence as two persistent "
+                                                "weight-stationary launches: 17 forward / 18 backward in-launch steps of ~5 / ~6.6 us, "
+                                                "each an all-to-all of h / dgates between 256 resident blocks)",
                                        "achieved": 3 * 4.56e9 * (args.batch / 32.0) / (at_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": 3 * 4.56e9 * (args.batch / 32.0) / (at_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                        "samples_per_s": 16 * args.batch / (at_ms * 1e-3),
                                        "note": "config 4 shape, T=16: 4.56 GFLOP forward, x3 for forward + backward (SURVEY.md 8d); "
-                                               "the step is ~75 dependent launches of 5-20 us (18 + 19 recurrence launches, 5 GEMM "
-                                               "launches, ~30 small ones), not a matrix-core workload"}),
+                                               "one hipGraph replay per step (at_eager_ms_per_step: the same step issued "
+                                               "launch by launch, host-bound); not a matrix-core workload"}),
                       "lf_step": lf_block,
                       "at_note": ("AT alone (BASELINE config 4 shape): lstmnet T=16, B=%d forward + MSE + backward + Adam, "
                                   "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),

@@ -111,7 +111,8 @@ SIGNATURES = {
     "egz_lstm_cell_bwd": (c_int, [P, P, P, P, P, P, P, c_int, c_int, S]),
     "egz_lstm_wave_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "egz_lstm_persist_sync_words": (c_int, []),
-    "egz_lstm_persist_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_lstm_persist_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
+    "egz_lstm_persist_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "egz_lstm_wave_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, S]),
     "egz_lstm_b1_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "egz_lstm_b1_fwd": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, S]),

@@ -313,21 +313,42 @@ namespace {
 //     stored AFTER the arrival.
 // Every block must be resident for the counters to fill: 128 or 256 blocks of 512 threads at 142 VGPRs = one block per CU, so the
 // launch needs that many CUs to come free (work of other streams drains by itself; a SECOND persistent launch of another process
-// on the same device could interleave with this one).  A poll that sees no progress for ~0.2 s therefore gives up and raises
-// the error word -- the launch then finishes with garbage and egz_lstm_persist_fwd's status word reports it -- instead of
-// hanging the queue.
+// on the same device could interleave with this one).  A poll that sees no progress for ~0.2 s therefore gives up, raises the
+// error word and turns everything the block produces from then on into NaN (which reaches h_n / c_n, every later h_t and, in the
+// backward kernel, every later gradient) -- loud, instead of hanging the queue.
 typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
 constexpr int PF_H = 512, PF_SHARDS = 8, PF_LINE = 32;       // counters one per 128-byte line
+// -DEGZ_PERSIST_TRACE (tools/lstm_persist_trace.py, a variant build): thread 0 of block (0, 0) stamps the 100 MHz wall clock at the
+// phase boundaries of every global step into the tail of the sync scratch ([step][8] x 64 bit from word 1280).
+// -DEGZ_PERSIST_ACQ (A/B only): the consumer side as "one agent-scope acquire after the poll, then plain loads" instead of sc1 loads.
+#ifdef EGZ_PERSIST_ACQ
+#define PF_LOAD_AUX 0
+#define PF_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define PF_LOAD_AUX 16
+#define PF_ACQUIRE() do {} while (0)
+#endif
+#ifdef EGZ_PERSIST_TRACE
+constexpr int PF_TRACE_WORDS = 64 * 8 * 2;
+#define PF_TRACE(ph)                                                                                              \
+    do {                                                                                                          \
+        if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && s < 64)                                             \
+            reinterpret_cast<unsigned long long*>(a.sync + 5 * PF_SHARDS * PF_LINE)[s * 8 + (ph)] = wall_clock64(); \
+    } while (0)
+#else
+constexpr int PF_TRACE_WORDS = 0;
+#define PF_TRACE(ph) do {} while (0)
+#endif
 struct PersistFwd {
-    const float* gx0;                       // [T][B][4H] layer 0's input projection, bias included
+    const float* gx0;                       // [T][B][4H] layer 0's input projection x W_ih_l0^T, WITHOUT bias
     const float* w_hh0; const float* w_ih1; const float* w_hh1;      // [4H][H]
-    const float* bsum1;                     // [4H]
+    const float* b_ih[2]; const float* b_hh[2];                      // [4H] each; their sum is formed once per cell lane
     const float* h0; const float* c0;       // [2][B][H]
     float* hs;                              // [2][T + 1][B][H], slot 0 of a layer receives its h0
     float* cs;                              // [2][T][B][H]
     float* acts;                            // [2][T][B][4H] or null
     float* hn; float* cn;                   // [2][B][H]
-    unsigned int* sync;                     // [2 tiles][8 shards][32] arrival counters, then the error word at [512]
+    unsigned int* sync;                     // [2 tiles][8 shards][32] arrival counters; the error word at [1024]
 };
 
 __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd a, int T, int B) {
@@ -364,27 +385,27 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd 
     float c_state = 0.f, bs[4] = {0.f, 0.f, 0.f, 0.f};
     if (epi) {
         c_state = a.c0[elayer * bh + eo];
-        if (elayer)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bs[g] = a.bsum1[g * H + j0 + eu];
+        for (int g = 0; g < 4; ++g) bs[g] = a.b_ih[elayer][g * H + j0 + eu] + a.b_hh[elayer][g * H + j0 + eu];
         // slot 0 of each layer = its h0: published like a step (arrival below), so step 0 reads it like any other
         const float hv = a.h0[elayer * bh + eo];
         if (evalid) __hip_atomic_store(a.hs + elayer * hs_layer + eo, hv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     unsigned int* cnt = a.sync + (tile * PF_SHARDS) * PF_LINE;
     unsigned int* my_cnt = cnt + (unit_blk & (PF_SHARDS - 1)) * PF_LINE;
-    unsigned int* err = a.sync + 2 * PF_SHARDS * PF_LINE;
+    unsigned int* err = a.sync + 4 * PF_SHARDS * PF_LINE;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     for (int s = 0; s <= T; ++s) {
         const bool run0 = s < T, run1 = s >= 1;
+        PF_TRACE(0);
         // layer 0's pre-activation base of this step: in flight while the block waits
         float base[4] = {bs[0], bs[1], bs[2], bs[3]};
         if (epi && elayer == 0 && run0)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) base[g] = a.gx0[((long)s * B + (eb < B ? eb : B - 1)) * 4 * H + g * H + j0 + eu];
+            for (int g = 0; g < 4; ++g) base[g] = a.gx0[((long)s * B + (eb < B ? eb : B - 1)) * 4 * H + g * H + j0 + eu] + bs[g];
         // --- wait until all 128 blocks of this tile have published step s - 1 (16 arrivals per shard and step, + the h0 one)
         if (wave == 0 && !dead) {
             const unsigned int target = 16u * (unsigned)(s + 1);
@@ -401,15 +422,17 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd 
                     }
                 }
             } while (!ok);
+            PF_ACQUIRE();
         }
         __syncthreads();
+        PF_TRACE(1);
         // --- operands: h0_{s-1} = slot s of layer 0, h1_{s-2} = slot s - 1 of layer 1 (sc1: served from the coherent level)
         f32x4 x0[4], x1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            x0[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hs_rs, a_vo + 64u * u, (unsigned)((long)s * bh * 4), 16));
+            x0[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hs_rs, a_vo + 64u * u, (unsigned)((long)s * bh * 4), PF_LOAD_AUX));
             x1[u] = run1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                               hs_rs, a_vo + 64u * u, (unsigned)((hs_layer + (long)(s - 1) * bh) * 4), 16))
+                               hs_rs, a_vo + 64u * u, (unsigned)((hs_layer + (long)(s - 1) * bh) * 4), PF_LOAD_AUX))
                          : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -430,6 +453,7 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd 
             red[1][wave][(4 * q + e) * 16 + r] = acc1[e];
         }
         __syncthreads();
+        PF_TRACE(2);
         // --- cells
         float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, hv = 0.f;
         const int t = elayer ? s - 1 : s;
@@ -444,7 +468,9 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd 
             gi = sigm(pre[0]); gf = sigm(pre[1]); gg = tanhf(pre[2]); go = sigm(pre[3]);
             c_state = gf * c_state + gi * gg;
             hv = go * tanhf(c_state);
+            if (dead) hv = c_state = __builtin_nanf("");          // a hand-off never arrived: poison what this launch returns
         }
+        PF_TRACE(3);
         // publish h_t: the 4 units of a row sit in 4 neighbouring lanes -> one 16-byte write-through store per row
         if (epi) {
             f32x4 h4;
@@ -456,7 +482,9 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        PF_TRACE(4);
         if (tid == 0 && s < T) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PF_TRACE(5);
         // what only the backward pass / the caller reads: after the arrival
         if (act && evalid) {
             a.cs[(elayer * (long)T + t) * bh + eo] = c_state;
@@ -472,31 +500,313 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The backward wavefront of the same network in ONE persistent launch.  The reduction of a backward step runs over the GATE index
+// (K = 4H = 2048 per product), its outputs are hidden units -- so what the blocks exchange is dgates, 4x wider than the forward's
+// h.  To halve what a block has to pull per step the batch is cut into tiles of 8 rows:
+//   * grid = 64 unit slices x ceil(B / 8) batch tiles = 256 blocks at B = 32; a block owns 8 hidden units of BOTH layers for its 8
+//     rows: rows 8 units x 2048 of W_hh_l1^T, W_ih_l1^T and W_hh_l0^T = 192 KB of weights in registers (96 VGPRs per lane; one
+//     block of 512 threads per CU).
+//   * MFMA shape: 8 rows x 8 units per block would waste a 16x16 tile, so the products run on v_mfma_f32_4x4x1 (16 independent
+//     4x4 blocks per instruction): block index = 16 consecutive reduction indices, A = 4 batch rows, B = 4 units; a lane
+//     (ks = lane >> 2, i = lane & 3) feeds row i / unit i at k = 256 wave + 64 c + 4 ks + e.  The 16 blocks' partial sums are
+//     folded across lanes (two DPP row shifts, then LDS), then across the 8 waves.
+//   * global step s: layer 1's cell at t = T - 1 - s, layer 0's cell at t = T - s (one behind: it needs dgates_{1,t}); both read
+//     what step s - 1 published: G1 = dgates_{1,T-s} (feeds W_hh_l1 for layer 1 AND W_ih_l1 for layer 0: loaded once) and
+//     G0 = dgates_{0,T-s+1}: 8 rows x 2048 x 2 = 128 KB per block and step.  Steps T and T + 1 form dh0 of layer 1 / layer 0.
+//   * hand-off as in the forward kernel: dgates stored write-through (16 bytes per lane), drained, one arrival per block on the
+//     counter of its (tile, shard); the running dc of a cell stays in its epilogue lane's register.
+constexpr int PB_SHARDS = 8;
+constexpr int PB_TICKET_OFF = 4 * PB_SHARDS * PF_LINE + PF_LINE;      // 64 fold tickets behind the error word's line
+constexpr int PB_PART_OFF = 5 * PB_SHARDS * PF_LINE + PF_TRACE_WORDS;  // [4 tiles][2][4H] bias-gradient partials (not zeroed)
+struct PersistBwd {
+    const float* dh_top;                    // [T][B][H] gradient w.r.t. the top layer's outputs, or null
+    const float* dhn; const float* dcn;     // [2][B][H] or null
+    const float* acts;                      // [2][T][B][4H]
+    const float* cs;                        // [2][T][B][H]
+    const float* c0;                        // [2][B][H]
+    const float* w_hh0; const float* w_ih1; const float* w_hh1;            // the weights as the module holds them: [4H][H]
+    float* dgates;                          // [2][T][B][4H] out
+    float* dh0; float* dc0;                 // [2][B][H] out
+    float* db[4];                           // bias gradients (b_ih_l0, b_hh_l0, b_ih_l1, b_hh_l1), [4H] each, null = not wanted
+    unsigned int* sync;                     // [4 tiles][8 shards][32] arrival counters, the error word's line, fold tickets, partials
+};
+
+__device__ __forceinline__ float dpp_row_shr_add(float v, const int shift4) {        // v + (v of the lane `4` or `8` below in the row of 16)
+    const int t = shift4 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)
+                         : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
+
+__global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwd a, int T, int B) {
+    constexpr int H = PF_H, K = 4 * PF_H, RS = 132;            // RS: row stride of the reduction buffer (128 outputs + pad)
+    __shared__ float red[32 * RS];
+    __shared__ float dbl[4][128];           // running sums over the steps of this block's dgates (bias gradients), per cell lane
+    __shared__ int dead;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = lane >> 2, li = lane & 3;
+    if (tid < 128) dbl[0][tid] = dbl[1][tid] = dbl[2][tid] = dbl[3][tid] = 0.f;
+    const int unit_blk = blockIdx.x, tile = blockIdx.y;
+    const int j0 = unit_blk * 8, r0 = tile * 8;
+    const long bh = (long)B * H, bk = (long)B * K;
+    if (tid == 0) dead = 0;
+    // --- the block's weights: unit j0 + 4 ug + li, k = 256 wave + 64 c + 4 ks .. + 3
+    f32x4 whh1[2][4], wih1[2][4], whh0[2][4];
+#pragma unroll
+    for (int ug = 0; ug < 2; ++ug)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // W^T[unit][k] = W[k][unit], gathered once per launch (4 neighbouring lanes read 16 contiguous bytes of a row)
+                const long o = (long)(256 * wave + 64 * c + 4 * ks + e) * H + j0 + 4 * ug + li;
+                whh1[ug][c][e] = a.w_hh1[o];
+                wih1[ug][c][e] = a.w_ih1[o];
+                whh0[ug][c][e] = a.w_hh0[o];
+            }
+    // --- A operand addressing: rows r0 + 4 g + li of a [B][4H] slot of dgates
+    unsigned a_vo[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        int b = r0 + 4 * g + li;
+        b = b < B ? b : B - 1;
+        a_vo[g] = (unsigned)((b * K + 256 * wave + 4 * ks) * 4);
+    }
+    const __amdgpu_buffer_rsrc_t dg_rs = __builtin_amdgcn_make_buffer_rsrc(a.dgates, 0, (int)(2 * T * bk * 4), 0x00020000);
+    // --- epilogue role: thread o < 128 owns one (layer, row, unit): o = layer * 64 + g * 32 + ug * 16 + e * 4 + j
+    const bool epi = tid < 128;
+    const int el = tid >> 6, erow = 4 * ((tid >> 5) & 1) + ((tid >> 2) & 3), eunit = 4 * ((tid >> 4) & 1) + (tid & 3);
+    const int eb = r0 + erow;
+    const bool evalid = epi && eb < B;
+    const int ebc = eb < B ? eb : B - 1;
+    const long eo = (long)ebc * H + j0 + eunit;
+    float dc_run = 0.f;
+    unsigned int* cnt = a.sync + (tile * PB_SHARDS) * PF_LINE;
+    unsigned int* my_cnt = cnt + (unit_blk & (PB_SHARDS - 1)) * PF_LINE;
+    unsigned int* err = a.sync + 4 * PB_SHARDS * PF_LINE;
+    __syncthreads();
+
+    for (int s = 0; s <= T + 1; ++s) {
+        // this thread's cell (if any) of the step, and everything about it that does not depend on the hand-off
+        PF_TRACE(0);
+        const int t = el ? T - 1 - s : T - s;
+        const bool cell = epi && t >= 0 && t < T;
+        const bool fin = epi && t == -1;
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cv = 0.f, cpv = 0.f, dh_add = 0.f, dc_in = 0.f;
+        if (cell) {
+            const float* aa = a.acts + ((long)(el * T + t) * B + ebc) * K + j0 + eunit;
+            gi = aa[0]; gf = aa[H]; gg = aa[2 * H]; go = aa[3 * H];
+            cv = a.cs[(long)(el * T + t) * bh + eo];
+            cpv = t ? a.cs[(long)(el * T + t - 1) * bh + eo] : a.c0[el * bh + eo];
+            if (el && a.dh_top) dh_add = a.dh_top[(long)t * bh + eo];
+            if (t == T - 1) {
+                if (a.dhn) dh_add += a.dhn[el * bh + eo];
+                dc_in = a.dcn ? a.dcn[el * bh + eo] : 0.f;
+            }
+        }
+        // --- wait until the 64 blocks of this tile have published step s - 1 (8 arrivals per shard and step)
+        if (s && wave == 0 && !dead) {
+            const unsigned int target = 8u * (unsigned)s;
+            unsigned int spins = 0;
+            bool ok;
+            do {
+                const unsigned int v = lane < PB_SHARDS ? __hip_atomic_load(cnt + lane * PF_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                ok = __all(v >= target);
+                if (!ok) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 100000u) {
+                        if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        break;
+                    }
+                }
+            } while (!ok);
+            PF_ACQUIRE();
+        }
+        __syncthreads();
+        PF_TRACE(1);
+        // --- operands (sc1 loads): G1 = dgates_{1, T - s} for 1 <= s <= T, G0 = dgates_{0, T - s + 1} for 2 <= s <= T + 1
+        const bool has1 = s >= 1 && s <= T, has0 = s >= 2;
+        f32x4 x1[2][4], x0[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                x1[g][c] = has1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                      dg_rs, a_vo[g] + 256u * c, (unsigned)(((long)(T + T - s)) * bk * 4), PF_LOAD_AUX))
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+                x0[g][c] = has0 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                      dg_rs, a_vo[g] + 256u * c, (unsigned)(((long)(T - s + 1)) * bk * 4), PF_LOAD_AUX))
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        f32x4 acc1[2][2], acc0[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ug = 0; ug < 2; ++ug) acc1[g][ug] = acc0[g][ug] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int ug = 0; ug < 2; ++ug) {
+                            acc1[g][ug] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1[g][c][e], whh1[ug][c][e], acc1[g][ug], 0, 0, 0);
+                            acc0[g][ug] = __builtin_amdgcn_mfma_f32_4x4x1f32(x1[g][c][e], wih1[ug][c][e], acc0[g][ug], 0, 0, 0);
+                            acc0[g][ug] = __builtin_amdgcn_mfma_f32_4x4x1f32(x0[g][c][e], whh0[ug][c][e], acc0[g][ug], 0, 0, 0);
+                        }
+        }
+        // fold the 16 reduction blocks of the instruction: ks & 3 by two DPP row shifts (lanes 12..15 of every row of 16 end up with
+        // the sum of their 4), ks >> 2 and the 8 waves through LDS
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ug = 0; ug < 2; ++ug)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v1 = dpp_row_shr_add(dpp_row_shr_add(acc1[g][ug][e], 1), 0);
+                    float v0 = dpp_row_shr_add(dpp_row_shr_add(acc0[g][ug][e], 1), 0);
+                    if ((lane & 15) >= 12) {
+                        float* rr = red + (wave * 4 + (lane >> 4)) * RS + g * 32 + ug * 16 + e * 4 + li;
+                        rr[64] = v1;
+                        rr[0] = v0;
+                    }
+                }
+        __syncthreads();
+        PF_TRACE(2);
+        float val = 0.f;
+        if (epi) {
+            float p[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) p[i] = red[i * RS + tid];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] += p[i + 16];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] += p[i + 8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i] += p[i + 4];
+            val = (p[0] + p[2]) + (p[1] + p[3]);
+            if (dead) val = __builtin_nanf("");                   // a hand-off never arrived: poison every gradient from here on
+        }
+        float d4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell) {
+            const float dhv = dh_add + val;
+            const float dcin = (t == T - 1) ? dc_in : dc_run;
+            const float tc = tanhf(cv);
+            const float dct = dcin + dhv * go * (1.f - tc * tc);
+            d4[0] = dct * gg * gi * (1.f - gi);
+            d4[1] = dct * cpv * gf * (1.f - gf);
+            d4[2] = dct * gi * (1.f - gg * gg);
+            d4[3] = dhv * tc * go * (1.f - go);
+            dc_run = dct * gf;
+            if (evalid)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) dbl[g][tid] += d4[g];
+        }
+        PF_TRACE(3);
+        // publish dgates_t: the 4 units tid & 3 of a (row, gate) sit in 4 neighbouring lanes -> one 16-byte write-through store
+        if (epi) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v4;
+                v4[0] = __shfl(d4[g], (lane & ~3) + 0); v4[1] = __shfl(d4[g], (lane & ~3) + 1);
+                v4[2] = __shfl(d4[g], (lane & ~3) + 2); v4[3] = __shfl(d4[g], (lane & ~3) + 3);
+                if (cell && evalid && (tid & 3) == 0)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4p, v4), dg_rs,
+                                                           (unsigned)((eb * K + g * H + j0 + (eunit & ~3)) * 4),
+                                                           (unsigned)(((long)(el * T + t)) * bk * 4), 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        PF_TRACE(4);
+        if (tid == 0 && s <= T) __hip_atomic_fetch_add(my_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PF_TRACE(5);
+        if (evalid) {
+            if (cell && t == 0) a.dc0[el * bh + eo] = dc_run;
+            if (fin) a.dh0[el * bh + eo] = val;
+        }
+    }
+    // --- bias gradients = the sums of dgates over steps and batch rows: the steps are summed in dbl, the block's 8 rows here, the
+    // (<= 4) batch tiles by whichever block of the unit slice draws the last ticket -- in tile order, so the result does not
+    // depend on who that is.  Partials travel write-through like every other hand-off of the launch.
+    if (a.db[0] || a.db[1] || a.db[2] || a.db[3]) {
+        float* part = reinterpret_cast<float*>(a.sync + PB_PART_OFF);
+        unsigned int* ticket = a.sync + PB_TICKET_OFF + unit_blk;
+        const int fl = tid >> 5, fg = (tid >> 3) & 3, fu = tid & 7;            // tid < 64: (layer, gate, unit)
+        const int fidx = fl * K + fg * H + j0 + fu;
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum += dbl[fg][fl * 64 + (r >> 2) * 32 + (fu >> 2) * 16 + (r & 3) * 4 + (fu & 3)];
+            __hip_atomic_store(part + tile * 2 * K + fidx, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (tid == 0) dead = (int)__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (dead == (int)gridDim.y - 1 && tid < 64) {
+            float sum = 0.f;
+            for (int tl = 0; tl < (int)gridDim.y; ++tl)
+                sum += __hip_atomic_load(part + tl * 2 * K + fidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.db[2 * fl]) a.db[2 * fl][fg * H + j0 + fu] = sum;
+            if (a.db[2 * fl + 1]) a.db[2 * fl + 1][fg * H + j0 + fu] = sum;
+        }
+    }
+}
+
 }  // namespace
 
-// Words of the `sync` scratch of egz_lstm_persist_fwd (zeroed by the call itself); word [words - 32] is the error word: 0 = every hand-off arrived, 1 + s = a block gave up waiting in global step s.
-constexpr int PF_SYNC_WORDS = 2 * PF_SHARDS * PF_LINE + PF_LINE;
+// Words of the `sync` scratch of egz_lstm_persist_fwd (zeroed by the call itself); word [1024] is the error word: 0 = every hand-off arrived, 1 + s = a block gave up waiting in global step s.
+constexpr int PF_ZERO_WORDS = 5 * PF_SHARDS * PF_LINE + PF_TRACE_WORDS;      // counters, error word, tickets (+ trace)
+constexpr int PF_SYNC_WORDS = PF_ZERO_WORDS + 4 * 2 * 4 * PF_H;      // the backward form's 4 tiles x 8 shards; the forward uses the first half
 EGZ_API int egz_lstm_persist_sync_words(void) { return PF_SYNC_WORDS; }
 
-// The same recurrence as egz_lstm_wave_fwd for L = 2, H = 512, B <= 32 in ONE persistent launch (lstm_persist_fwd_kernel): same
-// arguments and outputs (w_ih[0] / bsum[0] unused), plus `sync`: egz_lstm_persist_sync_words() uints of device scratch; after the
-// launch sync[words - 32] is 0, or 1 + s if a block's wait timed out in step s (outputs then undefined).  Returns
-// hipErrorNotSupported for any other geometry (the caller launches the wavefront instead).
-EGZ_API int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
-                                 const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn,
-                                 unsigned int* sync, int L, int T, int B, int H, hipStream_t st) {
-    EGZ_CHECK_ARG(gx0 && w_ih && w_hh && bsum && h0 && c0 && hs && cs && hn && cn && sync, "egz_lstm_persist_fwd: null pointer");
+// The recurrence of egz_lstm_wave_fwd for L = 2, H = 512, B <= 32 in ONE persistent launch (lstm_persist_fwd_kernel).  Differences in
+// the arguments: gx0 [T][B][4H] = x W_ih_l0^T WITHOUT bias, and the biases as the module holds them -- b_ih / b_hh: HOST arrays of
+// L device pointers ([4H] each) -- summed inside the kernel (no separate b_ih + b_hh launches); w_ih[0] unused.  Outputs as
+// egz_lstm_wave_fwd.  `sync`: egz_lstm_persist_sync_words() uints of device scratch; after the launch sync[1024] is 0, or 1 + s if
+// a block's wait timed out in step s (outputs then undefined).  Returns hipErrorNotSupported for any other geometry (the caller
+// launches the wavefront instead).
+EGZ_API int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                                 const float* const* b_hh, const float* h0, const float* c0, float* hs, float* cs, float* acts,
+                                 float* hn, float* cn, unsigned int* sync, int L, int T, int B, int H, hipStream_t st) {
+    EGZ_CHECK_ARG(gx0 && w_ih && w_hh && b_ih && b_hh && h0 && c0 && hs && cs && hn && cn && sync, "egz_lstm_persist_fwd: null pointer");
     if (L != 2 || H != PF_H || B < 1 || B > 32 || T < 1) {
         egz_set_error("egz_lstm_persist_fwd: L=%d T=%d B=%d H=%d (built for L = 2, H = 512, B <= 32)", L, T, B, H);
         return (int)hipErrorNotSupported;
     }
-    EGZ_CHECK_ARG(w_hh[0] && w_hh[1] && w_ih[1] && bsum[1], "egz_lstm_persist_fwd: null weight pointer");
-    const long bh = (long)B * H;
-    (void)bh;
-    PersistFwd a{gx0, w_hh[0], w_ih[1], w_hh[1], bsum[1], h0, c0, hs, cs, acts, hn, cn, sync};
-    hipError_t e = hipMemsetAsync(sync, 0, PF_SYNC_WORDS * sizeof(unsigned int), st);
+    EGZ_CHECK_ARG(w_hh[0] && w_hh[1] && w_ih[1] && b_ih[0] && b_ih[1] && b_hh[0] && b_hh[1], "egz_lstm_persist_fwd: null weight pointer");
+    PersistFwd a{gx0, w_hh[0], w_ih[1], w_hh[1], {b_ih[0], b_ih[1]}, {b_hh[0], b_hh[1]}, h0, c0, hs, cs, acts, hn, cn, sync};
+    hipError_t e = hipMemsetAsync(sync, 0, PF_ZERO_WORDS * sizeof(unsigned int), st);
     if (e != hipSuccess) { egz_set_error("egz_lstm_persist_fwd: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     hipLaunchKernelGGL(lstm_persist_fwd_kernel, dim3(128, egz_cdiv(B, 16)), dim3(512), 0, st, a, T, B);
     EGZ_CHECK_LAUNCH("egz_lstm_persist_fwd");
+    return 0;
+}
+
+// Its backward for the same geometry in ONE persistent launch (lstm_persist_bwd_kernel): egz_lstm_wave_bwd's inputs and outputs
+// without dhin, except that the weights come AS THE MODULE HOLDS THEM -- w_hh / w_ih: HOST arrays of L device pointers [4H][H]
+// (w_ih[0] unused; no transposed copies) -- and that the launch also forms the bias gradients: db = HOST array of 2 L device
+// pointers (b_ih_l0, b_hh_l0, b_ih_l1, b_hh_l1; [4H] each, = the sums of dgates_l over steps and batch rows; null entries are
+// skipped, db itself may be null).  `sync` as above.  hipErrorNotSupported for any other geometry.
+EGZ_API int egz_lstm_persist_bwd(const float* dh_top, const float* dhn, const float* dcn, const float* acts, const float* cs,
+                                 const float* c0, const float* const* w_hh, const float* const* w_ih, float* dgates, float* dh0,
+                                 float* dc0, float* const* db, unsigned int* sync, int L, int T, int B, int H, hipStream_t st) {
+    EGZ_CHECK_ARG(acts && cs && c0 && w_hh && w_ih && dgates && dh0 && dc0 && sync, "egz_lstm_persist_bwd: null pointer");
+    if (L != 2 || H != PF_H || B < 1 || B > 32 || T < 1) {
+        egz_set_error("egz_lstm_persist_bwd: L=%d T=%d B=%d H=%d (built for L = 2, H = 512, B <= 32)", L, T, B, H);
+        return (int)hipErrorNotSupported;
+    }
+    EGZ_CHECK_ARG(w_hh[0] && w_hh[1] && w_ih[1], "egz_lstm_persist_bwd: null weight pointer");
+    PersistBwd a{dh_top, dhn, dcn, acts, cs, c0, w_hh[0], w_ih[1], w_hh[1], dgates, dh0, dc0,
+                 {db ? db[0] : nullptr, db ? db[1] : nullptr, db ? db[2] : nullptr, db ? db[3] : nullptr}, sync};
+    hipError_t e = hipMemsetAsync(sync, 0, PF_ZERO_WORDS * sizeof(unsigned int), st);
+    if (e != hipSuccess) { egz_set_error("egz_lstm_persist_bwd: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    hipLaunchKernelGGL(lstm_persist_bwd_kernel, dim3(64, egz_cdiv(B, 8)), dim3(512), 0, st, a, T, B);
+    EGZ_CHECK_LAUNCH("egz_lstm_persist_bwd");
     return 0;
 }

@@ -1448,10 +1448,30 @@ def copy_into(dst: torch.Tensor, src: torch.Tensor):
     check(LIB.egz_copy(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "egz_copy")
 
 
-# EGAZE_LSTM_PERSIST=1: the forward recurrence of the AT network as ONE persistent launch (egz_lstm_persist_fwd) where its geometry
-# allows (L = 2, H = 512, B <= 32); 0: always the T + L - 1 wavefront launches.
-LSTM_PERSIST = _os.environ.get("EGAZE_LSTM_PERSIST", "0") != "0"
+# The recurrence of the AT network as ONE persistent, weight-stationary launch per direction (egz_lstm_persist_fwd / _bwd) where its
+# geometry allows (L = 2, H = 512, B <= 32): T=16 / B=32 forward 167 -> 90 us, backward 190 -> 119 us (profiles/r05_ab_notes.txt).
+# EGAZE_LSTM_PERSIST=0: always the wavefront launches (egz_lstm_wave_fwd / _bwd: T + 1 / T + 3 launches).
+LSTM_PERSIST = _os.environ.get("EGAZE_LSTM_PERSIST", "1") != "0"
 _PERSIST_SYNC: list = []
+
+
+class lstm_persistent:
+    """``with hipops.lstm_persistent(False): ...`` -- the wavefront launches inside the block.  The persistent kernels hold one block
+    per CU until the sequence is over, so they are the wrong form for an AT step that runs in the shadow of other work on the same
+    device (bench.py's combined step: the SP step's MFMA kernels occupy every CU; measured +0.1 ... +0.2 ms on the SP step)."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global LSTM_PERSIST
+        self.prev, LSTM_PERSIST = LSTM_PERSIST, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global LSTM_PERSIST
+        LSTM_PERSIST = self.prev
+        return False
 
 
 def lstm_persist_status() -> int:
@@ -1459,7 +1479,7 @@ def lstm_persist_status() -> int:
     gave up waiting in global step s (the outputs of that launch are undefined)."""
     if not _PERSIST_SYNC:
         return 0
-    return int(_PERSIST_SYNC[0][-32].item())
+    return int(_PERSIST_SYNC[0][1024].item())
 
 
 def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
@@ -1484,16 +1504,6 @@ def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
     hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
     cn = torch.empty_like(hn)
     PROF.note_flops("egz_lstm_wave_fwd", 2.0 * T * B * H4 * Hd * (2 * L - 1))
-    if LSTM_PERSIST and L == 2 and Hd == 512 and B <= 32:
-        # one persistent, weight-stationary launch (csrc/lstm_seq.hip, lstm_persist_fwd_kernel); its hand-off counters live in a
-        # scratch of this call's own (the launch zeroes it), kept reachable for lstm_persist_status()
-        sync = torch.empty((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
-        check(LIB.egz_lstm_persist_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh),
-                                       _ptr_table([None] + list(bsum[1:])), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(),
-                                       cs.data_ptr(), _p(acts), hn.data_ptr(), cn.data_ptr(), sync.data_ptr(), L, T, B, Hd,
-                                       _stream()), "egz_lstm_persist_fwd")
-        _PERSIST_SYNC[:] = [sync]
-        return hs, cs, acts, hn, cn
     check(LIB.egz_lstm_wave_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh),
                                 _ptr_table([None] + list(bsum[1:])), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(),
                                 _p(acts), hn.data_ptr(), cn.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_wave_fwd")
@@ -1517,6 +1527,69 @@ def lstm_wave_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh_t, w_ih_t):
     check(LIB.egz_lstm_wave_bwd(_p(dh_top), _p(dhn), _p(dcn), acts.data_ptr(), cs.data_ptr(), c0.data_ptr(),
                                 _ptr_table(w_hh_t), _ptr_table([None] + list(w_ih_t[1:])), dgates.data_ptr(), dh0.data_ptr(),
                                 dc0.data_ptr(), _p(dhin), L, T, B, Hd, _stream()), "egz_lstm_wave_bwd")
+    return dgates, dh0, dc0
+
+
+def lstm_persist_ok(L: int, B: int, Hd: int) -> bool:
+    """Whether the recurrence runs as the persistent launches (knob on and the geometry they are built for)."""
+    return LSTM_PERSIST and L == 2 and Hd == 512 and 1 <= B <= 32
+
+
+def lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0, want_acts: bool = True):
+    """The stacked recurrence in ONE persistent, weight-stationary launch (egz_lstm_persist_fwd; L = 2, H = 512, B <= 32): gx0
+    (T,B,4H) = layer 0's input projection WITHOUT bias; w_ih / w_hh / b_ih / b_hh: lists of L tensors as the module holds them
+    (w_ih[0] unused) -> the outputs of lstm_wave_fwd.  The launch's hand-off counters live in a scratch of this call's own (the
+    call zeroes it), kept reachable for lstm_persist_status()."""
+    _req(gx0, "gx0"); _req(h0, "h0"); _req(c0, "c0")
+    L = len(w_hh)
+    T, B, H4 = gx0.shape
+    Hd = H4 // 4
+    for l in range(L):
+        _req(w_hh[l], "w_hh"); _req(b_ih[l], "b_ih"); _req(b_hh[l], "b_hh")
+        if l:
+            _req(w_ih[l], "w_ih")
+    dev = gx0.device
+    hs = torch.empty((L, T + 1, B, Hd), dtype=torch.float32, device=dev)
+    cs = torch.empty((L, T, B, Hd), dtype=torch.float32, device=dev)
+    acts = torch.empty((L, T, B, H4), dtype=torch.float32, device=dev) if want_acts else None
+    hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
+    cn = torch.empty_like(hn)
+    sync = torch.empty((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
+    PROF.note_flops("egz_lstm_persist_fwd", 2.0 * T * B * H4 * Hd * (2 * L - 1))
+    check(LIB.egz_lstm_persist_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh), _ptr_table(b_ih),
+                                   _ptr_table(b_hh), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(), _p(acts),
+                                   hn.data_ptr(), cn.data_ptr(), sync.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_persist_fwd")
+    _PERSIST_SYNC[:] = [sync]
+    return hs, cs, acts, hn, cn
+
+
+def lstm_persist_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh, w_ih, db=None):
+    """Backward through time in ONE persistent launch (egz_lstm_persist_bwd) -> (dgates (L,T,B,4H), dh0, dc0 (L,B,H)); w_hh / w_ih:
+    the UNtransposed weights (w_ih[0] unused); db: list of 2 L destinations (b_ih_l0, b_hh_l0, b_ih_l1, b_hh_l1; None entries
+    skipped) that receive the bias gradients -- the sums of dgates over steps and batch rows -- from the same launch."""
+    L, T, B, Hd = cs.shape
+    dev = cs.device
+    dgates = torch.empty((L, T, B, 4 * Hd), dtype=torch.float32, device=dev)
+    dh0 = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
+    dc0 = torch.empty_like(dh0)
+    for name, t in (("dh_top", dh_top), ("dhn", dhn), ("dcn", dcn)):
+        if t is not None:
+            _req(t, name)
+    for l in range(L):
+        _req(w_hh[l], "w_hh")
+        if l:
+            _req(w_ih[l], "w_ih")
+    if db is not None:
+        for t in db:
+            if t is not None and (not t.is_contiguous() or t.numel() != 4 * Hd):
+                raise RuntimeError("lstm_persist_bwd: a bias-gradient destination must be a contiguous (4H,) tensor")
+    sync = torch.empty((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
+    PROF.note_flops("egz_lstm_persist_bwd", 2.0 * (T + 1) * B * 4 * Hd * Hd * L + 2.0 * T * B * 4 * Hd * Hd * (L - 1))
+    check(LIB.egz_lstm_persist_bwd(_p(dh_top), _p(dhn), _p(dcn), acts.data_ptr(), cs.data_ptr(), c0.data_ptr(), _ptr_table(w_hh),
+                                   _ptr_table([None] + list(w_ih[1:])), dgates.data_ptr(), dh0.data_ptr(), dc0.data_ptr(),
+                                   _ptr_table(db) if db is not None else None, sync.data_ptr(), L, T, B, Hd, _stream()),
+          "egz_lstm_persist_bwd")
+    _PERSIST_SYNC[:] = [sync]
     return dgates, dh0, dc0
 
 

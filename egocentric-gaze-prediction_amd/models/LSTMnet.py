@@ -39,10 +39,18 @@ class _LSTMNetFn(torch.autograd.Function):
         x = H.tanh_fwd(inp_c)
         w_ih = [params[4 * l].detach() for l in range(L)]
         w_hh = [H._req(params[4 * l + 1].detach(), "w_hh") for l in range(L)]
-        bsum = [H.add(params[4 * l + 2].detach(), params[4 * l + 3].detach()) for l in range(L)]
-        gx0 = H.linear_fwd(x.view(T * B, C), w_ih[0], bias=bsum[0]).view(T, B, 4 * Hd)      # all time steps at once
+        persist = C == Hd and H.lstm_persist_ok(L, B, Hd)
         # hs: (L, T + 1, B, H) -- slot 0 of a layer holds its h0, slots 1 .. T the outputs
-        hs, cs, acts, hn, cn = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0c, c0c, want_acts=train)
+        if persist:
+            # ONE persistent weight-stationary launch (csrc/lstm_seq.hip): it adds b_ih + b_hh itself, so the projection of all time
+            # steps carries no bias and no bias-sum launches precede it
+            gx0 = H.linear_fwd(x.view(T * B, C), w_ih[0]).view(T, B, 4 * Hd)
+            hs, cs, acts, hn, cn = H.lstm_persist_fwd(gx0, w_ih, w_hh, [params[4 * l + 2].detach() for l in range(L)],
+                                                      [params[4 * l + 3].detach() for l in range(L)], h0c, c0c, want_acts=train)
+        else:
+            bsum = [H.add(params[4 * l + 2].detach(), params[4 * l + 3].detach()) for l in range(L)]
+            gx0 = H.linear_fwd(x.view(T * B, C), w_ih[0], bias=bsum[0]).view(T, B, 4 * Hd)      # all time steps at once
+            hs, cs, acts, hn, cn = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0c, c0c, want_acts=train)
         lin_w, lin_b = params[-2].detach(), params[-1].detach()
         out2d = H.linear_fwd(hs[L - 1, 1:].view(T * B, Hd), lin_w, bias=lin_b, relu=True)
         # the node keeps the 2-D base and hands out a VIEW: the returned tensor (whose grad_fn is this node) must not be
@@ -51,6 +59,7 @@ class _LSTMNetFn(torch.autograd.Function):
         ctx.saved = (x, h0c, c0c, hs, cs, acts, out2d)
         ctx.params = list(params)
         ctx.dims = (T, B, C, Hd, L)
+        ctx.persist = persist
         ctx.set_materialize_grads(False)
         return out2d.view(T, B, lin_w.shape[0]), hn, cn
 
@@ -78,10 +87,28 @@ class _LSTMNetFn(torch.autograd.Function):
         if ng[3 + len(params) - 1]:
             grads[-1] = H.colsum(dpre, out=sinks[-1])
         dh_top = H.matmul_nn(dpre, lin_w).view(T, B, Hd)          # gradient into the top layer's outputs
-        w_hh_t = [H.transpose2d(H._req(params[4 * l + 1].detach(), "w_hh")) for l in range(L)]
-        w_ih_t = [None] + [H.transpose2d(H._req(params[4 * l].detach(), "w_ih")) for l in range(1, L)]
-        dgates, dh0, dc0 = H.lstm_wave_bwd(dh_top, dhn.contiguous() if dhn is not None else None,
-                                           dcn.contiguous() if dcn is not None else None, acts, cs, c0c, w_hh_t, w_ih_t)
+        bias_done = False
+        if ctx.persist:
+            # one persistent launch: reads the weights as they are (no transposed copies) and forms the bias gradients -- the column
+            # sums of dgates -- on the way, straight into their sinks
+            db = []
+            for l in range(L):
+                for i in (4 * l + 2, 4 * l + 3):
+                    if ng[3 + i]:
+                        grads[i] = H._out(sinks[i], (4 * Hd,), out.device)
+                        db.append(grads[i])
+                    else:
+                        db.append(None)
+            dgates, dh0, dc0 = H.lstm_persist_bwd(dh_top, dhn.contiguous() if dhn is not None else None,
+                                                  dcn.contiguous() if dcn is not None else None, acts, cs, c0c,
+                                                  [params[4 * l + 1].detach() for l in range(L)],
+                                                  [params[4 * l].detach() for l in range(L)], db)
+            bias_done = True
+        else:
+            w_hh_t = [H.transpose2d(H._req(params[4 * l + 1].detach(), "w_hh")) for l in range(L)]
+            w_ih_t = [None] + [H.transpose2d(H._req(params[4 * l].detach(), "w_ih")) for l in range(1, L)]
+            dgates, dh0, dc0 = H.lstm_wave_bwd(dh_top, dhn.contiguous() if dhn is not None else None,
+                                               dcn.contiguous() if dcn is not None else None, acts, cs, c0c, w_hh_t, w_ih_t)
         # d W_ih = dgates^T layer_in, d W_hh = sum_t dgates_t^T h_{t-1} (slots 0 .. T - 1 of hs are (h0, h_1 .. h_{T-1}): one product
         # each) -- all 2 L products of one shape in ONE launch when C == H (egz_gemm_batched)
         prods = []
@@ -99,7 +126,7 @@ class _LSTMNetFn(torch.autograd.Function):
         else:
             for i, a, b in prods:
                 grads[i] = H.matmul_tn(a, b, out=sinks[i])
-        for l in range(L):
+        for l in range(0 if not bias_done else L, L):
             dg2 = dgates[l].view(T * B, 4 * Hd)
             # d b_ih = d b_hh = the column sums of dgates: summed once, the second one is a copy of the first
             gb = None

@@ -307,14 +307,16 @@ int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* c
                       int B, int H, hipStream_t stream);
 /* The same forward recurrence for the AT network's own geometry (L = 2, H = 512, B <= 32) as ONE persistent, weight-stationary
  * launch: each of 128 x ceil(B / 16) blocks keeps its 16 x 1536 weights in registers for the whole sequence and the blocks hand
- * h_t to each other inside the launch (write-through stores + arrival counters, csrc/lstm_seq.hip).  Arguments and outputs as
- * egz_lstm_wave_fwd, plus `sync`: egz_lstm_persist_sync_words() uints of device scratch (zeroed by the call); after the launch
- * word [words - 32] is 0, or 1 + s when a block gave up waiting in global step s (outputs then undefined).  Any other geometry:
- * returns hipErrorNotSupported (801) and launches nothing -- call egz_lstm_wave_fwd. */
+ * h_t to each other inside the launch (write-through stores + arrival counters, csrc/lstm_seq.hip).  Outputs as
+ * egz_lstm_wave_fwd; inputs differ in two places: gx0 = x W_ih0^T WITHOUT bias, and b_ih / b_hh = HOST arrays of L device pointers
+ * to the module's own bias vectors ([4H] each), summed inside the kernel.  `sync`: egz_lstm_persist_sync_words() uints of device
+ * scratch (its counters are zeroed by the call); after the launch word [1024] is 0, or 1 + s when a block gave up waiting in
+ * global step s (outputs then undefined).  Any other geometry: returns hipErrorNotSupported (801) and launches nothing -- call
+ * egz_lstm_wave_fwd. */
 int egz_lstm_persist_sync_words(void);
-int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* bsum,
-                         const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn, float* cn,
-                         unsigned int* sync, int L, int T, int B, int H, hipStream_t stream);
+int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                         const float* const* b_hh, const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn,
+                         float* cn, unsigned int* sync, int L, int T, int B, int H, hipStream_t stream);
 /* Its backward through time (autograd of the same call): T + 2 L - 1 launches of uniform K = 4H blocks; the gradient a lower layer
  * receives from the layer above (dgates_above,t W_ih_above) is formed by blocks of its own one launch ahead of the cell backward
  * that consumes it and parked in dhin.  dh_top: [T][B][H] or null; dhn, dcn: [L][B][H] or null; w_hh_t / w_ih_t: HOST arrays of L
@@ -323,6 +325,16 @@ int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float
 int egz_lstm_wave_bwd(const float* dh_top, const float* dhn, const float* dcn, const float* acts, const float* cs,
                       const float* c0, const float* const* w_hh_t, const float* const* w_ih_t, float* dgates, float* dh0,
                       float* dc0, float* dhin, int L, int T, int B, int H, hipStream_t stream);
+/* egz_lstm_wave_bwd for the AT network's own geometry (L = 2, H = 512, B <= 32) as ONE persistent launch: 64 x ceil(B / 8) blocks,
+ * each keeping 8 units x 2048 of W_hh_l1^T, W_ih_l1^T, W_hh_l0^T in registers; the dgates of a step are handed over inside the
+ * launch (csrc/lstm_seq.hip, lstm_persist_bwd_kernel).  Inputs and outputs as egz_lstm_wave_bwd without dhin, except: w_hh / w_ih
+ * are the weights AS THE MODULE HOLDS THEM ([4H][H]; HOST arrays of L device pointers, w_ih[0] unused) -- no transposed copies --
+ * and the launch also forms the bias gradients: db = HOST array of 2 L device pointers (b_ih_l0, b_hh_l0, b_ih_l1, b_hh_l1: [4H]
+ * each = the sum of dgates_l over steps and batch rows; null entries skipped; db may be null).  `sync` as in
+ * egz_lstm_persist_fwd.  Any other geometry: hipErrorNotSupported, nothing launched. */
+int egz_lstm_persist_bwd(const float* dh_top, const float* dhn, const float* dcn, const float* acts, const float* cs,
+                         const float* c0, const float* const* w_hh, const float* const* w_ih, float* dgates, float* dh0,
+                         float* dc0, float* const* db, unsigned int* sync, int L, int T, int B, int H, hipStream_t stream);
 /* The same network at T = 1, B = 1 -- the reference's own stepping (AT.py:127-145 training loop, AT.py:246 inference): the
  * whole step in ONE call (L + 1 launches forward, 2L + 1 backward; csrc/lstm_b1.hip).  params / grads: HOST arrays of
  * 4L + 2 device pointers in state-dict order (w_ih, w_hh, b_ih, b_hh per layer, lin.weight [N][H], lin.bias [N]); a null

@@ -316,32 +316,121 @@ def test_lstm_wavefront_vs_torch(L, T, B):
         assert rel(getattr(net.lstm, name).grad.cpu().numpy(), p.grad.numpy()) < 2e-4, name
 
 
-@pytest.mark.parametrize("T,B", [(16, 32), (1, 1), (3, 16), (5, 20), (16, 7)])
-def test_lstm_persistent_forward_matches_wavefront(T, B, monkeypatch):
-    """egz_lstm_persist_fwd (ONE weight-stationary launch, blocks hand h_t to each other inside it) against egz_lstm_wave_fwd (T + 1
-    launches) on the AT network's geometry (models/LSTMnet.py:18: nn.LSTM(512, 512, 2)): every output -- all h_t and c_t of both
-    layers, the gate activations the backward pass reads, the returned state.  Same products in another summation order (8 K-slices
-    of 64 instead of 4 of 128): equal to a few ulp.  40 calls on recycled buffers with fresh inputs: a hand-off that read a stale
-    line (the previous call's h at the same address) would show up as a mismatch; the status word must stay 0."""
-    from egaze_amd import hipops as H
-    g = torch.Generator().manual_seed(11)
+def _persist_weights(g):
     w_ih = [None, (torch.randn(2048, 512, generator=g) * 0.05).to(DEV)]
     w_hh = [(torch.randn(2048, 512, generator=g) * 0.05).to(DEV) for _ in range(2)]
-    bsum = [None, (torch.randn(2048, generator=g) * 0.1).to(DEV)]
+    b_ih = [(torch.randn(2048, generator=g) * 0.1).to(DEV) for _ in range(2)]
+    b_hh = [(torch.randn(2048, generator=g) * 0.1).to(DEV) for _ in range(2)]
+    return w_ih, w_hh, b_ih, b_hh
+
+
+@pytest.mark.parametrize("T,B", [(16, 32), (1, 1), (3, 16), (5, 20), (16, 7)])
+def test_lstm_persistent_forward_matches_wavefront(T, B):
+    """egz_lstm_persist_fwd (ONE weight-stationary launch, blocks hand h_t to each other inside it, biases summed in the kernel)
+    against egz_lstm_wave_fwd (T + 1 launches, bias sum folded into the projection) on the AT network's geometry
+    (models/LSTMnet.py:18: nn.LSTM(512, 512, 2)): every output -- all h_t and c_t of both layers, the gate activations the backward
+    pass reads, the returned state.  Same products in another summation order (8 K-slices of 64 instead of 4 of 128): equal to a
+    few ulp.  40 calls on recycled buffers with fresh inputs: a hand-off that read a stale line (the previous call's h at the same
+    address) would show up as a mismatch; the status word must stay 0."""
+    from egaze_amd import hipops as H
+    g = torch.Generator().manual_seed(11)
+    w_ih, w_hh, b_ih, b_hh = _persist_weights(g)
+    bsum = [a + b for a, b in zip(b_ih, b_hh)]
     for it in range(40 if (T, B) == (16, 32) else 3):
         gx0 = torch.randn(T, B, 2048, generator=g).to(DEV)
         h0, c0 = (torch.randn(2, B, 512, generator=g) * 0.5).to(DEV), (torch.randn(2, B, 512, generator=g) * 0.5).to(DEV)
-        monkeypatch.setattr(H, "LSTM_PERSIST", False)
-        want = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0)
-        monkeypatch.setattr(H, "LSTM_PERSIST", True)
-        got = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0)
+        want = H.lstm_wave_fwd(gx0 + bsum[0], w_ih, w_hh, bsum, h0, c0)
+        got = H.lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0)
         assert H.lstm_persist_status() == 0
         for name, a, b in zip(("hs", "cs", "acts", "hn", "cn"), got, want):
             assert torch.allclose(a, b, rtol=0, atol=3e-6), (it, name, float((a - b).abs().max()))
         del want, got
     # no-grad form (no gate activations kept)
-    got = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts=False)
+    got = H.lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0, want_acts=False)
     assert got[2] is None and H.lstm_persist_status() == 0
-    monkeypatch.setattr(H, "LSTM_PERSIST", False)
-    want = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts=False)
+    want = H.lstm_wave_fwd(gx0 + bsum[0], w_ih, w_hh, bsum, h0, c0, want_acts=False)
     assert torch.allclose(got[0], want[0], rtol=0, atol=3e-6) and torch.allclose(got[3], want[3], rtol=0, atol=3e-6)
+    # any other geometry is refused, nothing launched
+    with pytest.raises(RuntimeError, match="built for L = 2"):
+        H.lstm_persist_fwd(torch.zeros(2, 33, 2048, device=DEV), w_ih, w_hh, b_ih, b_hh, torch.zeros(2, 33, 512, device=DEV),
+                           torch.zeros(2, 33, 512, device=DEV))
+
+
+@pytest.mark.parametrize("T,B,top,state", [(16, 32, True, True), (16, 32, True, False), (1, 1, True, True), (3, 16, False, True),
+                                           (5, 20, True, True), (16, 7, True, False), (2, 9, True, True)])
+def test_lstm_persistent_backward_matches_wavefront(T, B, top, state):
+    """egz_lstm_persist_bwd (one launch: 8-row batch tiles, v_mfma_f32_4x4x1 products, dgates handed over inside the launch, weights
+    read untransposed, bias gradients folded by the last-arriving tile) against egz_lstm_wave_bwd (T + 3 launches on transposed
+    weight copies) + egz_colsum on activations of a real forward pass: dgates of every step and layer, dh0, dc0, the four bias
+    gradients.  With / without a gradient through the outputs and through the returned state (models/LSTMnet.py:35 returns both),
+    ragged 8-row tiles (B = 20, 7, 9, 1), T = 1.  Repeated on recycled buffers like the forward test; bitwise repeatable."""
+    from egaze_amd import hipops as H
+    g = torch.Generator().manual_seed(13 + T + B)
+    w_ih, w_hh, b_ih, b_hh = _persist_weights(g)
+    bsum = [a + b for a, b in zip(b_ih, b_hh)]
+    w_hh_t = [w.t().contiguous() for w in w_hh]
+    w_ih_t = [None, w_ih[1].t().contiguous()]
+    for it in range(30 if (T, B) == (16, 32) else 3):
+        gx0 = torch.randn(T, B, 2048, generator=g).to(DEV)
+        h0, c0 = (torch.randn(2, B, 512, generator=g) * 0.5).to(DEV), (torch.randn(2, B, 512, generator=g) * 0.5).to(DEV)
+        hs, cs, acts, hn, cn = H.lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0)
+        dh_top = torch.randn(T, B, 512, generator=g).to(DEV) if top else None
+        dhn = torch.randn(2, B, 512, generator=g).to(DEV) if state else None
+        dcn = torch.randn(2, B, 512, generator=g).to(DEV) if state else None
+        want = H.lstm_wave_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh_t, w_ih_t)
+        db = [torch.full((2048,), 7.0, device=DEV) for _ in range(4)]
+        db[1] = None                                             # a bias whose gradient is not wanted
+        got = H.lstm_persist_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh, w_ih, db)
+        assert H.lstm_persist_status() == 0
+        for name, a, b in zip(("dgates", "dh0", "dc0"), got, want):
+            scale = float(b.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 2e-5 * scale, (it, name, float((a - b).abs().max()), scale)
+        for i in (0, 2, 3):
+            ref = H.colsum(want[0][i // 2].view(T * B, 2048))
+            assert float((db[i] - ref).abs().max()) <= 2e-5 * (float(ref.abs().max()) + 1e-30), (it, "db", i)
+        if it == 0:
+            db2 = [torch.empty(2048, device=DEV) for _ in range(4)]
+            again = H.lstm_persist_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh, w_ih, db2)
+            assert all(torch.equal(a, b) for a, b in zip(got, again)) and all(torch.equal(db[i], db2[i]) for i in (0, 2, 3))
+            assert torch.equal(db2[0], db2[1])
+        del want, got
+
+
+def test_at_batched_step_graphed_matches_eager():
+    """The T = 16 / B = 32 AT step (lstmnet forward + MSE + backward + Adam; AT.py:138-145 at BASELINE config 4's shape) captured
+    into one hipGraph (graphs.GraphedTrainStep: the two persistent recurrence launches and their counter memsets become graph nodes)
+    against the same steps issued eagerly: identical parameters after 5 steps, status word clean."""
+    from egaze_amd import hipops as H
+    from egaze_amd.functions import MSELoss
+    from egaze_amd.graphs import GraphedTrainStep
+    from egaze_amd.models.LSTMnet import lstmnet
+    from egaze_amd.optim import FusedAdam
+    assert H.LSTM_PERSIST
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 32, 512, generator=g).to(DEV)
+    tgt = torch.tanh(torch.randn(16, 32, 512, generator=g)).to(DEV)
+    h0, c0 = torch.zeros(2, 32, 512, device=DEV), torch.zeros(2, 32, 512, device=DEV)
+    torch.manual_seed(3)
+    nets = [lstmnet().to(DEV) for _ in range(2)]
+    nets[1].load_state_dict(nets[0].state_dict())
+    opts = [FusedAdam(n.parameters(), lr=1e-3) for n in nets]
+
+    def make(net):
+        def forward_loss(a, b):
+            pred, _ = net(a, (h0, c0))
+            return MSELoss.apply(pred, b), pred
+        return forward_loss
+    losses = []
+    for _ in range(5):
+        opts[0].zero_grad()
+        l, _ = make(nets[0])(x, tgt)
+        l.backward()
+        opts[0].step()
+        losses.append(float(l))
+    gs = GraphedTrainStep(make(nets[1]), opts[1], (x, tgt))
+    glosses = [float(gs(x, tgt)[0]) for _ in range(5)]
+    gs.close()
+    assert H.lstm_persist_status() == 0
+    assert glosses == losses, (glosses, losses)
+    for (n, a), b in zip(nets[0].state_dict().items(), nets[1].state_dict().values()):
+        assert torch.equal(a, b), n

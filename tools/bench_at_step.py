@@ -1,4 +1,5 @@
-"""AT step alone at BASELINE config 4's shape (lstmnet T = 16, B = 32: forward + MSE + backward + Adam), ms per step."""
+"""AT step alone at BASELINE config 4's shape (lstmnet T = 16, B = 32: forward + MSE + backward + Adam), ms per step: issued launch
+by launch, and as one hipGraph replay.  EGAZE_LSTM_PERSIST=0: the recurrence as wavefront launches instead of the two persistent ones."""
 import argparse
 import os
 import sys
@@ -46,7 +47,25 @@ def main():
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    print(f"AT step T={args.T} B={args.B}: {ms:.3f} ms  ({args.T * args.B / ms * 1e3:.0f} (t, b) samples/s)")
+    print(f"AT step T={args.T} B={args.B} eager: {ms:.3f} ms  ({args.T * args.B / ms * 1e3:.0f} (t, b) samples/s)")
+
+    # the same step as one hipGraph replay (graphs.GraphedTrainStep)
+    from egaze_amd.graphs import GraphedTrainStep
+
+    def forward_loss(x, tgt):
+        pred, _ = lstm(x, (h0, c0))
+        return MSELoss.apply(pred, tgt), pred
+    gs = GraphedTrainStep(forward_loss, opt, (at_in, at_tgt))
+    for _ in range(6):
+        gs(at_in, at_tgt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gs(at_in, at_tgt)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    print(f"AT step T={args.T} B={args.B} hipGraph replay: {ms:.3f} ms  ({args.T * args.B / ms * 1e3:.0f} (t, b) samples/s)")
+    gs.close()
 
 
 if __name__ == "__main__":
