@@ -1430,7 +1430,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __r
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
     const float* p = part + (long)(c0 + cs) * K + k0 + kl;
-    for (int sp = 0; sp < S; ++sp, p += n)
+    // four rows' loads in flight per step, added in row order (the sums are those of the plain loop): the 32 x 32 filters of the
+    // late-fusion head have 4 blocks here and a row-by-row loop cost them one L2 round trip per row (90 us for 16 rows)
+    int sp = 0;
+    for (; sp + 3 < S; sp += 4, p += 4 * n) {
+        float v[4][9];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[r][t] = p[r * n + t * ck];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += v[r][t];
+    }
+    for (; sp < S; ++sp, p += n)
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] += p[t * ck];
 #pragma unroll
