@@ -100,7 +100,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     float* __restrict__ y, double* __restrict__ stat, int B, int H, int W, int C, int K, int Cp, int Kp, float out_scale,
     int mt, int total, const unsigned int* __restrict__ a_absmax, const float* __restrict__ mask_src,
     unsigned int* __restrict__ absmax_out, int nsplit, unsigned int* __restrict__ mm_out) {
-    static_assert(!PRE || (MODE == PLAIN && std::is_same<T, _Float16>::value), "pre-split operands: plain convolutions, f16 x3");
+    static_assert(!PRE || (MODE == PLAIN && IS_F16<T>), "pre-split operands: plain convolutions, f16 x3");
     using G = Geo<WM>;
     constexpr int BM = G::BM, NWN = G::NWN, BN = G::BN, HSLOTS = G::HSLOTS, HZERO = G::HZERO, NJ = G::NJ;
     constexpr int MR = G::MR, RPW = G::RPW, NTHR = G::NTHR, SPP = G::SPP;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
-                acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl : bh, acc[mr]);
+                if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl : bh, acc[mr]);
     };
 
     // ---- prologue
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
                     for (int i = 0; i < NM; ++i) {
                         const int term = i / MR, mr = i % MR;
-                        acc[mr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bq[ring][1] : bq[ring][0], acc[mr]);
+                        if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bq[ring][1] : bq[ring][0], acc[mr]);
                         if (i < MR) {
                             ah1[i] = *reinterpret_cast<const u32x4*>(Ab + (cur[i] ^ 32));
                             al1[i] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[i] ^ 32));
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
                     for (int i = 0; i < NM; ++i) {
                         const int term = i / MR, mr = i % MR;
-                        acc[mr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bq[ring][3] : bq[ring][2], acc[mr]);
+                        if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bq[ring][3] : bq[ring][2], acc[mr]);
                         if (!last && i < MR) {
                             ah0[i] = *reinterpret_cast<const u32x4*>(Ab + cur[i]);
                             al0[i] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[i]);
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
-                    acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bq[t][ks * 2 + 1] : bq[t][ks * 2], acc[mr]);
+                    if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bq[t][ks * 2 + 1] : bq[t][ks * 2], acc[mr]);
             if (g < 16) {                                       // two epilogue elements of the previous tile
                 epi_elem((2 * g) >> 4, (2 * g) & 15);
                 epi_elem((2 * g + 1) >> 4, (2 * g + 1) & 15);
@@ -1379,7 +1379,7 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
 #define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out)
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS && epi != EPI_BIAS && epi != EPI_BNSUMS) absmax_out = nullptr;
     if (pre) {                         // pre-split activation operand: the training forward of the wide encoder layers
-        if constexpr (MODE == PLAIN && (WM == 1 || WM == 2) && std::is_same<T, _Float16>::value) {
+        if constexpr (MODE == PLAIN && (WM == 1 || WM == 2) && IS_F16<T>) {
 #define EGZ_X3P(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, PLAIN, true>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out)
             // epi 2: the training forward over pre-split activations; epi 0 / 5: data gradients over a pre-split gradient
             if (epi == EPI_BIAS_STATS) { if (patch) EGZ_X3P(EPI_BIAS_STATS, true); else EGZ_X3P(EPI_BIAS_STATS, false); }
@@ -1524,6 +1524,9 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                                      const unsigned int* x_absmax, const float* mask_src, unsigned int* absmax_out,
                                      const float* bn_coef, float* minmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
+    const bool p2 = (dtype & 0x10) != 0;      // two products per MAC (egz_f16p2): f16 only, wide tiles; elsewhere three
+    dtype &= 0xf;
+    EGZ_CHECK_ARG(!p2 || dtype == 1, "egz_conv3x3_fwd_streamed: dtype 0x10 (two products) goes with f16 (dtype 0x11)");
     // mode | 0x100 (mode 0, f16 x3, epi 2, K % 64 == 0, C % 32 == 0): x holds PRE-SPLIT activations (egz_bn_relu_pool_fwd's
     // presplit form; x_absmax = the abs-max the pairs were scaled with)
     const bool pre = (mode & 0x100) != 0;
@@ -1556,10 +1559,10 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         // wide tiles: the coefficient rows travel in the kernel's (otherwise unused) bias argument
         // (absmax_out, optional: max |y| -- the gradient's abs-max bounds the BatchNorm backward of the block below)
         if (K % 128 == 0) {
-            if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre);
+            if (dtype == 1) return p2 ? launch_x3s<egz_f16p2, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre) : launch_x3s<_Float16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre);
             return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st);
         }
-        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre);
+        if (dtype == 1) return p2 ? launch_x3s<egz_f16p2, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre) : launch_x3s<_Float16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st, nullptr, pre);
         return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16b, bn_coef, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, absmax_out, st);
     }
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, mode), "egz_conv3x3_fwd_streamed: geometry B=%d H=%d W=%d C=%d K=%d "
@@ -1576,15 +1579,15 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         return launch_x3s<_Float16, 2, UPSF>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
     if (mode == 1) {
-        if (dtype == 1) return launch_x3s<_Float16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+        if (dtype == 1) return p2 ? launch_x3s<egz_f16p2, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st) : launch_x3s<_Float16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
         return launch_x3s<__bf16, 1, UPSD>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     }
     if (K % 128 == 0) {
-        if (dtype == 1) return launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre);
+        if (dtype == 1) return p2 ? launch_x3s<egz_f16p2, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre) : launch_x3s<_Float16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre);
         return launch_x3s<__bf16, 1, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw);
     }
     if (K % 64 == 0) {
-        if (dtype == 1) return launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre);
+        if (dtype == 1) return p2 ? launch_x3s<egz_f16p2, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre) : launch_x3s<_Float16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw, pre);
         return launch_x3s<__bf16, 2, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st, mmw);
     }
     EGZ_CHECK_ARG(!(absmax_out && epi == EPI_BIAS_RELU), "egz_conv3x3_fwd_streamed: the abs-max epilogue exists for 64- and "
@@ -1593,7 +1596,7 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, bn_coef, minmax_out, st);
         return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, bn_coef, minmax_out, st);
     }
-    if (dtype == 1) return launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
+    if (dtype == 1) return p2 ? launch_x3s<egz_f16p2, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st) : launch_x3s<_Float16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
     return launch_x3s<__bf16, 4, PLAIN>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, mask_src, absmax_out, st);
 }
 
@@ -1613,6 +1616,7 @@ EGZ_API int egz_conv3x3_fwd_streamed_splitk(const float* x, const void* wq, cons
                                             int B, int H, int W, int C, int K, int epi, int dtype,
                                             const unsigned int* x_absmax, void* workspace, size_t ws_bytes, int nsplit,
                                             unsigned int* absmax_out, hipStream_t st) {
+    dtype &= 0xf;      // (the two-product bit 0x10 is honoured by egz_conv3x3_fwd_streamed only: split-K launches stay three-product)
     EGZ_CHECK_ARG(x && wq && y && workspace, "egz_conv3x3_fwd_streamed_splitk: null pointer");
     EGZ_CHECK_ARG(egz_conv3x3_streamed_ok(B, H, W, C, K, 0) && K % 128 == 0 && C % 32 == 0,
                   "egz_conv3x3_fwd_streamed_splitk: geometry B=%d H=%d W=%d C=%d K=%d is not covered", B, H, W, C, K);

@@ -318,6 +318,7 @@ template <> struct W16<_Float16> {
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float scale(const unsigned int* am) { return absmax_scale(am); }
 };
+template <> struct W16<egz_f16p2> : W16<_Float16> {};      // two products per MAC: dy's lo half is not multiplied (egz_common.h)
 
 // XCD-aware (tile, split) of a block of a (tiles, splits[, z]) grid.  Hardware places consecutive flat block ids on
 // consecutive XCDs (id % 8) and every XCD has its own L2.  The natural map puts the 64 (c, k) tiles of ONE pixel range on all
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
                     for (int ts = 0; ts < 3; ++ts)
-                        acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
+                        if (!(egz_drop_blo<T>::value && term == 1)) acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
             }
         }
         if (g + 1 < g1) lstore(buf ^ 1);
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
             for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int ts = 0; ts < 3; ++ts)
-                    acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
+                    if (!(egz_drop_blo<T>::value && term == 1)) acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
         }
         if (g + 1 < g1) lstore(buf ^ 1);
         __syncthreads();
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3t_kernel(
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                acc[j] = W16<T>::mfma(term == 0 ? xl : xh, term == 1 ? dl[j] : dh[j], acc[j]);
+                if (!(egz_drop_blo<T>::value && term == 1)) acc[j] = W16<T>::mfma(term == 0 ? xl : xh, term == 1 ? dl[j] : dh[j], acc[j]);
         if (g + 1 < g1) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -1151,7 +1152,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
                     for (int px = 0; px < 2; ++px)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            acc[px * 4 + a * 2 + b] = W16<T>::mfma(term == 0 ? xl[px + b] : xh[px + b], term == 1 ? dl[px] : dh[px], acc[px * 4 + a * 2 + b]);
+                            if (!(egz_drop_blo<T>::value && term == 1)) acc[px * 4 + a * 2 + b] = W16<T>::mfma(term == 0 ? xl[px + b] : xh[px + b], term == 1 ? dl[px] : dh[px], acc[px * 4 + a * 2 + b]);
             }
         }
         if (g + 1 < g1) lstore(buf ^ 1);
@@ -1597,6 +1598,8 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 //        no scaling) when dy_absmax is NULL, f16 x3 (22 bits) with dy scaled by absmax_scale(*dy_absmax) when it is given;
 //        x_absmax (optional, f16 x3 only): max |x| -- x is scaled the same way (activations outside [2^-3, 6e4] otherwise
 //        leave the f16 pair's 22-bit domain).
+//        0x20000 = with f16 split halves: TWO products per MAC instead of three -- dy's lo half is not multiplied (11 significant
+//        bits of dy, 22 of x; per-element error ~2^-12 instead of 2^-22) -- on conv3x3_wgrad9_x3_kernel / conv3x3_wgrad_ups_x3_kernel.
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
 // 1 when a plain split-half weight gradient of this geometry runs on the narrow kernel (C, K <= 32, W % 16 == 0, 32-bit
 // buffer offsets) -- the only one that takes a deferred-BatchNorm activation operand (x_bn)
@@ -1636,6 +1639,9 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     }
     // flags 0x8000: x holds pre-split activations (see conv3x3_wgrad9_x3_kernel) -- only where that kernel runs
     const bool xpre = (flags & 0x8000) != 0, dpre = (flags & 0x10000) != 0;
+    // 0x20000: two products per MAC on the split-half f16 kernels of the wide layers (x_hi dy_hi + x_lo dy_hi: dy enters with its hi
+    // half only; egz_f16p2 in egz_common.h).  Ignored where the launch is not one of those (bf16, exact f32, the narrow kernels).
+    const bool p2 = (flags & 0x20000) != 0 && dy_absmax;
     EGZ_CHECK_ARG(!(xpre || dpre) || (egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) && (flags & 0x2000) && !ups && dy_absmax && x_absmax && !x_bn),
                   "egz_conv3x3_wgrad: a pre-split x / dy operand (flags 0x8000 / 0x10000) needs the split-half 9-tap kernel's geometry "
                   "(egz_conv3x3_wgrad_presplit_ok), f16 x3 (dy_absmax, x_absmax) and a plain conv");
@@ -1650,7 +1656,8 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
             const int pps = (int)((np + S - 1) / S);
             dim3 grid((C / 64) * (K / 64), S, 2);
 #define EGZ_WUX(TT, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad_ups_x3_kernel<TT, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
-            if (dy_absmax) { if (WD == 32) EGZ_WUX(_Float16, 1, 32); else if (WD == 16) EGZ_WUX(_Float16, 2, 16); else EGZ_WUX(_Float16, 4, 8); }
+            if (dy_absmax && p2) { if (WD == 32) EGZ_WUX(egz_f16p2, 1, 32); else if (WD == 16) EGZ_WUX(egz_f16p2, 2, 16); else EGZ_WUX(egz_f16p2, 4, 8); }
+            else if (dy_absmax) { if (WD == 32) EGZ_WUX(_Float16, 1, 32); else if (WD == 16) EGZ_WUX(_Float16, 2, 16); else EGZ_WUX(_Float16, 4, 8); }
             else           { if (WD == 32) EGZ_WUX(__bf16, 1, 32); else if (WD == 16) EGZ_WUX(__bf16, 2, 16); else EGZ_WUX(__bf16, 4, 8); }
 #undef EGZ_WUX
             EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(ups-phase split)");
@@ -1705,7 +1712,8 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         const int pps = (int)((np + S - 1) / S);
         dim3 grid(((C + 63) / 64) * ((K + 63) / 64), S);
 #define EGZ_W9X(TT, U, RR, WW) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, U, RR, WW>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, dy_absmax ? x_absmax : nullptr)
-#define EGZ_W9Q(RR, WW, XP, DP) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<_Float16, false, RR, WW, XP, DP>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, x_absmax)
+#define EGZ_W9QT(TT, RR, WW, XP, DP) hipLaunchKernelGGL((conv3x3_wgrad9_x3_kernel<TT, false, RR, WW, XP, DP>), grid, dim3(256), 0, st, x, dy, part, B, H, W, C, K, pps, dy_absmax, x_absmax)
+#define EGZ_W9Q(RR, WW, XP, DP) do { if (p2) EGZ_W9QT(egz_f16p2, RR, WW, XP, DP); else EGZ_W9QT(_Float16, RR, WW, XP, DP); } while (0)
 #define EGZ_W9P(RR, WW) do { if (xpre && dpre) EGZ_W9Q(RR, WW, true, true); else if (xpre) EGZ_W9Q(RR, WW, true, false); else EGZ_W9Q(RR, WW, false, true); } while (0)
 #define EGZ_W9T(TT)                                                                                                    \
         if (ups) { if (WD == 32) EGZ_W9X(TT, true, 1, 32); else if (WD == 16) EGZ_W9X(TT, true, 2, 16); else EGZ_W9X(TT, true, 4, 8); } \
@@ -1713,9 +1721,10 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         if (xpre || dpre) {        // pre-split x (flags 0x8000) and / or dy (0x10000) operand: f16 x3, plain conv
             if (WD == 32) EGZ_W9P(1, 32); else if (WD == 16) EGZ_W9P(2, 16); else EGZ_W9P(4, 8);
         } else
-        if (dy_absmax) { EGZ_W9T(_Float16) } else { EGZ_W9T(__bf16) }
+        if (dy_absmax && p2) { EGZ_W9T(egz_f16p2) } else if (dy_absmax) { EGZ_W9T(_Float16) } else { EGZ_W9T(__bf16) }
 #undef EGZ_W9P
 #undef EGZ_W9Q
+#undef EGZ_W9QT
 #undef EGZ_W9T
 #undef EGZ_W9X
         EGZ_CHECK_LAUNCH("egz_conv3x3_wgrad(9-tap split)");

@@ -2,6 +2,7 @@
 // conv3x3_igemm_x3s.hip): packed conversions of 4 floats and the three-product MFMA wrapper.
 #pragma once
 #include "egz_common.h"
+#include <type_traits>
 
 namespace x3 {
 
@@ -76,5 +77,7 @@ template <> struct Half<__bf16> {
     }
 };
 
+template <> struct Half<egz_f16p2> : Half<_Float16> {};
+template <typename T> constexpr bool IS_F16 = std::is_same<T, _Float16>::value || std::is_same<T, egz_f16p2>::value;
 
 }  // namespace x3

@@ -539,6 +539,21 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
 # the BatchNorm's monotonic map by egz_bn_finalize_bound.  Consumers (the next conv's forward and weight gradient) then stage
 # the pair without touching the vector ALU; the pair is bit-identical to the one they would have formed, so every result is.
 # EGAZE_PRESPLIT=0 keeps fp32 activations everywhere (A/B runs; test_presplit_activations_bit_identical flips the constant).
+# EGAZE_BWD_PRODUCTS=2: the BACKWARD convolutions of the wide layers (data gradients, weight gradients; f16 split halves) issue TWO
+# MFMA products per MAC instead of three -- a_hi b_hi + a_lo b_hi: the second operand (the weights in a data gradient, dy in a
+# weight gradient) enters with its f16 hi half only, the first keeps its 22 bits (csrc/egz_common.h, egz_f16p2).  Gradients move by
+# ~1e-4 relative -- a fraction of what the summation order of ANY fp32 implementation moves them (tests/report_grad_accuracy.py) --
+# the forward pass and with it every predicted map is untouched.  3: three products everywhere (fp32-class gradients, 2e-7 per op).
+BWD_PRODUCTS = int(_os.environ.get("EGAZE_BWD_PRODUCTS", "2"))
+P2_DTYPE = 0x10          # egz_conv3x3_fwd_streamed: dtype | 0x10
+P2_WGRAD = 0x20000       # egz_conv3x3_wgrad: flags | 0x20000
+
+
+def _p2(dtype: int) -> int:
+    """dtype of a data-gradient launch on the streamed kernel: the two-product bit where the knob and the type allow it."""
+    return dtype | P2_DTYPE if (BWD_PRODUCTS == 2 and dtype == F16X3) else dtype
+
+
 PRESPLIT = _os.environ.get("EGAZE_PRESPLIT", "1") != "0"
 PRESPLIT_STATS = {"produced": 0, "fwd": 0, "wgrad": 0, "grad_produced": 0, "dgrad": 0, "wgrad_dy": 0}
 
@@ -590,7 +605,7 @@ ALGO_CHANNELS = [None]
 
 
 def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], K: int, ups=False,
-                epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, absmax: Optional[torch.Tensor] = None,
+                epi: int = EPI_BIAS, tile_flag: int = 0, dtype: int = 0, p2: bool = False, absmax: Optional[torch.Tensor] = None,
                 streamed: bool = False, bn_in: Optional[torch.Tensor] = None, want_minmax: bool = False,
                 pre_in: bool = False, want_bound: bool = False, want_amax: bool = False):
     """x: (B, Hin, Win, C) NHWC.  Returns (y (B,H,W,K), stat_partial or None); H,W = 2*Hin,2*Win if ups.
@@ -667,7 +682,7 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
             amo = _new_absmax(x.device)
             y._egz_absmax = amo
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
-                                           epi, dtype, 0x100 if pre_in else 0, _p(absmax), None, _p(amo), _p(bn_in), _p(mm),
+                                           epi, _p2(dtype) if p2 else dtype, 0x100 if pre_in else 0, _p(absmax), None, _p(amo), _p(bn_in), _p(mm),
                                            _stream()), "egz_conv3x3_fwd_split")
         return y, stat
     if pre_in:
@@ -694,7 +709,7 @@ def conv3x3_dgrad(dy: torch.Tensor, wp_dgrad: torch.Tensor, C: int, dtype: int =
     can emit it."""
     y, _ = conv3x3_fwd(dy, wp_dgrad, None, C, ups=False, epi=EPI_BIAS, dtype=dtype,
                        absmax=absmax_of(dy) if dtype == F16X3 else None, streamed=streamed, pre_in=pre_in,
-                       want_amax=_want_absmax() and PRESPLIT_GRAD)
+                       want_amax=_want_absmax() and PRESPLIT_GRAD, p2=True)
     return y
 
 
@@ -708,7 +723,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         am = absmax_of(dy) if dtype == F16X3 else None
         check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
-                                           0, dtype, 1, _p(am), None, None, None, None, _stream()),
+                                           0, _p2(dtype), 1, _p(am), None, None, None, None, _stream()),
               "egz_conv3x3_fwd_streamed(ups_dgrad)")
         return dx
     if dtype:      # GEMM roles: reduction over the conv's K, output channels = the conv's C
@@ -754,7 +769,7 @@ def conv3x3_dgrad_masked(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
     PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
     am = absmax_of(dy) if dtype == F16X3 else None
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
-                                       EPI_MASK_SUMS, dtype, 1 if ups else 0, _p(am), mask_src.data_ptr(), amo.data_ptr(),
+                                       EPI_MASK_SUMS, _p2(dtype), 1 if ups else 0, _p(am), mask_src.data_ptr(), amo.data_ptr(),
                                        None, None, _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
     return dx, stat, amo
 
@@ -808,7 +823,7 @@ def conv3x3_dgrad_bnsums(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
             raise RuntimeError("a pre-split gradient reached a data-gradient launch that cannot take it")
         PRESPLIT_STATS["dgrad"] += 1
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
-                                       EPI_BNSUMS, dtype, 0x100 if pre_in else 0, _p(am), bn_y.data_ptr(), _p(amo), coef.data_ptr(),
+                                       EPI_BNSUMS, _p2(dtype), 0x100 if pre_in else 0, _p(am), bn_y.data_ptr(), _p(amo), coef.data_ptr(),
                                        None, _stream()), "egz_conv3x3_fwd_streamed(dgrad + BN sums)")
     return dx, stat
 
@@ -862,6 +877,8 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ups: bool = False, variant_
             raise RuntimeError("a pre-split gradient reached a weight-gradient launch that cannot take it")
         flags |= 0x10000
         PRESPLIT_STATS["wgrad_dy"] += 1
+    if BWD_PRODUCTS == 2 and am is not None:
+        flags |= P2_WGRAD          # two products per MAC on the wide split-half kernels (ignored by the others)
     nb = LIB.egz_conv3x3_wgrad_ws_bytes(B, H, W, C, K, flags)
     ws = workspace(nb, x.device)
     PROF.note_flops("egz_conv3x3_wgrad", 2.0 * B * H * W * K * 9 * (ALGO_CHANNELS[0] or C))

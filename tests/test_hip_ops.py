@@ -88,7 +88,7 @@ def test_conv3x3_upsample_fused(B, Hh, Ww, C, K, mode):
     (1, 16, 64, 64, 64, True), (2, 14, 14, 192, 128, False), (1, 28, 56, 64, 64, False),
     (1, 56, 56, 64, 64, True), (2, 6, 56, 128, 64, True),        # phase-decomposed upsample wgrad, L = 28
 ])
-def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
+def test_conv3x3_backward(B, Hh, Ww, C, K, ups, three_products):
     """dgrad (same kernel, tap-flipped transposed weights), wgrad (split-K MFMA), bias grad, upsample bwd."""
     h = H()
     hin, win = (Hh // 2, Ww // 2) if ups else (Hh, Ww)
@@ -125,7 +125,7 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     (1, 48, 48, 32, 8, False), (2, 17, 16, 32, 8, False), (1, 224, 224, 32, 8, False), (2, 6, 96, 20, 4, False), (1, 1, 16, 32, 8, False),
     (1, 20, 48, 32, 4, False), (2, 9, 16, 8, 4, False),        # K = 4 on the 4 x 16 patch (the entry point requires K % 4 == 0: 4 and 8 are the tap-packed widths)
 ])
-def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups, monkeypatch):
+def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups, monkeypatch, three_products):
     """f16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes; dy scaled by its abs-max): patch geometries 1x32 / 2x16 / 4x8,
     masked narrow rows (28 in 32, 14 and 12 in 16), odd row counts, upsample-fused gather.  Compared with the fp64
     weight gradient; the exact-f32 kernel is held to the same bound for reference."""
@@ -475,7 +475,7 @@ def test_conv3x3_split_half_upsample(dtype, tol):
     assert rel(nchw(dx), xd.grad) < tol
 
 
-def test_split_kernels_shape_fuzz():
+def test_split_kernels_shape_fuzz(three_products):
     """Geometry dispatch fuzz: random (B, H, W, C, K) through every split-half kernel family (halo patch / halo raster run /
     per-tap gather forward and data gradient, 9-tap and phase-form weight gradients, upsample forms) against the exact-f32
     kernels of the same library.  Catches holes in the patch / run / mask selection rather than arithmetic."""
@@ -517,7 +517,7 @@ def test_split_kernels_shape_fuzz():
 
 
 @pytest.mark.parametrize("mag", [1.0, 3e-4, 1e-8, 7e-13, 2e5])
-def test_gradient_absmax_scaling(mag):
+def test_gradient_absmax_scaling(mag, three_products):
     """f16 x3 data / weight gradients of a gradient tensor of ANY magnitude: the abs-max of dy (a producer's or
     egz_absmax) picks a power-of-two scale, so 1e-8-sized gradients keep fp32-class accuracy (unscaled f16 would flush
     them to zero, bf16 x3 carries 16 bits)."""
@@ -550,7 +550,7 @@ def test_gradient_absmax_scaling(mag):
 
 
 @pytest.mark.parametrize("mag", [1e-5, 1e-2, 1.0, 1e3, 2e5])
-def test_forward_activation_scaling(mag):
+def test_forward_activation_scaling(mag, three_products):
     """f16 x3 forward operands of ANY magnitude (round-3 parity item): the pass that writes a post-ReLU activation also
     emits max |a| (BN apply + ReLU [+ pool]; the bias + ReLU epilogue of the streamed / phase-upsample conv kernels) and the
     consuming convolution -- forward operand, weight-gradient x operand -- scales by the matching power of two before the
@@ -631,7 +631,7 @@ def test_forward_scaling_off_loses_the_small_range(monkeypatch):
 
 
 @pytest.mark.parametrize("B,Hh,Ww,C", [(2, 16, 32, 20), (1, 24, 28, 20), (2, 9, 7, 17)])
-def test_first_conv_padded_split_path(B, Hh, Ww, C):
+def test_first_conv_padded_split_path(B, Hh, Ww, C, three_products):
     """The flow-stack first conv (Cin = 20, SP.py:53) on the split-half kernels after zero-padding Cin to 32:
     padded transpose, forward with BN statistics, and the C = 32 half-tile weight gradient."""
     h = H()
@@ -670,7 +670,7 @@ def test_first_conv_padded_split_path(B, Hh, Ww, C):
     # registers, halo of the next tile prefetched): several images (border masks between them), K = 8, C = 8, and more
     # tiles than blocks (320 tiles on 256 CUs: the per-XCD tile ranges and the double-buffered image switch)
     (3, 32, 32, 32, 8), (2, 48, 16, 8, 32), (5, 128, 128, 32, 32), (9, 16, 16, 12, 20)])
-def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
+def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol, three_products):
     """Streamed-weight halo kernel (fragment-ordered weights L2 -> registers, activation halo through LDS) against an fp64
     reference: forward with all three epilogues (BN partial sums included) and the data gradient, f16 x3 and bf16 x3."""
     h = H()
@@ -779,7 +779,7 @@ def test_conv3x3_streamed_shape_fuzz():
     (1, 8, 16, 256, 32),
     (3, 28, 28, 128, 64),      # raster runs on the polyphase components, several channel blocks
     (2, 14, 14, 128, 96), (1, 5, 3, 128, 64), (2, 9, 7, 256, 128)])
-def test_conv3x3_streamed_ups_dgrad(B, Hl, Wl, C, K, dtype, tol):
+def test_conv3x3_streamed_ups_dgrad(B, Hl, Wl, C, K, dtype, tol, three_products):
     """Streamed polyphase form of the data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res input
     (models/model_SP.py:17-18 etc.) against autograd in fp64 and against the per-tap gather kernel."""
     h = H()
@@ -997,14 +997,15 @@ HEADLINE_SHAPES = [        # (Cin, Cout, H (output), upsampled): the 12 distinct
 
 
 @pytest.mark.parametrize("C,K,Hh,ups", HEADLINE_SHAPES[:11])
-def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups):
+def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups, monkeypatch):
     """VERDICT r4 (parity soft spot a): every element-wise gradient check of the whole model runs at 32 x 32 with split-K pinned;
     at the headline geometry (batch 32, 224 x 224) the whole-model comparison is limited by ReLU / max-pool subgradient flips
     (tests/report_headline_grads.py).  Here each convolution of the step is checked ELEMENT-WISE in exactly the launch geometry
     bench.py times -- batch 32, the real image sizes (3136 / 6272 / 1568 / ... tiles per launch, the weight gradient's real
     split-K depth, default SPLITK decision) -- against torch-CPU fp32 on the same operands: forward, data gradient and weight
-    gradient, every entry within 2e-5 (5e-5 for the 1.6 M-pixel weight-gradient reductions) of max |ref|.  A mis-indexed tile
-    moves 1 / 3136 of the entries by O(1)."""
+    gradient, every entry within 2e-5 (5e-5 for the 1.6 M-pixel weight-gradient reductions) of max |ref| with three products per
+    MAC; the two-product backward arithmetic (hipops.BWD_PRODUCTS = 2, the default) on the same launches: every entry within 2e-3,
+    relative L2 error below 1e-3.  A mis-indexed tile moves 1 / 3136 of the entries by O(1)."""
     h = H()
     B = 32
     keep = torch.get_num_threads()
@@ -1029,12 +1030,22 @@ def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups):
         e_f = rel(nchw(y), want)
         ddt = h.conv_dtype("dgrad", C, K, dyd)
         wq, sq = h.conv_weight(wd, "ups_dgrad" if ups else "dgrad", ddt, dyd, C)
-        dx = h.conv3x3_ups_dgrad(dyd, wq, C, dtype=ddt, streamed=sq) if ups else h.conv3x3_dgrad(dyd, wq, C, dtype=ddt, streamed=sq)
-        e_d = rel(nchw(dx), xr.grad)
-        dw = h.conv3x3_wgrad(xd, dyd, ups=ups)
-        e_w = rel(dw.cpu(), wr.grad)
-        print(f"B=32 {C}->{K} @{Hh}{'u' if ups else ''}: fwd {e_f:.1e}  dgrad {e_d:.1e}  wgrad {e_w:.1e}")
+        err = {}
+        for products in (3, 2):           # backward arithmetic: three MFMA products per MAC (fp32 class), two (the default)
+            monkeypatch.setattr(h, "BWD_PRODUCTS", products)
+            dx = h.conv3x3_ups_dgrad(dyd, wq, C, dtype=ddt, streamed=sq) if ups else h.conv3x3_dgrad(dyd, wq, C, dtype=ddt, streamed=sq)
+            dw = h.conv3x3_wgrad(xd, dyd, ups=ups)
+            err[products] = (rel(nchw(dx), xr.grad), rel(dw.cpu(), wr.grad),
+                             float((nchw(dx).double() - xr.grad.double()).norm() / xr.grad.double().norm()),
+                             float((dw.cpu().double() - wr.grad.double()).norm() / wr.grad.double().norm()))
+        (e_d, e_w, _, _), (p_d, p_w, l_d, l_w) = err[3], err[2]
+        print(f"B=32 {C}->{K} @{Hh}{'u' if ups else ''}: fwd {e_f:.1e}  dgrad {e_d:.1e}  wgrad {e_w:.1e}  | two products: "
+              f"dgrad {p_d:.1e} (L2 {l_d:.1e})  wgrad {p_w:.1e} (L2 {l_w:.1e})")
         assert e_f < 2e-5 and e_d < 2e-5 and e_w < 5e-5, (e_f, e_d, e_w)
+        # two products: one operand enters with 11 significant bits (the weights, rounded to nearest, in the data gradient; dy,
+        # truncated, in the weight gradient): every entry within 2e-3 of max |ref|, relative L2 error below 1e-3 (a mis-indexed
+        # tile would still show as O(1) entries)
+        assert p_d < 2e-3 and p_w < 2e-3 and l_d < 1e-3 and l_w < 1e-3, (p_d, p_w, l_d, l_w)
     finally:
         torch.set_num_threads(keep)
 
@@ -1043,7 +1054,7 @@ def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups):
     (2, 32, 32, 64, 64, False), (1, 112, 112, 64, 128, True), (2, 28, 28, 128, 256, False), (3, 14, 14, 256, 128, False),
     (1, 224, 224, 64, 64, False), (2, 56, 56, 128, 64, True),
 ])
-def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch):
+def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_products):
     """Pre-split GRADIENTS (hipops.PRESPLIT_GRAD): the BatchNorm backward of a C -> K block writes dy as f16 pairs scaled by a
     bound of max |dy| derived in its finalize step (from max |dout|, the per-channel max / min of y and the two sums).
     (a) the bound holds and is tight: max |dy| <= bound <= 8 max |dy|;  (b) dgamma / dbeta are untouched (torch.equal);
@@ -1093,3 +1104,42 @@ def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch):
             d1, s1 = h.conv3x3_dgrad_bnsums(dy_ref, wq, C, h.F16X3, ybelow, cbelow)
             d2, s2 = h.conv3x3_dgrad_bnsums(dy_pre, wq, C, h.F16X3, ybelow, cbelow, pre_in=True)
             assert rel(d2, d1) < 2e-6 and rel(s2.sum(0), s1.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [(2, 28, 28, 64, 128, False), (1, 56, 56, 128, 64, True), (3, 14, 14, 256, 256, False),
+                                             (2, 32, 32, 64, 64, False)])
+def test_backward_two_products(B, Hh, Ww, C, K, ups, monkeypatch):
+    """hipops.BWD_PRODUCTS = 2 (the default): the backward convolutions issue a_hi b_hi + a_lo b_hi -- two MFMA products per MAC,
+    the B operand with its f16 hi half only (csrc/egz_common.h, egz_f16p2).  Against torch fp64 on the same operands:
+    (a) the FORWARD launch does not know the knob (bit-identical output);  (b) data and weight gradient stay within 2e-3 of
+    max |ref| per entry and 1e-3 in relative L2 -- and are NOT the three-product results (the knob reaches the launches);
+    (c) three products: the fp32 class (2e-5).  Plain and upsample-fused geometries, 64- and 128-column tiles."""
+    h = H()
+    monkeypatch.setattr(h, "SPLITK", False)       # (split-K launches of few-tile geometries stay three-product)
+    hin, win = (Hh // 2, Ww // 2) if ups else (Hh, Ww)
+    x = rnd(B, C, hin, win, seed=31).clamp_(min=0)
+    w = rnd(K, C, 3, 3, seed=32, scale=(2.0 / (9 * C)) ** 0.5)
+    dy = rnd(B, K, Hh, Ww, seed=33, scale=1e-3)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if ups else xr
+    F.conv2d(xin, wr, None, padding=1).backward(dy.double())
+    xd, dyd, wd = nhwc(x), nhwc(dy), w.to(DEV)
+    dt = h.conv_dtype("fwd", K, C, xd)
+    wp, st = h.conv_weight(wd, "ups_fwd" if ups else "fwd", dt, xd, K)
+    ddt = h.conv_dtype("dgrad", C, K, dyd)
+    wq, sq = h.conv_weight(wd, "ups_dgrad" if ups else "dgrad", ddt, dyd, C)
+    assert dt == h.F16X3 and ddt == h.F16X3 and st and sq
+    got = {}
+    for products in (3, 2):
+        monkeypatch.setattr(h, "BWD_PRODUCTS", products)
+        y, _ = h.conv3x3_fwd(xd, wp, None, K, ups="phase" if ups else False, epi=h.EPI_BIAS_RELU if ups else h.EPI_BIAS, dtype=dt, streamed=st)
+        dx = h.conv3x3_ups_dgrad(dyd, wq, C, dtype=ddt, streamed=sq) if ups else h.conv3x3_dgrad(dyd, wq, C, dtype=ddt, streamed=sq)
+        dw = h.conv3x3_wgrad(xd, dyd, ups=ups)
+        got[products] = (y, dx, dw)
+    assert torch.equal(got[2][0], got[3][0])
+    for products, tol_max, tol_l2 in ((3, 2e-5, 2e-6), (2, 2e-3, 1e-3)):
+        _, dx, dw = got[products]
+        for name, a, ref in (("dgrad", nchw(dx), xr.grad), ("wgrad", dw.cpu(), wr.grad)):
+            l2 = float((a.double() - ref).norm() / ref.norm())
+            assert rel(a, ref) < tol_max and l2 < tol_l2, (products, name, rel(a, ref), l2)
+    assert not torch.equal(got[2][1], got[3][1]) and not torch.equal(got[2][2], got[3][2])
