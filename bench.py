@@ -298,6 +298,7 @@ def main():
     roofline = None
     breakdown = None
     f32_ms = None
+    bwd3_ms = None
     at_ms = None
     at_eager_ms = None
     pcie_ms = {}
@@ -347,8 +348,8 @@ def main():
                                    "geometries it does not cover: all conv fwd + dgrad launches -- the streamed-weight halo "
                                    "kernel for plain convs, the four-phase upsample forward and the polyphase upsample "
                                    "dgrad; split-half f16x3 / bf16x3 operands on "
-                                   "v_mfma_f32_32x32x16_{f16,bf16}; each algorithmic MAC costs 3 MFMA MACs, priced against "
-                                   "the dense 16-bit MFMA peak)" if split else
+                                   "v_mfma_f32_32x32x16_{f16,bf16}; an algorithmic MAC costs 3 MFMA MACs in the forward launches and "
+                                   "2 in the data gradients (hipops.BWD_PRODUCTS), priced against the dense 16-bit MFMA peak)" if split else
                                    "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
                                    "launches, exact-f32 MFMA)") +
                                   "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
@@ -360,12 +361,16 @@ def main():
                         "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
                         "algorithmic_flop_per_step": ig["flops"]}
             if probe is not None and split:
-                # this box's own ceiling: bare MFMA rate on random bits / 3 MFMA MACs per algorithmic MAC
+                # this box's own ceiling: bare MFMA rate on random bits / MFMA MACs per algorithmic MAC of this family (3 for the
+                # forward launches, 2 for the data gradients under hipops.BWD_PRODUCTS = 2, weighted by their algorithmic FLOPs)
+                p2_flops = prof.get("two_product_conv", {}).get("flops", 0.0)
+                mfma_per_mac = 3.0 - min(1.0, p2_flops / ig["flops"]) if ig["flops"] else 3.0
                 roofline.update({"power_ceiling_tflops": probe["tflops"], "effective_clock_ghz": probe["effective_clock_ghz"],
-                                 "frac_of_power_ceiling": achieved / (probe["tflops"] / 3.0),
+                                 "mfma_macs_per_algorithmic_mac": mfma_per_mac,
+                                 "frac_of_power_ceiling": achieved / (probe["tflops"] / mfma_per_mac),
                                  "power_ceiling_note": "egz_mfma_probe (csrc/probe.hip) run for ~30 ms before the timed region: "
                                                        "sustained v_mfma_f32_32x32x16_f16 TFLOP/s on random operand bits; "
-                                                       "frac_of_power_ceiling = achieved / (ceiling / 3)"})
+                                                       "frac_of_power_ceiling = achieved / (ceiling / mfma_macs_per_algorithmic_mac)"})
         if use_at:
             # config 4 standalone: the AT step alone (lstmnet T=16, B=32 forward + MSE + backward + Adam), untimed leg
             torch.cuda.synchronize()
@@ -471,6 +476,21 @@ def main():
                 del lfm, lfo, lfb, lfg, lfi
             except Exception as e:
                 lf_block = {"error": repr(e)[:300]}
+        if split and not args.no_f32_leg and H.BWD_PRODUCTS == 2:
+            # the same step with three MFMA products per MAC in the backward convolutions too (EGAZE_BWD_PRODUCTS=3: fp32-class
+            # gradients), untimed leg, reported beside the headline
+            H.BWD_PRODUCTS = 3
+            for _ in range(3):
+                step()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            bwd3_ms = (time.perf_counter() - t1) / 10 * 1e3
+            H.BWD_PRODUCTS = 2
         if split and not args.no_f32_leg:
             # the same step on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), untimed leg, reported beside the headline
             H.PRECISION = "f32"
@@ -580,7 +600,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": (f"f32 (conv fwd: f16x3 split-half MFMA, 22 significant bits per operand; dgrad and wgrad: "
-                      f"{'f16x3 (22 bits, abs-max scaled)' if H.GRAD_SPLIT == 'f16' else 'bf16x3 (16 bits)'} split-half MFMA; "
+                      f"{'f16 split halves, abs-max scaled, ' + ('two products per MAC (22 x 11 significant bits)' if H.BWD_PRODUCTS == 2 else 'three products per MAC (22 x 22 bits)') if H.GRAD_SPLIT == 'f16' else 'bf16x3 (16 bits)'}; "
                       f"fp32 accumulate; everything else exact f32)" if H.PRECISION == "split" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"SP two-stream (RGB + 10-pair flow stack) forward + floss + backward + Adam, "
@@ -593,8 +613,9 @@ def main():
                                       "path on one GPU)" if dp_forced else None if world == 1 else
                                       f"gradient all-reduce, backend {'rccl' if backend == 'nccl' else backend}, "
                                       f"{'ALL RANKS ON ONE GPU (functional run, not a scaling number)' if shared_device else 'one GPU per rank'}"),
-                       "precision": (f"split-half f16x3 MFMA for conv fwd, {'f16x3' if H.GRAD_SPLIT == 'f16' else 'bf16x3'} "
-                                     "for dgrad / wgrad, operands abs-max scaled (fp32-class accuracy: gaze map within 1e-5 of "
+                       "precision": (f"split-half f16x3 MFMA for conv fwd, {'f16 halves' if H.GRAD_SPLIT == 'f16' else 'bf16x3'} "
+                                     f"for dgrad / wgrad ({'two products per MAC: one operand of every backward product enters with 11 significant bits, gradients move by 2e-4 ... 9e-4 relative L2; EGAZE_BWD_PRODUCTS=3 = three products, bwd3_ms_per_step' if H.BWD_PRODUCTS == 2 else 'three products per MAC'}), "
+                                     "operands abs-max scaled (forward fp32-class: gaze map within 1e-5 of "
                                      "the reference at batch 2 and batch 32; an 8-step lr 1e-4 training trajectory: per-step loss inside "
                                      "4x, end state (eval gaze map, BN statistics) inside 2x the CPU fp32 path's own distance from an "
                                      "fp64 run of the same steps -- such a trajectory is chaotic at the 1e-3 level for any fp32 "
@@ -629,6 +650,9 @@ def main():
                       "lf_step": lf_block,
                       "at_note": ("AT alone (BASELINE config 4 shape): lstmnet T=16, B=%d forward + MSE + backward + Adam, "
                                   "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),
+                      "bwd3_ms_per_step": bwd3_ms,
+                      "bwd3_note": "same step with EGAZE_BWD_PRODUCTS=3 (three MFMA products per MAC in the data and weight gradients "
+                                   "too: fp32-class gradients, the arithmetic of rounds 2-4), 10 untimed-leg steps",
                       "f32_ms_per_step": f32_ms,
                       "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps",
                       "rccl_world1": rccl,

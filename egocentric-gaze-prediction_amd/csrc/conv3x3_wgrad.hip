@@ -280,6 +280,17 @@ __device__ __forceinline__ void f16_split4(const f32x4 v, u32x2_t& hi, u32x2_t& 
         lo[e] = __builtin_bit_cast(unsigned, l);
     }
 }
+// The hi-only (B) operand of the two-product arithmetic, rounded to NEAREST: of 4 floats, and of a stored pair quad (its hi halves
+// are round-toward-zero images; hi + lo in packed f16 arithmetic is the nearest f16 of the value the pair holds) -- the weight
+// gradient then sums zero-mean rounding errors over its pixels instead of a -2^-11 relative bias.
+__device__ __forceinline__ void f16_rne4(const f32x4 v, u32x2_t& hi) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        hi[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{v[2 * e], v[2 * e + 1]}, f16x2_t));
+}
+__device__ __forceinline__ u32x2_t f16_pair_rne(const u32x2_t h, const u32x2_t l) {
+    return __builtin_bit_cast(u32x2_t, __builtin_bit_cast(f16x4_t, h) + __builtin_bit_cast(f16x4_t, l));      // two v_pk_add_f16
+}
 __device__ __forceinline__ f16x8_t tr_frag(const EGZ_LDS unsigned short* p0, const EGZ_LDS unsigned short* p1) {
     const f16x4_t a = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((EGZ_LDS fp16x4_t*)p0));
     const f16x4_t b = __builtin_bit_cast(f16x4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((EGZ_LDS fp16x4_t*)p1));
@@ -523,12 +534,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                 const u32x4_t bq = __builtin_bit_cast(u32x4_t, rd[j]);
                 hi = u32x2_t{bq[0], bq[1]};
                 lo = u32x2_t{bq[2], bq[3]};
+                if constexpr (egz_drop_blo<T>::value) hi = f16_pair_rne(hi, lo);
+            } else if constexpr (egz_drop_blo<T>::value) {
+                f16_rne4(rd[j] * d_scale, hi);
             } else {
                 W16<T>::split4s(rd[j], d_scale, hi, lo);
             }
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
-            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
+            if constexpr (!egz_drop_blo<T>::value) *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;      // two products: dy's lo plane is never read
         }
     };
 
@@ -1097,10 +1111,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int i = tid + 256 * j;
             const int slot = i >> 4, k4 = i & 15;
             u32x2_t hi, lo;
-            W16<T>::split4s(rd[j], d_scale, hi, lo);
+            if constexpr (egz_drop_blo<T>::value) f16_rne4(rd[j] * d_scale, hi);
+            else W16<T>::split4s(rd[j], d_scale, hi, lo);
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + slot * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
-            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
+            if constexpr (!egz_drop_blo<T>::value) *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
         }
     };
 

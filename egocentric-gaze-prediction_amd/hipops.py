@@ -549,6 +549,12 @@ P2_DTYPE = 0x10          # egz_conv3x3_fwd_streamed: dtype | 0x10
 P2_WGRAD = 0x20000       # egz_conv3x3_wgrad: flags | 0x20000
 
 
+def _note_p2(dtype: int, flops: float) -> None:
+    """bench.py's roofline leg: algorithmic FLOPs of the conv launches that ran on two products (to price the family's MFMA work)."""
+    if _p2(dtype) != dtype:
+        PROF.note_flops("two_product_conv", flops)
+
+
 def _p2(dtype: int) -> int:
     """dtype of a data-gradient launch on the streamed kernel: the two-product bit where the knob and the type allow it."""
     return dtype | P2_DTYPE if (BWD_PRODUCTS == 2 and dtype == F16X3) else dtype
@@ -681,6 +687,8 @@ def conv3x3_fwd(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
         if amax_dgrad:
             amo = _new_absmax(x.device)
             y._egz_absmax = amo
+        if p2:
+            _note_p2(dtype, 2.0 * B * H * W * K * 9 * C)
         check(LIB.egz_conv3x3_fwd_streamed(x.data_ptr(), wp.data_ptr(), _p(bias), y.data_ptr(), _p(stat), B, H, W, C, K,
                                            epi, _p2(dtype) if p2 else dtype, 0x100 if pre_in else 0, _p(absmax), None, _p(amo), _p(bn_in), _p(mm),
                                            _stream()), "egz_conv3x3_fwd_split")
@@ -722,6 +730,7 @@ def conv3x3_ups_dgrad(dy: torch.Tensor, wp_ups_dgrad: torch.Tensor, C: int, dtyp
     if dtype and streamed:
         PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
         am = absmax_of(dy) if dtype == F16X3 else None
+        _note_p2(dtype, 2.0 * B * H * W * K * 9 * C)
         check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wp_ups_dgrad.data_ptr(), None, dx.data_ptr(), None, B, H, W, K, C,
                                            0, _p2(dtype), 1, _p(am), None, None, None, None, _stream()),
               "egz_conv3x3_fwd_streamed(ups_dgrad)")
@@ -768,6 +777,7 @@ def conv3x3_dgrad_masked(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
     amo = _new_absmax(dy.device)
     PROF.note_flops("egz_conv3x3_fwd_split", 2.0 * B * H * W * K * 9 * C)
     am = absmax_of(dy) if dtype == F16X3 else None
+    _note_p2(dtype, 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
                                        EPI_MASK_SUMS, _p2(dtype), 1 if ups else 0, _p(am), mask_src.data_ptr(), amo.data_ptr(),
                                        None, None, _stream()), "egz_conv3x3_fwd_streamed(masked dgrad)")
@@ -822,6 +832,8 @@ def conv3x3_dgrad_bnsums(dy: torch.Tensor, wq: torch.Tensor, C: int, dtype: int,
         if not (dtype == F16X3 and C % 64 == 0 and getattr(dy, "_egz_absmax", None) is not None):
             raise RuntimeError("a pre-split gradient reached a data-gradient launch that cannot take it")
         PRESPLIT_STATS["dgrad"] += 1
+    if C % 64 == 0:        # (the narrow late-fusion form of this launch stays three-product)
+        _note_p2(dtype, 2.0 * B * H * W * K * 9 * C)
     check(LIB.egz_conv3x3_fwd_streamed(dy.data_ptr(), wq.data_ptr(), None, dx.data_ptr(), stat.data_ptr(), B, H, W, K, C,
                                        EPI_BNSUMS, _p2(dtype), 0x100 if pre_in else 0, _p(am), bn_y.data_ptr(), _p(amo), coef.data_ptr(),
                                        None, _stream()), "egz_conv3x3_fwd_streamed(dgrad + BN sums)")

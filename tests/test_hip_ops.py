@@ -1104,6 +1104,15 @@ def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_produ
             d1, s1 = h.conv3x3_dgrad_bnsums(dy_ref, wq, C, h.F16X3, ybelow, cbelow)
             d2, s2 = h.conv3x3_dgrad_bnsums(dy_pre, wq, C, h.F16X3, ybelow, cbelow, pre_in=True)
             assert rel(d2, d1) < 2e-6 and rel(s2.sum(0), s1.sum(0)) < 1e-5
+    # (d) the same consumers on two products per MAC (hipops.BWD_PRODUCTS = 2, the default outside this test): the pairs serve as
+    # the 22-bit A operand of the data gradient and -- rounded to nearest from hi + lo -- as the 11-bit B operand of the weight
+    # gradient; both stay in the two-product error class against the three-product results
+    monkeypatch.setattr(h, "BWD_PRODUCTS", 2)
+    for name, got, want in (("dgrad", h.conv3x3_dgrad(dy_pre, wq, C, dtype=h.F16X3, streamed=sq, pre_in=True), dx_ref),
+                            ("wgrad", h.conv3x3_wgrad(xd, dy_pre, precision="split_f16", dy_pre=True), dw_ref),
+                            ("wgrad, in-kernel split", h.conv3x3_wgrad(xd, dy_ref, precision="split_f16"), dw_ref)):
+        l2 = float((got.double() - want.double()).norm() / want.double().norm())
+        assert 1e-6 < l2 < 1e-3 and rel(got, want) < 2e-3, (name, l2, rel(got, want))
 
 
 @pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [(2, 28, 28, 64, 128, False), (1, 56, 56, 128, 64, True), (3, 14, 14, 256, 256, False),
