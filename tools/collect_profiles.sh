@@ -42,6 +42,26 @@ timeout 600 python tools/bench_conv.py --dtype 1 --iters 20 --zero > $O/r05_conv
 # 6. CPU baseline thread sweep (oracle SP train step, batch 8)
 for t in 8 16 32 64; do timeout 600 python tests/report_cpu_baseline_sweep.py $t 8; done > $O/r05_cpu_baseline_thread_sweep.txt 2>&1
 nproc >> $O/r05_cpu_baseline_thread_sweep.txt; lscpu | grep "Model name" >> $O/r05_cpu_baseline_thread_sweep.txt
+# 11. backward convolutions on two / three MFMA products per MAC: the step, alternating, and the accuracy report
+{ for rep in 1 2; do for v in 3 2; do
+    echo "--- EGAZE_BWD_PRODUCTS=$v"
+    EGAZE_BWD_PRODUCTS=$v timeout 300 python bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-f32-leg --no-roofline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
+print('ms/step %.3f  regions %s' % (d['ms_per_step'], [round(x,3) for x in d['extra']['timed_repeats']['ms_per_step']]))"
+  done; done; } > $O/r05_bwd_products_step_ab.txt 2>&1
+{ echo "# python -m pytest tests/test_hip_ops.py tests/test_hip_model_sp.py -m gpu -s -k 'headline_geometry or two_product'"
+  echo "# per convolution of the SP step at batch 32 (max-relative error vs torch-CPU fp32: forward, data gradient, weight gradient with three"
+  echo "# products | with two products: max-relative and relative L2), then the whole model: two-product vs three-product gradients"
+  timeout 900 python -m pytest tests/test_hip_ops.py tests/test_hip_model_sp.py -q -m gpu -s -k "headline_geometry or two_product" 2>&1 | grep -E "two product|two-product|passed|failed"; } > $O/r05_two_products_report.txt
+{ echo "# EGAZE_BWD_PRODUCTS=2 python tests/report_headline_grads.py --batch 8   (columns as in r05_headline_grads.txt, which holds the three-product run)"
+  EGAZE_BWD_PRODUCTS=2 timeout 900 python tests/report_headline_grads.py --batch 8 2>&1 | grep -v "amdgpu.ids\|tensors below"; } > $O/r05_headline_grads_two_products.txt
+# 12. the AT recurrence: wavefront launches against the persistent launches, phase trace of the persistent kernels
+{ timeout 300 python tools/bench_lstm_seq.py 2>&1 | grep -v amdgpu.ids
+  echo; echo "# EGAZE_HIP_LIB=.../variants/libegaze_hip_trace.so python tools/lstm_persist_trace.py   (build: EGZ_VARIANT=trace csrc/build.sh -DEGZ_PERSIST_TRACE)"
+  [ -f egocentric-gaze-prediction_amd/csrc/variants/libegaze_hip_trace.so ] && EGAZE_HIP_LIB=egocentric-gaze-prediction_amd/csrc/variants/libegaze_hip_trace.so timeout 120 python tools/lstm_persist_trace.py 2>&1 | grep -v amdgpu.ids
+  echo; echo "# tools/bench_at_step.py, alternating EGAZE_LSTM_PERSIST = 1 / 0"
+  for p in 1 0 1 0; do echo "EGAZE_LSTM_PERSIST=$p"; EGAZE_LSTM_PERSIST=$p timeout 200 python tools/bench_at_step.py 2>/dev/null; done; } > $O/r05_lstm_persistent.txt
 ls -la $O
 
 # 7. LF (config 3): step time with / without the device-side metric, and its kernel stats
