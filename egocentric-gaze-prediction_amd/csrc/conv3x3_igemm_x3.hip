@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_x3_kernel(
                 for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
                     for (int mr = 0; mr < 2; ++mr)
-                        if (!(egz_drop_blo<T>::value && term == 1)) acc[mr][nr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl[nr] : bh[nr], acc[mr][nr]);
+                        if (!(egz_drop_alo<T>::value && term == 0)) acc[mr][nr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl[nr] : bh[nr], acc[mr][nr]);
                 if (stage) {
                     if (term < 2) lstore_a(set, buf ^ 1, ks * 2 + term);
                     else if (ks == 1) lstore_b(set, buf ^ 1);
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
             for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
                 for (int mr = 0; mr < 2; ++mr) {
-                    if (!(egz_drop_blo<T>::value && term == 1)) acc[mr][nr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bl0[nr] : bh0[nr], acc[mr][nr]);
+                    if (!(egz_drop_alo<T>::value && term == 0)) acc[mr][nr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bl0[nr] : bh0[nr], acc[mr][nr]);
                 }
         __builtin_amdgcn_sched_barrier(0);
         if (next_a) read_a0(t + 1);
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, (XBN == 64) ? 3 : 2) void conv3x3_igemm_x3h_ke
             for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
                 for (int mr = 0; mr < 2; ++mr)
-                    if (!(egz_drop_blo<T>::value && term == 1)) acc[mr][nr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bl1[nr] : bh1[nr], acc[mr][nr]);
+                    if (!(egz_drop_alo<T>::value && term == 0)) acc[mr][nr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bl1[nr] : bh1[nr], acc[mr][nr]);
     };
 
     const int ncb = Cp / XBK, S = ncb * 9;

@@ -324,6 +324,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             const u32x4 b = __builtin_bit_cast(u32x4, v);
             hi = u32x2{b[0], b[1]};
             lo = u32x2{b[2], b[3]};
+            if constexpr (egz_drop_alo<T>::value) hi = Half<T>::pair_rne(hi, lo);
+        } else if constexpr (egz_drop_alo<T>::value) {
+            hi = Half<T>::rne4s(v, a_scale);
         } else {
             Half<T>::split4s(v, a_scale, hi, lo);
         }
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             split_q(ra[half * RAOFF + j], hi, lo);
             unsigned short* d = Ah + abuf * ABUF + lds_slot(half * (NJ / 2) + j);
             *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + APL) = lo;
+            if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2*>(d + APL) = lo;
         }
     };
 
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
-                if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl : bh, acc[mr]);
+                if (!(egz_drop_alo<T>::value && term == 0)) acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bl : bh, acc[mr]);
     };
 
     // ---- prologue
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             split_q(rp[j], hi, lo);
             unsigned short* d = Ah + lds_slot(NJ / 2 + j);
             *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + APL) = lo;
+            if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2*>(d + APL) = lo;
         }
     }
     lds_barrier();
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
                     for (int i = 0; i < NM; ++i) {
                         const int term = i / MR, mr = i % MR;
-                        if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bq[ring][1] : bq[ring][0], acc[mr]);
+                        if (!(egz_drop_alo<T>::value && term == 0)) acc[mr] = Half<T>::mfma(term == 0 ? al0[mr] : ah0[mr], term == 1 ? bq[ring][1] : bq[ring][0], acc[mr]);
                         if (i < MR) {
                             ah1[i] = *reinterpret_cast<const u32x4*>(Ab + (cur[i] ^ 32));
                             al1[i] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + (cur[i] ^ 32));
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
 #pragma unroll
                     for (int i = 0; i < NM; ++i) {
                         const int term = i / MR, mr = i % MR;
-                        if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bq[ring][3] : bq[ring][2], acc[mr]);
+                        if (!(egz_drop_alo<T>::value && term == 0)) acc[mr] = Half<T>::mfma(term == 0 ? al1[mr] : ah1[mr], term == 1 ? bq[ring][3] : bq[ring][2], acc[mr]);
                         if (!last && i < MR) {
                             ah0[i] = *reinterpret_cast<const u32x4*>(Ab + cur[i]);
                             al0[i] = *reinterpret_cast<const u32x4*>(Ab + APL * 2 + cur[i]);
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
                             split_q(ra[lhalf * RAOFF + j], hi, lo);
                             unsigned short* d = Ah + (abuf ^ 1) * ABUF + lds_slot(lhalf * NH + j);
                             *reinterpret_cast<u32x2*>(d) = hi;
-                            *reinterpret_cast<u32x2*>(d + APL) = lo;
+                            if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2*>(d + APL) = lo;
                         } else if (last && more) {
                             // the image boundary: every wave has staged its share (taps L0, L1) and read its last fragments
                             // (group 0); the first fragments of the next image ride on the remaining MFMAs of this group
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
-                    if (!(egz_drop_blo<T>::value && term == 1)) acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bq[t][ks * 2 + 1] : bq[t][ks * 2], acc[mr]);
+                    if (!(egz_drop_alo<T>::value && term == 0)) acc[mr] = Half<T>::mfma(term == 0 ? al[mr] : ah[mr], term == 1 ? bq[t][ks * 2 + 1] : bq[t][ks * 2], acc[mr]);
             if (g < 16) {                                       // two epilogue elements of the previous tile
                 epi_elem((2 * g) >> 4, (2 * g) & 15);
                 epi_elem((2 * g + 1) >> 4, (2 * g + 1) & 15);
@@ -1524,7 +1527,7 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
                                      const unsigned int* x_absmax, const float* mask_src, unsigned int* absmax_out,
                                      const float* bn_coef, float* minmax_out, hipStream_t st) {
     EGZ_CHECK_ARG(x && wq && y, "egz_conv3x3_fwd_streamed: null pointer");
-    const bool p2 = (dtype & 0x10) != 0;      // two products per MAC (egz_f16p2): f16 only, wide tiles; elsewhere three
+    const bool p2 = (dtype & 0x10) != 0;      // two products per MAC (egz_f16p2: x enters hi-only): f16 only, wide tiles; elsewhere three
     dtype &= 0xf;
     EGZ_CHECK_ARG(!p2 || dtype == 1, "egz_conv3x3_fwd_streamed: dtype 0x10 (two products) goes with f16 (dtype 0x11)");
     // mode | 0x100 (mode 0, f16 x3, epi 2, K % 64 == 0, C % 32 == 0): x holds PRE-SPLIT activations (egz_bn_relu_pool_fwd's

@@ -280,9 +280,9 @@ __device__ __forceinline__ void f16_split4(const f32x4 v, u32x2_t& hi, u32x2_t& 
         lo[e] = __builtin_bit_cast(unsigned, l);
     }
 }
-// The hi-only (B) operand of the two-product arithmetic, rounded to NEAREST: of 4 floats, and of a stored pair quad (its hi halves
-// are round-toward-zero images; hi + lo in packed f16 arithmetic is the nearest f16 of the value the pair holds) -- the weight
-// gradient then sums zero-mean rounding errors over its pixels instead of a -2^-11 relative bias.
+// The hi-only (x) operand of the two-product arithmetic, rounded to NEAREST: of 4 floats, and of a stored pair quad (its hi halves
+// are round-toward-zero images; hi + lo in packed f16 arithmetic is the nearest f16 of the value the pair holds): zero-mean
+// rounding errors instead of the -2^-11 relative bias of the truncated hi half.
 __device__ __forceinline__ void f16_rne4(const f32x4 v, u32x2_t& hi) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -329,7 +329,7 @@ template <> struct W16<_Float16> {
     static __device__ __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
     static __device__ __forceinline__ float scale(const unsigned int* am) { return absmax_scale(am); }
 };
-template <> struct W16<egz_f16p2> : W16<_Float16> {};      // two products per MAC: dy's lo half is not multiplied (egz_common.h)
+template <> struct W16<egz_f16p2> : W16<_Float16> {};      // two products per MAC: x enters hi-only (egz_common.h)
 
 // XCD-aware (tile, split) of a block of a (tiles, splits[, z]) grid.  Hardware places consecutive flat block ids on
 // consecutive XCDs (id % 8) and every XCD has its own L2.  The natural map puts the 64 (c, k) tiles of ONE pixel range on all
@@ -517,12 +517,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                     const u32x4_t bq = __builtin_bit_cast(u32x4_t, rx[j]);
                     hi = u32x2_t{bq[0], bq[1]};
                     lo = u32x2_t{bq[2], bq[3]};
+                    if constexpr (egz_drop_alo<T>::value) hi = f16_pair_rne(hi, lo);
+                } else if constexpr (egz_drop_alo<T>::value) {
+                    f16_rne4(rx[j] * x_scale, hi);
                 } else {
                     W16<T>::split4s(rx[j], x_scale, hi, lo);
                 }
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
-                *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
+                if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;      // (x hi-only: its lo plane is never read)
             }
         }
 #pragma unroll
@@ -534,15 +537,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                 const u32x4_t bq = __builtin_bit_cast(u32x4_t, rd[j]);
                 hi = u32x2_t{bq[0], bq[1]};
                 lo = u32x2_t{bq[2], bq[3]};
-                if constexpr (egz_drop_blo<T>::value) hi = f16_pair_rne(hi, lo);
-            } else if constexpr (egz_drop_blo<T>::value) {
-                f16_rne4(rd[j] * d_scale, hi);
             } else {
                 W16<T>::split4s(rd[j], d_scale, hi, lo);
             }
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + pp * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
-            if constexpr (!egz_drop_blo<T>::value) *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;      // two products: dy's lo plane is never read
+            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
         }
     };
 
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3_kernel(
                 for (int term = 0; term < 3; ++term)
 #pragma unroll
                     for (int ts = 0; ts < 3; ++ts)
-                        if (!(egz_drop_blo<T>::value && term == 1)) acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
+                        if (!(egz_drop_alo<T>::value && term == 0)) acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
             }
         }
         if (g + 1 < g1) lstore(buf ^ 1);
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
             for (int term = 0; term < 3; ++term)
 #pragma unroll
                 for (int ts = 0; ts < 3; ++ts)
-                    if (!(egz_drop_blo<T>::value && term == 1)) acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
+                    if (!(egz_drop_alo<T>::value && term == 0)) acc[tr * 3 + ts] = W16<T>::mfma(term == 0 ? xl[ts] : xh[ts], term == 1 ? dl : dh, acc[tr * 3 + ts]);
         }
         if (g + 1 < g1) lstore(buf ^ 1);
         __syncthreads();
@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3t_kernel(
         for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                if (!(egz_drop_blo<T>::value && term == 1)) acc[j] = W16<T>::mfma(term == 0 ? xl : xh, term == 1 ? dl[j] : dh[j], acc[j]);
+                if (!(egz_drop_alo<T>::value && term == 0)) acc[j] = W16<T>::mfma(term == 0 ? xl : xh, term == 1 ? dl[j] : dh[j], acc[j]);
         if (g + 1 < g1) lstore(buf ^ 1);
         __syncthreads();
     }
@@ -1100,10 +1100,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int pos = i >> 4, c4 = i & 15;
             if (pos < NH) {
                 u32x2_t hi, lo;
-                W16<T>::split4s(rx_[j], x_scale, hi, lo);
+                if constexpr (egz_drop_alo<T>::value) f16_rne4(rx_[j] * x_scale, hi);
+                else W16<T>::split4s(rx_[j], x_scale, hi, lo);
                 unsigned short* d = Xs + buf * XB + (c4 >> 3) * XH + pos * 32 + (c4 & 7) * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
-                *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
+                if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2_t*>(d + 2 * XH) = lo;
             }
         }
 #pragma unroll
@@ -1111,11 +1112,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
             const int i = tid + 256 * j;
             const int slot = i >> 4, k4 = i & 15;
             u32x2_t hi, lo;
-            if constexpr (egz_drop_blo<T>::value) f16_rne4(rd[j] * d_scale, hi);
-            else W16<T>::split4s(rd[j], d_scale, hi, lo);
+            W16<T>::split4s(rd[j], d_scale, hi, lo);
             unsigned short* d = Ds + buf * DB + (k4 >> 3) * DH + slot * 32 + (k4 & 7) * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
-            if constexpr (!egz_drop_blo<T>::value) *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
+            *reinterpret_cast<u32x2_t*>(d + 2 * DH) = lo;
         }
     };
 
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_ups_x3_kernel(
                     for (int px = 0; px < 2; ++px)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
-                            if (!(egz_drop_blo<T>::value && term == 1)) acc[px * 4 + a * 2 + b] = W16<T>::mfma(term == 0 ? xl[px + b] : xh[px + b], term == 1 ? dl[px] : dh[px], acc[px * 4 + a * 2 + b]);
+                            if (!(egz_drop_alo<T>::value && term == 0)) acc[px * 4 + a * 2 + b] = W16<T>::mfma(term == 0 ? xl[px + b] : xh[px + b], term == 1 ? dl[px] : dh[px], acc[px * 4 + a * 2 + b]);
             }
         }
         if (g + 1 < g1) lstore(buf ^ 1);
@@ -1613,8 +1613,8 @@ EGZ_API size_t egz_conv3x3_wgrad_ws_bytes(int B, int H, int W, int C, int K, int
 //        no scaling) when dy_absmax is NULL, f16 x3 (22 bits) with dy scaled by absmax_scale(*dy_absmax) when it is given;
 //        x_absmax (optional, f16 x3 only): max |x| -- x is scaled the same way (activations outside [2^-3, 6e4] otherwise
 //        leave the f16 pair's 22-bit domain).
-//        0x20000 = with f16 split halves: TWO products per MAC instead of three -- dy's lo half is not multiplied (11 significant
-//        bits of dy, 22 of x; per-element error ~2^-12 instead of 2^-22) -- on conv3x3_wgrad9_x3_kernel / conv3x3_wgrad_ups_x3_kernel.
+//        0x20000 = with f16 split halves: TWO products per MAC instead of three -- x's lo half is not multiplied (11 significant
+//        bits of x, rounded to nearest; 22 of dy; per-element error ~2^-12 instead of 2^-22) -- on conv3x3_wgrad9_x3_kernel / conv3x3_wgrad_ups_x3_kernel.
 // x: conv input (NHWC), dy: gradient of the conv output ([B][H][W][K]), dw: (K, C, 3, 3) like the reference.
 // 1 when a plain split-half weight gradient of this geometry runs on the narrow kernel (C, K <= 32, W % 16 == 0, 32-bit
 // buffer offsets) -- the only one that takes a deferred-BatchNorm activation operand (x_bn)
@@ -1654,8 +1654,8 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     }
     // flags 0x8000: x holds pre-split activations (see conv3x3_wgrad9_x3_kernel) -- only where that kernel runs
     const bool xpre = (flags & 0x8000) != 0, dpre = (flags & 0x10000) != 0;
-    // 0x20000: two products per MAC on the split-half f16 kernels of the wide layers (x_hi dy_hi + x_lo dy_hi: dy enters with its hi
-    // half only; egz_f16p2 in egz_common.h).  Ignored where the launch is not one of those (bf16, exact f32, the narrow kernels).
+    // 0x20000: two products per MAC on the split-half f16 kernels of the wide layers (x_hi dy_hi + x_hi dy_lo: x enters with its hi
+    // half only, rounded to nearest; egz_f16p2 in egz_common.h).  Ignored where the launch is not one of those (bf16, exact f32, the narrow kernels).
     const bool p2 = (flags & 0x20000) != 0 && dy_absmax;
     EGZ_CHECK_ARG(!(xpre || dpre) || (egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) && (flags & 0x2000) && !ups && dy_absmax && x_absmax && !x_bn),
                   "egz_conv3x3_wgrad: a pre-split x / dy operand (flags 0x8000 / 0x10000) needs the split-half 9-tap kernel's geometry "

@@ -31,13 +31,15 @@ void egz_set_error(const char* fmt, ...);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Operand-type tag "f16 split halves, TWO products per MAC": a b ~ a_hi b_hi + a_lo b_hi -- the SECOND (B) operand enters with its hi
-// half only (11 significant bits; the A operand keeps 22).  The split-half kernels (conv3x3_igemm_x3s / _x3 / conv3x3_wgrad) are
-// instantiated with it for the BACKWARD convolutions (dtype | 0x10 / wgrad flag 0x20000): B = the weights (their hi half is the
-// RNE f16 rounding of w) in a data gradient, dy in a weight gradient.  Same fragments, same packing, 2/3 of the MFMA work.
+// Operand-type tag "f16 split halves, TWO products per MAC": a b ~ a_hi b_hi + a_hi b_lo -- the FIRST (A) operand enters with its f16
+// hi half only, rounded to nearest (11 significant bits), the second keeps 22.  The split-half kernels (conv3x3_igemm_x3s,
+// conv3x3_wgrad) are instantiated with it for the BACKWARD convolutions (dtype | 0x10 / wgrad flag 0x20000): A is the operand that
+// goes through LDS as a halo image -- dy in a data gradient, x in a weight gradient -- so one plane is staged instead of two and one
+// fragment is read per MFMA pair (with two products per MAC the LDS reads, not the MFMAs, bound the mirror-image form that keeps
+// both halves of A and drops the weights' lo half: measured 5 % slower).  Same packings, 2/3 of the MFMA work.
 struct egz_f16p2 {};
-template <typename T> struct egz_drop_blo { static constexpr bool value = false; };
-template <> struct egz_drop_blo<egz_f16p2> { static constexpr bool value = true; };
+template <typename T> struct egz_drop_alo { static constexpr bool value = false; };
+template <> struct egz_drop_alo<egz_f16p2> { static constexpr bool value = true; };
 
 static inline int egz_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

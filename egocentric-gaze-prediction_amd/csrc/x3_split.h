@@ -77,7 +77,19 @@ template <> struct Half<__bf16> {
     }
 };
 
-template <> struct Half<egz_f16p2> : Half<_Float16> {};
+template <> struct Half<egz_f16p2> : Half<_Float16> {
+    // the hi-only operand, rounded to NEAREST: of 4 scaled floats, and of a stored pair quad (hi + lo in packed f16 arithmetic is the
+    // nearest f16 of the value the pair holds; the stored hi half itself is a round-toward-zero image)
+    static __device__ __forceinline__ u32x2 rne4s(const f32x4 v, const float scale) {
+        const f32x4 w = v * scale;
+        return u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{w[0], w[1]}, f16x2)),
+                     __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{w[2], w[3]}, f16x2))};
+    }
+    static __device__ __forceinline__ u32x2 pair_rne(const u32x2 h, const u32x2 l) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(u32x2, __builtin_bit_cast(f16x4, h) + __builtin_bit_cast(f16x4, l));
+    }
+};
 template <typename T> constexpr bool IS_F16 = std::is_same<T, _Float16>::value || std::is_same<T, egz_f16p2>::value;
 
 }  // namespace x3

@@ -539,10 +539,11 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
 # the BatchNorm's monotonic map by egz_bn_finalize_bound.  Consumers (the next conv's forward and weight gradient) then stage
 # the pair without touching the vector ALU; the pair is bit-identical to the one they would have formed, so every result is.
 # EGAZE_PRESPLIT=0 keeps fp32 activations everywhere (A/B runs; test_presplit_activations_bit_identical flips the constant).
-# EGAZE_BWD_PRODUCTS=2: the BACKWARD convolutions of the wide layers (data gradients, weight gradients; f16 split halves) issue TWO
-# MFMA products per MAC instead of three -- a_hi b_hi + a_lo b_hi: the second operand (the weights in a data gradient, dy in a
-# weight gradient) enters with its f16 hi half only, the first keeps its 22 bits (csrc/egz_common.h, egz_f16p2).  Gradients move by
-# ~1e-4 relative -- a fraction of what the summation order of ANY fp32 implementation moves them (tests/report_grad_accuracy.py) --
+# EGAZE_BWD_PRODUCTS=2 (default): the BACKWARD convolutions of the wide layers (data gradients, weight gradients; f16 split halves) issue
+# TWO MFMA products per MAC instead of three -- a_hi b_hi + a_hi b_lo: the operand that goes through LDS as a halo image (dy in a
+# data gradient, x in a weight gradient) enters with its f16 hi half only, rounded to nearest; the other keeps its 22 bits
+# (csrc/egz_common.h, egz_f16p2).  Gradients move by ~2e-4 relative L2 per convolution, <= 1e-3 through the whole backward chain -- a
+# fraction of what the summation order of ANY fp32 implementation moves the encoder gradients (profiles/r05_headline_grads*.txt) --
 # the forward pass and with it every predicted map is untouched.  3: three products everywhere (fp32-class gradients, 2e-7 per op).
 BWD_PRODUCTS = int(_os.environ.get("EGAZE_BWD_PRODUCTS", "2"))
 P2_DTYPE = 0x10          # egz_conv3x3_fwd_streamed: dtype | 0x10

@@ -96,10 +96,11 @@ int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, 
                              const float* mask_src, unsigned int* absmax_out, const float* bn_coef, float* minmax_out,
                              hipStream_t stream);
 /* dtype | 0x10 (with dtype 1, f16 split halves; the wide tiles K % 32 == 0 of modes 0 and 1): TWO MFMA products per MAC instead of
- * three -- x_hi w_hi + x_lo w_hi: the packed weights enter with their hi half (the round-to-nearest f16 image of w) only, the
- * activation / gradient operand keeps its 22 bits.  Meant for the data gradients (autograd of utils.py:70, models/model_SP.py:13-29):
- * the result moves by ~2e-4 relative L2 (tests/test_hip_ops.py::test_backward_two_products).  Ignored by the narrow (late-fusion)
- * kernels and by egz_conv3x3_fwd_streamed_splitk, which stay on three products. */
+ * three -- x_hi w_hi + x_hi w_lo: the x operand (the halo image that goes through LDS; dy in a data gradient) enters with its f16 hi
+ * half only, rounded to nearest from the fp32 value or from hi + lo of a pre-split pair, the packed weights keep their 22 bits.
+ * Meant for the data gradients (autograd of utils.py:70, models/model_SP.py:13-29): the result moves by ~2e-4 relative L2
+ * (tests/test_hip_ops.py::test_backward_two_products).  Ignored by the narrow (late-fusion) kernels and by
+ * egz_conv3x3_fwd_streamed_splitk, which stay on three products. */
 /* Deferred BatchNorm (narrow geometry, epi 0 / 1 / 2): with bn_coef != NULL, x is the PRE-BatchNorm conv output of the block
  * below and bn_coef that BatchNorm's 4 x C coefficient rows; relu(x * scale + shift) is applied while the halo is staged, so
  * the normalised tensor of late_fusion.py:11-12 is never materialised (x_absmax = its max, from egz_bn_finalize_deferred).
@@ -133,8 +134,8 @@ int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, 
                       void* workspace, size_t ws_bytes, const unsigned int* dy_absmax, const unsigned int* x_absmax,
                       const float* x_bn, hipStream_t stream);
 /* flags | 0x20000 (with 0x2000 and dy_absmax: f16 split halves on the wide kernels, C and K multiples of 32 / 64): TWO MFMA products
- * per MAC -- x_hi dy_hi + x_lo dy_hi: dy enters with 11 significant bits, rounded to nearest (from the fp32 value, or from hi + lo
- * of a pre-split pair), x keeps 22; dw moves by ~2e-4 relative L2.  Ignored by the narrow, bf16 and exact-f32 launches. */
+ * per MAC -- x_hi dy_hi + x_hi dy_lo: x enters with 11 significant bits, rounded to nearest (from the fp32 value, or from hi + lo
+ * of a pre-split pair), dy keeps 22; dw moves by ~2e-4 relative L2.  Ignored by the narrow, bf16 and exact-f32 launches. */
 /* x_bn (optional): x is the PRE-BatchNorm conv output of the block below and x_bn that BatchNorm's 4 x C coefficient rows;
  * relu(x * scale + shift) is applied while x is staged (deferred BatchNorm, late_fusion.py:11-12), x_absmax = the max of the
  * normalised values.  Only where egz_conv3x3_wgrad_narrow_ok(B, H, W, C, K) (C, K <= 32, W % 16 == 0, flags 0x2000). */

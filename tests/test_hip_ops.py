@@ -1042,8 +1042,8 @@ def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups, monkeypatc
         print(f"B=32 {C}->{K} @{Hh}{'u' if ups else ''}: fwd {e_f:.1e}  dgrad {e_d:.1e}  wgrad {e_w:.1e}  | two products: "
               f"dgrad {p_d:.1e} (L2 {l_d:.1e})  wgrad {p_w:.1e} (L2 {l_w:.1e})")
         assert e_f < 2e-5 and e_d < 2e-5 and e_w < 5e-5, (e_f, e_d, e_w)
-        # two products: one operand enters with 11 significant bits (the weights, rounded to nearest, in the data gradient; dy,
-        # truncated, in the weight gradient): every entry within 2e-3 of max |ref|, relative L2 error below 1e-3 (a mis-indexed
+        # two products: one operand enters with 11 significant bits, rounded to nearest (dy in the data gradient, x in the weight
+        # gradient): every entry within 2e-3 of max |ref|, relative L2 error below 1e-3 (a mis-indexed
         # tile would still show as O(1) entries)
         assert p_d < 2e-3 and p_w < 2e-3 and l_d < 1e-3 and l_w < 1e-3, (p_d, p_w, l_d, l_w)
     finally:
@@ -1105,8 +1105,7 @@ def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_produ
             d2, s2 = h.conv3x3_dgrad_bnsums(dy_pre, wq, C, h.F16X3, ybelow, cbelow, pre_in=True)
             assert rel(d2, d1) < 2e-6 and rel(s2.sum(0), s1.sum(0)) < 1e-5
     # (d) the same consumers on two products per MAC (hipops.BWD_PRODUCTS = 2, the default outside this test): the pairs serve as
-    # the 22-bit A operand of the data gradient and -- rounded to nearest from hi + lo -- as the 11-bit B operand of the weight
-    # gradient; both stay in the two-product error class against the three-product results
+    # the hi-only operand of the data gradient (rounded to nearest from hi + lo) and as the 22-bit operand of the weight gradient; both stay in the two-product error class against the three-product results
     monkeypatch.setattr(h, "BWD_PRODUCTS", 2)
     for name, got, want in (("dgrad", h.conv3x3_dgrad(dy_pre, wq, C, dtype=h.F16X3, streamed=sq, pre_in=True), dx_ref),
                             ("wgrad", h.conv3x3_wgrad(xd, dy_pre, precision="split_f16", dy_pre=True), dw_ref),
@@ -1119,7 +1118,7 @@ def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_produ
                                              (2, 32, 32, 64, 64, False)])
 def test_backward_two_products(B, Hh, Ww, C, K, ups, monkeypatch):
     """hipops.BWD_PRODUCTS = 2 (the default): the backward convolutions issue a_hi b_hi + a_lo b_hi -- two MFMA products per MAC,
-    the B operand with its f16 hi half only (csrc/egz_common.h, egz_f16p2).  Against torch fp64 on the same operands:
+    the halo operand (dy / x) with its f16 hi half only, rounded to nearest (csrc/egz_common.h, egz_f16p2).  Against torch fp64 on the same operands:
     (a) the FORWARD launch does not know the knob (bit-identical output);  (b) data and weight gradient stay within 2e-3 of
     max |ref| per entry and 1e-3 in relative L2 -- and are NOT the three-product results (the knob reaches the launches);
     (c) three products: the fp32 class (2e-5).  Plain and upsample-fused geometries, 64- and 128-column tiles."""

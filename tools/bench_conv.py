@@ -89,8 +89,16 @@ def main():
                                              tile_flag=a.tile, dtype=fdt, streamed=fst), a.iters)
             res.append(("fwd", t))
         if "dgrad" in a.what:
-            t = timeit(lambda: H.conv3x3_fwd(dy, wd, None, C, ups=False, epi=H.EPI_BIAS, tile_flag=a.tile, dtype=ddt,
-                                             streamed=dst), a.iters)
+            # the data gradient as the step issues it: hipops.conv3x3_dgrad (two MFMA products per MAC unless EGAZE_BWD_PRODUCTS=3),
+            # for an upsample-fused conv the polyphase form straight to the low-res gradient (hipops.conv3x3_ups_dgrad)
+            if ups and ddt:
+                wu, ust = H.conv_weight(w, "ups_dgrad", ddt, dy, C)
+                t = timeit(lambda: H.conv3x3_ups_dgrad(dy, wu, C, dtype=ddt, streamed=ust), a.iters)
+            elif ddt:
+                t = timeit(lambda: H.conv3x3_dgrad(dy, wd, C, dtype=ddt, streamed=dst), a.iters)
+            else:
+                t = timeit(lambda: H.conv3x3_fwd(dy, wd, None, C, ups=False, epi=H.EPI_BIAS, tile_flag=a.tile, dtype=ddt,
+                                                 streamed=dst), a.iters)
             res.append(("dgrad", t))
         if "wgrad" in a.what:
             t = timeit(lambda: H.conv3x3_wgrad(x, dy, ups=ups, variant_flag=a.wflag), a.iters)
