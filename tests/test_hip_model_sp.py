@@ -340,8 +340,10 @@ def test_model_sp_grads_vs_fp64_all_surveyed_seeds(monkeypatch, three_products):
 
 
 @pytest.mark.parametrize("batch,size,splitk", [(2, 224, False), (2, 224, True), (3, 96, True)])
-def test_presplit_activations_bit_identical(batch, size, splitk, monkeypatch):
-    """hipops.PRESPLIT (round 5): the encoder blocks hand their outputs to the next block's convolution and weight gradient as
+def test_presplit_activations_bit_identical(batch, size, splitk, monkeypatch, three_products):
+    """(Runs with three backward products: with two, the weight gradient rounds x to 11 bits from the fp32 value in one form and from
+    hi + lo of the stored pair in the other -- a double rounding apart on rare ties; tests/test_hip_ops.py::test_presplit_activation_chain
+    bounds that difference.)  hipops.PRESPLIT (round 5): the encoder blocks hand their outputs to the next block's convolution and weight gradient as
     pre-split f16 pairs.  The pairs are the ones those kernels would form themselves, so the whole training step -- gaze map,
     loss, every gradient, BatchNorm running statistics -- is BIT-IDENTICAL to the step with fp32 activations, and at 224 x 224
     most encoder blocks take the route (the first RGB block and the last block of each encoder keep fp32)."""

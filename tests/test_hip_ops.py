@@ -937,7 +937,7 @@ def test_pack_frag_batch_matches_per_layer(monkeypatch):
     (1, 224, 224, 64, 64, False),     # the 224-wide layers: 4 x 8 patches
     (2, 56, 56, 128, 64, True),       # pooled to 28 x 28, 64-column consumer
 ])
-def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch):
+def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_products):
     """Pre-split activations (hipops.PRESPLIT, round 5): conv (statistics epilogue + per-channel max / min) -> egz_bn_finalize_bound
     -> egz_bn_relu_pool_fwd_presplit -> consumer conv forward (mode | 0x100) and weight gradient (flags | 0x8000).
     (a) the bound is the EXACT maximum of the block output (== the abs-max the fp32 form measures in its own pass);
@@ -984,6 +984,11 @@ def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch):
     dw_ref = h.conv3x3_wgrad(out_ref, dy, precision="split_f16")
     dw_pre = h.conv3x3_wgrad(out_pre, dy, precision="split_f16", x_pre=True)
     assert torch.equal(dw_ref, dw_pre)
+    # two products per MAC (the default outside this test): x enters hi-only, rounded to nearest from the fp32 value in one launch
+    # and from hi + lo of the stored pair in the other -- a double rounding apart on rare ties: close, not bit-identical
+    monkeypatch.setattr(h, "BWD_PRODUCTS", 2)
+    assert rel(h.conv3x3_wgrad(out_pre, dy, precision="split_f16", x_pre=True), h.conv3x3_wgrad(out_ref, dy, precision="split_f16")) < 1e-5
+    monkeypatch.setattr(h, "BWD_PRODUCTS", 3)
     # a consumer that cannot take the pairs refuses them
     with pytest.raises(RuntimeError):
         h.conv3x3_fwd(out_pre, wp1, b1, K, epi=h.EPI_BIAS_RELU, dtype=h.F16X3, streamed=True, pre_in=True)
