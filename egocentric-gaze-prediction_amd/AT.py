@@ -146,7 +146,6 @@ class _GraphedSampleStep:
     in static buffers; the Adam step counter lives on the device (FusedAdam.set_capturable).  The first ``WARM`` steps run
     eagerly through the same function (they are real training steps), then the step is captured once and replayed."""
     WARM = 3
-    CHUNK = 8
 
     def __init__(self, lstm, criterion, optimizer, device, width, ring=None):
         self.lstm, self.criterion, self.opt = lstm, criterion, optimizer
@@ -154,12 +153,7 @@ class _GraphedSampleStep:
         # step) % len(ring) -- written by the loss kernel itself off the optimizer's device-side step counter, so reading the
         # losses back once per ring costs no launch per replay
         self.ring = ring
-        # (input, target) pairs of CHUNK consecutive steps: ONE host copy fills them all (step_chunk), and slot k has a captured
-        # graph of its own that reads pair k in place -- the per-sample 4 KB upload in front of every replay (a copy kernel and a
-        # dependent boundary per 80 us sample, profiles/r04_at_sample_loop.txt) is paid once per CHUNK samples
-        self.pairs = torch.zeros((self.CHUNK, 2, 1, 1, width), device=device)
-        self.both = self.pairs[0]
-        self.graphs = [None] * self.CHUNK
+        self.both = torch.zeros((2, 1, 1, width), device=device)          # (input, target) of the step: ONE host copy fills it
         self.state = torch.zeros((2, lstm.num_layer, 1, lstm.num_channel), device=device)      # (h, c)
         from .models import LSTMnet as _L
         # the (1, 1, C) step runs on the fused single-step path AND every gradient is written in full by a sink -- with
@@ -169,12 +163,11 @@ class _GraphedSampleStep:
         self.graph, self.calls = None, 0
         self.opt.set_capturable(True)
 
-    def _unit(self, k=0):
-        both = self.pairs[k]
-        pred, (hn, cn) = self.lstm(both[0], (self.state[0], self.state[1]))
+    def _unit(self):
+        pred, (hn, cn) = self.lstm(self.both[0], (self.state[0], self.state[1]))
         # criterion(pred, tanh(target)) AND its gradient for the unit seed of loss.backward() in one kernel (AT.py:138-141), which
         # also parks the loss in the ring: the backward pass starts at the network's output
-        loss, dpred = H.mse_fwd_grad(H._req(pred.detach().contiguous(), "pred"), both[1].view_as(pred).contiguous(), True,
+        loss, dpred = H.mse_fwd_grad(H._req(pred.detach().contiguous(), "pred"), self.both[1].view_as(pred).contiguous(), True,
                                      self.ring, self.opt.step_dev if self.ring is not None else None)
         # every gradient of a batch-1 step is written in full by the backward kernels (csrc/lstm_b1.hip): no zero fill
         self.opt.zero_grad(all_overwritten=self.single_step)
@@ -195,27 +188,22 @@ class _GraphedSampleStep:
 
     def step(self, host_pair):
         """host_pair: pinned (2, width) tensor = (input of the deferred sample, target of the current one) -> loss (0-d)."""
-        return self.step_chunk(host_pair.view(1, 2, -1))
-
-    def step_chunk(self, host_pairs):
-        """host_pairs: pinned (n <= CHUNK, 2, width) tensor, the pairs of n consecutive steps: one upload, n replays (slot k =
-        step k of the chunk).  -> the loss tensor of the last step."""
-        n = host_pairs.shape[0]
-        self.pairs[:n].copy_(host_pairs.view(n, 2, 1, 1, -1), non_blocking=True)
-        for k in range(n):
-            self.calls += 1
-            if self.calls <= self.WARM:
-                self._unit(k)
-                continue
-            if self.graphs[k] is None:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                count = self.opt.step_count
-                with H.capture(g, eager_arena=False):
-                    self._unit(k)
-                self.opt.step_count = count        # the capture ran the host side of step() without executing anything
-                self.graphs[k] = self.graph = g
-            self.graphs[k].replay()
+        self.both.copy_(host_pair.view_as(self.both), non_blocking=True)
+        self.calls += 1
+        if self.graph is None and self.calls <= self.WARM:
+            self._unit()
+        elif self.graph is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            count = self.opt.step_count
+            with H.capture(g, eager_arena=False):
+                self._unit()
+            self.opt.step_count = count        # the capture ran the host side of step() without executing anything
+            self.graph = g
+            g.replay()
+            self.opt.note_replays(1)
+        else:
+            self.graph.replay()
             self.opt.note_replays(1)
         return self.loss
 
@@ -270,16 +258,7 @@ class AT():
         RING = 64
         losses = AverageMeter()
         runner, stage, prev_inp, reset = None, None, None, True
-        ring, pending, first, gathered = None, 0, 0, 0
-
-        def flush():
-            # the pairs gathered since the last flush: one upload, one graph replay each (slots pending .. pending + gathered - 1 of
-            # the pinned ring; a slot is rewritten only after the read-back in drain() that proves its upload was consumed)
-            nonlocal pending, gathered
-            if gathered:
-                runner.step_chunk(stage[pending:pending + gathered])
-                pending += gathered
-                gathered = 0
+        ring, pending, first = None, 0, 0
 
         def drain():
             nonlocal pending, first
@@ -306,22 +285,19 @@ class AT():
                 same = int(sample['same'])
                 if prev_inp is not None:
                     # step on the previous sample's input (forward) scored against THIS sample's target
-                    if reset:                       # a state reset goes between two steps: whatever is gathered runs first
-                        flush()
-                        runner.reset_state()
-                    slot = stage[pending + gathered]
+                    slot = stage[pending]
                     slot[0].copy_(prev_inp)
                     slot[1].copy_(sample['gt'].reshape(-1))
-                    gathered += 1
-                    if gathered == runner.CHUNK or pending + gathered == RING // 2:
-                        flush()
+                    if reset:
+                        runner.reset_state()
+                    runner.step(slot)
+                    pending += 1
                     if pending == RING // 2:
                         drain()
                     reset = False
                 if same == 0:                       # the state is reset before THIS sample's forward pass (AT.py:129-130)
                     reset = True
                 prev_inp = sample['input'].reshape(-1).clone()
-            flush()
             drain()
         finally:
             if runner is not None:
