@@ -761,6 +761,17 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwd 
 }  // namespace
 
 // Words of the `sync` scratch of egz_lstm_persist_fwd (zeroed by the call itself); word [1024] is the error word: 0 = every hand-off arrived, 1 + s = a block gave up waiting in global step s.
+// every block of a persistent launch needs a CU of its own (the backward kernel's 252 VGPRs leave room for nothing else): refuse a
+// device with fewer CUs than blocks instead of relying on the hand-off time-out
+static int persist_cus_ok(int blocks) {
+    static int cus = -1;
+    if (cus < 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cus = n;
+    }
+    return cus >= blocks;
+}
 constexpr int PF_ZERO_WORDS = 5 * PF_SHARDS * PF_LINE + PF_TRACE_WORDS;      // counters, error word, tickets (+ trace)
 constexpr int PF_SYNC_WORDS = PF_ZERO_WORDS + 4 * 2 * 4 * PF_H;      // the backward form's 4 tiles x 8 shards; the forward uses the first half
 EGZ_API int egz_lstm_persist_sync_words(void) { return PF_SYNC_WORDS; }
@@ -777,6 +788,10 @@ EGZ_API int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, con
     EGZ_CHECK_ARG(gx0 && w_ih && w_hh && b_ih && b_hh && h0 && c0 && hs && cs && hn && cn && sync, "egz_lstm_persist_fwd: null pointer");
     if (L != 2 || H != PF_H || B < 1 || B > 32 || T < 1) {
         egz_set_error("egz_lstm_persist_fwd: L=%d T=%d B=%d H=%d (built for L = 2, H = 512, B <= 32)", L, T, B, H);
+        return (int)hipErrorNotSupported;
+    }
+    if (!persist_cus_ok(128 * egz_cdiv(B, 16))) {
+        egz_set_error("egz_lstm_persist_fwd: the device has fewer compute units than the launch has blocks (%d)", 128 * egz_cdiv(B, 16));
         return (int)hipErrorNotSupported;
     }
     EGZ_CHECK_ARG(w_hh[0] && w_hh[1] && w_ih[1] && b_ih[0] && b_ih[1] && b_hh[0] && b_hh[1], "egz_lstm_persist_fwd: null weight pointer");
@@ -799,6 +814,10 @@ EGZ_API int egz_lstm_persist_bwd(const float* dh_top, const float* dhn, const fl
     EGZ_CHECK_ARG(acts && cs && c0 && w_hh && w_ih && dgates && dh0 && dc0 && sync, "egz_lstm_persist_bwd: null pointer");
     if (L != 2 || H != PF_H || B < 1 || B > 32 || T < 1) {
         egz_set_error("egz_lstm_persist_bwd: L=%d T=%d B=%d H=%d (built for L = 2, H = 512, B <= 32)", L, T, B, H);
+        return (int)hipErrorNotSupported;
+    }
+    if (!persist_cus_ok(64 * egz_cdiv(B, 8))) {
+        egz_set_error("egz_lstm_persist_bwd: the device has fewer compute units than the launch has blocks (%d)", 64 * egz_cdiv(B, 8));
         return (int)hipErrorNotSupported;
     }
     EGZ_CHECK_ARG(w_hh[0] && w_hh[1] && w_ih[1], "egz_lstm_persist_bwd: null weight pointer");

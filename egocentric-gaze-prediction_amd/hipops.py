@@ -1562,7 +1562,10 @@ def lstm_wave_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh_t, w_ih_t):
 
 def lstm_persist_ok(L: int, B: int, Hd: int) -> bool:
     """Whether the recurrence runs as the persistent launches (knob on and the geometry they are built for)."""
-    return LSTM_PERSIST and L == 2 and Hd == 512 and 1 <= B <= 32
+    if not (LSTM_PERSIST and L == 2 and Hd == 512 and 1 <= B <= 32):
+        return False
+    # one block per CU, all resident at once (backward: 64 unit slices x ceil(B / 8) batch tiles)
+    return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count >= max(128 * ((B + 15) // 16), 64 * ((B + 7) // 8))
 
 
 def lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0, want_acts: bool = True):
