@@ -20,8 +20,6 @@ int main() {
     for (int l = 0; l < 64; ++l)
         for (int e = 0; e < 4; ++e) {
             const long v = (long)(h[l * 4 + e] + 0.5f);
-            const int bl = (int)(v / 100 % 100), al = 0;   // v = a * 100 * (1 + lb) -> factor pairs are ambiguous; print raw
-            (void)bl; (void)al;
             // expected if D_blk[i = e][j = l % 4] = A_blk[i] * B_blk[j] with blk = l / 4:  a lane = 4 * (l / 4) + e, b lane = l
             const long want = (long)(1 + 4 * (l / 4) + e) * 100 * (1 + l);
             if (v != want) ++bad;
