@@ -70,7 +70,11 @@ class GraphedTrainStep:
     optimizer must be a FusedAdam (its step counter moves to the device).  Inside the capture every weight-gradient fork joins
     back (functions._close_fork), BatchNorm running statistics and ``num_batches_tracked`` are updated by kernels, so a replay
     is exactly one eager step.  The first ``warm`` calls run eagerly (real steps: lazy packings, workspaces and helper
-    streams come into being), the next one is captured."""
+    streams come into being), the next one is captured.
+
+    For single-chain models (late_fusion, lstmnet).  The two-stream SP step is NOT capturable this way -- its encoder streams and
+    detached weight-gradient forks do not all rejoin the capturing stream inside the step (ending such a capture crashes inside
+    the HIP runtime) -- and has nothing to gain: at batch 32 the host issues its ~700 launches in a third of the device time (§4)."""
 
     def __init__(self, forward_loss, optimizer, example_inputs: Sequence[torch.Tensor], warm: int = 2):
         self.fn, self.opt, self.warm = forward_loss, optimizer, warm
