@@ -14,6 +14,7 @@ from ..streams import fork
 from ..utils import FusedSequential, init_like_reference
 
 _STAGGER = True        # the two encoders start one block apart so that they do not run in lock-step (+0.4 %, round 2)
+_INTERLEAVE = __import__('os').environ.get('EGAZE_INTERLEAVE', '1') != '0'     # the host issues the two encoders block by block, alternately
 
 # models/model_SP.py:13-31 as (Cin, Cout) 3x3+ReLU blocks and 'U' = nearest x2 upsample; a 1x1 head follows
 _DECODER_PLAN = [(512, 512), (512, 512), 'U', (512, 512), (512, 512), (512, 512), 'U', (512, 256), (256, 256),
@@ -71,8 +72,47 @@ class model_SP(nn.Module):
                     stack.record_stream(torch.cuda.current_stream())
                 if _STAGGER:
                     stagger = torch.cuda.Event()
-            x_t = self.features_t(x_t, out_buf=stack[B:] if stack is not None else None,
-                                  after_first_block=(lambda: stagger.record()) if stagger is not None else None)
+            interleave = (_INTERLEAVE and f.enabled and isinstance(self.features_t, FusedSequential)
+                          and isinstance(self.features_s, FusedSequential) and not self.features_t._forward_hooks
+                          and not self.features_t._forward_pre_hooks and not self.features_s._forward_pre_hooks)
+            if interleave:
+                gen_t = self.features_t.blocks(x_t, out_buf=stack[B:] if stack is not None else None,
+                                               after_first_block=(lambda: stagger.record()) if stagger is not None else None)
+                x_t = next(gen_t)                        # the flow encoder leads by one block
+            else:
+                x_t = self.features_t(x_t, out_buf=stack[B:] if stack is not None else None,
+                                      after_first_block=(lambda: stagger.record()) if stagger is not None else None)
+        if interleave:
+            # Both encoders block by block, alternately: the host issues ~100 launches per encoder, and issuing one encoder after
+            # the other left the second stream empty while the device ran the first (its BatchNorm passes with nothing beside
+            # them).  Autograd replays the nodes in reverse creation order, so the backward pass alternates the same way.
+            if stagger is not None:
+                torch.cuda.current_stream().wait_event(stagger)
+            x_in = x_s
+            gen_s = self.features_s.blocks(x_s, out_buf=stack[:B] if stack is not None else None)
+            live_s = live_t = True
+            while live_s or live_t:
+                if live_s:
+                    try:
+                        x_s = next(gen_s)
+                    except StopIteration:
+                        live_s = False
+                if live_t:
+                    with torch.cuda.stream(f.side):
+                        try:
+                            x_t = next(gen_t)
+                        except StopIteration:
+                            live_t = False
+            for hook in self.features_s._forward_hooks.values():         # (AT.py:105 hooks features_s; __call__ was bypassed)
+                r = hook(self.features_s, (x_in,), x_s)
+                if r is not None:
+                    x_s = r
+            f.join(x_t)
+            bn = self.bn
+            nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+            x_fused = FusionBlock.apply(x_s, x_t, self.fusion.weight, self.fusion.bias, bn.weight, bn.bias,
+                                        bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), nbt)
+            return self.decoder(x_fused, fuse_sigmoid=True)
         if stagger is not None:
             # The encoders have the same layer sequence; started together they stay in lock-step (both in a conv, then both in
             # a BN pass) and the matrix cores idle during every BN pass.  Holding the RGB encoder back by the flow encoder's

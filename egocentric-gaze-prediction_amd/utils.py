@@ -69,6 +69,14 @@ class FusedSequential(nn.Sequential):
         block (model_SP passes the two encoders the halves of one buffer, see functions.FusionBlock).
         ``after_first_block``: optional callable run once the first block's kernels have been issued (model_SP records a
         stream event there to run its two encoders half a layer apart)."""
+        for x in self.blocks(x, fuse_sigmoid, out_buf, after_first_block):
+            pass
+        return x
+
+    def blocks(self, x, fuse_sigmoid=False, out_buf=None, after_first_block=None):
+        """Generator form of ``forward``: issues one fused block per ``next()`` and yields its output (the last value is the
+        stack's output).  model_SP drives its two encoders alternately with it, each on its own HIP stream, so that the host
+        feeds both streams at the same pace instead of issuing one encoder's ~100 launches before the other's first."""
         mods = list(self.children())
         i, n = 0, len(mods)
         first, ups = True, False
@@ -113,7 +121,7 @@ class FusedSequential(nn.Sequential):
             if first and after_first_block is not None:
                 after_first_block()
             first = False
-        return x
+            yield x
 
 
 
