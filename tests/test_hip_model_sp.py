@@ -766,3 +766,34 @@ def test_eval_batchnorm_folded_into_conv(monkeypatch):
     o0b, _ = run(False)
     assert rel(o1b.cpu().numpy(), o0b.cpu().numpy()) < 1e-5
     assert rel(o0b.cpu().numpy(), o0.cpu().numpy()) > 1e-4       # (the change is visible at all)
+
+
+def test_interleaved_encoder_issue_is_the_same_step(monkeypatch):
+    """model_SP.forward drives its two encoders block by block, alternately (models/model_SP.py, _INTERLEAVE: both HIP streams are fed
+    at the same pace) instead of one after the other: the same kernels on the same streams in another host order -- output, loss,
+    every gradient and every BatchNorm running statistic are bit-identical, and a forward hook on features_s (AT.py:105) still
+    fires once with the post-ReLU (B, 512, h, w) activation."""
+    import egaze_amd.models.model_SP as M
+    from egaze_amd.floss import floss
+    res = []
+    for inter in (False, True):
+        monkeypatch.setattr(M, "_INTERLEAVE", inter)
+        model, _ = build_model()
+        seen = []
+        handle = model.features_s.register_forward_hook(lambda mod, inp, out: seen.append((tuple(inp[0].shape), out.detach().clone())))
+        x_s, x_t, gt, _ = synth.synth_sp_batch(2, 96, seed=21)
+        model.train()
+        out = model(x_s.to(DEV), x_t.to(DEV))
+        loss = floss().to(DEV)(out, gt.to(DEV).view(out.size()))
+        loss.backward()
+        torch.cuda.synchronize()
+        handle.remove()
+        assert len(seen) == 1 and seen[0][0] == (2, 3, 96, 96) and tuple(seen[0][1].shape) == (2, 512, 6, 6) and float(seen[0][1].min()) >= 0.0
+        res.append((out.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in model.named_parameters()},
+                    {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k}, seen[0][1]))
+    (o0, l0, g0, r0, h0), (o1, l1, g1, r1, h1) = res
+    assert torch.equal(o0, o1) and l0 == l1 and torch.equal(h0, h1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
