@@ -978,13 +978,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
                 const float ms = ((ra_ok >> j) & 1u) ? a_scale : 0.f;      // the zero-padding mask rides on the scale factor
 #pragma unroll
                 for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf(__builtin_fmaf(ra[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
-                Half<T>::split4(ra[j], hi, lo);
+                if constexpr (egz_drop_alo<T>::value) hi = Half<T>::rne4s(ra[j], 1.f);
+                else Half<T>::split4(ra[j], hi, lo);
+            } else if constexpr (egz_drop_alo<T>::value) {
+                hi = Half<T>::rne4s(ra[j], a_scale);
             } else {
                 Half<T>::split4s(ra[j], a_scale, hi, lo);
             }
             unsigned short* d = Ah + abuf * ABUF + a_lds[j];
             *reinterpret_cast<u32x2*>(d) = hi;
-            *reinterpret_cast<u32x2*>(d + APL) = lo;
+            if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2*>(d + APL) = lo;
         }
     };
 
@@ -1040,13 +1043,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_x3p_narrow_kernel(
             const float ms = ((ra_ok >> j) & 1u) ? a_scale : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf(__builtin_fmaf(ra[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
-            Half<T>::split4(ra[j], hi, lo);
+            if constexpr (egz_drop_alo<T>::value) hi = Half<T>::rne4s(ra[j], 1.f);
+            else Half<T>::split4(ra[j], hi, lo);
+        } else if constexpr (egz_drop_alo<T>::value) {
+            hi = Half<T>::rne4s(ra[j], a_scale);
         } else {
             Half<T>::split4s(ra[j], a_scale, hi, lo);
         }
         unsigned short* d = Ah + abuf * ABUF + a_lds[j];
         *reinterpret_cast<u32x2*>(d) = hi;
-        *reinterpret_cast<u32x2*>(d + APL) = lo;
+        if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2*>(d + APL) = lo;
     };
     static_assert(NJ <= 12, "one halo piece per MFMA group of the second half");
     f32x16 pacc[MR];
@@ -1556,6 +1562,7 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
         const unsigned short* w16b = static_cast<const unsigned short*>(wq);
         const float osb = (dtype == 1) ? 1.f / F16_WSCALE : 1.f;
         if (x3p_narrow_ok(B, H, W, C, K)) {
+            if (dtype == 1 && p2) return launch_x3p_narrow<egz_f16p2>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
             if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
             return launch_x3p_narrow<__bf16>(epi, x, w16b, nullptr, y, stat_partial, B, H, W, C, K, osb, x_absmax, mask_src, bn_coef, nullptr, st);
         }
@@ -1596,6 +1603,7 @@ EGZ_API int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float
     EGZ_CHECK_ARG(!(absmax_out && epi == EPI_BIAS_RELU), "egz_conv3x3_fwd_streamed: the abs-max epilogue exists for 64- and "
                   "128-column tiles only (K %% 64 == 0)");
     if (x3p_narrow_ok(B, H, W, C, K) && epi != EPI_MASK_SUMS) {   // persistent narrow form
+        if (dtype == 1 && p2 && epi == EPI_BIAS && !bn_coef) return launch_x3p_narrow<egz_f16p2>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, bn_coef, minmax_out, st);
         if (dtype == 1) return launch_x3p_narrow<_Float16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, bn_coef, minmax_out, st);
         return launch_x3p_narrow<__bf16>(epi, x, w16, bias, y, stat_partial, B, H, W, C, K, os, x_absmax, nullptr, bn_coef, minmax_out, st);
     }

@@ -721,13 +721,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3n_kernel(
                     const float ms = ((rx_ok >> j) & 1u) ? x_scale : 0.f;  // the zero-padding mask rides on the scale factor
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rx[j][e] = fmaxf(__builtin_fmaf(rx[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
-                    W16<T>::split4(rx[j], hi, lo);
+                    if constexpr (egz_drop_alo<T>::value) f16_rne4(rx[j], hi);
+                    else W16<T>::split4(rx[j], hi, lo);
+                } else if constexpr (egz_drop_alo<T>::value) {
+                    f16_rne4(rx[j] * x_scale, hi);
                 } else {
                     W16<T>::split4s(rx[j], x_scale, hi, lo);
                 }
                 unsigned short* d = Xs + buf * XB + pos * 32 + c4 * 4;
                 *reinterpret_cast<u32x2_t*>(d) = hi;
-                *reinterpret_cast<u32x2_t*>(d + XH) = lo;
+                if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2_t*>(d + XH) = lo;
             }
         }
 #pragma unroll
@@ -911,13 +914,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad9_x3t_kernel(
                 const float ms = ((rx_ok >> j) & 1u) ? x_scale : 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) rx[j][e] = fmaxf(__builtin_fmaf(rx[j][e], in_sc[e], in_sh[e]), 0.f) * ms;
-                W16<T>::split4(rx[j], hi, lo);
+                if constexpr (egz_drop_alo<T>::value) f16_rne4(rx[j], hi);
+                else W16<T>::split4(rx[j], hi, lo);
+            } else if constexpr (egz_drop_alo<T>::value) {
+                f16_rne4(rx[j] * x_scale, hi);
             } else {
                 W16<T>::split4s(rx[j], x_scale, hi, lo);
             }
             unsigned short* d = Xs + buf * XB + pp * 32 + c4 * 4;
             *reinterpret_cast<u32x2_t*>(d) = hi;
-            *reinterpret_cast<u32x2_t*>(d + XH) = lo;
+            if constexpr (!egz_drop_alo<T>::value) *reinterpret_cast<u32x2_t*>(d + XH) = lo;
         }
 #pragma unroll
         for (int j = 0; j < ND; ++j) {
@@ -1655,7 +1661,7 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
     // flags 0x8000: x holds pre-split activations (see conv3x3_wgrad9_x3_kernel) -- only where that kernel runs
     const bool xpre = (flags & 0x8000) != 0, dpre = (flags & 0x10000) != 0;
     // 0x20000: two products per MAC on the split-half f16 kernels of the wide layers (x_hi dy_hi + x_hi dy_lo: x enters with its hi
-    // half only, rounded to nearest; egz_f16p2 in egz_common.h).  Ignored where the launch is not one of those (bf16, exact f32, the narrow kernels).
+    // half only, rounded to nearest; egz_f16p2 in egz_common.h).  Also on the narrow (late-fusion) kernels; ignored by bf16 and exact-f32 launches.
     const bool p2 = (flags & 0x20000) != 0 && dy_absmax;
     EGZ_CHECK_ARG(!(xpre || dpre) || (egz_conv3x3_wgrad_presplit_ok(B, H, W, C, K) && (flags & 0x2000) && !ups && dy_absmax && x_absmax && !x_bn),
                   "egz_conv3x3_wgrad: a pre-split x / dy operand (flags 0x8000 / 0x10000) needs the split-half 9-tap kernel's geometry "
@@ -1710,10 +1716,12 @@ EGZ_API int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B,
         // few filters: (tap, k) pairs as GEMM columns (0x4000 keeps the nine-tile form: A/B runs).  The kernel fetches dy as one float4
         // per k-quad at a pixel stride of 4 K bytes: K is 4 or 8 here (K % 4 == 0 is an argument check above)
         if ((K == 4 || K == 8) && !(flags & 0x4000)) {
-            if (dy_absmax) { if (WD == 32) EGZ_W9T(_Float16, 2, 32); else EGZ_W9T(_Float16, 4, 16); }
+            if (dy_absmax && p2) { if (WD == 32) EGZ_W9T(egz_f16p2, 2, 32); else EGZ_W9T(egz_f16p2, 4, 16); }
+            else if (dy_absmax) { if (WD == 32) EGZ_W9T(_Float16, 2, 32); else EGZ_W9T(_Float16, 4, 16); }
             else           { if (WD == 32) EGZ_W9T(__bf16, 2, 32); else EGZ_W9T(__bf16, 4, 16); }
         } else
-        if (dy_absmax) { if (WD == 32) EGZ_W9N(_Float16, 2, 32); else EGZ_W9N(_Float16, 4, 16); }
+        if (dy_absmax && p2) { if (WD == 32) EGZ_W9N(egz_f16p2, 2, 32); else EGZ_W9N(egz_f16p2, 4, 16); }
+        else if (dy_absmax) { if (WD == 32) EGZ_W9N(_Float16, 2, 32); else EGZ_W9N(_Float16, 4, 16); }
         else           { if (WD == 32) EGZ_W9N(__bf16, 2, 32); else EGZ_W9N(__bf16, 4, 16); }
 #undef EGZ_W9T
 #undef EGZ_W9N

@@ -99,8 +99,8 @@ int egz_conv3x3_fwd_streamed(const float* x, const void* wq, const float* bias, 
  * three -- x_hi w_hi + x_hi w_lo: the x operand (the halo image that goes through LDS; dy in a data gradient) enters with its f16 hi
  * half only, rounded to nearest from the fp32 value or from hi + lo of a pre-split pair, the packed weights keep their 22 bits.
  * Meant for the data gradients (autograd of utils.py:70, models/model_SP.py:13-29): the result moves by ~2e-4 relative L2
- * (tests/test_hip_ops.py::test_backward_two_products).  Ignored by the narrow (late-fusion) kernels and by
- * egz_conv3x3_fwd_streamed_splitk, which stay on three products. */
+ * (tests/test_hip_ops.py::test_backward_two_products).  Honoured by the narrow (late-fusion) kernel for epi 0 and 5 too; ignored by
+ * egz_conv3x3_fwd_streamed_splitk, which stays on three products. */
 /* Deferred BatchNorm (narrow geometry, epi 0 / 1 / 2): with bn_coef != NULL, x is the PRE-BatchNorm conv output of the block
  * below and bn_coef that BatchNorm's 4 x C coefficient rows; relu(x * scale + shift) is applied while the halo is staged, so
  * the normalised tensor of late_fusion.py:11-12 is never materialised (x_absmax = its max, from egz_bn_finalize_deferred).
@@ -135,7 +135,7 @@ int egz_conv3x3_wgrad(const float* x, const float* dy, float* dw, int B, int H, 
                       const float* x_bn, hipStream_t stream);
 /* flags | 0x20000 (with 0x2000 and dy_absmax: f16 split halves on the wide kernels, C and K multiples of 32 / 64): TWO MFMA products
  * per MAC -- x_hi dy_hi + x_hi dy_lo: x enters with 11 significant bits, rounded to nearest (from the fp32 value, or from hi + lo
- * of a pre-split pair), dy keeps 22; dw moves by ~2e-4 relative L2.  Ignored by the narrow, bf16 and exact-f32 launches. */
+ * of a pre-split pair), dy keeps 22; dw moves by ~2e-4 relative L2.  Also on the narrow (late-fusion) kernels; ignored by the bf16 and exact-f32 launches. */
 /* x_bn (optional): x is the PRE-BatchNorm conv output of the block below and x_bn that BatchNorm's 4 x C coefficient rows;
  * relu(x * scale + shift) is applied while x is staged (deferred BatchNorm, late_fusion.py:11-12), x_absmax = the max of the
  * normalised values.  Only where egz_conv3x3_wgrad_narrow_ok(B, H, W, C, K) (C, K <= 32, W % 16 == 0, flags 0x2000). */
