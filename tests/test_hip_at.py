@@ -396,7 +396,7 @@ def test_lstm_persistent_backward_matches_wavefront(T, B, top, state):
         del want, got
 
 
-def test_at_batched_step_graphed_matches_eager():
+def test_at_batched_step_graphed_matches_eager(monkeypatch):
     """The T = 16 / B = 32 AT step (lstmnet forward + MSE + backward + Adam; AT.py:138-145 at BASELINE config 4's shape) captured
     into one hipGraph (graphs.GraphedTrainStep: the two persistent recurrence launches and their counter memsets become graph nodes)
     against the same steps issued eagerly: identical parameters after 5 steps, status word clean."""
@@ -405,7 +405,7 @@ def test_at_batched_step_graphed_matches_eager():
     from egaze_amd.graphs import GraphedTrainStep
     from egaze_amd.models.LSTMnet import lstmnet
     from egaze_amd.optim import FusedAdam
-    assert H.LSTM_PERSIST
+    monkeypatch.setattr(H, "LSTM_PERSIST", True)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(16, 32, 512, generator=g).to(DEV)
     tgt = torch.tanh(torch.randn(16, 32, 512, generator=g)).to(DEV)
