@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the untimed exact-f32-mode step timing")
+    ap.add_argument("--no-bwd-leg", action="store_true",
+                    help="skip the opt-in two-product backward leg (extra.bwd2): every step of the run is then the default arithmetic "
+                         "(what the committed kernel statistics / PMC profiles are collected with)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -272,24 +275,32 @@ def main():
     # The timed region: exactly --steps steps between barrier + synchronize on both sides, MAX over ranks.  It is run
     # --repeats times back to back in this process (a 20-step region is 0.6 s and one region per round cannot resolve the
     # sub-1 % changes the round's A/B notes argue about: VERDICT r4): value = the MEDIAN region, all regions reported.
-    regions = []
-    for _ in range(max(1, args.repeats)):
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = t.item()
-        regions.append(el)
-    elapsed = sorted(regions)[(len(regions) - 1) // 2]
+    def timed_regions():
+        """--repeats regions of exactly --steps steps, each bracketed by barrier + synchronize on both sides, MAX over ranks."""
+        regs, last = [], None
+        for _ in range(max(1, args.repeats)):
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                last = step()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = t.item()
+            regs.append(el)
+        return regs, last
+
+    def median(regs):
+        return sorted(regs)[(len(regs) - 1) // 2]
+
+    regions, loss = timed_regions()
+    elapsed = median(regions)
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = args.batch * world * args.steps / elapsed
     last_loss = loss.item()
@@ -298,7 +309,7 @@ def main():
     roofline = None
     breakdown = None
     f32_ms = None
-    bwd3_ms = None
+    other = None
     at_ms = None
     at_eager_ms = None
     pcie_ms = {}
@@ -308,69 +319,92 @@ def main():
         # Every rank runs these two extra (untimed) steps -- the gradient all-reduce inside step() is a collective --
         # but only rank 0 reports.  Per-kernel HIP-event timing needs the kernels serialised: the multi-stream
         # overlap is switched off so that an event pair brackets exactly one kernel family's launches.
-        from egaze_amd import streams
-        was = streams.ENABLED
-        streams.ENABLED = False
-        step()
-        torch.cuda.synchronize()
-        H.PROF.start()
-        step()
-        prof = H.PROF.stop()
-        streams.ENABLED = was
+        def profiled_step():
+            """One step with per-kernel-family HIP-event timing (hipops.PROF).  The kernels must be serialised for an event pair
+            to bracket exactly one family's launches: the multi-stream overlap is switched off for this step."""
+            was = streams.ENABLED
+            streams.ENABLED = False
+            step()
+            torch.cuda.synchronize()
+            H.PROF.start()
+            step()
+            pr = H.PROF.stop()
+            streams.ENABLED = was
+            return pr
+
         split = H.PRECISION == "split"
-        ig = {"calls": 0, "ms": 0.0, "flops": 0.0}
-        # split mode: every conv fwd / dgrad launch runs on the streamed-weight kernel (egz_conv3x3_fwd_streamed; the per-tap
-        # gather kernel egz_conv3x3_fwd_split only for geometries it does not cover); hipops notes the algorithmic FLOPs of the
-        # whole family under ONE name (egz_conv3x3_fwd_split), whether or not that entry point itself ran in the step
-        entries = ("egz_conv3x3_fwd_split", "egz_conv3x3_fwd_streamed", "egz_conv3x3_fwd_streamed_splitk") if split else ("egz_conv3x3_fwd", "egz_conv3x3_ups_dgrad")
-        for entry in entries:
-            for k2 in ig:
-                ig[k2] += prof.get(entry, {}).get(k2, 0)
-        # HBM bytes per launch of this kernel family: PMC counters cannot be sampled from inside the process, so the value
-        # comes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_profiles.sh
-        # -> tools/pmc_traffic.py; gfx950 FETCH half-count corrected).  The profile is stamped with a hash of the kernel
-        # sources it was taken from: if the kernels changed since, the number is NOT quoted (traffic = null).
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if not split or tj.get("kernel_src_sha") == kernel_src_sha():
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_note = f"profiles/{os.path.basename(tpath)}"
-            else:
-                traffic_note = (f"profiles/{os.path.basename(tpath)} was taken from other kernel sources "
-                                f"({tj.get('kernel_src_sha')} vs {kernel_src_sha()}): re-run tools/collect_profiles.sh")
-        if ig["ms"] > 0:
+
+        def conv_family_roofline(pr):
+            ig = {"calls": 0, "ms": 0.0, "flops": 0.0}
+            # split mode: every conv fwd / dgrad launch runs on the streamed-weight kernel (egz_conv3x3_fwd_streamed; the per-tap
+            # gather kernel egz_conv3x3_fwd_split only for geometries it does not cover); hipops notes the algorithmic FLOPs of the
+            # whole family under ONE name (egz_conv3x3_fwd_split), whether or not that entry point itself ran in the step
+            entries = ("egz_conv3x3_fwd_split", "egz_conv3x3_fwd_streamed", "egz_conv3x3_fwd_streamed_splitk") if split else ("egz_conv3x3_fwd", "egz_conv3x3_ups_dgrad")
+            for entry in entries:
+                for k2 in ig:
+                    ig[k2] += pr.get(entry, {}).get(k2, 0)
+            if ig["ms"] <= 0:
+                return None
+            p2_flops = pr.get("two_product_conv", {}).get("flops", 0.0)
+            mfma_per_mac = 3.0 - min(1.0, p2_flops / ig["flops"]) if ig["flops"] else 3.0
+            # HBM bytes per launch of this kernel family: PMC counters cannot be sampled from inside the process, so the value
+            # comes from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_profiles.sh
+            # -> tools/pmc_traffic.py; gfx950 FETCH half-count corrected), collected with --no-bwd-leg --no-f32-leg so that every
+            # profiled step is the default arithmetic.  The profile is stamped with a hash of the kernel sources it was taken
+            # from: if the kernels changed since, the number is NOT quoted (traffic = null).
+            traffic, traffic_note = None, None
+            tpath = os.path.join(ROOT, "profiles", "r06_pmc_traffic_conv_fwd_dgrad.json" if split else "r01_pmc_traffic_igemm.json")
+            if p2_flops:
+                traffic_note = "the committed PMC profile is of the default (three-product) arithmetic"
+            elif os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if not split or tj.get("kernel_src_sha") == kernel_src_sha():
+                    traffic = tj["traffic_bytes_per_launch"]
+                    traffic_note = f"profiles/{os.path.basename(tpath)}"
+                else:
+                    traffic_note = (f"profiles/{os.path.basename(tpath)} was taken from other kernel sources "
+                                    f"({tj.get('kernel_src_sha')} vs {kernel_src_sha()}): re-run tools/collect_profiles.sh")
             achieved = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
             peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
-            roofline = {"bound": "mfma",
-                        "kernel": ("conv3x3_igemm_x3s_kernel (egz_conv3x3_fwd_streamed, + egz_conv3x3_fwd_split for "
-                                   "geometries it does not cover: all conv fwd + dgrad launches -- the streamed-weight halo "
-                                   "kernel for plain convs, the four-phase upsample forward and the polyphase upsample "
-                                   "dgrad; split-half f16x3 / bf16x3 operands on "
-                                   "v_mfma_f32_32x32x16_{f16,bf16}; an algorithmic MAC costs 3 MFMA MACs in the forward launches and "
-                                   "2 in the data gradients (hipops.BWD_PRODUCTS), priced against the dense 16-bit MFMA peak)" if split else
-                                   "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
-                                   "launches, exact-f32 MFMA)") +
-                                  "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
-                                  "timed with HIP events on the launch stream with stream concurrency off, as in "
-                                  "profiles/r05_bench_b32_kernel_stats_streams0.txt",
-                        "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                        "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
-                        "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
-                        "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
-                        "algorithmic_flop_per_step": ig["flops"]}
+            rf = {"bound": "mfma",
+                  "kernel": ("conv3x3_igemm_x3s_kernel (egz_conv3x3_fwd_streamed, + egz_conv3x3_fwd_split for "
+                             "geometries it does not cover: all conv fwd + dgrad launches -- the streamed-weight halo "
+                             "kernel for plain convs, the four-phase upsample forward and the polyphase upsample "
+                             "dgrad; split-half f16x3 / bf16x3 operands on "
+                             "v_mfma_f32_32x32x16_{f16,bf16}; an algorithmic MAC costs mfma_macs_per_algorithmic_mac MFMA MACs "
+                             "(3 = three products in forward and data-gradient launches alike, hipops.BWD_PRODUCTS), priced "
+                             "against the dense 16-bit MFMA peak)" if split else
+                             "conv3x3_igemm_kernel (egz_conv3x3_fwd + egz_conv3x3_ups_dgrad: all fwd + dgrad "
+                             "launches, exact-f32 MFMA)") +
+                            "; FLOPs are the reference's algorithmic count, the upsample-fused launches execute 4/9 of it; "
+                            "timed with HIP events on the launch stream with stream concurrency off, as in "
+                            "profiles/r06_bench_b32_kernel_stats_streams0.txt",
+                  "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                  "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_note,
+                  "achieved_vs_f32_mfma_peak": achieved / F32_MFMA_PEAK_TFLOPS,
+                  "launches_per_step": ig["calls"], "avg_launch_ms": ig["ms"] / ig["calls"],
+                  "algorithmic_flop_per_step": ig["flops"]}
+            if split:
+                rf["mfma_macs_per_algorithmic_mac"] = mfma_per_mac
             if probe is not None and split:
-                # this box's own ceiling: bare MFMA rate on random bits / MFMA MACs per algorithmic MAC of this family (3 for the
-                # forward launches, 2 for the data gradients under hipops.BWD_PRODUCTS = 2, weighted by their algorithmic FLOPs)
-                p2_flops = prof.get("two_product_conv", {}).get("flops", 0.0)
-                mfma_per_mac = 3.0 - min(1.0, p2_flops / ig["flops"]) if ig["flops"] else 3.0
-                roofline.update({"power_ceiling_tflops": probe["tflops"], "effective_clock_ghz": probe["effective_clock_ghz"],
-                                 "mfma_macs_per_algorithmic_mac": mfma_per_mac,
-                                 "frac_of_power_ceiling": achieved / (probe["tflops"] / mfma_per_mac),
-                                 "power_ceiling_note": "egz_mfma_probe (csrc/probe.hip) run for ~30 ms before the timed region: "
-                                                       "sustained v_mfma_f32_32x32x16_f16 TFLOP/s on random operand bits; "
-                                                       "frac_of_power_ceiling = achieved / (ceiling / mfma_macs_per_algorithmic_mac)"})
+                # this box's own ceiling: bare MFMA rate on random bits / MFMA MACs per algorithmic MAC of this family
+                rf.update({"power_ceiling_tflops": probe["tflops"], "effective_clock_ghz": probe["effective_clock_ghz"],
+                           "frac_of_power_ceiling": achieved / (probe["tflops"] / mfma_per_mac),
+                           "power_ceiling_note": "egz_mfma_probe (csrc/probe.hip) run for ~30 ms before the timed region: "
+                                                 "sustained v_mfma_f32_32x32x16_f16 TFLOP/s on random operand bits; "
+                                                 "frac_of_power_ceiling = achieved / (ceiling / mfma_macs_per_algorithmic_mac)"})
+            return rf
+
+        def ms_breakdown(pr):
+            bd = {k: round(v["ms"], 3) for k, v in sorted(pr.items(), key=lambda kv: -kv[1]["ms"]) if v["calls"]}
+            bd["_sum_kernel_ms"] = round(sum(v["ms"] for v in pr.values()), 3)
+            return bd
+
+        # Every rank runs these extra (untimed) steps -- the gradient all-reduce inside step() is a collective -- but only
+        # rank 0 reports.
+        prof = profiled_step()
+        roofline = conv_family_roofline(prof)
+        breakdown = ms_breakdown(prof)
         if use_at:
             # config 4 standalone: the AT step alone (lstmnet T=16, B=32 forward + MSE + backward + Adam), untimed leg
             torch.cuda.synchronize()
@@ -476,21 +510,32 @@ def main():
                 del lfm, lfo, lfb, lfg, lfi
             except Exception as e:
                 lf_block = {"error": repr(e)[:300]}
-        if split and not args.no_f32_leg and H.BWD_PRODUCTS == 2:
-            # the same step with three MFMA products per MAC in the backward convolutions too (EGAZE_BWD_PRODUCTS=3: fp32-class
-            # gradients), untimed leg, reported beside the headline
-            H.BWD_PRODUCTS = 3
-            for _ in range(3):
+        if split and not args.no_bwd_leg and H.GRAD_SPLIT == "f16":
+            # The OTHER backward arithmetic with the SAME protocol as the headline (--warmup steps, --repeats regions of --steps
+            # steps between barrier + synchronize, median): by default the headline is three products per MAC (fp32-class
+            # gradients) and this leg the opt-in two-product backward (EGAZE_BWD_PRODUCTS=2), reported as extra.bwd2 with its
+            # own roofline -- never as `value`.
+            headline_products = H.BWD_PRODUCTS
+            H.BWD_PRODUCTS = 2 if headline_products == 3 else 3
+            for _ in range(max(args.warmup, 2)):
                 step()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
+            o_regions, _ = timed_regions()
+            o_prof = profiled_step()
+            other = {"bwd_products": H.BWD_PRODUCTS,
+                     "ms_per_step": median(o_regions) / args.steps * 1e3,
+                     "value": args.batch * world * args.steps / median(o_regions), "unit": "frames/s",
+                     "regions_ms_per_step": [r / args.steps * 1e3 for r in o_regions],
+                     "roofline": conv_family_roofline(o_prof),
+                     "kernel_ms_breakdown": ms_breakdown(o_prof),
+                     "note": ("OPT-IN arithmetic, not the headline: EGAZE_BWD_PRODUCTS=2 -- the backward convolutions issue two MFMA "
+                              "products per MAC, one operand of every backward product enters with 11 significant bits "
+                              "(per-op gradient error 2e-4 relative L2, <= 1e-3 through the chain; forward / gaze map "
+                              "bit-identical); same timing protocol as the headline" if H.BWD_PRODUCTS == 2 else
+                              "the default arithmetic (three products per MAC), same timing protocol as the headline, which "
+                              "was run with EGAZE_BWD_PRODUCTS=2 set")}
+            H.BWD_PRODUCTS = headline_products
+            for _ in range(2):
                 step()
-            torch.cuda.synchronize()
-            bwd3_ms = (time.perf_counter() - t1) / 10 * 1e3
-            H.BWD_PRODUCTS = 2
         if split and not args.no_f32_leg:
             # the same step on the exact-f32 MFMA kernels (v_mfma_f32_32x32x2_f32), untimed leg, reported beside the headline
             H.PRECISION = "f32"
@@ -594,9 +639,6 @@ def main():
                 rccl = {"error": repr(e)[:300]}
             finally:
                 redirect.__exit__()
-        tot = sum(v["ms"] for v in prof.values())
-        breakdown = {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]) if v["calls"]}
-        breakdown["_sum_kernel_ms"] = round(tot, 3)
     if dist is not None:
         dist.barrier()
 
@@ -611,22 +653,26 @@ def main():
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": (f"f32 (conv fwd: f16x3 split-half MFMA, 22 significant bits per operand; dgrad and wgrad: "
-                      f"{'f16 split halves, abs-max scaled, ' + ('two products per MAC (22 x 11 significant bits)' if H.BWD_PRODUCTS == 2 else 'three products per MAC (22 x 22 bits)') if H.GRAD_SPLIT == 'f16' else 'bf16x3 (16 bits)'}; "
-                      f"fp32 accumulate; everything else exact f32)" if H.PRECISION == "split" else "f32"),
+            "dtype": ("f32 (every convolution -- forward, data gradient, weight gradient -- as "
+                      + ("f16 split-half MFMA, abs-max scaled operands, " + ("THREE products per MAC: 22 significant bits on both operands of every product"
+                         if H.BWD_PRODUCTS == 3 else "three products per MAC forward; OPT-IN EGAZE_BWD_PRODUCTS=2 backward: 22 x 11 significant bits")
+                         if H.GRAD_SPLIT == "f16" else "f16x3 forward, bf16x3 (16 bits) backward: OPT-IN EGAZE_GRAD_SPLIT=bf16")
+                      + "; fp32 accumulate; everything else exact f32)" if H.PRECISION == "split" else "f32"),
             "data": "synthetic",
             "config": {"workload": f"SP two-stream (RGB + 10-pair flow stack) forward + floss + backward + Adam, "
                                    f"batch {args.batch}/GPU, {args.size}x{args.size}, train-mode BN, all "
                                    f"46.5M params trainable (--sp_resume 0)"
                                    + (f"; + AT lstmnet forward + MSE + backward + Adam over T=16, B={args.batch} "
-                                      f"512-vectors per step" if use_at else ""),
+                                      f"512-vectors per step, issued on a side stream beside the SP kernels in its WAVEFRONT "
+                                      f"form (one launch per (layer, step) diagonal; the persistent weight-stationary launches "
+                                      f"that extra.at_ms_per_step times stand-alone want every CU to themselves)" if use_at else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "collective": ("gradient all-reduce over rccl at world size 1 (EGAZE_DP_FORCE=1: the data-parallel code "
                                       "path on one GPU)" if dp_forced else None if world == 1 else
                                       f"gradient all-reduce, backend {'rccl' if backend == 'nccl' else backend}, "
                                       f"{'ALL RANKS ON ONE GPU (functional run, not a scaling number)' if shared_device else 'one GPU per rank'}"),
                        "precision": (f"split-half f16x3 MFMA for conv fwd, {'f16 halves' if H.GRAD_SPLIT == 'f16' else 'bf16x3'} "
-                                     f"for dgrad / wgrad ({'two products per MAC: one operand of every backward product enters with 11 significant bits, gradients move by 2e-4 ... 9e-4 relative L2; EGAZE_BWD_PRODUCTS=3 = three products, bwd3_ms_per_step' if H.BWD_PRODUCTS == 2 else 'three products per MAC'}), "
+                                     f"for dgrad / wgrad ({'three products per MAC (fp32-class gradients, 2e-7 per op; extra.bwd2 = the opt-in two-product backward, same protocol)' if H.BWD_PRODUCTS == 3 else 'OPT-IN two products per MAC: one operand of every backward product enters with 11 significant bits; extra.bwd3 = the default'}), "
                                      "operands abs-max scaled (forward fp32-class: gaze map within 1e-5 of "
                                      "the reference at batch 2 and batch 32; an 8-step lr 1e-4 training trajectory: per-step loss inside "
                                      "4x, end state (eval gaze map, BN statistics) inside 2x the CPU fp32 path's own distance from an "
@@ -662,9 +708,7 @@ def main():
                       "lf_step": lf_block,
                       "at_note": ("AT alone (BASELINE config 4 shape): lstmnet T=16, B=%d forward + MSE + backward + Adam, "
                                   "%s (t, b) samples/s" % (args.batch, ("%.0f" % (16 * args.batch / (at_ms * 1e-3))) if at_ms else "n/a")),
-                      "bwd3_ms_per_step": bwd3_ms,
-                      "bwd3_note": "same step with EGAZE_BWD_PRODUCTS=3 (three MFMA products per MAC in the data and weight gradients "
-                                   "too: fp32-class gradients, the arithmetic of rounds 2-4), 10 untimed-leg steps",
+                      ("bwd2" if other is None or other["bwd_products"] == 2 else "bwd3"): other,
                       "f32_ms_per_step": f32_ms,
                       "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps",
                       "rccl_world1": rccl,

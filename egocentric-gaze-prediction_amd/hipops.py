@@ -539,13 +539,18 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
 # the BatchNorm's monotonic map by egz_bn_finalize_bound.  Consumers (the next conv's forward and weight gradient) then stage
 # the pair without touching the vector ALU; the pair is bit-identical to the one they would have formed, so every result is.
 # EGAZE_PRESPLIT=0 keeps fp32 activations everywhere (A/B runs; test_presplit_activations_bit_identical flips the constant).
-# EGAZE_BWD_PRODUCTS=2 (default): the BACKWARD convolutions of the wide layers (data gradients, weight gradients; f16 split halves) issue
-# TWO MFMA products per MAC instead of three -- a_hi b_hi + a_hi b_lo: the operand that goes through LDS as a halo image (dy in a
-# data gradient, x in a weight gradient) enters with its f16 hi half only, rounded to nearest; the other keeps its 22 bits
-# (csrc/egz_common.h, egz_f16p2).  Gradients move by ~2e-4 relative L2 per convolution, <= 1e-3 through the whole backward chain -- a
-# fraction of what the summation order of ANY fp32 implementation moves the encoder gradients (profiles/r05_headline_grads*.txt) --
-# the forward pass and with it every predicted map is untouched.  3: three products everywhere (fp32-class gradients, 2e-7 per op).
-BWD_PRODUCTS = int(_os.environ.get("EGAZE_BWD_PRODUCTS", "2"))
+# Backward arithmetic.  Default (3): THREE MFMA products per MAC in the data and weight gradients too -- a_hi b_hi + a_hi b_lo +
+# a_lo b_hi, both operands with 22 significant bits, fp32-class gradients (2e-7 per op): the arithmetic class of the reference's
+# fp32 autograd (SP.py:132-138), and what every headline number is timed on.
+# EGAZE_BWD_PRODUCTS=2 is an OPT-IN (like EGAZE_GRAD_SPLIT=bf16): the backward convolutions of the wide layers issue TWO products
+# per MAC -- the operand that goes through LDS as a halo image (dy in a data gradient, x in a weight gradient) enters with its
+# f16 hi half only, rounded to nearest (11 significant bits); the other keeps its 22 (csrc/egz_common.h, egz_f16p2).  Gradients
+# move by ~2e-4 relative L2 per convolution, <= 1e-3 through the whole backward chain; the forward pass and with it every
+# predicted map is untouched.  tests: test_backward_two_products, test_two_product_backward_whole_model, the `two_products`
+# fixture; bench.py reports it as extra.bwd2, never as `value`.
+BWD_PRODUCTS = int(_os.environ.get("EGAZE_BWD_PRODUCTS", "3"))
+if BWD_PRODUCTS not in (2, 3):
+    raise ValueError(f"EGAZE_BWD_PRODUCTS={BWD_PRODUCTS}: 3 (default, fp32-class) or 2 (opt-in)")
 P2_DTYPE = 0x10          # egz_conv3x3_fwd_streamed: dtype | 0x10
 P2_WGRAD = 0x20000       # egz_conv3x3_wgrad: flags | 0x20000
 

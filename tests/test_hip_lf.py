@@ -29,7 +29,7 @@ def build():
 
 
 @pytest.mark.parametrize("C,K", [(32, 32), (32, 8), (8, 32)])
-def test_narrow_conv_ops(C, K, three_products):
+def test_narrow_conv_ops(C, K):
     """The 32-wide igemm tile, padded channel counts and the 32x32 wgrad tile used by late_fusion."""
     import egaze_amd.hipops as h
     g = torch.Generator().manual_seed(C * 100 + K)

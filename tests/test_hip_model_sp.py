@@ -314,7 +314,7 @@ def _grads_vs_fp64(seed):
     return True, (seed, float(np.median(eh)), float(eh.max()))
 
 
-def test_model_sp_grads_vs_fp64(monkeypatch, three_products):
+def test_model_sp_grads_vs_fp64(monkeypatch):
     """Accuracy, not just agreement: the same train step in fp64 on the CPU oracle is the truth; the HIP
     path's gradient error must be of the same size as the fp32 CPU reference path's own error.  (Summation order pinned
     to the unsplit launches, like test_model_sp_vs_oracle_full_grads_small: which seeds are flip-free depends on it.)"""
@@ -325,7 +325,7 @@ def test_model_sp_grads_vs_fp64(monkeypatch, three_products):
     assert sum(ok for ok, _ in results) >= 2, results
 
 
-def test_model_sp_grads_vs_fp64_all_surveyed_seeds(monkeypatch, three_products):
+def test_model_sp_grads_vs_fp64_all_surveyed_seeds(monkeypatch):
     """The seed survey itself as a test (GRAD_SEEDS above were picked from it after the fact).  On EVERY seed 0..11
     every gradient tensor agrees with the fp64 truth in direction and size (cosine >= 0.995, norm within 3 %: asserted inside
     _grads_vs_fp64) and the forward map is within the fp32 reference's own error class; and -- without choosing -- at least
@@ -340,7 +340,7 @@ def test_model_sp_grads_vs_fp64_all_surveyed_seeds(monkeypatch, three_products):
 
 
 @pytest.mark.parametrize("batch,size,splitk", [(2, 224, False), (2, 224, True), (3, 96, True)])
-def test_presplit_activations_bit_identical(batch, size, splitk, monkeypatch, three_products):
+def test_presplit_activations_bit_identical(batch, size, splitk, monkeypatch):
     """(Runs with three backward products: with two, the weight gradient rounds x to 11 bits from the fp32 value in one form and from
     hi + lo of the stored pair in the other -- a double rounding apart on rare ties; tests/test_hip_ops.py::test_presplit_activation_chain
     bounds that difference.)  hipops.PRESPLIT (round 5): the encoder blocks hand their outputs to the next block's convolution and weight gradient as
@@ -383,7 +383,7 @@ def test_presplit_activations_bit_identical(batch, size, splitk, monkeypatch, th
 
 @pytest.mark.parametrize("size,batch", [(32, 2), (224, 2)])
 def test_two_product_backward_whole_model(size, batch, monkeypatch):
-    """hipops.BWD_PRODUCTS = 2 (the default) against 3 on one SP train step: the forward pass does not know the knob (bit-identical
+    """hipops.BWD_PRODUCTS = 2 (opt-in) against 3 (the default) on one SP train step: the forward pass does not know the knob (bit-identical
     gaze map and loss -- the parity bar of BASELINE.json's north_star is on the predicted map), every gradient tensor of the
     two-stream network stays within 3e-3 of the three-product one in relative L2 through the whole 40-conv backward chain
     (observed 2e-4 ... 1.0e-3: one operand of each backward product carries 11 instead of 22 significant bits), cosine >= 0.999995.
@@ -420,7 +420,7 @@ def test_two_product_backward_whole_model(size, batch, monkeypatch):
     assert differ > 100          # the knob reaches the launches
 
 
-def test_presplit_gradients_match(monkeypatch, three_products):
+def test_presplit_gradients_match(monkeypatch):
     """hipops.PRESPLIT_GRAD: the BatchNorm backward of an encoder block stores its gradient as f16 pairs scaled by a BOUND of its
     maximum (derived before the pass runs), consumed by the block's data gradient and weight gradient.  The forward pass is
     untouched (bit-identical output and loss, hence identical ReLU / pool decisions), the gradients agree with the
@@ -665,7 +665,7 @@ def test_relu_backward_folded_into_dgrad_above(monkeypatch):
             assert torch.equal(a, b), k
 
 
-def test_bn_backward_sums_folded_into_encoder_dgrad(monkeypatch, three_products):
+def test_bn_backward_sums_folded_into_encoder_dgrad(monkeypatch):
     """Encoder chains conv -> BN -> ReLU -> conv (no pool in between: 8 of the 13 VGG convs per stream): the BatchNorm-backward
     sums of the lower block come out of the data-gradient epilogue of the upper one (hipops.BNSUMS_WIDE) instead of a reduce
     pass.  The folded form must run and be picked up 16 times, and give the same gradients as the separate pass up to the

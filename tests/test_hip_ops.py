@@ -88,7 +88,7 @@ def test_conv3x3_upsample_fused(B, Hh, Ww, C, K, mode):
     (1, 16, 64, 64, 64, True), (2, 14, 14, 192, 128, False), (1, 28, 56, 64, 64, False),
     (1, 56, 56, 64, 64, True), (2, 6, 56, 128, 64, True),        # phase-decomposed upsample wgrad, L = 28
 ])
-def test_conv3x3_backward(B, Hh, Ww, C, K, ups, three_products):
+def test_conv3x3_backward(B, Hh, Ww, C, K, ups):
     """dgrad (same kernel, tap-flipped transposed weights), wgrad (split-K MFMA), bias grad, upsample bwd."""
     h = H()
     hin, win = (Hh // 2, Ww // 2) if ups else (Hh, Ww)
@@ -125,7 +125,7 @@ def test_conv3x3_backward(B, Hh, Ww, C, K, ups, three_products):
     (1, 48, 48, 32, 8, False), (2, 17, 16, 32, 8, False), (1, 224, 224, 32, 8, False), (2, 6, 96, 20, 4, False), (1, 1, 16, 32, 8, False),
     (1, 20, 48, 32, 4, False), (2, 9, 16, 8, 4, False),        # K = 4 on the 4 x 16 patch (the entry point requires K % 4 == 0: 4 and 8 are the tap-packed widths)
 ])
-def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups, monkeypatch, three_products):
+def test_conv3x3_wgrad_split(B, Hh, Ww, C, K, ups, monkeypatch):
     """f16 x3 split-half 9-tap wgrad (ds_read_b64_tr_b16 operand transposes; dy scaled by its abs-max): patch geometries 1x32 / 2x16 / 4x8,
     masked narrow rows (28 in 32, 14 and 12 in 16), odd row counts, upsample-fused gather.  Compared with the fp64
     weight gradient; the exact-f32 kernel is held to the same bound for reference."""
@@ -475,7 +475,7 @@ def test_conv3x3_split_half_upsample(dtype, tol):
     assert rel(nchw(dx), xd.grad) < tol
 
 
-def test_split_kernels_shape_fuzz(three_products):
+def test_split_kernels_shape_fuzz():
     """Geometry dispatch fuzz: random (B, H, W, C, K) through every split-half kernel family (halo patch / halo raster run /
     per-tap gather forward and data gradient, 9-tap and phase-form weight gradients, upsample forms) against the exact-f32
     kernels of the same library.  Catches holes in the patch / run / mask selection rather than arithmetic."""
@@ -517,7 +517,7 @@ def test_split_kernels_shape_fuzz(three_products):
 
 
 @pytest.mark.parametrize("mag", [1.0, 3e-4, 1e-8, 7e-13, 2e5])
-def test_gradient_absmax_scaling(mag, three_products):
+def test_gradient_absmax_scaling(mag):
     """f16 x3 data / weight gradients of a gradient tensor of ANY magnitude: the abs-max of dy (a producer's or
     egz_absmax) picks a power-of-two scale, so 1e-8-sized gradients keep fp32-class accuracy (unscaled f16 would flush
     them to zero, bf16 x3 carries 16 bits)."""
@@ -550,7 +550,7 @@ def test_gradient_absmax_scaling(mag, three_products):
 
 
 @pytest.mark.parametrize("mag", [1e-5, 1e-2, 1.0, 1e3, 2e5])
-def test_forward_activation_scaling(mag, three_products):
+def test_forward_activation_scaling(mag):
     """f16 x3 forward operands of ANY magnitude (round-3 parity item): the pass that writes a post-ReLU activation also
     emits max |a| (BN apply + ReLU [+ pool]; the bias + ReLU epilogue of the streamed / phase-upsample conv kernels) and the
     consuming convolution -- forward operand, weight-gradient x operand -- scales by the matching power of two before the
@@ -631,7 +631,7 @@ def test_forward_scaling_off_loses_the_small_range(monkeypatch):
 
 
 @pytest.mark.parametrize("B,Hh,Ww,C", [(2, 16, 32, 20), (1, 24, 28, 20), (2, 9, 7, 17)])
-def test_first_conv_padded_split_path(B, Hh, Ww, C, three_products):
+def test_first_conv_padded_split_path(B, Hh, Ww, C):
     """The flow-stack first conv (Cin = 20, SP.py:53) on the split-half kernels after zero-padding Cin to 32:
     padded transpose, forward with BN statistics, and the C = 32 half-tile weight gradient."""
     h = H()
@@ -670,7 +670,7 @@ def test_first_conv_padded_split_path(B, Hh, Ww, C, three_products):
     # registers, halo of the next tile prefetched): several images (border masks between them), K = 8, C = 8, and more
     # tiles than blocks (320 tiles on 256 CUs: the per-XCD tile ranges and the double-buffered image switch)
     (3, 32, 32, 32, 8), (2, 48, 16, 8, 32), (5, 128, 128, 32, 32), (9, 16, 16, 12, 20)])
-def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol, three_products):
+def test_conv3x3_streamed(B, Hh, Ww, C, K, dtype, tol):
     """Streamed-weight halo kernel (fragment-ordered weights L2 -> registers, activation halo through LDS) against an fp64
     reference: forward with all three epilogues (BN partial sums included) and the data gradient, f16 x3 and bf16 x3."""
     h = H()
@@ -779,7 +779,7 @@ def test_conv3x3_streamed_shape_fuzz():
     (1, 8, 16, 256, 32),
     (3, 28, 28, 128, 64),      # raster runs on the polyphase components, several channel blocks
     (2, 14, 14, 128, 96), (1, 5, 3, 128, 64), (2, 9, 7, 256, 128)])
-def test_conv3x3_streamed_ups_dgrad(B, Hl, Wl, C, K, dtype, tol, three_products):
+def test_conv3x3_streamed_ups_dgrad(B, Hl, Wl, C, K, dtype, tol):
     """Streamed polyphase form of the data gradient of [nearest x2 upsample -> conv3x3] w.r.t. the low-res input
     (models/model_SP.py:17-18 etc.) against autograd in fp64 and against the per-tap gather kernel."""
     h = H()
@@ -937,7 +937,7 @@ def test_pack_frag_batch_matches_per_layer(monkeypatch):
     (1, 224, 224, 64, 64, False),     # the 224-wide layers: 4 x 8 patches
     (2, 56, 56, 128, 64, True),       # pooled to 28 x 28, 64-column consumer
 ])
-def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_products):
+def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch):
     """Pre-split activations (hipops.PRESPLIT, round 5): conv (statistics epilogue + per-channel max / min) -> egz_bn_finalize_bound
     -> egz_bn_relu_pool_fwd_presplit -> consumer conv forward (mode | 0x100) and weight gradient (flags | 0x8000).
     (a) the bound is the EXACT maximum of the block output (== the abs-max the fp32 form measures in its own pass);
@@ -984,7 +984,7 @@ def test_presplit_activation_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_pro
     dw_ref = h.conv3x3_wgrad(out_ref, dy, precision="split_f16")
     dw_pre = h.conv3x3_wgrad(out_pre, dy, precision="split_f16", x_pre=True)
     assert torch.equal(dw_ref, dw_pre)
-    # two products per MAC (the default outside this test): x enters hi-only, rounded to nearest from the fp32 value in one launch
+    # two products per MAC (the opt-in, EGAZE_BWD_PRODUCTS=2): x enters hi-only, rounded to nearest from the fp32 value in one launch
     # and from hi + lo of the stored pair in the other -- a double rounding apart on rare ties: close, not bit-identical
     monkeypatch.setattr(h, "BWD_PRODUCTS", 2)
     assert rel(h.conv3x3_wgrad(out_pre, dy, precision="split_f16", x_pre=True), h.conv3x3_wgrad(out_ref, dy, precision="split_f16")) < 1e-4       # observed 2.5e-5
@@ -1009,7 +1009,7 @@ def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups, monkeypatc
     bench.py times -- batch 32, the real image sizes (3136 / 6272 / 1568 / ... tiles per launch, the weight gradient's real
     split-K depth, default SPLITK decision) -- against torch-CPU fp32 on the same operands: forward, data gradient and weight
     gradient, every entry within 2e-5 (5e-5 for the 1.6 M-pixel weight-gradient reductions) of max |ref| with three products per
-    MAC; the two-product backward arithmetic (hipops.BWD_PRODUCTS = 2, the default) on the same launches: every entry within 2e-3,
+    MAC; the two-product backward arithmetic (hipops.BWD_PRODUCTS = 2, opt-in) on the same launches: every entry within 2e-3,
     relative L2 error below 1e-3.  A mis-indexed tile moves 1 / 3136 of the entries by O(1)."""
     h = H()
     B = 32
@@ -1036,7 +1036,7 @@ def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups, monkeypatc
         ddt = h.conv_dtype("dgrad", C, K, dyd)
         wq, sq = h.conv_weight(wd, "ups_dgrad" if ups else "dgrad", ddt, dyd, C)
         err = {}
-        for products in (3, 2):           # backward arithmetic: three MFMA products per MAC (fp32 class), two (the default)
+        for products in (3, 2):           # backward arithmetic: three MFMA products per MAC (fp32 class, the default), two (opt-in)
             monkeypatch.setattr(h, "BWD_PRODUCTS", products)
             dx = h.conv3x3_ups_dgrad(dyd, wq, C, dtype=ddt, streamed=sq) if ups else h.conv3x3_dgrad(dyd, wq, C, dtype=ddt, streamed=sq)
             dw = h.conv3x3_wgrad(xd, dyd, ups=ups)
@@ -1059,7 +1059,7 @@ def test_conv_ops_elementwise_at_the_headline_geometry(C, K, Hh, ups, monkeypatc
     (2, 32, 32, 64, 64, False), (1, 112, 112, 64, 128, True), (2, 28, 28, 128, 256, False), (3, 14, 14, 256, 128, False),
     (1, 224, 224, 64, 64, False), (2, 56, 56, 128, 64, True),
 ])
-def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_products):
+def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch):
     """Pre-split GRADIENTS (hipops.PRESPLIT_GRAD): the BatchNorm backward of a C -> K block writes dy as f16 pairs scaled by a
     bound of max |dy| derived in its finalize step (from max |dout|, the per-channel max / min of y and the two sums).
     (a) the bound holds and is tight: max |dy| <= bound <= 8 max |dy|;  (b) dgamma / dbeta are untouched (torch.equal);
@@ -1109,7 +1109,7 @@ def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_produ
             d1, s1 = h.conv3x3_dgrad_bnsums(dy_ref, wq, C, h.F16X3, ybelow, cbelow)
             d2, s2 = h.conv3x3_dgrad_bnsums(dy_pre, wq, C, h.F16X3, ybelow, cbelow, pre_in=True)
             assert rel(d2, d1) < 2e-6 and rel(s2.sum(0), s1.sum(0)) < 1e-5
-    # (d) the same consumers on two products per MAC (hipops.BWD_PRODUCTS = 2, the default outside this test): the pairs serve as
+    # (d) the same consumers on two products per MAC (hipops.BWD_PRODUCTS = 2, opt-in): the pairs serve as
     # the hi-only operand of the data gradient (rounded to nearest from hi + lo) and as the 22-bit operand of the weight gradient; both stay in the two-product error class against the three-product results
     monkeypatch.setattr(h, "BWD_PRODUCTS", 2)
     for name, got, want in (("dgrad", h.conv3x3_dgrad(dy_pre, wq, C, dtype=h.F16X3, streamed=sq, pre_in=True), dx_ref),
@@ -1122,7 +1122,7 @@ def test_presplit_gradient_chain(B, Hh, Ww, C, K, pool, monkeypatch, three_produ
 @pytest.mark.parametrize("B,Hh,Ww,C,K,ups", [(2, 28, 28, 64, 128, False), (1, 56, 56, 128, 64, True), (3, 14, 14, 256, 256, False),
                                              (2, 32, 32, 64, 64, False)])
 def test_backward_two_products(B, Hh, Ww, C, K, ups, monkeypatch):
-    """hipops.BWD_PRODUCTS = 2 (the default): the backward convolutions issue a_hi b_hi + a_lo b_hi -- two MFMA products per MAC,
+    """hipops.BWD_PRODUCTS = 2 (opt-in; 3 is the default): the backward convolutions issue a_hi b_hi + a_lo b_hi -- two MFMA products per MAC,
     the halo operand (dy / x) with its f16 hi half only, rounded to nearest (csrc/egz_common.h, egz_f16p2).  Against torch fp64 on the same operands:
     (a) the FORWARD launch does not know the knob (bit-identical output);  (b) data and weight gradient stay within 2e-3 of
     max |ref| per entry and 1e-3 in relative L2 -- and are NOT the three-product results (the knob reaches the launches);
