@@ -270,6 +270,10 @@ class AT():
                 done = int(self.optimizer_lstm.step_dev[0].item())
                 if done != first + pending:
                     raise RuntimeError(f"AT loss ring out of step: device counter {done}, host expected {first + pending}")
+                # the same synchronisation point also looks at the two device-side failure words: a persistent
+                # LSTM hand-off that timed out, and gradient elements the optimizer skipped because they were NaN / inf
+                H.lstm_persist_check()
+                self.optimizer_lstm.check_finite()
                 for i in range(pending):                        # slot of a step = optimizer steps completed before it
                     losses.update(vals[(first + i) % len(vals)])
                 first += pending
@@ -514,4 +518,6 @@ class AT():
             if prev is not None:
                 finish(ring[prev])
         self._extract_buffers = [(ch.bufs, ch.sig, ch.out) for ch in ring]
+        if self.device.type == 'cuda':
+            H.lstm_persist_check()          # every chunk has been read back: a lost in-launch hand-off of the saccade-frame LSTM calls surfaces here
         print('Finished extracting files for LF module!')

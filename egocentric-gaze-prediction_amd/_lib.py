@@ -128,8 +128,8 @@ SIGNATURES = {
     "egz_pixel_weighted_sum": (c_int, [P, P, P, c_int, c_int, c_int, S]),
     "egz_weighted_minmax": (c_int, [P, P, P, c_int, c_int, c_int, S]),
     "egz_aae_auc": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_double, P, S]),
-    "egz_adam_step": (c_int, [P, P, P, P, c_long, c_double, c_double, c_double, c_double, c_int, c_double, S]),
-    "egz_adam_step_dev": (c_int, [P, P, P, P, c_long, c_double, c_double, c_double, c_double, P, c_double, S]),
+    "egz_adam_step": (c_int, [P, P, P, P, c_long, c_double, c_double, c_double, c_double, c_int, c_double, P, S]),
+    "egz_adam_step_dev": (c_int, [P, P, P, P, c_long, c_double, c_double, c_double, c_double, P, c_double, P, S]),
 }
 
 

@@ -9,8 +9,10 @@
 namespace {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float omb1, float beta2, float omb2, float eps,
-                                                   float step_size, float bc2_sqrt, float grad_scale) {
+                                                   float step_size, float bc2_sqrt, float grad_scale,
+                                                   unsigned int* __restrict__ nonfinite) {
     const long n4 = n >> 2;
+    bool bad = false;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
@@ -19,6 +21,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ge = gv[e] * grad_scale;
+            if (!(fabsf(ge) <= 3.402823466e38f)) { bad = true; continue; }       // NaN / inf: this element keeps p, m, v
             mv[e] = mv[e] + omb1 * (ge - mv[e]);
             vv[e] = vv[e] * beta2 + omb2 * ge * ge;
             const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
@@ -32,12 +35,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const long t = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (t < n) {
         const float ge = g[t] * grad_scale;
-        const float mm = m[t] + omb1 * (ge - m[t]);
-        const float vq = v[t] * beta2 + omb2 * ge * ge;
-        m[t] = mm;
-        v[t] = vq;
-        p[t] = p[t] - step_size * (mm / (sqrtf(vq) / bc2_sqrt + eps));
+        if (!(fabsf(ge) <= 3.402823466e38f)) bad = true;
+        else {
+            const float mm = m[t] + omb1 * (ge - m[t]);
+            const float vq = v[t] * beta2 + omb2 * ge * ge;
+            m[t] = mm;
+            v[t] = vq;
+            p[t] = p[t] - step_size * (mm / (sqrtf(vq) / bc2_sqrt + eps));
+        }
     }
+    if (bad && nonfinite) atomicOr(nonfinite, 1u);
 }
 // Step count on the device (hipGraph-captured training steps: a replay cannot receive a new host scalar).  The bias
 // corrections are formed in fp64 from step[0] + 1 exactly as the host form does; adam_bump_kernel increments the counter after
@@ -47,7 +54,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // launch stays.  step[1] is reserved (0).
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, double lr, double beta1, double beta2,
-                                                       float eps, int* __restrict__ step, float grad_scale) {
+                                                       float eps, int* __restrict__ step, float grad_scale,
+                                                       unsigned int* __restrict__ nonfinite) {
+    bool bad = false;
     const double t = (double)(*static_cast<volatile int*>(step) + 1);
     const float omb1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2);
     const float step_size = (float)(lr / (1.0 - pow(beta1, t)));
@@ -61,6 +70,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float ge = gv[e] * grad_scale;
+            if (!(fabsf(ge) <= 3.402823466e38f)) { bad = true; continue; }       // NaN / inf: this element keeps p, m, v
             mv[e] = mv[e] + omb1 * (ge - mv[e]);
             vv[e] = vv[e] * b2 + omb2 * ge * ge;
             const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
@@ -73,12 +83,16 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
     const long tl = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (tl < n) {
         const float ge = g[tl] * grad_scale;
-        const float mm = m[tl] + omb1 * (ge - m[tl]);
-        const float vq = v[tl] * b2 + omb2 * ge * ge;
-        m[tl] = mm;
-        v[tl] = vq;
-        p[tl] = p[tl] - step_size * (mm / (sqrtf(vq) / bc2_sqrt + eps));
+        if (!(fabsf(ge) <= 3.402823466e38f)) bad = true;
+        else {
+            const float mm = m[tl] + omb1 * (ge - m[tl]);
+            const float vq = v[tl] * b2 + omb2 * ge * ge;
+            m[tl] = mm;
+            v[tl] = vq;
+            p[tl] = p[tl] - step_size * (mm / (sqrtf(vq) / bc2_sqrt + eps));
+        }
     }
+    if (bad && nonfinite) atomicOr(nonfinite, 1u);
 }
 __global__ void adam_bump_kernel(int* step) { *step += 1; }
 }  // namespace
@@ -86,7 +100,7 @@ __global__ void adam_bump_kernel(int* step) { *step += 1; }
 // egz_adam_step with the (0-based, completed-steps) counter on the device: applies step step[0] + 1 and increments step[0].
 // step points at TWO ints: {completed steps, reserved 0}.
 EGZ_API int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                              double eps, int* step, double grad_scale, hipStream_t st) {
+                              double eps, int* step, double grad_scale, unsigned int* nonfinite, hipStream_t st) {
     EGZ_CHECK_ARG(p && g && m && v && step && n > 0, "egz_adam_step_dev: bad arguments");
     EGZ_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "egz_adam_step_dev: buffers must be 16-byte aligned");
@@ -94,7 +108,7 @@ EGZ_API int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long
     if (g4 < 1) g4 = 1;
     const int grid = (int)(g4 > 8192 ? 8192 : g4);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, (float)eps, step,
-                       (float)grad_scale);
+                       (float)grad_scale, nonfinite);
     EGZ_CHECK_LAUNCH("egz_adam_step_dev");
     hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, step);
     EGZ_CHECK_LAUNCH("egz_adam_step_dev(bump)");
@@ -102,8 +116,11 @@ EGZ_API int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long
 }
 
 // Hyper-parameters are doubles (Python floats) so 1-beta keeps its precision.  step: 1-based step count.  grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+// An element whose (scaled) gradient is NaN / inf is SKIPPED -- p, m, v keep their values -- and `nonfinite` (device word, may be
+// null; the caller zeroes it) gets bit 0 set: a poisoned backward pass (a persistent-LSTM hand-off that timed out, an overflow
+// upstream) cannot destroy the weights before the host looks (FusedAdam.check_finite).  Finite gradients: unchanged bits.
 EGZ_API int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                          double eps, int step, double grad_scale, hipStream_t st) {
+                          double eps, int step, double grad_scale, unsigned int* nonfinite, hipStream_t st) {
     EGZ_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "egz_adam_step: bad arguments");
     EGZ_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                   "egz_adam_step: buffers must be 16-byte aligned");
@@ -115,7 +132,7 @@ EGZ_API int egz_adam_step(float* p, const float* g, float* m, float* v, long n, 
     if (g4 < 1) g4 = 1;
     const int grid = (int)(g4 > 8192 ? 8192 : g4);
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n,
-                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt, (float)grad_scale);
+                       (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt, (float)grad_scale, nonfinite);
     EGZ_CHECK_LAUNCH("egz_adam_step");
     return 0;
 }

@@ -313,11 +313,18 @@ namespace {
 //     stored AFTER the arrival.
 // Every block must be resident for the counters to fill: 128 or 256 blocks of 512 threads at 142 VGPRs = one block per CU, so the
 // launch needs that many CUs to come free (work of other streams drains by itself; a SECOND persistent launch of another process
-// on the same device could interleave with this one).  A poll that sees no progress for ~0.2 s therefore gives up, raises the
+// on the same device could interleave with this one).  A poll that sees no progress for 0.5 s of wall clock therefore gives up, raises the
 // error word and turns everything the block produces from then on into NaN (which reaches h_n / c_n, every later h_t and, in the
 // backward kernel, every later gradient) -- loud, instead of hanging the queue.
 typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
 constexpr int PF_H = 512, PF_SHARDS = 8, PF_LINE = 32;       // counters one per 128-byte line
+// A poll that sees no progress for PF_TIMEOUT_TICKS of the 100 MHz wall clock (0.5 s; the clock, not a spin count: a poll iteration
+// takes as long as the memory system lets it) gives up.  Besides the per-launch error word at sync[1024] (zeroed by every call)
+// the block raises a STICKY word behind the scratch -- sync[PF_STICKY_OFF] for a forward launch, [PF_STICKY_OFF + 1] for a
+// backward launch (atomic max of 1 + step) -- that no call ever clears: the owner of the scratch zeroes it once and reads it at a
+// synchronisation point of its own (hipops.lstm_persist_check: the AT loss-ring drain), so a failed forward launch is not
+// overwritten by the backward launch that follows it, nor by the next replay of a captured step.
+constexpr unsigned long long PF_TIMEOUT_TICKS = 50000000ull;
 // -DEGZ_PERSIST_TRACE (tools/lstm_persist_trace.py, a variant build): thread 0 of block (0, 0) stamps the 100 MHz wall clock at the
 // phase boundaries of every global step into the tail of the sync scratch ([step][8] x 64 bit from word 1280).
 // -DEGZ_PERSIST_ACQ (A/B only): the consumer side as "one agent-scope acquire after the poll, then plain loads" instead of sc1 loads.
@@ -339,6 +346,8 @@ constexpr int PF_TRACE_WORDS = 64 * 8 * 2;
 constexpr int PF_TRACE_WORDS = 0;
 #define PF_TRACE(ph) do {} while (0)
 #endif
+constexpr int PF_ZERO_WORDS = 5 * PF_SHARDS * PF_LINE + PF_TRACE_WORDS;      // counters, error word, tickets (+ trace): zeroed by every call
+constexpr int PF_STICKY_OFF = PF_ZERO_WORDS + 4 * 2 * 4 * PF_H;             // behind the backward form's partial sums (4 tiles x 8 shards; the forward uses the first half)
 struct PersistFwd {
     const float* gx0;                       // [T][B][4H] layer 0's input projection x W_ih_l0^T, WITHOUT bias
     const float* w_hh0; const float* w_ih1; const float* w_hh1;      // [4H][H]
@@ -410,15 +419,24 @@ __global__ __launch_bounds__(512) void lstm_persist_fwd_kernel(const PersistFwd 
         if (wave == 0 && !dead) {
             const unsigned int target = 16u * (unsigned)(s + 1);
             unsigned int spins = 0;
+            unsigned long long t_wait = 0;
             bool ok;
             do {
                 const unsigned int v = lane < PF_SHARDS ? __hip_atomic_load(cnt + lane * PF_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
                 ok = __all(v >= target);
                 if (!ok) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > 100000u) {
-                        if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                        break;
+                    if ((++spins & 255u) == 0) {
+                        const unsigned long long now = wall_clock64();
+                        if (!t_wait) t_wait = now;
+                        else if (now - t_wait > PF_TIMEOUT_TICKS) {
+                            if (lane == 0) {
+                                dead = 1;
+                                __hip_atomic_store(err, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                atomicMax(a.sync + PF_STICKY_OFF, 1u + (unsigned)s);
+                            }
+                            break;
+                        }
                     }
                 }
             } while (!ok);
@@ -609,15 +627,24 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwd 
         if (s && wave == 0 && !dead) {
             const unsigned int target = 8u * (unsigned)s;
             unsigned int spins = 0;
+            unsigned long long t_wait = 0;
             bool ok;
             do {
                 const unsigned int v = lane < PB_SHARDS ? __hip_atomic_load(cnt + lane * PF_LINE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
                 ok = __all(v >= target);
                 if (!ok) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > 100000u) {
-                        if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                        break;
+                    if ((++spins & 255u) == 0) {
+                        const unsigned long long now = wall_clock64();
+                        if (!t_wait) t_wait = now;
+                        else if (now - t_wait > PF_TIMEOUT_TICKS) {
+                            if (lane == 0) {
+                                dead = 1;
+                                __hip_atomic_store(err, 1u + (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                atomicMax(a.sync + PF_STICKY_OFF + 1, 1u + (unsigned)s);
+                            }
+                            break;
+                        }
                     }
                 }
             } while (!ok);
@@ -760,7 +787,10 @@ __global__ __launch_bounds__(512) void lstm_persist_bwd_kernel(const PersistBwd 
 
 }  // namespace
 
-// Words of the `sync` scratch of egz_lstm_persist_fwd (zeroed by the call itself); word [1024] is the error word: 0 = every hand-off arrived, 1 + s = a block gave up waiting in global step s.
+// Words of the `sync` scratch of egz_lstm_persist_fwd / _bwd.  The first part is zeroed by every call; word [1024] is the per-launch error word: 0 = every
+// hand-off arrived, 1 + s = a block gave up waiting in global step s.  The LAST 32 words are never written by a call except on such a
+// time-out (word 0 of them: forward launches, word 1: backward launches; atomic max of 1 + s): the caller zeroes the scratch once
+// when it allocates it and reads them when it synchronises.
 // every block of a persistent launch needs a CU of its own (the backward kernel's 252 VGPRs leave room for nothing else): refuse a
 // device with fewer CUs than blocks instead of relying on the hand-off time-out
 static int persist_cus_ok(int blocks) {
@@ -772,8 +802,7 @@ static int persist_cus_ok(int blocks) {
     }
     return cus >= blocks;
 }
-constexpr int PF_ZERO_WORDS = 5 * PF_SHARDS * PF_LINE + PF_TRACE_WORDS;      // counters, error word, tickets (+ trace)
-constexpr int PF_SYNC_WORDS = PF_ZERO_WORDS + 4 * 2 * 4 * PF_H;      // the backward form's 4 tiles x 8 shards; the forward uses the first half
+constexpr int PF_SYNC_WORDS = PF_STICKY_OFF + PF_LINE;      // ... + the line of the two sticky error words (never zeroed by a call)
 EGZ_API int egz_lstm_persist_sync_words(void) { return PF_SYNC_WORDS; }
 
 // The recurrence of egz_lstm_wave_fwd for L = 2, H = 512, B <= 32 in ONE persistent launch (lstm_persist_fwd_kernel).  Differences in
@@ -788,6 +817,10 @@ EGZ_API int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, con
     EGZ_CHECK_ARG(gx0 && w_ih && w_hh && b_ih && b_hh && h0 && c0 && hs && cs && hn && cn && sync, "egz_lstm_persist_fwd: null pointer");
     if (L != 2 || H != PF_H || B < 1 || B > 32 || T < 1) {
         egz_set_error("egz_lstm_persist_fwd: L=%d T=%d B=%d H=%d (built for L = 2, H = 512, B <= 32)", L, T, B, H);
+        return (int)hipErrorNotSupported;
+    }
+    if ((long)T * B * 4 * H * 4 * 2 >= (1l << 31)) {        // 32-bit buffer-resource sizes / offsets over acts and gx0
+        egz_set_error("egz_lstm_persist_fwd: T=%d B=%d: sequence too long for the 32-bit offsets of the persistent form", T, B);
         return (int)hipErrorNotSupported;
     }
     if (!persist_cus_ok(128 * egz_cdiv(B, 16))) {
@@ -814,6 +847,10 @@ EGZ_API int egz_lstm_persist_bwd(const float* dh_top, const float* dhn, const fl
     EGZ_CHECK_ARG(acts && cs && c0 && w_hh && w_ih && dgates && dh0 && dc0 && sync, "egz_lstm_persist_bwd: null pointer");
     if (L != 2 || H != PF_H || B < 1 || B > 32 || T < 1) {
         egz_set_error("egz_lstm_persist_bwd: L=%d T=%d B=%d H=%d (built for L = 2, H = 512, B <= 32)", L, T, B, H);
+        return (int)hipErrorNotSupported;
+    }
+    if ((long)T * B * 4 * H * 4 * 2 >= (1l << 31)) {
+        egz_set_error("egz_lstm_persist_bwd: T=%d B=%d: sequence too long for the 32-bit offsets of the persistent form", T, B);
         return (int)hipErrorNotSupported;
     }
     if (!persist_cus_ok(64 * egz_cdiv(B, 8))) {

@@ -25,6 +25,12 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     the producing kernel attached to ``x`` (hipops.carry_absmax) follows the values."""
     am = getattr(x, "_egz_absmax", None)
     pre = getattr(x, "_egz_presplit", False)
+    if am is not None and getattr(x, "_egz_am_version", x._version) != x._version:
+        # written in place since its producer attached the maximum (autograd accumulating a second gradient into it, a hook): the
+        # scalar no longer bounds the values (ADVICE r5) -- the consumer takes a standalone reduction / the fp32 route instead
+        if pre:
+            raise RuntimeError("a pre-split tensor was modified in place (it holds f16 pairs, not fp32 values)")
+        am = None
     x = x.detach()
     xp = x.permute(0, 2, 3, 1)
     if not xp.is_contiguous():
@@ -41,7 +47,10 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
 
 
 def from_nhwc(y: torch.Tensor) -> torch.Tensor:
-    return H.carry_absmax(y.permute(0, 3, 1, 2), y)
+    res = H.carry_absmax(y.permute(0, 3, 1, 2), y)
+    if getattr(res, "_egz_absmax", None) is not None:
+        res._egz_am_version = res._version          # to_nhwc drops the scalar when the tensor has been written since
+    return res
 
 
 DETACH_WGRAD = True       # weight-gradient forks that end in a gradient sink are left running (streams.fork.detach)

@@ -219,9 +219,9 @@ def conv_dtype(role: str, gemm_out: int, gemm_in: int, operand: Optional[torch.T
 STREAMED = True           # plain convs on the streamed-weight halo kernel (False: the round-1 LDS-DMA halo / gather kernels)
 UPSF_STREAMED = True      # forward of the four upsample-fused decoder convs on the streamed kernel (MODE UPSF)
 # Split-K form of the streamed kernel when a launch has too few pixel tiles to fill the chip (egz_conv3x3_streamed_splits):
-# batch-1 inference runs its 28 x 28 / 14 x 14 layers on 8-28 of 512 block slots otherwise.  A/B knob: EGAZE_SPLITK=0
+# batch-1 inference runs its 28 x 28 / 14 x 14 layers on 8-28 of 512 block slots otherwise.  (tests flip the constant)
 # (tests: test_conv3x3_streamed_splitk, the whole-model gradient tests pin the summation order with it).
-SPLITK = _os.environ.get("EGAZE_SPLITK", "1") != "0"
+SPLITK = True
 
 
 def conv_weight(w: torch.Tensor, role: str, dtype: int, x: torch.Tensor, gemm_out: int):
@@ -496,8 +496,8 @@ def _want_absmax() -> bool:
 # Forward activations get the same treatment as gradients: the pass that WRITES a post-ReLU activation (BN apply + ReLU
 # [+ pool], the bias + ReLU epilogue of a decoder conv) also emits max |a|, and the consuming convolution (forward operand)
 # and weight gradient (x operand) multiply by the matching power of two before the f16 split -- without it the pair's 22 bits
-# only hold for max |a| in [2^-3, 65504] (lo goes subnormal below, hi saturates above).  A/B knob: EGAZE_FWD_SCALE=0.
-FWD_SCALE = _os.environ.get("EGAZE_FWD_SCALE", "1") != "0"
+# only hold for max |a| in [2^-3, 65504] (lo goes subnormal below, hi saturates above).  (test_forward_scaling_is_needed flips the constant).
+FWD_SCALE = True
 ABSMAX_STATS = {"standalone": 0}         # standalone egz_absmax passes (an operand arrived without its producer's abs-max)
 
 
@@ -538,7 +538,7 @@ def absmax_of(x: torch.Tensor) -> torch.Tensor:
 # abs-max comes from the per-channel max / min of the conv output (atomic max in the conv's statistics epilogue) pushed through
 # the BatchNorm's monotonic map by egz_bn_finalize_bound.  Consumers (the next conv's forward and weight gradient) then stage
 # the pair without touching the vector ALU; the pair is bit-identical to the one they would have formed, so every result is.
-# EGAZE_PRESPLIT=0 keeps fp32 activations everywhere (A/B runs; test_presplit_activations_bit_identical flips the constant).
+# hipops.PRESPLIT = False keeps fp32 activations everywhere (test_presplit_activations_bit_identical flips the constant).
 # Backward arithmetic.  Default (3): THREE MFMA products per MAC in the data and weight gradients too -- a_hi b_hi + a_hi b_lo +
 # a_lo b_hi, both operands with 22 significant bits, fp32-class gradients (2e-7 per op): the arithmetic class of the reference's
 # fp32 autograd (SP.py:132-138), and what every headline number is timed on.
@@ -566,7 +566,7 @@ def _p2(dtype: int) -> int:
     return dtype | P2_DTYPE if (BWD_PRODUCTS == 2 and dtype == F16X3) else dtype
 
 
-PRESPLIT = _os.environ.get("EGAZE_PRESPLIT", "1") != "0"
+PRESPLIT = True          # (A/B decided in round 5: -0.24 ms, bit-identical; test_presplit_activations_bit_identical flips it)
 PRESPLIT_STATS = {"produced": 0, "fwd": 0, "wgrad": 0, "grad_produced": 0, "dgrad": 0, "wgrad_dy": 0}
 
 
@@ -592,8 +592,8 @@ def presplit_ok(B: int, H: int, W: int, C: int, K_next: int) -> bool:
 # is 2^b above the true maximum only moves the f16 window: elements more than 2^(16 - b) below the maximum lose low-order bits
 # of their lo half (absolute error <= 2^-37 of the bound), nothing saturates.  Unlike the forward activations this is not
 # bit-identical to the fp32-gradient path (another power-of-two scale rounds sub-window elements differently): the step's
-# gradients move by ~1e-7 relative (test_presplit_gradients_match).  EGAZE_PRESPLIT_GRAD=0 keeps fp32 gradients.
-PRESPLIT_GRAD = _os.environ.get("EGAZE_PRESPLIT_GRAD", "1") != "0"
+# gradients move by ~1e-7 relative (test_presplit_gradients_match flips the constant).
+PRESPLIT_GRAD = True     # (A/B decided in round 5: -0.19 ms; test_presplit_gradients_match flips it)
 
 
 def presplit_grad_ok(B: int, H: int, W: int, C: int, K: int) -> bool:
@@ -1043,8 +1043,8 @@ def _stream_device(t):
 # affine map is folded into the convolution (w' = w * scale[k], b' = b * scale[k] + shift[k], the bias + ReLU epilogue), so the
 # normalise pass (one read + one write of the layer's output, 8 of the 13 blocks of a VGG16-BN encoder) disappears.  The folded
 # tensors are cached on the weight and rebuilt when the weight, the bias or the BatchNorm's coefficients change.  Rounding: the
-# product w * scale is rounded once per weight (relative 6e-8) -- eval outputs move by ~1e-7 relative.  A/B knob: EGAZE_EVAL_FOLD=0.
-EVAL_FOLD = _os.environ.get("EGAZE_EVAL_FOLD", "1") != "0"
+# product w * scale is rounded once per weight (relative 6e-8) -- eval outputs move by ~1e-7 relative.  (tests flip the constant).
+EVAL_FOLD = True
 EVAL_FOLD_STATS = {"folded": 0}
 INFER_CALL = False      # set by utils.conv_bn_relu_pool right before ConvBNReLUPool.apply: the block runs under torch.no_grad()
 
@@ -1394,20 +1394,21 @@ def mse_bwd(a, b, grad_out, tanh_target: bool = False) -> torch.Tensor:
     return da
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, lo: int = 0, hi: Optional[int] = None):
-    """One Adam step over the flat buffers, or over their slice [lo, hi) (element offsets, multiples of 4)."""
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, lo: int = 0, hi: Optional[int] = None, nonfinite=None):
+    """One Adam step over the flat buffers, or over their slice [lo, hi) (element offsets, multiples of 4).  ``nonfinite``: int32
+    device word that gets bit 0 set when the step skipped an element because its gradient was NaN / inf (csrc/adam.hip)."""
     hi = p.numel() if hi is None else hi
     if hi <= lo:
         return
     o = 4 * lo
     check(LIB.egz_adam_step(p.data_ptr() + o, g.data_ptr() + o, m.data_ptr() + o, v.data_ptr() + o, hi - lo, lr, beta1, beta2,
-                            eps, int(step), grad_scale, _stream()), "egz_adam_step")
+                            eps, int(step), grad_scale, _p(nonfinite), _stream()), "egz_adam_step")
 
 
-def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0):
+def adam_step_dev(p, g, m, v, lr, beta1, beta2, eps, step_dev, grad_scale=1.0, nonfinite=None):
     """Adam step whose counter of completed steps lives on the device (int32 tensor): usable inside a captured hipGraph."""
     check(LIB.egz_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
-                                step_dev.data_ptr(), grad_scale, _stream()), "egz_adam_step_dev")
+                                step_dev.data_ptr(), grad_scale, _p(nonfinite), _stream()), "egz_adam_step_dev")
 
 
 # ----------------------------------------------------------------------------- AT: GEMM + LSTM cell
@@ -1487,7 +1488,61 @@ def copy_into(dst: torch.Tensor, src: torch.Tensor):
 # geometry allows (L = 2, H = 512, B <= 32): T=16 / B=32 forward 167 -> 90 us, backward 190 -> 119 us (profiles/r05_ab_notes.txt).
 # EGAZE_LSTM_PERSIST=0: always the wavefront launches (egz_lstm_wave_fwd / _bwd: T + 1 / T + 3 launches).
 LSTM_PERSIST = _os.environ.get("EGAZE_LSTM_PERSIST", "1") != "0"
-_PERSIST_SYNC: list = []
+# Hand-off scratch of the persistent launches: ONE buffer per (device, stream), zeroed when it is allocated and kept -- launches
+# on a stream are ordered, so they may share their counters (every call zeroes those itself); its last line holds the two STICKY
+# error words (forward, backward) that a timed-out hand-off raises and that no launch clears, so a failure survives the launches
+# and graph replays that follow it until lstm_persist_check() looks.
+_PERSIST_SYNC: dict = {}
+
+
+def _persist_sync(dev: torch.device) -> torch.Tensor:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+    buf = _PERSIST_SYNC.get(key)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            # (an allocation inside a capture would come from the graph's private pool and be zeroed by nothing)
+            raise RuntimeError("persistent LSTM launch inside a hipGraph capture on a stream that never ran one eagerly: run a "
+                               "warm-up step on this stream before capturing (graphs.GraphedTrainStep does)")
+        buf = torch.zeros((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
+        _PERSIST_SYNC[key] = buf
+    return buf
+
+
+def lstm_persist_errors() -> dict:
+    """The sticky error words of every persistent-LSTM scratch (synchronises): {'fwd': e, 'bwd': e}, 0 = every in-launch hand-off
+    arrived since the last reset, 1 + s = some launch had a block give up waiting in global step s (that launch's outputs -- and
+    every gradient derived from them -- are NaN from that step on)."""
+    out = {"fwd": 0, "bwd": 0}
+    for buf in _PERSIST_SYNC.values():
+        w = buf[-32:-30].tolist()
+        out["fwd"] = max(out["fwd"], int(w[0]))
+        out["bwd"] = max(out["bwd"], int(w[1]))
+    return out
+
+
+def lstm_persist_status() -> int:
+    """0 when no persistent LSTM launch since the last reset lost a hand-off, else the larger of the two sticky words."""
+    e = lstm_persist_errors()
+    return max(e["fwd"], e["bwd"])
+
+
+def lstm_persist_check(reset: bool = True) -> None:
+    """Raise if a persistent LSTM launch timed out since the last check.  Called where the training loops synchronise anyway (the
+    AT loss-ring drain, AT.trainLSTM's per-epoch read-back).  The poisoned step did not reach the weights (FusedAdam skips
+    non-finite gradient elements), so the caller can continue on the wavefront launches: the check switches the persistent form
+    off for the rest of the process before it raises."""
+    e = lstm_persist_errors()
+    if e["fwd"] or e["bwd"]:
+        global LSTM_PERSIST
+        LSTM_PERSIST = False
+        if reset:
+            for buf in _PERSIST_SYNC.values():
+                buf[-32:].zero_()
+        raise RuntimeError(f"persistent LSTM launch lost an in-launch hand-off (forward: {e['fwd']}, backward: {e['bwd']}; 1 + the "
+                           f"global step a block gave up in): not every block got a compute unit -- another kernel was holding CUs "
+                           f"for longer than 0.5 s.  The outputs of that step were NaN and FusedAdam skipped them; the "
+                           f"persistent form is now off (wavefront launches from here on; EGAZE_LSTM_PERSIST=0 selects them "
+                           f"from the start)")
 
 
 class lstm_persistent:
@@ -1507,14 +1562,6 @@ class lstm_persistent:
         global LSTM_PERSIST
         LSTM_PERSIST = self.prev
         return False
-
-
-def lstm_persist_status() -> int:
-    """Error word of the most recent persistent LSTM launch (synchronises): 0 = every in-launch hand-off arrived, 1 + s = a block
-    gave up waiting in global step s (the outputs of that launch are undefined)."""
-    if not _PERSIST_SYNC:
-        return 0
-    return int(_PERSIST_SYNC[0][1024].item())
 
 
 def lstm_wave_fwd(gx0, w_ih, w_hh, bsum, h0, c0, want_acts: bool = True):
@@ -1577,7 +1624,7 @@ def lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0, want_acts: bool = True
     """The stacked recurrence in ONE persistent, weight-stationary launch (egz_lstm_persist_fwd; L = 2, H = 512, B <= 32): gx0
     (T,B,4H) = layer 0's input projection WITHOUT bias; w_ih / w_hh / b_ih / b_hh: lists of L tensors as the module holds them
     (w_ih[0] unused) -> the outputs of lstm_wave_fwd.  The launch's hand-off counters live in a scratch of this call's own (the
-    call zeroes it), kept reachable for lstm_persist_status()."""
+    call zeroes them) and sticky error words live in this (device, stream)'s scratch (_persist_sync; lstm_persist_check())."""
     _req(gx0, "gx0"); _req(h0, "h0"); _req(c0, "c0")
     L = len(w_hh)
     T, B, H4 = gx0.shape
@@ -1592,12 +1639,11 @@ def lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0, want_acts: bool = True
     acts = torch.empty((L, T, B, H4), dtype=torch.float32, device=dev) if want_acts else None
     hn = torch.empty((L, B, Hd), dtype=torch.float32, device=dev)
     cn = torch.empty_like(hn)
-    sync = torch.empty((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
+    sync = _persist_sync(dev)
     PROF.note_flops("egz_lstm_persist_fwd", 2.0 * T * B * H4 * Hd * (2 * L - 1))
     check(LIB.egz_lstm_persist_fwd(gx0.data_ptr(), _ptr_table([None] + list(w_ih[1:])), _ptr_table(w_hh), _ptr_table(b_ih),
                                    _ptr_table(b_hh), h0.data_ptr(), c0.data_ptr(), hs.data_ptr(), cs.data_ptr(), _p(acts),
                                    hn.data_ptr(), cn.data_ptr(), sync.data_ptr(), L, T, B, Hd, _stream()), "egz_lstm_persist_fwd")
-    _PERSIST_SYNC[:] = [sync]
     return hs, cs, acts, hn, cn
 
 
@@ -1621,13 +1667,12 @@ def lstm_persist_bwd(dh_top, dhn, dcn, acts, cs, c0, w_hh, w_ih, db=None):
         for t in db:
             if t is not None and (not t.is_contiguous() or t.numel() != 4 * Hd):
                 raise RuntimeError("lstm_persist_bwd: a bias-gradient destination must be a contiguous (4H,) tensor")
-    sync = torch.empty((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
+    sync = _persist_sync(dev)
     PROF.note_flops("egz_lstm_persist_bwd", 2.0 * (T + 1) * B * 4 * Hd * Hd * L + 2.0 * T * B * 4 * Hd * Hd * (L - 1))
     check(LIB.egz_lstm_persist_bwd(_p(dh_top), _p(dhn), _p(dcn), acts.data_ptr(), cs.data_ptr(), c0.data_ptr(), _ptr_table(w_hh),
                                    _ptr_table([None] + list(w_ih[1:])), dgates.data_ptr(), dh0.data_ptr(), dc0.data_ptr(),
                                    _ptr_table(db) if db is not None else None, sync.data_ptr(), L, T, B, Hd, _stream()),
           "egz_lstm_persist_bwd")
-    _PERSIST_SYNC[:] = [sync]
     return dgates, dh0, dc0
 
 

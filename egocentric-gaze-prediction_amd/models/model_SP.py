@@ -6,6 +6,7 @@ HIP blocks of ``functions.py``.  A forward hook on ``features_s`` (AT.py:105) st
 post-ReLU (B,512,14,14) activation.
 """
 import torch.nn as nn
+import torch.nn.modules.module as _mod
 
 import torch
 
@@ -14,7 +15,7 @@ from ..streams import fork
 from ..utils import FusedSequential, init_like_reference
 
 _STAGGER = True        # the two encoders start one block apart so that they do not run in lock-step (+0.4 %, round 2)
-_INTERLEAVE = __import__('os').environ.get('EGAZE_INTERLEAVE', '1') != '0'     # the host issues the two encoders block by block, alternately
+_INTERLEAVE = True     # the host issues the two encoders block by block, alternately (A/B decided in round 5: 25.63 -> 25.38 ms; test_interleaved_encoders_* flips it)
 
 # models/model_SP.py:13-31 as (Cin, Cout) 3x3+ReLU blocks and 'U' = nearest x2 upsample; a 1x1 head follows
 _DECODER_PLAN = [(512, 512), (512, 512), 'U', (512, 512), (512, 512), (512, 512), 'U', (512, 256), (256, 256),
@@ -72,9 +73,15 @@ class model_SP(nn.Module):
                     stack.record_stream(torch.cuda.current_stream())
                 if _STAGGER:
                     stagger = torch.cuda.Event()
+            # (the interleaved issue bypasses features_s.__call__ and fires its plain forward hooks by hand below; anything else
+            # hooked onto either encoder -- pre-hooks, kwargs hooks, always-call hooks, GLOBAL module hooks -- takes the
+            # sequential path, where __call__ runs them all: ADVICE r5)
             interleave = (_INTERLEAVE and f.enabled and isinstance(self.features_t, FusedSequential)
                           and isinstance(self.features_s, FusedSequential) and not self.features_t._forward_hooks
-                          and not self.features_t._forward_pre_hooks and not self.features_s._forward_pre_hooks)
+                          and not self.features_t._forward_pre_hooks and not self.features_s._forward_pre_hooks
+                          and not getattr(self.features_s, "_forward_hooks_with_kwargs", None)
+                          and not getattr(self.features_s, "_forward_hooks_always_called", None)
+                          and not _mod._global_forward_hooks and not _mod._global_forward_pre_hooks)
             if interleave:
                 gen_t = self.features_t.blocks(x_t, out_buf=stack[B:] if stack is not None else None,
                                                after_first_block=(lambda: stagger.record()) if stagger is not None else None)

@@ -70,6 +70,8 @@ class FusedAdam:
         self.pre_step_hooks = []          # dp.GradReducer registers its wait() here
         self.capturable = False
         self.step_dev = None
+        # bit 0 set by the Adam kernel when it skipped an element whose gradient was NaN / inf (csrc/adam.hip): check_finite()
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def set_capturable(self, on: bool = True):
         """Keep the step counter on the device (egz_adam_step_dev), so that step() can sit inside a captured hipGraph.  Every
@@ -80,6 +82,16 @@ class FusedAdam:
         elif self.capturable:
             self.step_count = int(self.step_dev[0].item())
         self.capturable = on
+
+    def check_finite(self, reset: bool = True) -> None:
+        """Raise if a step since the last check met NaN / inf gradients (synchronises: call where the loop reads back anyway).
+        The kernel skipped those elements -- the weights are the ones from before the poisoned step(s), not NaN."""
+        if int(self.nonfinite.item()):
+            if reset:
+                self.nonfinite.zero_()
+            raise FloatingPointError("FusedAdam: a step since the last check saw NaN / inf gradient elements and skipped them "
+                                     "(parameters untouched there); the backward pass that produced them is broken -- e.g. a "
+                                     "persistent-LSTM hand-off that timed out (hipops.lstm_persist_check)")
 
     def note_replays(self, n: int = 1):
         """A captured graph containing step() was replayed n times: the host-side count follows the device counter."""
@@ -116,12 +128,12 @@ class FusedAdam:
         if self.capturable:
             # the step counter lives on the device so that a captured step can be replayed (set_capturable)
             H.adam_step_dev(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
-                            self.eps, self.step_dev, self.grad_scale)
+                            self.eps, self.step_dev, self.grad_scale, nonfinite=self.nonfinite)
         else:
             if capturing:
                 raise RuntimeError("FusedAdam.step() inside a hipGraph capture needs set_capturable(True)")
             H.adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.lr, self.betas[0], self.betas[1],
-                        self.eps, self.step_count, self.grad_scale)
+                        self.eps, self.step_count, self.grad_scale, nonfinite=self.nonfinite)
         H.touch_params(self.params)
         H.refresh_packings(self.params)     # one launch for every packing this step made stale (the next forward finds them fresh)
 

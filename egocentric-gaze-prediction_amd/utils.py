@@ -101,7 +101,10 @@ class FusedSequential(nn.Sequential):
                 next_k = nm.out_channels if (isinstance(nm, nn.Conv2d) and nm.kernel_size == (3, 3) and nm.padding == (1, 1)
                                              and nm.stride == (1, 1) and nm.in_channels == m.out_channels
                                              and isinstance(mods[i + step + 1], nn.BatchNorm2d)
-                                             and isinstance(mods[i + step + 2], nn.ReLU)) else 0
+                                             and isinstance(mods[i + step + 2], nn.ReLU)
+                                             # (a consumer whose BatchNorm is frozen while this one trains -- mixed-mode
+                                             # fine-tuning -- cannot take deferred / pre-split input: it gets plain fp32)
+                                             and mods[i + step + 1].training == nxt.training) else 0
                 x = conv_bn_relu_pool(x, m, nxt, pool, first and m.in_channels < 32,
                                       out_buf if i + step >= n else None, next_k)
                 relu_below = False

@@ -320,8 +320,11 @@ int egz_lstm_wave_fwd(const float* gx0, const float* const* w_ih, const float* c
  * egz_lstm_wave_fwd; inputs differ in two places: gx0 = x W_ih0^T WITHOUT bias, and b_ih / b_hh = HOST arrays of L device pointers
  * to the module's own bias vectors ([4H] each), summed inside the kernel.  `sync`: egz_lstm_persist_sync_words() uints of device
  * scratch (its counters are zeroed by the call); after the launch word [1024] is 0, or 1 + s when a block gave up waiting in
- * global step s (outputs then undefined).  Any other geometry: returns hipErrorNotSupported (801) and launches nothing -- call
- * egz_lstm_wave_fwd. */
+ * global step s (0.5 s of wall clock without progress; outputs then NaN from that step on).  The LAST 32 words of the scratch are
+ * sticky: a call writes them only on such a time-out (word 0: forward launches, word 1: backward launches; atomic max of 1 + s) and
+ * never clears them -- zero the scratch once when allocating it, keep it across calls, read the two words wherever the host
+ * synchronises anyway.  Any other geometry (or T * B beyond the 32-bit offsets of this form): returns hipErrorNotSupported (801)
+ * and launches nothing -- call egz_lstm_wave_fwd. */
 int egz_lstm_persist_sync_words(void);
 int egz_lstm_persist_fwd(const float* gx0, const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
                          const float* const* b_hh, const float* h0, const float* c0, float* hs, float* cs, float* acts, float* hn,
@@ -361,14 +364,17 @@ int egz_tanh_bwd(const float* y, const float* dy, float* dx, long n, hipStream_t
 int egz_add(const float* a, const float* b, float* out, long n, hipStream_t stream);
 
 /* ---- torch.optim.Adam step (defaults as configured at SP.py:110-113, AT.py:84, LF.py:77) over one flat buffer;
- *      grad_scale multiplies the gradient first (1/world_size after the RCCL sum all-reduce). */
+ *      grad_scale multiplies the gradient first (1/world_size after the RCCL sum all-reduce).
+ *      nonfinite: device word (may be null; zeroed by its owner).  An element whose scaled gradient is NaN / inf is skipped (p, m, v
+ *      keep their values) and bit 0 of *nonfinite is set -- torch.optim.Adam would write NaN into the weights there; every finite
+ *      gradient gives torch's bits. */
 int egz_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                  double eps, int step, double grad_scale, hipStream_t stream);
+                  double eps, int step, double grad_scale, unsigned int* nonfinite, hipStream_t stream);
 /* the same step with the counter of COMPLETED steps on the device (applies step step[0] + 1, then increments step[0]): for
  * optimizer steps inside a captured hipGraph, where a replay cannot receive a new host scalar.  step -> TWO ints {completed
  * steps, reserved (0)} */
 int egz_adam_step_dev(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2,
-                      double eps, int* step, double grad_scale, hipStream_t stream);
+                      double eps, int* step, double grad_scale, unsigned int* nonfinite, hipStream_t stream);
 
 /* utils.computeAAEAUC (utils.py:96-140) per sample on the device: res (B,6) doubles = (AAE deg, fp = #{z > z[gp]}, gaze row,
  * gaze col, centroid row, centroid col); gw = the 2R+1 weights of scipy's gaussian kernel (sigma 14, R = 56),

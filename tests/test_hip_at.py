@@ -434,3 +434,46 @@ def test_at_batched_step_graphed_matches_eager(monkeypatch):
     assert glosses == losses, (glosses, losses)
     for (n, a), b in zip(nets[0].state_dict().items(), nets[1].state_dict().values()):
         assert torch.equal(a, b), n
+
+
+@pytest.mark.gpu
+def test_lstm_persistent_failure_words_are_sticky_and_checked():
+    """a persistent launch that loses a hand-off raises a STICKY word in the tail of its (device, stream) scratch that
+    no later launch clears (forward and backward kept apart), hipops.lstm_persist_check() turns it into an exception at the
+    loops' synchronisation points and switches the process to the wavefront launches.  The time-out itself cannot be provoked
+    on an idle device, so the test plants the words where the kernels would, and checks that real launches leave them alone."""
+    from egaze_amd import hipops as H
+    if not H.lstm_persist_ok(2, 32, 512):
+        pytest.skip("persistent LSTM launches not available on this device")
+    T, B = 4, 32
+    g = torch.Generator().manual_seed(3)
+    w_ih = [None, (torch.randn(2048, 512, generator=g) * 0.04).to(DEV)]
+    w_hh = [(torch.randn(2048, 512, generator=g) * 0.04).to(DEV) for _ in range(2)]
+    b_ih = [torch.zeros(2048, device=DEV) for _ in range(2)]
+    b_hh = [torch.zeros(2048, device=DEV) for _ in range(2)]
+    gx0 = (torch.randn(T, B, 2048, generator=g) * 0.1).to(DEV)
+    h0, c0 = torch.zeros(2, B, 512, device=DEV), torch.zeros(2, B, 512, device=DEV)
+    hs, cs, acts, hn, cn = H.lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0)
+    H.lstm_persist_check()                                   # clean
+    assert H.lstm_persist_errors() == {"fwd": 0, "bwd": 0}
+    sync = next(iter(H._PERSIST_SYNC.values()))
+    assert sync.numel() == H.LIB.egz_lstm_persist_sync_words()
+    sync[-32] = 7                                            # "a forward launch gave up in global step 6"
+    H.lstm_persist_fwd(gx0, w_ih, w_hh, b_ih, b_hh, h0, c0)  # the launches that follow (the counters ARE zeroed by each call) ...
+    dh = torch.randn(T, B, 512, generator=g).to(DEV)
+    H.lstm_persist_bwd(dh, None, None, acts, cs, c0, w_hh, w_ih, None)
+    assert H.lstm_persist_errors() == {"fwd": 7, "bwd": 0}  # ... do not clear it, and the backward word is its own
+    assert int(sync[1024].item()) == 0                       # per-launch word of the (clean) last launch
+    was = H.LSTM_PERSIST
+    try:
+        with pytest.raises(RuntimeError, match="hand-off"):
+            H.lstm_persist_check()
+        assert H.LSTM_PERSIST is False and not H.lstm_persist_ok(2, 32, 512)      # wavefront launches from here on
+        H.lstm_persist_check()                               # reset by the failed check
+    finally:
+        H.LSTM_PERSIST = was
+    # a sequence whose extent would overflow the 32-bit offsets of the persistent form is refused, not launched (ADVICE r5)
+    tabs = [H._ptr_table(t) for t in ([None, w_ih[1]], w_hh, b_ih, b_hh)]
+    rc = H._RAW_LIB.egz_lstm_persist_fwd(gx0.data_ptr(), *tabs, h0.data_ptr(), c0.data_ptr(), hs.data_ptr(),
+                                         cs.data_ptr(), None, hn.data_ptr(), cn.data_ptr(), sync.data_ptr(), 2, 1 << 14, 32, 512, None)
+    assert rc == 801, rc                                     # hipErrorNotSupported: the caller launches the wavefront

@@ -361,6 +361,52 @@ def test_adam_matches_oracle():
     assert rel(pd.cpu(), p) < 1e-6 and rel(md.cpu(), m) < 1e-6 and rel(vd.cpu(), v) < 1e-6
 
 
+def test_adam_skips_nonfinite_gradients():
+    """a NaN / inf gradient element must not reach the weights.  The kernel leaves p, m, v of such an element alone,
+    sets bit 0 of the device word and updates every other element with exactly the bits of a clean step; FusedAdam.check_finite
+    raises at the next look (both counter forms: host scalar and device counter)."""
+    h = H()
+    n = 4099
+    g = rnd(n, seed=41, scale=0.01)
+    bad = g.clone()
+    bad[5], bad[1030], bad[n - 1] = float("nan"), float("inf"), float("-inf")        # vector body, another block, scalar tail
+    for dev_counter in (False, True):
+        res = {}
+        for tag, grad in (("clean", g), ("bad", bad)):
+            pd, md, vd = rnd(n, seed=40).to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+            cnt = torch.zeros(2, dtype=torch.int32, device=DEV)
+            for step in (1, 2):
+                if dev_counter:
+                    h.adam_step_dev(pd, grad.to(DEV), md, vd, 1e-3, 0.9, 0.999, 1e-8, cnt, nonfinite=flag)
+                else:
+                    h.adam_step(pd, grad.to(DEV), md, vd, 1e-3, 0.9, 0.999, 1e-8, step, nonfinite=flag)
+            res[tag] = (pd.cpu(), md.cpu(), vd.cpu(), int(flag.item()))
+        assert res["clean"][3] == 0 and res["bad"][3] == 1
+        keep = torch.ones(n, dtype=torch.bool)
+        keep[[5, 1030, n - 1]] = False
+        p0 = rnd(n, seed=40)
+        for a, b in zip(res["clean"][:3], res["bad"][:3]):
+            assert torch.equal(a[keep], b[keep])                       # untouched elsewhere, bit for bit
+        assert torch.equal(res["bad"][0][~keep], p0[~keep])            # the poisoned elements kept their parameters ...
+        assert res["bad"][1][~keep].abs().max().item() == 0.0 and res["bad"][2][~keep].abs().max().item() == 0.0    # ... and moments
+        assert torch.isfinite(res["bad"][0]).all()
+    from egaze_amd.optim import FusedAdam
+    w = torch.nn.Parameter(rnd(64, seed=42).to(DEV))
+    opt = FusedAdam([w], lr=1e-3)
+    opt.zero_grad()
+    w.grad.copy_(rnd(64, seed=43).to(DEV))
+    opt.step()
+    opt.check_finite()
+    before = w.detach().clone()
+    w.grad[3] = float("nan")
+    opt.step()
+    with pytest.raises(FloatingPointError):
+        opt.check_finite()
+    opt.check_finite()                                                 # the flag was reset by the failed check
+    assert torch.isfinite(w).all() and w[3].item() == before[3].item()
+
+
 def test_mse():
     h = H()
     a, b = rnd(1, 1, 512, seed=32).requires_grad_(True), rnd(1, 1, 512, seed=33)
@@ -614,7 +660,7 @@ def test_forward_activation_scaling(mag):
 
 
 def test_forward_scaling_off_loses_the_small_range(monkeypatch):
-    """The knob that switches the forward scaling off (EGAZE_FWD_SCALE=0, A/B runs) shows what it is for: at max |a| = 1e-5
+    """The knob that switches the forward scaling off (hipops.FWD_SCALE = False) shows what it is for: at max |a| = 1e-5
     the unscaled f16 pair is two orders of magnitude less accurate than the scaled one."""
     h = H()
     B, Hh, Ww, C, K = 1, 16, 16, 64, 128

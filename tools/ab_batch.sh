@@ -1,6 +1,6 @@
 #!/bin/bash
 # small-batch training step (the reference's default --batch_size_sp is 8) with / without the split-K launches
-for b in 8 4; do for v in "EGAZE_SPLITK=0" "EGAZE_SPLITK=1"; do
+for b in 8 4; do for v in "EGAZE_NOOP=0"; do   # (the split-K switch is a module constant now: hipops.SPLITK)
   echo "=== batch $b $v"
   env $v python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-f32-leg 2>/dev/null | python -c "
 import json,sys

@@ -43,7 +43,7 @@ for direction, nsteps in (("fwd", T + 1), ("bwd", T + 2)):
         else:
             worst = max(float((x - y).abs().max() / y.abs().max()) for x, y in zip(got_b, ref_b))
         assert worst < 1e-4 and H.lstm_persist_status() == 0, (direction, rep, worst, H.lstm_persist_status())
-        sync = H._PERSIST_SYNC[0].clone()
+        sync = next(iter(H._PERSIST_SYNC.values())).clone()
         st = sync[1280:1280 + 64 * 16].cpu().numpy().view(np.uint64).reshape(64, 8)[:nsteps, :6].astype(np.int64)
         if rep >= 2:
             acc.append(st)
