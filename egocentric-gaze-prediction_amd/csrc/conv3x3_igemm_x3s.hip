@@ -126,8 +126,18 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
     const int ntn = Kp / BN;
     // XCD-aware tile id: block b runs on XCD b % 8; give every XCD a contiguous range of tiles
     const int per = (total + 7) >> 3;
+#ifdef EGZ_TILE_LOOP
+    // Timing-only variant (stage (i); profiles/r06_tile_loop_gonogo.txt): the launch is capped at EGZ_GRID_CAP
+    // blocks (a fixed share of the CUs x 2 resident blocks) and every block walks its XCD's tile range with that stride, so that
+    // the kernels of other streams find CUs free for the whole duration of the launch instead of queueing behind it.
+    for (unsigned vb = blockIdx.x; vb < (unsigned)(per * 8); vb += gridDim.x) {
+    if (vb != blockIdx.x) __syncthreads();
+    const int gts = (int)(vb & 7) * per + (int)(vb >> 3);
+    if (gts >= total) continue;
+#else
     const int gts = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);      // total = tiles x splits
     if (gts >= total) return;
+#endif
     const int split = (EPI == EPI_PARTIAL) ? gts % nsplit : 0;
     const int gt = (EPI == EPI_PARTIAL) ? gts / nsplit : gts;
     const int phase = (MODE == UPSF) ? (gt & 3) : 0, ph_p = phase >> 1, ph_q = phase & 1;    // UPSF: block-uniform
@@ -711,6 +721,9 @@ __global__ __launch_bounds__(Geo<WM>::NTHR, Geo<WM>::OCC) void conv3x3_igemm_x3s
             }
         }
     }
+#ifdef EGZ_TILE_LOOP
+    }
+#endif
 }
 
 // pre-summed 3x3 weights of the upsample-fused forms (same definition as weff9 in conv3x3_igemm_x3.hip)
@@ -1384,7 +1397,13 @@ int launch_x3s(int epi, const float* x, const unsigned short* wq, const float* b
     const bool patch = (Wo % 16 == 0) && (Ho % G::PROWS == 0);
     const int mt = patch ? (int)(M / G::BM) : egz_cdiv(M, G::BM);
     const int total = mt * (Kp / G::BN) * ((MODE == UPSF) ? 4 : 1);
-    const dim3 grid(((total + 7) / 8) * 8);
+    dim3 grid(((total + 7) / 8) * 8);
+#ifdef EGZ_TILE_LOOP
+    {
+        static const int cap = getenv("EGZ_GRID_CAP") ? atoi(getenv("EGZ_GRID_CAP")) / 8 * 8 : 0;
+        if (cap > 0 && (int)grid.x > cap) grid.x = cap;
+    }
+#endif
 #define EGZ_X3S(E, P) hipLaunchKernelGGL((conv3x3_igemm_x3s_kernel<T, WM, E, P, MODE>), grid, dim3(G::NTHR), 0, st, x, wq, bias, y, stat, B, H, W, C, K, Cp, Kp, out_scale, mt, total, a_absmax, mask_src, absmax_out, 1, mm_out)
     if (epi != EPI_BIAS_RELU && epi != EPI_MASK_SUMS && epi != EPI_BIAS && epi != EPI_BNSUMS) absmax_out = nullptr;
     if (pre) {                         // pre-split activation operand: the training forward of the wide encoder layers
