@@ -646,6 +646,31 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
+    weak = None
+    if rank == 0:
+        # Weak-scaling bookkeeping across the driver's back-to-back runs (N = 1, 2, 4, 8 on one node): the N = 1 run leaves its
+        # line's key numbers in $TMPDIR, an N > 1 run of the same per-GPU workload on the same host reports its step time against
+        # it.  (The driver computes efficiency ITSELF from the per-N values; this block is a convenience for whoever reads one line.)
+        import socket as _so
+        import tempfile
+        n1_path = os.path.join(os.environ.get("TMPDIR") or tempfile.gettempdir(), "egaze_bench_n1.json")
+        sig = {"batch": args.batch, "size": args.size, "at": use_at, "host": _so.gethostname(), "bwd_products": H.BWD_PRODUCTS,
+               "precision": H.PRECISION, "steps": args.steps}
+        if world == 1 and not dp_forced:
+            try:
+                json.dump({"sig": sig, "ms_per_step": ms_per_step, "frames_per_s": frames_per_s}, open(n1_path, "w"))
+            except OSError:
+                pass
+        elif world > 1 and os.path.exists(n1_path):
+            try:
+                n1 = json.load(open(n1_path))
+                if n1.get("sig") == sig:
+                    weak = {"n1_ms": n1["ms_per_step"], "this_ms": ms_per_step, "efficiency": n1["ms_per_step"] / ms_per_step,
+                            "n1_frames_per_s": n1["frames_per_s"], "speedup": frames_per_s / n1["frames_per_s"],
+                            "note": f"per-GPU workload fixed (weak scaling): efficiency = N=1 step time / this run's step time; "
+                                    f"the N = 1 line was saved by an earlier run of this script on this host ({n1_path})"}
+            except (OSError, ValueError, KeyError):
+                weak = None
     if rank == 0:
         step_flops = FLOP_PER_FRAME_FWD_BWD * args.batch * (args.size / 224.0) ** 2
         out = {
@@ -712,6 +737,7 @@ def main():
                       "f32_ms_per_step": f32_ms,
                       "f32_note": "same step with EGAZE_PRECISION=f32 (exact-f32 MFMA everywhere), 3 untimed-leg steps",
                       "rccl_world1": rccl,
+                      "weak_scaling": weak,
                       "pcie_inclusive_ms_per_step": pcie_ms or None,
                       "pcie_note": ("the step with its batch starting in pinned host memory and the loss read back every step "
                                     "(SP.trainSP's loop): 'u8' = raw bytes + egz_u8_normalize on the device (38.5 MB/batch), "

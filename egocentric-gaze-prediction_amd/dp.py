@@ -67,7 +67,7 @@ class GradReducer:
         # still to come).  Every bucket hand-over costs event records / stream waits on the compute streams (~35 of each per SP
         # step with seven 25 MB buckets: +0.5 ms per step at world size 1, profiles/r05_dp_world1.txt), so few buckets are
         # cheaper -- but what the step waits for at its end is the LAST bucket's collective, so that one stays small: 186 MB of
-        # SP gradients become 93 + 47 + 25 + 21 MB instead of 7 x 25 + 11.
+        # SP gradients become 92 + 47 + 27 + 11 MiB (four buckets; tests/test_dp_gloo.py pins the cut) instead of 7 x 25 + 11.
         remaining = sum((p.numel() + 3) // 4 * 4 for p in params) * 4
         target = max(bucket_bytes, remaining // 2) if geometric else bucket_bytes
         for i in order:

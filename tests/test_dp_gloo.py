@@ -121,6 +121,37 @@ def test_bucket_sizes_halve_along_the_backward_pass():
         print("geometric" if geometric else "equal", [round(v / 2 ** 20, 1) for v in nbytes])
 
 
+def test_real_sp_parameter_list_buckets():
+    """the REAL model_SP parameter list (215 state-dict entries, 134 trainable tensors, 46.5 M floats), laid out
+    as FusedAdam lays it out (16-byte aligned slots in registration order), cut by the default policy: four in-place all-reduce
+    buckets in backward order (decoder first), whatever the world size -- the cut depends on the
+    parameter list only, so every rank of an 8-GPU run issues the same four collectives in the same order.  (Exact sizes: 92.1 +
+    47.2 + 27.0 + 11.2 MiB = 96.6 + 49.4 + 28.3 + 11.7 MB of the 186.1 MB of gradients; "93 + 47 + 25 + 21" in the round-5 notes was
+    the halving rule before parameter granularity: the 9.4 MB fusion / 512-channel tensors do not split.)"""
+    sys.path.insert(0, ROOT)
+    import egaze_amd  # noqa: F401
+    from egaze_amd.dp import GradReducer
+    from egaze_amd.models.model_SP import model_SP
+    from egaze_amd.utils import make_layers, cfg
+    model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20))
+    params = [p for p in model.parameters() if p.requires_grad]
+    assert sum(p.numel() for p in params) == 46529409 and len(params) == 134
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4
+    red = GradReducer(torch.empty(0), params, offsets)                  # (bucket cutting reads sizes only; no process group)
+    nbytes = [(e - s_) * 4 for s_, e, _ in red.buckets]
+    assert nbytes == [96623376, 49449216, 28329984, 11715072] and sum(nbytes) == off * 4 == 186117648, nbytes
+    assert [b[2] for b in red.buckets] == [42, 48, 12, 32]              # tensors per bucket
+    assert red.buckets[0][1] == off and red.buckets[-1][0] == 0
+    names = {id(p): n for n, p in model.named_parameters()}
+    first = {names[id(params[i])].split(".")[0] for i, b in red.bucket_of.items() if b == 0}
+    last = {names[id(params[i])].split(".")[0] for i, b in red.bucket_of.items() if b == len(red.buckets) - 1}
+    # backward order: the decoder's gradients fill the first bucket (with bn / fusion), the encoders' first layers the last one
+    assert "decoder" in first and last <= {"features_s", "features_t"}, (first, last)
+
+
 def test_rank_shard_sampler_partitions_and_pads():
     """Every rank sees a disjoint share, the same number of minibatches (the all-reduce is a collective), a new
     order per epoch; pad=False (validation) never repeats a sample."""

@@ -64,3 +64,35 @@ def test_bench_gpus2_self_launch():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert "ranks: 2" in r.stderr
     assert r.stdout.count("parameters identical to rank 0: True") == 2
+
+
+def test_bench_world4_dry_run_every_leg(tmp_path):
+    """`bench.py --gpus 4` as the driver launches it at N > 1, WITH every leg the default run takes (bare-MFMA
+    probe on rank 0 only, per-kernel profiled step, the opt-in-arithmetic leg with the headline's protocol, the exact-f32 leg;
+    the cpu_baseline / LF / PCIe / RCCL-world-1 legs are world-1 only) -- four ranks on the one GPU of the test box over gloo.
+    Every rank has to reach the same collectives in the same order or this hangs (timeout) / dies: one JSON line on rank 0,
+    n_gpus 4, identical replicas afterwards, both arithmetics timed, and a weak_scaling block computed from a saved N = 1 line."""
+    env = _env()
+    env["EGAZE_DP_CHECK"] = "1"
+    env["TMPDIR"] = str(tmp_path)
+    common = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--batch", "2", "--size", "64", "--no-cpu-baseline"]
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-roofline"] + common, env=env,
+                        capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
+    n1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert n1["n_gpus"] == 1 and n1["extra"]["weak_scaling"] is None
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4"] + common
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp4"
+    assert out["scaling"] == "weak" and out["roofline"]["mfma_macs_per_algorithmic_mac"] == 3.0
+    assert out["extra"]["bwd2"]["bwd_products"] == 2 and len(out["extra"]["bwd2"]["regions_ms_per_step"]) == 2
+    assert out["extra"]["f32_ms_per_step"] > 0
+    ws = out["extra"]["weak_scaling"]
+    assert ws["n1_ms"] == n1["ms_per_step"] and ws["this_ms"] == out["ms_per_step"]
+    assert abs(ws["efficiency"] - ws["n1_ms"] / ws["this_ms"]) < 1e-12
+    assert r.stdout.count("parameters identical to rank 0: True") == 4
