@@ -117,9 +117,9 @@ def cpu_baseline(batch=8, size=224, threads=16, timed_steps=3):
     return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle SP train step (fwd+floss+bwd+Adam; the reference's PyTorch-CPU algorithm), batch "
                       f"{batch}, {size}x{size}, 1 warm-up + {timed_steps} timed steps, {dt:.2f} s/step, torch-CPU "
-                      f"fp32 on {cores} threads (best of an 8/16/32/64 sweep, profiles/r02_cpu_baseline_thread_sweep.txt; host has "
+                      f"fp32 on {cores} threads (best of an 8/16/32/64 sweep, profiles/r06_cpu_baseline_thread_sweep.txt; host has "
                       f"{avail}); the same oracle step at batch 32 was measured once per round on a GPU box "
-                      f"(profiles/r03_cpu_baseline_b32.txt) -- batch 8 is the bounded sample, and the faster of the two per frame"}
+                      f"(profiles/r06_cpu_baseline_b32.txt) -- batch 8 is the bounded sample, and the faster of the two per frame"}
 
 
 def main():
@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per GPU (BASELINE: 32)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-at", action="store_true", help="leave the AT (lstmnet T=16, B=32) training step out")
+    ap.add_argument("--at-form", choices=("wave", "persist"), default="wave",
+                    help="form of the AT recurrence INSIDE the combined step: the wavefront launches (default: they share the chip "
+                         "with the SP kernels) or the persistent weight-stationary launches (A/B runs; stand-alone AT always times the latter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the untimed exact-f32-mode step timing")
@@ -258,7 +261,7 @@ def main():
             if at_stream is not None and streams.ENABLED:
                 # beside the SP step's kernels: the wavefront form (the persistent LSTM kernels want every CU to themselves; the
                 # stand-alone AT leg below -- BASELINE config 4 -- runs them)
-                with torch.cuda.stream(at_stream), H.lstm_persistent(False):
+                with torch.cuda.stream(at_stream), H.lstm_persistent(args.at_form == "persist"):
                     at_step()
             else:
                 at_step()
