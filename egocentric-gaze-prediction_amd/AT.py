@@ -334,6 +334,9 @@ class AT():
                 losses.update(loss.item())
             hidden = repackage_hidden(hidden)
             pred_chn_weight, hidden = self.lstm(inp, hidden)
+        if train and self.device.type == 'cuda':
+            H.lstm_persist_check()
+            self.optimizer_lstm.check_finite()
         return losses.avg
 
     def trainLSTM(self):

@@ -176,6 +176,8 @@ class LF():
                                                                       loss=losses, aae=aae))
         if graphed is not None:
             _update(graphed.drain())
+        if train:
+            self.optimizer.check_finite()            # (NaN / inf gradient elements are skipped by the Adam kernel and reported here)
         if dp.world_size() > 1:                      # global averages so that every rank agrees on the best epoch
             return tuple(dp.reduce_meters((losses.sum, losses.count), (auc.sum, auc.count), (aae.sum, aae.count)))
         return losses.avg, auc.avg, aae.avg

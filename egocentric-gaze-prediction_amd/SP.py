@@ -130,6 +130,7 @@ class SP():
                 print('Epoch: [{0}][{1}/{2}]\t''Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t'
                       'Loss {loss.val:.4f} ({loss.avg:.4f})\t'.format(self.epochnow, i + 1, len(self.STTrainLoader) + 1,
                                                                       batch_time=batch_time, loss=losses))
+        self.optimizer.check_finite()        # raises if a step of the epoch met NaN / inf gradients (the kernel skipped those elements)
         return losses.avg
 
     def testSP(self):

@@ -11,6 +11,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ v, long n, float omb1, float beta2, float omb2, float eps,
                                                    float step_size, float bc2_sqrt, float grad_scale,
                                                    unsigned int* __restrict__ nonfinite) {
+#pragma clang fp contract(off)       // the host-counter and device-counter forms must round alike (no fused multiply-add in one of them)
     const long n4 = n >> 2;
     bool bad = false;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
                                                        float* __restrict__ v, long n, double lr, double beta1, double beta2,
                                                        float eps, int* __restrict__ step, float grad_scale,
                                                        unsigned int* __restrict__ nonfinite) {
+#pragma clang fp contract(off)
     bool bad = false;
     const double t = (double)(*static_cast<volatile int*>(step) + 1);
     const float omb1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2);

@@ -465,6 +465,13 @@ class capture:
         self.eager_arena = eager_arena
 
     def __enter__(self):
+        # the persistent LSTM launches keep their hand-off scratch per (device, stream), zeroed ONCE when it is allocated (its
+        # sticky error words must survive replays): a buffer allocated inside the capture would come from the graph's pool and
+        # be re-zeroed by nothing / by every replay -- so the capture stream's scratch is created here, eagerly, before the
+        # capture begins (torch.cuda.graph synchronises the device on entry: the zero fill has landed by then)
+        st = getattr(self.ctx, "capture_stream", None)
+        if st is not None and LSTM_PERSIST:
+            _persist_sync(torch.device("cuda", torch.cuda.current_device()), st.cuda_stream)
         self.ctx.__enter__()
         try:
             ABSMAX_ARENA.capture_begin(torch.device("cuda", torch.cuda.current_device()), eager=self.eager_arena)
@@ -1495,14 +1502,14 @@ LSTM_PERSIST = _os.environ.get("EGAZE_LSTM_PERSIST", "1") != "0"
 _PERSIST_SYNC: dict = {}
 
 
-def _persist_sync(dev: torch.device) -> torch.Tensor:
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream())
+def _persist_sync(dev: torch.device, stream_handle=None) -> torch.Tensor:
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream() if stream_handle is None else stream_handle)
     buf = _PERSIST_SYNC.get(key)
     if buf is None:
         if torch.cuda.is_current_stream_capturing():
             # (an allocation inside a capture would come from the graph's private pool and be zeroed by nothing)
-            raise RuntimeError("persistent LSTM launch inside a hipGraph capture on a stream that never ran one eagerly: run a "
-                               "warm-up step on this stream before capturing (graphs.GraphedTrainStep does)")
+            raise RuntimeError("persistent LSTM launch inside a hipGraph capture that did not go through hipops.capture() "
+                               "(which creates the capture stream's hand-off scratch before the capture begins)")
         buf = torch.zeros((LIB.egz_lstm_persist_sync_words(),), dtype=torch.int32, device=dev)
         _PERSIST_SYNC[key] = buf
     return buf
