@@ -915,3 +915,73 @@ def test_interleaved_encoder_issue_is_the_same_step(monkeypatch):
         assert torch.equal(g0[k], g1[k]), k
     for k in r0:
         assert torch.equal(r0[k], r1[k]), k
+
+
+def test_global_and_kwargs_hooks_take_the_sequential_encoder_path():
+    """the interleaved encoder issue bypasses features_s.__call__ and fires plain forward hooks by hand; a GLOBAL module
+    forward hook or a with_kwargs hook on features_s would be skipped by that -- with one registered, model_SP.forward takes the
+    sequential path, where __call__ runs every kind of hook, and the step is the same step (bit-identical output)."""
+    import torch.nn.modules.module as nnm
+    from egaze_amd.utils import FusedSequential
+    model, _ = build_model()
+    model.train()
+    x_s, x_t, _, _ = synth.synth_sp_batch(2, 64, seed=22)
+    x_s, x_t = x_s.to(DEV), x_t.to(DEV)
+    with torch.no_grad():
+        ref = model(x_s, x_t).clone()
+    seen = {"global": 0, "kwargs": 0}
+
+    def global_hook(mod, inp, out):
+        if mod is model.features_s:
+            seen["global"] += 1
+    h = nnm.register_module_forward_hook(global_hook)
+    try:
+        with torch.no_grad():
+            out = model(x_s, x_t)
+    finally:
+        h.remove()
+    assert seen["global"] == 1 and torch.equal(out, ref)
+    hk = model.features_s.register_forward_hook(lambda mod, args, kwargs, out: seen.__setitem__("kwargs", seen["kwargs"] + 1),
+                                                with_kwargs=True)
+    try:
+        with torch.no_grad():
+            out = model(x_s, x_t)
+    finally:
+        hk.remove()
+    assert seen["kwargs"] == 1 and torch.equal(out, ref)
+    assert isinstance(model.features_s, FusedSequential)
+
+
+def test_mixed_mode_batchnorm_runs_and_matches_the_fp32_activation_path(monkeypatch):
+    """fine-tuning with ONE BatchNorm frozen (eval mode) while the rest of the encoder trains.  The block in front of the
+    frozen one must not hand it pre-split / deferred activations (the frozen block's eval-mode launches take fp32 input): the
+    forward pass runs, and it is bit-identical to the same model with the pre-split pairs switched off everywhere."""
+    import egaze_amd.hipops as H
+    outs = []
+    for presplit in (True, False):
+        monkeypatch.setattr(H, "PRESPLIT", presplit)
+        model, _ = build_model()
+        model.train()
+        frozen = [m for m in model.features_t.children() if isinstance(m, torch.nn.BatchNorm2d)][3]
+        frozen.eval()
+        before = frozen.running_mean.clone()
+        x_s, x_t, _, _ = synth.synth_sp_batch(2, 64, seed=23)
+        with torch.no_grad():
+            outs.append(model(x_s.to(DEV), x_t.to(DEV)).clone())
+        torch.cuda.synchronize()
+        assert torch.equal(frozen.running_mean, before)              # eval mode: statistics untouched
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+
+
+def test_absmax_of_a_gradient_written_in_place_is_dropped():
+    """a gradient tensor carries the abs-max scalar its producer kernel attached; if something writes the tensor in place
+    afterwards (autograd accumulating a second gradient into it, a hook) the scalar no longer bounds the values.  from_nhwc notes
+    the tensor's version, to_nhwc drops a scalar whose tensor has moved on."""
+    import egaze_amd.hipops as H
+    from egaze_amd.functions import from_nhwc, to_nhwc
+    y = torch.randn(2, 8, 8, 64, device=DEV)
+    am = H.absmax_of(y)
+    g = from_nhwc(y)
+    assert getattr(to_nhwc(g), "_egz_absmax", None) is am            # untouched: the scalar follows the values
+    g.add_(1.0)                                                      # AccumulateGrad-style in-place accumulation
+    assert getattr(to_nhwc(g), "_egz_absmax", None) is None          # stale: dropped (the consumer takes its own maximum)
