@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--at-form", choices=("wave", "persist"), default="wave",
                     help="form of the AT recurrence INSIDE the combined step: the wavefront launches (default: they share the chip "
                          "with the SP kernels) or the persistent weight-stationary launches (A/B runs; stand-alone AT always times the latter)")
+    ap.add_argument("--no-input-prefetch", action="store_true",
+                    help="A/B: convert the flow stack to its NHWC-32 form at the head of the forward pass instead of one step ahead on a helper stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the untimed exact-f32-mode step timing")
@@ -248,11 +250,19 @@ def main():
         at_stream = streams.side_stream("at")
         at_stream.wait_stream(torch.cuda.current_stream())
 
+    prefetch_stream = streams.side_stream("input") if (streams.ENABLED and not args.no_input_prefetch) else None
+
     def step(staged=None):
         # SP: the body of SP.trainSP's loop (SP.py:132-138); ``staged`` = (image, flow, gt) of this step when the batch
         # crosses PCIe inside the step (the untimed PCIe-inclusive leg below), else the HBM-resident synthetic batch
         x_s, x_t, tgt = staged if staged is not None else (input_s, input_t, target)
         output = model(x_s, x_t)
+        if prefetch_stream is not None and staged is None and streams.ENABLED:
+            # the NEXT step's input-side work (flow stack -> NHWC-32 + its abs-max: no weights involved), issued now on a helper
+            # stream exactly as SP.trainSP's loader does for batch k + 1 (data.STdatas.staged_batches): it runs under this step's
+            # backward pass instead of at the serial head of the next forward pass.  Still once per step, inside the timed region.
+            with torch.cuda.stream(prefetch_stream):
+                H.prepare_network_input(x_t)
         loss = criterion(output, tgt.view(output.size()))
         loss.backward()
         optimizer.step()

@@ -63,6 +63,11 @@ def staged_batches(loader, device, stage=None):
     def issue(sample):
         with torch.cuda.stream(copy):
             staged = stage(sample, device)
+            if stage is stage_batch:
+                # the flow stack's NHWC-32 form and its abs-max, behind the copy on the same stream (hipops.prepare_network_input):
+                # two weight-independent HBM passes less at the head of the consumer's forward pass
+                from .. import hipops
+                hipops.prepare_network_input(staged[1])
         ev = torch.cuda.Event()
         ev.record(copy)
         return sample, staged, ev

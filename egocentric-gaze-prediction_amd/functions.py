@@ -157,7 +157,9 @@ class ConvBNReLUPool(torch.autograd.Function):
         if padded:
             # the 20-channel flow stack, zero-padded to 32 channels, on the split-half kernels (2.2 -> ~0.9 ms per step
             # for this one layer); the packed weight is padded the same way by the pack kernel
-            xin = H.nchw_to_nhwc_pad(H._req(x.detach(), "network input (NCHW)"), 32)
+            xin = H.take_prepared_input(x, 32)              # (re-laid out ahead of time by the driver: hipops.prepare_network_input)
+            if xin is None:
+                xin = H.nchw_to_nhwc_pad(H._req(x.detach(), "network input (NCHW)"), 32)
             wp, st = H.conv_weight(weight, "fwd", H.F16X3, xin, K)
             H.ALGO_CHANNELS[0] = C
             try:

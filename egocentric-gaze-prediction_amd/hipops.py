@@ -1299,6 +1299,40 @@ def nchw_to_nhwc_pad(x: torch.Tensor, Cp: int) -> torch.Tensor:
     return out
 
 
+def prepare_network_input(x: torch.Tensor, Cp: int = 32):
+    """Input-side work of the NEXT forward pass, issued NOW on the current stream (a copy / helper stream): the re-layout of a
+    16 ... 32-channel NCHW network input (the 20-channel flow stack, SP.py:128) into the zero-padded NHWC-32 form its first
+    convolution reads, and the abs-max of the result (the scale of its f16 split).  Neither depends on the weights, so a driver
+    that has batch k + 1 on the device while step k computes (data.STdatas.staged_batches, bench.py) moves these two HBM passes
+    (~0.14 ms at batch 32) out of the serial head of the forward pass and under the MFMA-bound kernels of the step before.  The
+    prepared tensor rides on ``x`` and is consumed ONCE by functions.ConvBNReLUPool (the tensor's version and shape are
+    checked; anything else falls back to the in-step conversion)."""
+    if not (x.is_cuda and x.dim() == 4 and 16 <= x.shape[1] <= Cp and PRECISION == "split" and x.is_contiguous()):
+        return None
+    xin = nchw_to_nhwc_pad(x.detach(), Cp)
+    if _want_fwd_absmax():
+        absmax_of(xin)
+    ev = torch.cuda.Event()
+    ev.record()
+    x._egz_prepared = (xin, x._version, ev)
+    return xin
+
+
+def take_prepared_input(x: torch.Tensor, Cp: int = 32):
+    """The tensor prepare_network_input left on ``x`` (or None), handed over to the current stream; one-shot."""
+    prep = getattr(x, "_egz_prepared", None)
+    if prep is None:
+        return None
+    del x._egz_prepared
+    xin, version, ev = prep
+    if version != x._version or xin.shape[0] != x.shape[0] or xin.shape[3] != Cp or tuple(xin.shape[1:3]) != tuple(x.shape[2:]):
+        return None
+    cur = torch.cuda.current_stream()
+    cur.wait_event(ev)
+    xin.record_stream(cur)
+    return xin
+
+
 def nhwc_to_nchw(x: torch.Tensor) -> torch.Tensor:
     _req(x, "x")
     B, H, W, C = x.shape

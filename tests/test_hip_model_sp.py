@@ -985,3 +985,38 @@ def test_absmax_of_a_gradient_written_in_place_is_dropped():
     assert getattr(to_nhwc(g), "_egz_absmax", None) is am            # untouched: the scalar follows the values
     g.add_(1.0)                                                      # AccumulateGrad-style in-place accumulation
     assert getattr(to_nhwc(g), "_egz_absmax", None) is None          # stale: dropped (the consumer takes its own maximum)
+
+
+def test_prepared_network_input_is_the_same_step():
+    """hipops.prepare_network_input: the flow stack's NHWC-32 re-layout and its abs-max issued ahead of the forward pass on a helper
+    stream (what data.STdatas.staged_batches does behind the host-to-device copy, and bench.py one step ahead).  The forward pass
+    picks the prepared tensor up once, waits for its event, and gives bit-identical output / loss / gradients; a tensor written
+    after it was prepared, or a second forward pass, falls back to the in-step conversion."""
+    import egaze_amd.hipops as H
+    from egaze_amd.floss import floss
+    x_s, x_t, gt, _ = synth.synth_sp_batch(2, 64, seed=31)
+    x_s, x_t, gt = x_s.to(DEV), x_t.to(DEV), gt.to(DEV)
+    res = []
+    for prep in (False, True):
+        model, _ = build_model()
+        model.train()
+        if prep:
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                assert H.prepare_network_input(x_t) is not None
+            assert hasattr(x_t, "_egz_prepared")
+        out = model(x_s, x_t)
+        assert not hasattr(x_t, "_egz_prepared")                         # consumed once
+        loss = floss().to(DEV)(out, gt.view(out.size()))
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), loss.item(), {k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    (o0, l0, g0), (o1, l1, g1) = res
+    assert torch.equal(o0, o1) and l0 == l1
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    # stale: the input was written after the preparation -> ignored
+    H.prepare_network_input(x_t)
+    x_t.mul_(1.0)
+    assert H.take_prepared_input(x_t) is None and not hasattr(x_t, "_egz_prepared")
+    assert H.prepare_network_input(x_s) is None                          # 3 channels: the direct first-layer kernel reads NCHW itself
