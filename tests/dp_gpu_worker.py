@@ -1,6 +1,8 @@
-"""Worker of tests/test_hip_dp.py: ONE rank of a 2-rank data-parallel run of the real SP model (split-half kernels,
+"""Worker of tests/test_hip_dp.py: ONE rank of a 2-rank data-parallel run of a real model of the path (split-half kernels,
 HIP streams on, FusedAdam + dp.GradReducer) -- both ranks share GPU 0 and exchange gradients over gloo, the recipe for
-exercising the N>1 path on a 1-GPU box.  Launched by torch.distributed.run; writes its observations to argv[1].<rank>."""
+exercising the N>1 path on a 1-GPU box.  argv: out-prefix size batch [kind]; kind = sp (model_SP + floss, BASELINE config 3;
+default), at (lstmnet over T = size steps of 512-vectors + MSE, config 4) or lf (late_fusion + floss, config 5's last stage).
+Launched by torch.distributed.run; writes its observations to argv[1].<rank>."""
 import os
 import sys
 
@@ -27,19 +29,56 @@ def main():
     from egaze_amd.utils import cfg, make_layers
 
     assert H.PRECISION == "split" and streams.ENABLED, "the test is about the default (split-half, streams on) path"
+    kind = sys.argv[4] if len(sys.argv) > 4 else "sp"
     torch.manual_seed(1234 + rank)                       # replicas start DIFFERENT: attach() must broadcast rank 0's
-    model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20)).to(dev)
-    model.train()
-    crit = floss().to(dev)
-    opt = FusedAdam(model.parameters(), lr=1e-4)
-    b = synthetic.sp_batch(batch, size, dev, seed=100 + rank)
+    bucket_bytes = 8 * 1024 * 1024
+    if kind == "sp":
+        model = model_SP(make_layers(cfg['D'], 3), make_layers(cfg['D'], 20)).to(dev)
+        model.train()
+        crit = floss().to(dev)
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+        b = synthetic.sp_batch(batch, size, dev, seed=100 + rank)
 
-    def fwd_bwd():
-        opt.zero_grad()
-        out = model(b["image"], b["flow"])
-        loss = crit(out, b["gt"].view(out.size()))
-        loss.backward()
-        return loss
+        def fwd_bwd():
+            opt.zero_grad()
+            out = model(b["image"], b["flow"])
+            loss = crit(out, b["gt"].view(out.size()))
+            loss.backward()
+            return loss
+    elif kind == "at":
+        from egaze_amd.functions import MSELoss
+        from egaze_amd.models.LSTMnet import lstmnet
+        model = lstmnet().to(dev)
+        model.train()
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+        ab = synthetic.at_batch(size, batch, dev, seed=200 + rank)        # (T, B, 512) inputs and targets
+        tgt = torch.tanh(ab["gt"])
+        h0 = torch.zeros(2, batch, 512, device=dev)
+        c0 = torch.zeros(2, batch, 512, device=dev)
+        bucket_bytes = 4 * 1024 * 1024
+
+        def fwd_bwd():
+            opt.zero_grad()
+            pred, _ = model(ab["input"], (h0, c0))
+            loss = MSELoss.apply(pred, tgt)
+            loss.backward()
+            return loss
+    else:
+        from egaze_amd.models.late_fusion import late_fusion
+        model = late_fusion().to(dev)
+        model.train()
+        crit = floss().to(dev)
+        opt = FusedAdam(model.parameters(), lr=1e-4)
+        g = torch.Generator().manual_seed(300 + rank)
+        maps = [torch.rand(batch, 1, size, size, generator=g).to(dev) for _ in range(3)]
+        bucket_bytes = 4 * 1024
+
+        def fwd_bwd():
+            opt.zero_grad()
+            out = model(maps[0], maps[1])
+            loss = crit(out, maps[2])
+            loss.backward()
+            return loss
 
     # (0) make the replicas identical first (what dp.attach does), then take the LOCAL gradient without any reducer
     dist_p = opt.flat_p.detach().cpu()
@@ -54,8 +93,8 @@ def main():
     dist.all_gather(gathered, g_local)
 
     # (1) the same backward with the reducer attached: bucketed async all-reduce launched from the hooks
-    red = dp.attach(opt, bucket_bytes=8 * 1024 * 1024)
-    assert len(red.buckets) >= 4
+    red = dp.attach(opt, bucket_bytes=bucket_bytes)
+    assert len(red.buckets) >= (4 if kind == "sp" else 2), len(red.buckets)
     fwd_bwd()
     red.wait()
     torch.cuda.synchronize()

@@ -52,6 +52,28 @@ def test_two_ranks_one_gpu_real_model(tmp_path):
     assert obs[0]["losses"] != obs[1]["losses"]                         # per-rank batches, per-rank losses
 
 
+@pytest.mark.parametrize("kind,size,batch", [("at", 16, 32), ("lf", 224, 4)])
+def test_two_ranks_one_gpu_at_and_lf(kind, size, batch, tmp_path):
+    """The multi-GPU forms of BASELINE configs 4 and 5 (AT lstmnet at T = 16 / B = 32 per rank -- the persistent recurrence
+    launches; the late-fusion stage at 224 x 224) through the same data-parallel machinery as the SP model: 2 ranks on the one GPU
+    over gloo, gradient buckets reduced from the sink hooks.  (a) reduced gradient = the sum of the two local gradients bit for bit,
+    (b) bit-identical replicas after two Adam steps, finite per-rank losses that differ."""
+    prefix = str(tmp_path / "obs")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dp_gpu_worker.py"), prefix,
+           str(size), str(batch), kind]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    obs = [torch.load(f"{prefix}.{k}") for k in range(2)]
+    g0, g1 = obs[0]["g_local"]
+    assert not torch.equal(g0, g1) and g0.abs().max() > 0 and g1.abs().max() > 0
+    for o in obs:
+        assert o["n_buckets"] >= 2 and o["grad_scale"] == 0.5
+        assert torch.equal(o["g_sum"], g0 + g1), (o["g_sum"] - (g0 + g1)).abs().max()
+    assert torch.equal(obs[0]["flat_p"], obs[1]["flat_p"])
+    assert all(l == l for o in obs for l in o["losses"]) and obs[0]["losses"] != obs[1]["losses"]
+
+
 def test_bench_gpus2_self_launch():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
            "--size", "64", "--no-cpu-baseline", "--no-roofline"]
