@@ -53,7 +53,7 @@ timeout 900 python tools/cpu_baseline_b32.py 16 > $O/r06_cpu_baseline_b32.txt 2>
 import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
 print('ms/step %.3f  regions %s' % (d['ms_per_step'], [round(x,3) for x in d['extra']['timed_repeats']['ms_per_step']]))"
-  done; done; } > $O/r06_bwd_products_step_ab.txt 2>&1
+  done; done; } 2>/dev/null | grep -E '^--- |^ms/step' > $O/r06_bwd_products_step_ab.txt
 { echo "# python -m pytest tests/test_hip_ops.py tests/test_hip_model_sp.py -m gpu -s -k 'headline_geometry or two_product'"
   echo "# per convolution of the SP step at batch 32 (max-relative error vs torch-CPU fp32: forward, data gradient, weight gradient with three"
   echo "# products | with two products: max-relative and relative L2), then the whole model: two-product vs three-product gradients"
