@@ -53,6 +53,7 @@ def from_nhwc(y: torch.Tensor) -> torch.Tensor:
     return res
 
 
+BIAS_ON_HELPER = True     # decoder bias gradients (column sums of the masked-dgrad stat rows) on the weight-gradient helper stream
 DETACH_WGRAD = True       # weight-gradient forks that end in a gradient sink are left running (streams.fork.detach)
 # (Issuing the weight gradient W_L BEHIND the data gradient D_L instead of in front of it measured no difference -- 35.58 vs
 # 35.57 ms per step, profiles/r02_bench_ab_knobs.txt: with detached weight-gradient streams the helper queue is never empty --
@@ -342,6 +343,7 @@ class ConvReLU(torch.autograd.Function):
         dx = dw = db = None
         sbias = H.grad_sink(bias, ng[2])
         pre = getattr(dout, "_egz_premasked", None)
+        bias_stat = None
         if pre is not None and tuple(dout.shape) == (y.shape[0], K, y.shape[1], y.shape[2]):
             # the block above already applied this block's ReLU mask in its dgrad epilogue
             dy = to_nhwc(dout)
@@ -349,8 +351,13 @@ class ConvReLU(torch.autograd.Function):
             H.MASK_FUSE_STATS["consumed"] += 1
             if am is not None:
                 dy._egz_absmax = am
-            if ng[2]:
-                db = H.colsum_f64(stat, K, out=sbias)
+            # (the bias gradient -- column sums of the stat rows the dgrad kernel above left -- is issued on the weight-gradient
+            # helper stream below: on this stream its two small launches sat between two data-gradient launches of the serial
+            # decoder chain with nothing beside them, ~20 us per layer; profiles/r06_step_windows.txt)
+            bias_stat = stat if ng[2] else None
+            if bias_stat is not None and not BIAS_ON_HELPER:
+                db = H.colsum_f64(bias_stat, K, out=sbias)
+                bias_stat = None
         elif ng[2]:
             dy, db = H.relu_bwd_bias(y, to_nhwc(dout), out_db=sbias)
         else:
@@ -373,11 +380,20 @@ class ConvReLU(torch.autograd.Function):
             return from_nhwc(H.conv3x3_dgrad(dy, wp, C, dtype=dt, streamed=st))
 
         with fork("wgrad") as f:
+            if bias_stat is not None:
+                db = H.colsum_f64(bias_stat, K, out=sbias)
             if ng[1]:
                 dw = H.conv3x3_wgrad(xin, dy, ups=ups, out=sw)
         dx = data_grad()
-        _close_fork(f, sw, dw, xin, dy)
-        return dx, _finish(weight, sw, dw), _finish(bias, sbias, db), None, None
+        _close_fork(f, sw, dw, xin, dy, bias_stat)
+        side = H.PENDING_PRODUCER[0]                      # the helper stream both gradients are being written on (detached fork)
+        gw = _finish(weight, sw, dw)
+        if bias_stat is not None:
+            if sbias is not None:
+                H.PENDING_PRODUCER[0] = side              # (the bias sink's hooks must see the same producer stream)
+            elif f.enabled:
+                f.join(db)                                # no sink: the tensor goes back to autograd on this stream
+        return dx, gw, _finish(bias, sbias, db), None, None
 
 
 class FusionBlock(torch.autograd.Function):
