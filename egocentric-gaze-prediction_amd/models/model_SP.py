@@ -14,7 +14,9 @@ from ..functions import FusionBlock
 from ..streams import fork
 from ..utils import FusedSequential, init_like_reference
 
-_STAGGER = True        # the two encoders start one block apart so that they do not run in lock-step (+0.4 %, round 2)
+_STAGGER = False       # (round 2: the two encoders started one block apart so that they did not run in lock-step, +0.4 %.  Since the
+                       # host issues them block by block, alternately, and the flow stack arrives re-laid out, the delay only costs:
+                       # 30.12 / 30.17 / 30.13 -> 30.07 / 30.01 / 29.97 ms same box, round 6; test_interleaved_encoder_issue_* runs both)
 _INTERLEAVE = True     # the host issues the two encoders block by block, alternately (A/B decided in round 5: 25.63 -> 25.38 ms; test_interleaved_encoders_* flips it)
 
 # models/model_SP.py:13-31 as (Cin, Cout) 3x3+ReLU blocks and 'U' = nearest x2 upsample; a 1x1 head follows
