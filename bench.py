@@ -325,6 +325,7 @@ def main():
     other = None
     at_ms = None
     at_eager_ms = None
+    at_graph_error = None
     pcie_ms = {}
     rccl = None
     lf_block = None
@@ -437,15 +438,29 @@ def main():
                     pred, _ = lstm(x, (h0, c0))
                     return MSELoss.apply(pred, tgt), pred
                 gat = GraphedTrainStep(at_forward_loss, opt_at, (at_in, at_tgt))
-                for _ in range(6):
-                    gat(at_in, at_tgt)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(50):
-                    gat(at_in, at_tgt)
-                torch.cuda.synchronize()
-                at_ms = (time.perf_counter() - t1) / 50 * 1e3
-                gat.close()
+                try:                       # (a side leg must not lose the headline line: on failure the eager figure stands)
+                    for _ in range(6):
+                        gat(at_in, at_tgt)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(50):
+                        gat(at_in, at_tgt)
+                    torch.cuda.synchronize()
+                    at_ms = (time.perf_counter() - t1) / 50 * 1e3
+                except Exception as e:
+                    at_graph_error = repr(e)[:300]
+                    print(f"[bench] graphed AT leg failed: {at_graph_error}", file=sys.stderr, flush=True)
+                finally:
+                    gat.close()
+            # the persistent recurrence launches of this leg report lost hand-offs through sticky words; a bench that timed a broken
+            # step must say so
+            try:
+                H.lstm_persist_check()
+                opt_at.check_finite()
+            except Exception as e:
+                at_graph_error = ((at_graph_error + "; ") if at_graph_error else "") + repr(e)[:300]
+                at_ms = at_eager_ms = None          # (not a number to quote)
+                print(f"[bench] AT leg: {at_graph_error}", file=sys.stderr, flush=True)
         if world == 1:
             # BASELINE config 5's last stage beside the headline (untimed leg): one LF.trainLate iteration (late_fusion forward
             # + floss + backward + Adam, LF.py:90-100) at the same batch, HBM-bound -- 88 MB of algorithmic traffic per frame
@@ -733,6 +748,7 @@ def main():
                                                     "bracketed by barrier + synchronize, max over ranks"},
                       "at_ms_per_step": at_ms,
                       "at_eager_ms_per_step": at_eager_ms,
+                      "at_graph_error": at_graph_error,
                       "at_roofline": (None if not at_ms else
                                       {"bound": "latency (5 batched f32-MFMA GEMM launches + the recurrence as two persistent "
                                                 "weight-stationary launches: 17 forward / 18 backward in-launch steps of ~5 / ~6.6 us, "
