@@ -68,7 +68,7 @@ class FusedSequential(nn.Sequential):
         """``out_buf``: optional NHWC destination for the output of the LAST block when that block is a conv-BN-ReLU
         block (model_SP passes the two encoders the halves of one buffer, see functions.FusionBlock).
         ``after_first_block``: optional callable run once the first block's kernels have been issued (model_SP records a
-        stream event there to run its two encoders half a layer apart)."""
+        stream event there when its encoder stagger is on)."""
         for x in self.blocks(x, fuse_sigmoid, out_buf, after_first_block):
             pass
         return x
