@@ -25,9 +25,38 @@ _SHARED = {"wgrad"}
 # interleaving -- 42.7 vs 35.6 ms -- and the switches were removed.)
 
 
+# torch.cuda.current_stream() / torch.cuda.stream(...) go through several Python layers (~10 / ~25 us per use); the SP step forks
+# ~45 times and asks for the current stream ~150 times, and at the reference's default batch (8, gaze_full.py:45) the step is
+# bound by the host issuing it (tools/host_issue.py).  The raw accessors cost ~0.3 us: Stream objects are looked up by raw
+# handle (torch's streams come from a fixed pool: a handle always names the same stream), the current stream is switched with
+# the C call the context manager ends up in.
+_raw_get = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_set = getattr(torch._C, "_cuda_setStream", None)
+_OBJS = {}
+
+
+def current() -> torch.cuda.Stream:
+    """torch.cuda.current_stream() of the current device, without the Python layers."""
+    if _raw_get is None:
+        return torch.cuda.current_stream()
+    dev = torch._C._cuda_getDevice()
+    key = (dev, _raw_get(dev))
+    st = _OBJS.get(key)
+    if st is None:
+        st = _OBJS[key] = torch.cuda.current_stream()
+    return st
+
+
+def _set_current(st: torch.cuda.Stream) -> None:
+    if _raw_set is not None:
+        _raw_set(stream_id=st.stream_id, device_index=st.device_index, device_type=st.device_type)
+    else:
+        torch.cuda.set_stream(st)
+
+
 def side_stream(kind: str) -> torch.cuda.Stream:
     """A persistent helper stream per (current stream, kind)."""
-    cur = torch.cuda.current_stream()
+    cur = current()
     key = (cur.device.index, 0 if kind in _SHARED else cur.cuda_stream, kind)
     st = _SIDE.get(key)
     if st is None:
@@ -46,16 +75,15 @@ class fork:
 
     def __enter__(self):
         if self.enabled:
-            self.cur = torch.cuda.current_stream()
+            self.cur = current()
             self.side = side_stream(self.kind)
             self.side.wait_stream(self.cur)
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
+            _set_current(self.side)
         return self
 
     def __exit__(self, *exc):
         if self.enabled:
-            self.ctx.__exit__(*exc)
+            _set_current(self.cur)
         return False
 
     def join(self, *tensors):
@@ -81,7 +109,7 @@ class fork:
 
 def join_all_into(target: torch.cuda.Stream, include_comm: bool = True):
     """Make ``target`` wait for every helper stream created so far, the current stream and the default stream."""
-    cur = torch.cuda.current_stream()
+    cur = current()
     seen = {target.cuda_stream}
     side = [st for key, st in _SIDE.items() if include_comm or key[2] != "comm"]
     for st in side + [cur, torch.cuda.default_stream(target.device)]:
@@ -95,7 +123,7 @@ def join_all_into_current(include_comm: bool = True):
     place by kernels on several streams).  ``include_comm=False`` leaves the collective stream out (the end-of-backward
     join: the gradient buckets still in flight are joined by the reducer's wait() in front of the optimizer step)."""
     if torch.cuda.is_available():
-        join_all_into(torch.cuda.current_stream(), include_comm)
+        join_all_into(current(), include_comm)
 
 
 _COMM = {}
