@@ -456,3 +456,40 @@ def test_lf_epoch_trailing_partial_batch_and_interrupted_epoch(monkeypatch):
     # (the loader runs one batch ahead of the step: the interrupt arrives while step 3 or 4 is the last one issued)
     assert not s.optimizer.capturable and s.optimizer.step_count in (3, 4)
     assert int(s.optimizer.step_dev[0].item()) == s.optimizer.step_count
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [32, 224])
+def test_late_fusion_two_product_backward(size, two_products):
+    """The opt-in backward arithmetic (EGAZE_BWD_PRODUCTS=2, the `two_products` fixture) on the late-fusion stack: its narrow kernels
+    (persistent narrow data gradient, the tap-packed and 32 x 32 weight-gradient kernels) stage the halo operand as ONE f16 plane.
+    Against the default (three products) on the same step: the forward pass does not know the knob (bit-identical map and loss),
+    every gradient tensor within 3e-3 relative L2 (one operand with 11 significant bits; observed ~3e-4), and the knob reaches the
+    launches (at least one tensor differs)."""
+    import egaze_amd.hipops as H
+    from egaze_amd.floss import floss
+    assert H.BWD_PRODUCTS == 2
+    im, feat, gt = synth.synth_lf_batch(2, size, seed=11)
+    res = []
+    for products in (2, 3):
+        H.BWD_PRODUCTS = products                      # (the fixture's monkeypatch restores the module default afterwards)
+        net = build()
+        net.train()
+        out = net(feat.to(DEV), im.to(DEV))
+        loss = floss().to(DEV)(out, gt.to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), loss.item(), {k: p.grad.detach().double().cpu() for k, p in net.named_parameters()}))
+    (o2, l2, g2), (o3, l3, g3) = res
+    assert torch.equal(o2, o3) and l2 == l3
+    differ, worst = 0, 0.0
+    for k in g3:
+        n = g3[k].norm().item()
+        if n == 0.0:
+            continue
+        e = (g2[k] - g3[k]).norm().item() / n
+        worst = max(worst, e)
+        differ += int(e > 0)
+        assert e < 3e-3, (k, e)
+    print(f"late fusion {size} x {size}: two- vs three-product gradients, worst relative L2 {worst:.2e}")
+    assert differ >= 1
